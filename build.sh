@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libmsegk.so (gfx950 HIP kernels + C ABI) and the oracle's C restatement.
+# hipcc cross-compiles without a GPU.  Usage: ./build.sh [-v]
+set -e
+cd "$(dirname "$0")"
+OUT=medicalseg_amd/lib
+mkdir -p $OUT build
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Imedicalseg_amd/csrc -Wno-unused-value -Wno-comment"
+OBJS=""
+for f in medicalseg_amd/csrc/*.hip; do
+  o=build/$(basename ${f%.hip}).o
+  if [ ! -f $o ] || [ $f -nt $o ] || [ include/msegk.h -nt $o ] || [ medicalseg_amd/csrc/msk_common.h -nt $o ] || [ medicalseg_amd/csrc/msk_conv.h -nt $o ]; then
+    hipcc $FLAGS $EXTRA -c $f -o $o &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsegk.so $OBJS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo "built $OUT/libmsegk.so"
+if [ -f oracle/c/Makefile ]; then make -s -C oracle/c; fi

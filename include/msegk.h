@@ -1,0 +1,212 @@
+/*
+ * msegk.h -- C ABI of libmsegk.so: the MI355X (gfx950) kernels behind the
+ * medicalseg VNet hot path.
+ *
+ * The reference (PaddleCV-SIG/MedicalSeg) has no FFI of its own: its "operator
+ * API" is the set of paddle.* calls made by medicalseg/models/vnet.py,
+ * the medicalseg/models/losses modules, medicalseg/core/train.py and the
+ * tools/preprocess_utils modules.  Each entry point below names the reference call
+ * site(s) it replaces (file:line relative to the reference root).  The Python
+ * package medicalseg_amd binds these with ctypes (medicalseg_amd/_lib.py); see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error (msk_last_error() has text);
+ *   - tensors are caller-owned DEVICE pointers described by msk_tensor:
+ *     fp32, NDHWC, `ld` floats between consecutive voxels (ld >= c lets a tensor
+ *     be a channel slice of a wider buffer -> zero-copy concat);
+ *   - weights cross the boundary in the reference's layouts
+ *     (Conv3D [Cout,Cin,kD,kH,kW]; Conv3DTranspose [Cin,Cout,kD,kH,kW]);
+ *   - all launches are asynchronous on the context's stream; msk_sync blocks;
+ *   - one context per device per process; a context is not thread-safe.
+ */
+#ifndef MSEGK_H
+#define MSEGK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msk_ctx msk_ctx;
+
+typedef struct {
+  void* p;                 /* device pointer to element (n=0,d=0,h=0,w=0,c=0) */
+  int32_t n, d, h, w, c;   /* logical dims */
+  int32_t ld;              /* floats per voxel in memory (>= c) */
+} msk_tensor;
+
+typedef struct {
+  int32_t kd, kh, kw;      /* kernel */
+  int32_t sd, sh, sw;      /* stride */
+  int32_t pd, ph, pw;      /* zero padding (Conv3D only; 0 for Conv3DTranspose) */
+} msk_conv_desc;
+
+/* ---- context / memory ----------------------------------------------------- */
+int msk_version(void);
+int msk_device_count(int* count);
+int msk_ctx_create(int device, msk_ctx** out);
+int msk_ctx_destroy(msk_ctx* ctx);
+const char* msk_last_error(msk_ctx* ctx);        /* ctx may be NULL (global error) */
+int msk_sync(msk_ctx* ctx);
+int msk_device_name(msk_ctx* ctx, char* buf, int buflen);
+int msk_malloc(msk_ctx* ctx, size_t bytes, void** out);
+int msk_free(msk_ctx* ctx, void* p);
+int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes);
+int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* blocking for pageable src */
+int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* synchronises the stream */
+int msk_d2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);
+int msk_pinned_alloc(msk_ctx* ctx, size_t bytes, void** out);
+int msk_pinned_free(msk_ctx* ctx, void* p);
+int msk_mem_info(msk_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+
+/* ---- timing / profiling (HIP events on the context stream) ---------------- */
+int msk_timer_start(msk_ctx* ctx);               /* records an event */
+int msk_timer_stop(msk_ctx* ctx, float* ms);     /* records + synchronises; elapsed ms */
+/* per-kernel profile: when enabled every launch is bracketed by events and its
+ * duration accumulated under the kernel's tag. */
+int msk_prof_enable(msk_ctx* ctx, int on);
+int msk_prof_reset(msk_ctx* ctx);
+/* writes "tag\tcalls\ttotal_ms\n" lines into buf (NUL terminated); returns needed size via *len */
+int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
+/* knobs: "conv_impl" 0=auto 1=direct(VALU reference kernels) 2=mfma */
+int msk_set_option(msk_ctx* ctx, const char* key, int value);
+
+/* ---- layout at the boundary ------------------------------------------------ */
+/* NCDHW (reference layout, core/train.py:123) <-> NDHWC (device layout) */
+int msk_ncdhw_to_ndhwc(msk_ctx* ctx, const float* src, msk_tensor dst);
+int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst);
+
+/* ---- convolutions ---------------------------------------------------------- */
+/* paddle.nn.Conv3D forward   (models/vnet.py:36,67-68,98-99,165-166,169)
+ *   y[N,OD,OH,OW,Cout] = conv(x[N,ID,IH,IW,Cin], w[Cout,Cin,k]) + bias        */
+int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
+                   const float* bias /*nullable*/, msk_tensor y);
+/* autograd of the above (core/train.py:139 loss.backward()):
+ *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
+int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,
+                     msk_tensor dx, int accumulate);
+/*   dw[Cout,Cin,k] (+)= sum_voxels dy * x ;  db[Cout] (+)= sum dy  (db nullable) */
+int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy,
+                     float* dw, float* db /*nullable*/, int accumulate);
+/* paddle.nn.Conv3DTranspose forward (models/vnet.py:133-137), w[Cin,Cout,k],
+ * out = (in-1)*s + k                                                           */
+int msk_convT3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
+                    const float* bias /*nullable*/, msk_tensor y);
+int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,
+                      msk_tensor dx, int accumulate);
+int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy,
+                      float* dw, float* db /*nullable*/, int accumulate);
+
+/* ---- BatchNorm3D / SyncBatchNorm + PReLU + residual ------------------------- */
+/* paddle.nn.BatchNorm3D -> SyncBatchNorm statistics (models/vnet.py:38,70,100,139,167;
+ * cvlibs/config.py:322).  Welford/Chan merge, biased variance over N*D*H*W.
+ * stats_local[2*C] = {mean[C], M2[C]} of THIS rank's x.                        */
+int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local);
+/* Merge `world` rank-local stats (gathered[world][2*C], equal counts `count_per_rank`)
+ * into mean/var, write scale = gamma*invstd, shift = beta - mean*scale, save
+ * mean[C], invstd[C]; running <- momentum*running + (1-momentum)*batch when
+ * running_mean/var are non-NULL.                                               */
+int msk_bn_finalize(msk_ctx* ctx, const float* gathered, int world, double count_per_rank,
+                    int C, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* save_mean,
+                    float* save_invstd, float* scale, float* shift);
+/* eval mode: scale/shift from running statistics (model.eval(), core/val.py:57) */
+int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, float eps,
+                       float* save_mean, float* save_invstd, float* scale, float* shift);
+/* out = prelu(scale[c]*x + shift[c] + res, alpha[c])
+ *   scale/shift NULL -> identity affine;  res.p NULL -> no residual;
+ *   res.c < out.c -> residual channel = c % res.c (x.tile, vnet.py:78);
+ *   alpha NULL -> no activation.  Replaces bn1/relu1/relu2/paddle.add chains
+ *   (vnet.py:41,77-79,107-111,150-154,173).                                    */
+int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
+                       msk_tensor res, const float* alpha, msk_tensor out);
+/* backward pass 1: per-channel sums over this rank:
+ *   sums[0..C)   = sum du            (du = dout * (u>0 ? 1 : alpha))
+ *   sums[C..2C)  = sum du * xhat     (xhat = (x-mean)*invstd; 0 if no BN)
+ *   sums[2C..3C) = sum dout * u * [u<=0]   (d alpha)                           */
+int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
+                              msk_tensor res, const float* alpha, const float* mean,
+                              const float* invstd, msk_tensor dout, float* sums);
+/* backward pass 2: dx = BN-backward(du) and dres (+)= du.
+ *   bn_mode 0: no BN (dx = du); 1: training BN (uses sums, total count M over all
+ *   ranks); 2: eval BN (dx = scale*du).  dres.p NULL -> skipped; dres_acc adds.   */
+int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
+                             msk_tensor res, const float* alpha, const float* mean,
+                             const float* invstd, const float* gamma, msk_tensor dout,
+                             const float* sums_total, double M_total, int bn_mode,
+                             msk_tensor dx, msk_tensor dres, int dres_acc);
+/* parameter gradients of the above from the (all-reduced) sums:
+ *   dgamma (+)= sums[C..2C), dbeta (+)= sums[0..C), dalpha (+)= sums[2C..3C)     */
+int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma,
+                               float* dbeta, float* dalpha, int accumulate);
+
+/* ---- concat / dropout / small elementwise ---------------------------------- */
+/* dst = src * mask[n*C+c] (mask NULL -> 1): paddle.concat slices (vnet.py:152) and
+ * nn.Dropout3D with a given mask (vnet.py:103,144-145);  accumulate adds.       */
+int msk_copy_scale(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate);
+/* counter-based Dropout3D mask: mask[n*C+c] = keep ? 1/(1-p) : 0, keyed by
+ * (seed, step, site).                                                          */
+int msk_dropout_mask(msk_ctx* ctx, uint64_t seed, uint64_t step, uint32_t site, int count,
+                     float p, float* mask);
+/* out[c] (+)= sum over voxels of x[..,c]  (bias gradients)                      */
+int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate);
+/* paddle.argmax(logit, axis=1) (core/infer.py:92) */
+int msk_argmax_c(msk_ctx* ctx, msk_tensor x, int32_t* out);
+
+/* ---- loss ------------------------------------------------------------------ */
+/* losses/loss_utils.py:31-40 class_weights: w_c = sum(1-softmax_c)/sum(softmax_c) */
+int msk_class_weights(msk_ctx* ctx, msk_tensor logits, float* weights);
+/* Fused CrossEntropyLoss + DiceLoss forward (losses/cross_entropy_loss.py:47-87,
+ * losses/dice_loss.py:76-102).  out[0]=CE, out[1]=dice loss, out[2..2+C)=per-channel
+ * dice; stats (device, 3*C+2 doubles) keeps {I_c, S_c, T_c, ce_num, ce_den} for bwd. */
+int msk_loss_fwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, float* out, double* stats);
+/* dlogits = coef_ce * dCE/dz + coef_dice * dDice/dz */
+int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, const double* stats, float coef_ce, float coef_dice,
+                 msk_tensor dlogits);
+
+/* ---- optimizer --------------------------------------------------------------- */
+/* paddle.optimizer.Momentum(momentum, weight_decay=L2) over one flat arena
+ * (cvlibs/config.py:212-214): g += wd*p; v = mu*v + g; p -= lr*v.
+ * grad_scale multiplies g first (1/nranks after a sum all-reduce).              */
+int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity,
+                     size_t count, float lr, float momentum, float weight_decay,
+                     float grad_scale);
+
+/* ---- preprocessing (tools/preprocess_utils) ----------------------------------- */
+/* geometry.py:31-69 resample == scipy.ndimage.zoom(order 0|1, grid_mode=False):
+ * align-corner coordinate map; order 0 = floor(c+0.5), order 1 = trilinear.
+ * dtype: 0 = float32, 1 = int32 (labels).                                       */
+int msk_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, void* dst,
+                   int dd, int dh, int dw, int order, int dtype);
+/* values.py:67-87 HUnorm */
+int msk_hu_norm(msk_ctx* ctx, const float* src, float* dst, size_t count, float hu_min,
+                float hu_max, float hu_nan);
+/* values.py:54-64 normalize; use_bounds==0 -> min/max of the volume */
+int msk_minmax_norm(msk_ctx* ctx, const float* src, float* dst, size_t count, int use_bounds,
+                    float min_val, float max_val);
+/* transforms/transform.py:67-69: im / im.max() when max > 0 */
+int msk_max_norm(msk_ctx* ctx, const float* src, float* dst, size_t count);
+/* values.py:37-51 label_remap (sequential key->value passes) */
+int msk_label_remap(msk_ctx* ctx, int32_t* label, size_t count, const int32_t* keys,
+                    const int32_t* vals, int npairs);
+
+/* ---- data parallel (RCCL over xGMI; core/train.py:81-85 fleet DataParallel) ---- */
+#define MSK_UNIQUE_ID_BYTES 128
+int msk_dp_unique_id(char* id128);                       /* rank 0 */
+int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world);
+int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);
+int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank);
+int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root);
+int msk_dp_barrier(msk_ctx* ctx);
+int msk_dp_destroy(msk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSEGK_H */

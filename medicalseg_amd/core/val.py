@@ -1,0 +1,61 @@
+"""Evaluation loop (reference medicalseg/core/val.py:29-187): eval-mode forward per
+validation volume (batch 1), mDice = mean over volumes of the mean over classes of the
+soft V-Net dice that DiceLoss returns as a side output."""
+import os
+import time
+
+import numpy as np
+
+from ..datasets import DataLoader
+from ..device import to_tensor
+from ..utils import TimeAverager, logger, loss_computation, save_array
+from . import infer
+
+np.set_printoptions(suppress=True)
+
+
+def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_roc=False, writer=None,
+             save_dir=None):
+    new_loss = {'types': [losses['types'][0]], 'coef': [losses['coef'][0]]}
+    model.eval()
+    from ..parallel import ParallelEnv
+    env = ParallelEnv()
+    local_rank = env.local_rank
+    loader = DataLoader(eval_dataset, batch_size=1, shuffle=False, drop_last=False, num_workers=num_workers)
+    total_iters = len(loader)
+    if print_detail:
+        logger.info("Start evaluating (total_samples: {}, total_iters: {})...".format(len(eval_dataset), total_iters))
+    reader_cost_averager = TimeAverager()
+    batch_cost_averager = TimeAverager()
+    batch_start = time.time()
+    mdice = 0.0
+    channel_dice_array = np.array([])
+    loss_all = 0.0
+    for it, (im, label, idx) in enumerate(loader):
+        reader_cost_averager.record(time.time() - batch_start)
+        label_t = to_tensor(label.astype('int32'))
+        pred, logits = infer.inference(model, to_tensor(im), ori_shape=label.shape[-3:],
+                                       transforms=eval_dataset.transforms.transforms)
+        loss, per_channel_dice = loss_computation(logits, label_t, new_loss)
+        loss = sum(loss)
+        loss_all += loss.numpy()
+        pcd = np.asarray(per_channel_dice)
+        mdice += np.mean(pcd)
+        channel_dice_array = pcd.copy() if channel_dice_array.size == 0 else channel_dice_array + pcd
+        if it < 5 and save_dir is not None:
+            save_array(save_path=os.path.join(save_dir, str(it)),
+                       save_content={'pred': pred.numpy(), 'label': label, 'img': im}, form=('npy', ))
+        batch_cost_averager.record(time.time() - batch_start, num_samples=len(label))
+        reader_cost_averager.reset()
+        batch_cost_averager.reset()
+        batch_start = time.time()
+    total_iters = max(total_iters, 1)
+    mdice /= total_iters
+    channel_dice_array = channel_dice_array / total_iters
+    loss_all = loss_all / total_iters
+    result_dict = {"mdice": float(mdice)}
+    if print_detail and local_rank == 0:
+        logger.info("[EVAL] #Images: {}, Dice: {:.4f}, Loss: {:6f}".format(len(eval_dataset), mdice,
+                                                                           float(np.ravel(loss_all)[0])))
+        logger.info("[EVAL] Class dice: \n" + str(np.round(channel_dice_array, 4)))
+    return result_dict

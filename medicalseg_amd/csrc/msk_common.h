@@ -1,0 +1,93 @@
+// Internal definitions shared by the libmsegk translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "msegk.h"
+
+struct msk_prof_entry {
+  double total_ms = 0.0;
+  long calls = 0;
+};
+
+struct msk_pending_event {
+  hipEvent_t a, b;
+  const char* tag;
+};
+
+struct msk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // scratch workspace (grown on demand, never shrunk)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  void* ws2 = nullptr;  // second independent scratch (packed weights)
+  size_t ws2_bytes = 0;
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // profiling
+  bool prof = false;
+  std::map<std::string, msk_prof_entry> prof_map;
+  std::vector<msk_pending_event> prof_pending;
+  std::vector<hipEvent_t> event_pool;
+  // options
+  int conv_impl = 0;  // 0 auto, 1 direct, 2 mfma
+  // data parallel
+  void* comm = nullptr;  // ncclComm_t
+  int rank = 0, world = 1;
+  int num_cu = 256;
+};
+
+extern thread_local std::string g_msk_global_err;
+
+int msk_fail(msk_ctx* ctx, const char* file, int line, const char* what, const char* detail);
+void* msk_workspace(msk_ctx* ctx, size_t bytes);   // returns nullptr on failure (error set)
+void* msk_workspace2(msk_ctx* ctx, size_t bytes);
+void msk_prof_begin(msk_ctx* ctx, const char* tag);
+void msk_prof_end(msk_ctx* ctx);
+
+#define MSK_CHECK_HIP(ctx, expr)                                                        \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) return msk_fail(ctx, __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define MSK_REQUIRE(ctx, cond, msg)                                       \
+  do {                                                                    \
+    if (!(cond)) return msk_fail(ctx, __FILE__, __LINE__, #cond, msg);    \
+  } while (0)
+
+// Launch bracket: set device stream, optional per-kernel profiling, error check.
+struct msk_launch_scope {
+  msk_ctx* ctx;
+  msk_launch_scope(msk_ctx* c, const char* tag) : ctx(c) { if (c->prof) msk_prof_begin(c, tag); }
+  ~msk_launch_scope() { if (ctx->prof) msk_prof_end(ctx); }
+};
+
+#define MSK_LAUNCH_CHECK(ctx)                                                            \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess) return msk_fail(ctx, __FILE__, __LINE__, "kernel launch", hipGetErrorString(_e)); \
+  } while (0)
+
+static inline int msk_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long msk_voxels(const msk_tensor& t) { return (long)t.n * t.d * t.h * t.w; }
+
+// device helpers ------------------------------------------------------------
+__device__ __forceinline__ float msk_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double msk_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

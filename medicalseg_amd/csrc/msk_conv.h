@@ -1,0 +1,52 @@
+// Internal convolution problem descriptors shared by msk_conv.hip (dispatch, packing,
+// VALU reference kernels) and msk_conv_mfma.hip (MFMA kernels).
+#pragma once
+#include "msk_common.h"
+
+// "Gather convolution": every dst voxel gathers from src voxels
+//   transposed == 0:  spos = dpos*s - p + k                      (Conv3D forward, ConvT dgrad)
+//   transposed == 1:  spos = (dpos + p - k)/s when divisible     (Conv3D dgrad, ConvT forward)
+// dst[m][n] (+)= bias[n] + sum_{tap,k} src[spos(m,tap)][k] * W[tap][k][n]
+struct GConv {
+  const float* src;
+  int sld;
+  float* dst;
+  int dld;
+  int N, SD, SH, SW, DD, DH, DW;  // src / dst spatial dims
+  int CK, CN;                     // reduction channels (src), output channels (dst)
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int transposed;
+  const float* bias;  // [CN] or null
+  int accumulate;
+  int flip;           // MFMA halo path: taps are enumerated flipped (conv dgrad as a 'same' conv)
+};
+
+// Weight gradient: dW[cb][ca][tap] (+)= sum_opos A[opos*s - p + k][ca] * B[opos][cb]
+struct WGrad {
+  const float* A;  // "input-side" tensor  [N][AD][AH][AW][CA]
+  int ald;
+  const float* B;  // "output-side" tensor [N][BD][BH][BW][CB]
+  int bld;
+  int N, AD, AH, AW, BD, BH, BW;
+  int CA, CB;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  float* dw;  // canonical [CB][CA][taps]
+  int accumulate;
+};
+
+// Packed-weight layouts
+//   direct: Wp[tap][k][n]                       (n fastest)
+//   mfma:   Wm[tap][kc][h][npad][4], k = kc*8 + h*4 + q, zero padded (K -> 8*KC, N -> npad)
+// Source canonical weight w[a][b][tap]; swap != 0 -> (k, n) = (b, a) else (k, n) = (a, b).
+int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps,
+                     int kd, int kh, int kw, int mfma, int K, int N, int KC, int npad, float* out);
+
+// MFMA kernels (msk_conv_mfma.hip).  Return 1 if the problem was handled, 0 if not eligible,
+// <0 on error.
+int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
+
+// split-K reducer shared by both wgrad implementations:
+// dw[cb][ca][tap] (+)= sum_s P[s][tap][ca][cb]
+int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
+                     int accumulate);

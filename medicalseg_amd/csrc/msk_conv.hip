@@ -1,0 +1,340 @@
+// Convolution entry points of the C ABI: weight packing, dispatch between the MFMA
+// kernels (msk_conv_mfma.hip) and the VALU reference kernels below, split-K reduce.
+//
+// The six public ops (Conv3D fwd/dgrad/wgrad, Conv3DTranspose fwd/dgrad/wgrad) reduce to
+// two device problems (msk_conv.h): a "gather convolution" and a weight gradient.
+#include "msk_conv.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+pack_weights_k(const float* __restrict__ w, int A, int B, int taps, int swap, int flip, int kd, int kh,
+               int kw, int mfma, int K, int N, int KC, int npad, float* __restrict__ out, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int tap, k, n;
+    if (mfma) {
+      // idx = ((((tap*KC + kc)*2 + h)*npad + n)*4 + q)
+      int q = (int)(idx & 3);
+      long r = idx >> 2;
+      n = (int)(r % npad);
+      r /= npad;
+      int h = (int)(r & 1);
+      r >>= 1;
+      int kc = (int)(r % KC);
+      tap = (int)(r / KC);
+      k = kc * 8 + h * 4 + q;
+    } else {
+      n = (int)(idx % N);
+      long r = idx / N;
+      k = (int)(r % K);
+      tap = (int)(r / K);
+    }
+    float v = 0.f;
+    if (k < K && n < N) {
+      int st = tap;
+      if (flip) {
+        int a = tap / (kh * kw), b = (tap / kw) % kh, c = tap % kw;
+        st = ((kd - 1 - a) * kh + (kh - 1 - b)) * kw + (kw - 1 - c);
+      }
+      int ia = swap ? n : k, ib = swap ? k : n;  // w[a][b][tap]
+      v = w[((long)ia * B + ib) * taps + st];
+    }
+    out[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// VALU reference gather convolution (any shape).  One thread per (dst voxel, out channel).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+gconv_direct_k(GConv g, const float* __restrict__ wp /*[tap][CK][CN]*/) {
+  const long M = (long)g.N * g.DD * g.DH * g.DW;
+  const long total = M * g.CN;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / g.CN;
+    const int cn = (int)(idx - m * g.CN);
+    const int ow = (int)(m % g.DW);
+    const int oh = (int)((m / g.DW) % g.DH);
+    const int od = (int)((m / ((long)g.DW * g.DH)) % g.DD);
+    const int n = (int)(m / ((long)g.DW * g.DH * g.DD));
+    float acc = g.bias ? g.bias[cn] : 0.f;
+    for (int a = 0; a < g.kd; ++a) {
+      int id;
+      if (!g.transposed) {
+        id = od * g.sd - g.pd + a;
+      } else {
+        int t = od + g.pd - a;
+        if (t < 0 || t % g.sd) continue;
+        id = t / g.sd;
+      }
+      if (id < 0 || id >= g.SD) continue;
+      for (int b = 0; b < g.kh; ++b) {
+        int ih;
+        if (!g.transposed) {
+          ih = oh * g.sh - g.ph + b;
+        } else {
+          int t = oh + g.ph - b;
+          if (t < 0 || t % g.sh) continue;
+          ih = t / g.sh;
+        }
+        if (ih < 0 || ih >= g.SH) continue;
+        for (int c = 0; c < g.kw; ++c) {
+          int iw;
+          if (!g.transposed) {
+            iw = ow * g.sw - g.pw + c;
+          } else {
+            int t = ow + g.pw - c;
+            if (t < 0 || t % g.sw) continue;
+            iw = t / g.sw;
+          }
+          if (iw < 0 || iw >= g.SW) continue;
+          const float* sp = g.src + ((((long)n * g.SD + id) * g.SH + ih) * g.SW + iw) * g.sld;
+          const int tap = (a * g.kh + b) * g.kw + c;
+          const float* wq = wp + (long)tap * g.CK * g.CN + cn;
+          for (int k = 0; k < g.CK; ++k) acc = fmaf(sp[k], wq[(long)k * g.CN], acc);
+        }
+      }
+    }
+    float* dp = g.dst + m * g.dld + cn;
+    *dp = g.accumulate ? *dp + acc : acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// VALU reference weight gradient: block = (tap, 16x16 (ca,cb) tile, voxel split)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+wgrad_direct_k(WGrad g, int splits, float* __restrict__ partial /*[split][tap][CA][CB]*/) {
+  const int t = threadIdx.x;
+  const int ca_tiles = (g.CA + 15) / 16, cb_tiles = (g.CB + 15) / 16;
+  int b = blockIdx.x;
+  const int cbt = b % cb_tiles;
+  b /= cb_tiles;
+  const int cat = b % ca_tiles;
+  const int tap = b / ca_tiles;
+  const int split = blockIdx.y;
+  const int ca = cat * 16 + t / 16, cb = cbt * 16 + t % 16;
+  const int a = tap / (g.kh * g.kw), bb = (tap / g.kw) % g.kh, c = tap % g.kw;
+  const long M = (long)g.N * g.BD * g.BH * g.BW;
+  const long per = (M + splits - 1) / splits;
+  const long m0 = split * per;
+  long m1 = m0 + per;
+  if (m1 > M) m1 = M;
+  float acc = 0.f;
+  const bool live = ca < g.CA && cb < g.CB;
+  for (long m = m0; m < m1; ++m) {
+    const int ow = (int)(m % g.BW);
+    const int oh = (int)((m / g.BW) % g.BH);
+    const int od = (int)((m / ((long)g.BW * g.BH)) % g.BD);
+    const int n = (int)(m / ((long)g.BW * g.BH * g.BD));
+    const int id = od * g.sd - g.pd + a, ih = oh * g.sh - g.ph + bb, iw = ow * g.sw - g.pw + c;
+    if (id < 0 || id >= g.AD || ih < 0 || ih >= g.AH || iw < 0 || iw >= g.AW) continue;
+    if (live) {
+      const float av = g.A[((((long)n * g.AD + id) * g.AH + ih) * g.AW + iw) * g.ald + ca];
+      const float bv = g.B[m * g.bld + cb];
+      acc = fmaf(av, bv, acc);
+    }
+  }
+  if (live) partial[(((long)split * (g.kd * g.kh * g.kw) + tap) * g.CA + ca) * g.CB + cb] = acc;
+}
+
+__global__ void __launch_bounds__(kThreads)
+wgrad_reduce_k(const float* __restrict__ partial, int splits, int taps, int CA, int CB, float* __restrict__ dw,
+               int accumulate) {
+  const long per = (long)taps * CA * CB;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (long)gridDim.x * blockDim.x) {
+    // idx = (tap*CA + ca)*CB + cb  (cb fastest: coalesced reads of the partial slabs)
+    const int cb = (int)(idx % CB);
+    const long r = idx / CB;
+    const int ca = (int)(r % CA);
+    const int tap = (int)(r / CA);
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += partial[(long)k * per + idx];
+    float* o = dw + ((long)cb * CA + ca) * taps + tap;
+    *o = accumulate ? *o + (float)s : (float)s;
+  }
+}
+
+inline int grid_for(long total, int num_cu) {
+  long b = (total + kThreads - 1) / kThreads;
+  long cap = (long)num_cu * 32;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& in, const msk_tensor& out,
+                      bool transposed_op) {
+  MSK_REQUIRE(ctx, cd.kd > 0 && cd.kh > 0 && cd.kw > 0 && cd.sd > 0 && cd.sh > 0 && cd.sw > 0, "bad kernel/stride");
+  MSK_REQUIRE(ctx, in.n == out.n, "batch mismatch");
+  if (!transposed_op) {
+    MSK_REQUIRE(ctx,
+                out.d == (in.d + 2 * cd.pd - cd.kd) / cd.sd + 1 && out.h == (in.h + 2 * cd.ph - cd.kh) / cd.sh + 1 &&
+                    out.w == (in.w + 2 * cd.pw - cd.kw) / cd.sw + 1,
+                "Conv3D output dims must be floor((in+2p-k)/s)+1");
+  } else {
+    MSK_REQUIRE(ctx, cd.pd == 0 && cd.ph == 0 && cd.pw == 0, "Conv3DTranspose supports padding 0 only");
+    MSK_REQUIRE(ctx,
+                out.d == (in.d - 1) * cd.sd + cd.kd && out.h == (in.h - 1) * cd.sh + cd.kh &&
+                    out.w == (in.w - 1) * cd.sw + cd.kw,
+                "Conv3DTranspose output dims must be (in-1)*s+k");
+  }
+  return 0;
+}
+
+// Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
+int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
+  const int taps = g.kd * g.kh * g.kw;
+  if (ctx->conv_impl != 1) {
+    int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
+  // reference path
+  g.flip = 0;
+  const long wn = (long)taps * g.CK * g.CN;
+  float* wp = (float*)msk_workspace2(ctx, wn * sizeof(float));
+  if (!wp) return -1;
+  if (msk_pack_weights(ctx, w, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 0, g.CK, g.CN, 0, 0, wp) != 0) return -1;
+  const long total = (long)g.N * g.DD * g.DH * g.DW * g.CN;
+  msk_launch_scope ls(ctx, tag);
+  hipLaunchKernelGGL(gconv_direct_k, dim3(grid_for(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* db, int accumulate) {
+  if (db) {
+    if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
+  }
+  if (ctx->conv_impl != 1) {
+    int r = msk_wgrad_mfma(ctx, g);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
+  const int taps = g.kd * g.kh * g.kw;
+  const long M = (long)g.N * g.BD * g.BH * g.BW;
+  const int ca_tiles = (g.CA + 15) / 16, cb_tiles = (g.CB + 15) / 16;
+  const long blocks = (long)taps * ca_tiles * cb_tiles;
+  long splits = (2048 + blocks - 1) / blocks;
+  if (splits > M / 64) splits = M / 64;
+  if (splits < 1) splits = 1;
+  if (splits > 4096) splits = 4096;
+  const size_t pbytes = (size_t)splits * taps * g.CA * g.CB * sizeof(float);
+  float* partial = (float*)msk_workspace(ctx, pbytes);
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "wgrad_direct");
+    hipLaunchKernelGGL(wgrad_direct_k, dim3((int)blocks, (int)splits), dim3(kThreads), 0, ctx->stream, g, (int)splits, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return msk_wgrad_reduce(ctx, partial, (int)splits, taps, g.CA, g.CB, g.dw, g.accumulate);
+}
+
+}  // namespace
+
+int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps, int kd,
+                     int kh, int kw, int mfma, int K, int N, int KC, int npad, float* out) {
+  const long total = mfma ? (long)taps * KC * 2 * npad * 4 : (long)taps * K * N;
+  msk_launch_scope ls(ctx, mfma ? "pack_weights_mfma" : "pack_weights_direct");
+  hipLaunchKernelGGL(pack_weights_k, dim3(grid_for(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, A, B, taps,
+                     swap, flip_taps, kd, kh, kw, mfma, K, N, KC, npad, out, total);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
+                     int accumulate) {
+  const long per = (long)taps * CA * CB;
+  msk_launch_scope ls(ctx, "wgrad_reduce");
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(per, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, partial, splits,
+                     taps, CA, CB, dw, accumulate);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" {
+
+int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  // w[Cout][Cin][tap]: k = Cin = b, n = Cout = a -> swap
+  return run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct");
+}
+
+int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate) {
+  if (check_conv_shapes(ctx, cd, dx, dy, false) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)dy.p; g.sld = dy.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
+  g.N = dx.n; g.SD = dy.d; g.SH = dy.h; g.SW = dy.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
+  g.CK = dy.c; g.CN = dx.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 1; g.bias = nullptr; g.accumulate = accumulate; g.flip = 1;
+  // w[Cout][Cin][tap]: k = Cout = a, n = Cin = b -> no swap
+  return run_gconv(ctx, g, w, dy.c, dx.c, 0, "conv3d_dgrad_direct");
+}
+
+int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
+  if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
+  WGrad g{};
+  g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
+  g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
+  g.CA = x.c; g.CB = dy.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.dw = dw; g.accumulate = accumulate;
+  return run_wgrad(ctx, g, dy, db, accumulate);
+}
+
+int msk_convT3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y) {
+  if (check_conv_shapes(ctx, cd, x, y, true) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = 0; g.ph = 0; g.pw = 0;
+  g.transposed = 1; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  // w[Cin][Cout][tap]: k = Cin = a, n = Cout = b -> no swap
+  return run_gconv(ctx, g, w, x.c, y.c, 0, "convT3d_fwd_direct");
+}
+
+int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate) {
+  if (check_conv_shapes(ctx, cd, dx, dy, true) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)dy.p; g.sld = dy.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
+  g.N = dx.n; g.SD = dy.d; g.SH = dy.h; g.SW = dy.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
+  g.CK = dy.c; g.CN = dx.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = 0; g.ph = 0; g.pw = 0;
+  g.transposed = 0; g.bias = nullptr; g.accumulate = accumulate; g.flip = 0;
+  // w[Cin][Cout][tap]: k = Cout = b, n = Cin = a -> swap
+  return run_gconv(ctx, g, w, dx.c, dy.c, 1, "convT3d_dgrad_direct");
+}
+
+int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
+  if (check_conv_shapes(ctx, cd, x, dy, true) != 0) return -1;
+  // dWT[ci][co][tap] = sum_ipos x[ipos][ci] * dy[ipos*s + k][co]: conv wgrad with A = dy, B = x
+  WGrad g{};
+  g.A = (const float*)dy.p; g.ald = dy.ld; g.B = (const float*)x.p; g.bld = x.ld;
+  g.N = x.n; g.AD = dy.d; g.AH = dy.h; g.AW = dy.w; g.BD = x.d; g.BH = x.h; g.BW = x.w;
+  g.CA = dy.c; g.CB = x.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = 0; g.ph = 0; g.pw = 0;
+  g.dw = dw; g.accumulate = accumulate;
+  return run_wgrad(ctx, g, dy, db, accumulate);
+}
+
+}  // extern "C"

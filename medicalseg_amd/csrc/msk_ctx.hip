@@ -1,0 +1,228 @@
+// Context, memory, timing and per-kernel profiling for libmsegk (gfx950).
+#include "msk_common.h"
+
+thread_local std::string g_msk_global_err;
+
+int msk_fail(msk_ctx* ctx, const char* file, int line, const char* what, const char* detail) {
+  char buf[1024];
+  const char* base = strrchr(file, '/');
+  snprintf(buf, sizeof(buf), "%s:%d: %s: %s", base ? base + 1 : file, line, what, detail ? detail : "");
+  if (ctx) ctx->err = buf;
+  g_msk_global_err = buf;
+  return -1;
+}
+
+static void* grow(msk_ctx* ctx, void** p, size_t* cur, size_t bytes) {
+  if (bytes <= *cur) return *p;
+  if (*p) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(*p);
+    *p = nullptr;
+    *cur = 0;
+  }
+  size_t want = bytes + (bytes >> 2);
+  if (hipMalloc(p, want) != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "workspace hipMalloc", "out of memory");
+    *p = nullptr;
+    return nullptr;
+  }
+  *cur = want;
+  return *p;
+}
+void* msk_workspace(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes); }
+void* msk_workspace2(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws2, &ctx->ws2_bytes, bytes); }
+
+static hipEvent_t get_event(msk_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+static void drain_prof(msk_ctx* ctx) {
+  for (auto& pe : ctx->prof_pending) {
+    hipEventSynchronize(pe.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pe.a, pe.b);
+    auto& ent = ctx->prof_map[pe.tag];
+    ent.total_ms += ms;
+    ent.calls += 1;
+    ctx->event_pool.push_back(pe.a);
+    ctx->event_pool.push_back(pe.b);
+  }
+  ctx->prof_pending.clear();
+}
+
+void msk_prof_begin(msk_ctx* ctx, const char* tag) {
+  msk_pending_event pe;
+  pe.a = get_event(ctx);
+  pe.b = get_event(ctx);
+  pe.tag = tag;
+  hipEventRecord(pe.a, ctx->stream);
+  ctx->prof_pending.push_back(pe);
+}
+void msk_prof_end(msk_ctx* ctx) {
+  hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
+  if (ctx->prof_pending.size() > 4096) drain_prof(ctx);
+}
+
+extern "C" {
+
+int msk_version(void) { return 100; }
+
+int msk_device_count(int* count) {
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return msk_fail(nullptr, __FILE__, __LINE__, "hipGetDeviceCount", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int msk_ctx_create(int device, msk_ctx** out) {
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return msk_fail(nullptr, __FILE__, __LINE__, "msk_ctx_create", "no HIP device visible (libmsegk has no CPU fallback)");
+  if (device < 0 || device >= n) return msk_fail(nullptr, __FILE__, __LINE__, "msk_ctx_create", "bad device index");
+  msk_ctx* ctx = new msk_ctx();
+  ctx->device = device;
+  MSK_CHECK_HIP(ctx, hipSetDevice(device));
+  MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t0));
+  MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t1));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return 0;
+}
+
+int msk_ctx_destroy(msk_ctx* ctx) {
+  if (!ctx) return 0;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  msk_dp_destroy(ctx);
+  drain_prof(ctx);
+  for (auto e : ctx->event_pool) hipEventDestroy(e);
+  if (ctx->ws) hipFree(ctx->ws);
+  if (ctx->ws2) hipFree(ctx->ws2);
+  hipEventDestroy(ctx->t0);
+  hipEventDestroy(ctx->t1);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+const char* msk_last_error(msk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_msk_global_err.c_str(); }
+
+int msk_sync(msk_ctx* ctx) {
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int msk_device_name(msk_ctx* ctx, char* buf, int buflen) {
+  hipDeviceProp_t prop;
+  MSK_CHECK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+int msk_malloc(msk_ctx* ctx, size_t bytes, void** out) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 16;
+  MSK_CHECK_HIP(ctx, hipMalloc(out, bytes));
+  return 0;
+}
+int msk_free(msk_ctx* ctx, void* p) {
+  if (!p) return 0;
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MSK_CHECK_HIP(ctx, hipFree(p));
+  return 0;
+}
+int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes) {
+  if (bytes == 0) return 0;
+  MSK_CHECK_HIP(ctx, hipMemsetAsync(p, value, bytes, ctx->stream));
+  return 0;
+}
+int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // pageable host memory: the runtime stages it; make the call safe w.r.t. src reuse
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int msk_d2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+int msk_pinned_alloc(msk_ctx* ctx, size_t bytes, void** out) {
+  MSK_CHECK_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return 0;
+}
+int msk_pinned_free(msk_ctx* ctx, void* p) {
+  MSK_CHECK_HIP(ctx, hipHostFree(p));
+  return 0;
+}
+int msk_mem_info(msk_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  MSK_CHECK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
+
+int msk_timer_start(msk_ctx* ctx) {
+  MSK_CHECK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return 0;
+}
+int msk_timer_stop(msk_ctx* ctx, float* ms) {
+  MSK_CHECK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  MSK_CHECK_HIP(ctx, hipEventSynchronize(ctx->t1));
+  MSK_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return 0;
+}
+
+int msk_prof_enable(msk_ctx* ctx, int on) {
+  if (!on) drain_prof(ctx);
+  ctx->prof = on != 0;
+  return 0;
+}
+int msk_prof_reset(msk_ctx* ctx) {
+  drain_prof(ctx);
+  ctx->prof_map.clear();
+  return 0;
+}
+int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len) {
+  drain_prof(ctx);
+  std::string s;
+  char line[256];
+  for (auto& kv : ctx->prof_map) {
+    snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", kv.first.c_str(), kv.second.calls, kv.second.total_ms);
+    s += line;
+  }
+  if (len) *len = (int)s.size() + 1;
+  if (buf && buflen > 0) {
+    strncpy(buf, s.c_str(), buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return 0;
+}
+
+int msk_set_option(msk_ctx* ctx, const char* key, int value) {
+  if (strcmp(key, "conv_impl") == 0) {
+    ctx->conv_impl = value;
+    return 0;
+  }
+  return msk_fail(ctx, __FILE__, __LINE__, "msk_set_option", "unknown key");
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// Data-parallel collectives: RCCL over xGMI, one process per GPU.
+// Replaces paddle.distributed.fleet DataParallel / SyncBatchNorm communication
+// (core/train.py:81-85, cvlibs/config.py:322).  All collectives are enqueued on the
+// context's compute stream so they order with the kernels that produce/consume them.
+#include <rccl/rccl.h>
+
+#include "msk_common.h"
+
+#define MSK_CHECK_NCCL(ctx, expr)                                                        \
+  do {                                                                                   \
+    ncclResult_t _r = (expr);                                                            \
+    if (_r != ncclSuccess) return msk_fail(ctx, __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
+  } while (0)
+
+extern "C" {
+
+int msk_dp_unique_id(char* id128) {
+  static_assert(sizeof(ncclUniqueId) <= MSK_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return msk_fail(nullptr, __FILE__, __LINE__, "ncclGetUniqueId", ncclGetErrorString(r));
+  memset(id128, 0, MSK_UNIQUE_ID_BYTES);
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
+  MSK_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised");
+  MSK_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  MSK_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  ncclComm_t comm;
+  MSK_CHECK_NCCL(ctx, ncclCommInitRank(&comm, world, id, rank));
+  ctx->comm = (void*)comm;
+  ctx->rank = rank;
+  ctx->world = world;
+  return 0;
+}
+
+int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_launch_scope ls(ctx, "rccl_allreduce");
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  return 0;
+}
+
+int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank) {
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_launch_scope ls(ctx, "rccl_allgather");
+  MSK_CHECK_NCCL(ctx, ncclAllGather(send, recv, count_per_rank, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+  return 0;
+}
+
+int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root) {
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_launch_scope ls(ctx, "rccl_broadcast");
+  MSK_CHECK_NCCL(ctx, ncclBroadcast(buf, buf, count, ncclFloat, root, (ncclComm_t)ctx->comm, ctx->stream));
+  return 0;
+}
+
+int msk_dp_barrier(msk_ctx* ctx) {
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  float* tok = (float*)msk_workspace(ctx, 256);
+  if (!tok) return -1;
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(tok, tok, 1, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int msk_dp_destroy(msk_ctx* ctx) {
+  if (ctx && ctx->comm) {
+    ncclCommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,710 @@
+// HBM-bound per-voxel kernels of the VNet path on gfx950: BatchNorm statistics,
+// fused affine(+residual)(+PReLU) forward/backward, channel-slice copies
+// (concat / Dropout3D), layout changes at the boundary, argmax.
+//
+// Layout: NDHWC fp32 with an explicit voxel stride `ld` (channel slices of a wider
+// buffer are first-class).  Threads map (channel fastest) so that a wavefront
+// reads 256 contiguous bytes (or 1 KiB with the float4 variants).
+#include "msk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Channel-block geometry for per-channel reductions: CB channels per block row
+// (power of two <= 256), VPB = 256/CB voxel lanes.
+struct ChanGeom {
+  int CB, VPB, cblocks;
+};
+inline ChanGeom chan_geom(int C) {
+  ChanGeom g;
+  g.CB = pow2ceil(C) < kThreads ? pow2ceil(C) : kThreads;
+  g.VPB = kThreads / g.CB;
+  g.cblocks = (C + g.CB - 1) / g.CB;
+  return g;
+}
+
+inline int reduce_blocks(long voxels, int VPB, int num_cu) {
+  long want = (voxels + (long)VPB * 64 - 1) / ((long)VPB * 64);  // >= 64 voxels per lane
+  long cap = (long)num_cu * 8;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm statistics: shifted sums per thread, Chan merge across threads/blocks
+// ---------------------------------------------------------------------------
+struct WF {
+  float n, mean, m2;
+};
+__device__ __forceinline__ WF wf_merge(WF a, WF b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  WF r;
+  r.n = a.n + b.n;
+  float d = b.mean - a.mean;
+  float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+__global__ void __launch_bounds__(kThreads)
+bn_stats_partial(const float* __restrict__ x, long voxels, int C, int ld, int CB, int VPB,
+                 float* __restrict__ partial /*[cblocks][nb][CB][3]*/) {
+  __shared__ WF sh[kThreads];
+  const int t = threadIdx.x;
+  const int cl = t % CB, vl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  WF w = {0.f, 0.f, 0.f};
+  if (c < C && v0 + vl < v1) {
+    const float K = x[(v0 + vl) * ld + c];
+    float s1 = 0.f, s2 = 0.f, n = 0.f;
+    for (long v = v0 + vl; v < v1; v += VPB) {
+      float d = x[v * ld + c] - K;
+      s1 += d;
+      s2 = fmaf(d, d, s2);
+      n += 1.f;
+    }
+    w.n = n;
+    w.mean = K + s1 / n;
+    w.m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
+  }
+  sh[t] = w;
+  __syncthreads();
+  for (int s = VPB >> 1; s > 0; s >>= 1) {
+    if (vl < s) sh[t] = wf_merge(sh[t], sh[t + s * CB]);
+    __syncthreads();
+  }
+  if (vl == 0) {
+    float* p = partial + (((long)blockIdx.y * nb + blockIdx.x) * CB + cl) * 3;
+    p[0] = sh[t].n;
+    p[1] = sh[t].mean;
+    p[2] = sh[t].m2;
+  }
+}
+
+__global__ void bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB,
+                               float* __restrict__ stats /*[2C]*/) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int cb = c / CB, cl = c % CB;
+  double n = 0, mean = 0, m2 = 0;
+  for (int b = 0; b < nb; ++b) {
+    const float* p = partial + (((long)cb * nb + b) * CB + cl) * 3;
+    double bn = p[0];
+    if (bn == 0) continue;
+    double d = (double)p[1] - mean;
+    double tot = n + bn;
+    double f = bn / tot;
+    m2 = m2 + (double)p[2] + d * d * n * f;
+    mean = mean + d * f;
+    n = tot;
+  }
+  stats[c] = (float)mean;
+  stats[C + c] = (float)m2;
+}
+
+__global__ void bn_finalize_k(const float* __restrict__ gathered, int world, double cnt, int C,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float eps, float momentum, float* running_mean, float* running_var,
+                              float* save_mean, float* save_invstd, float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0, mean = 0, m2 = 0;
+  for (int r = 0; r < world; ++r) {
+    double bm = gathered[(long)r * 2 * C + c], bm2 = gathered[(long)r * 2 * C + C + c];
+    double d = bm - mean, tot = n + cnt, f = cnt / tot;
+    m2 = m2 + bm2 + d * d * n * f;
+    mean = mean + d * f;
+    n = tot;
+  }
+  double var = m2 / n;  // biased (paddle BatchNorm training)
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)invstd;
+  float sc = (float)(g * invstd);
+  scale[c] = sc;
+  shift[c] = (float)(b - mean * g * invstd);
+  if (running_mean) running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)mean;
+  if (running_var) running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)var;
+}
+
+__global__ void bn_eval_coeffs_k(int C, const float* gamma, const float* beta, const float* rm,
+                                 const float* rv, float eps, float* save_mean, float* save_invstd,
+                                 float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(rv[c] + eps);
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  save_mean[c] = rm[c];
+  save_invstd[c] = invstd;
+  scale[c] = g * invstd;
+  shift[c] = b - rm[c] * g * invstd;
+}
+
+// ---------------------------------------------------------------------------
+// fused affine + residual + PReLU, forward
+// ---------------------------------------------------------------------------
+template <int V>
+struct VecT;
+template <>
+struct VecT<1> { using T = float; };
+template <>
+struct VecT<4> { using T = float4; };
+
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  } else {
+    o[0] = *p;
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    *p = o[0];
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kThreads)
+affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                 const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
+                 const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C) {
+  const int cv = C / V;
+  const long total = voxels * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / cv;
+    const int c = (int)(i - v * cv) * V;
+    float xv[V], o[V];
+    ldv<V>(x + v * ldx + c, xv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float u = xv[j];
+      if (scale) u = fmaf(u, scale[c + j], shift[c + j]);
+      o[j] = u;
+    }
+    if (res) {
+      if (cres == C) {
+        float rv[V];
+        ldv<V>(res + v * ldr + c, rv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] += rv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] += res[v * ldr + (c + j) % cres];
+      }
+    }
+    if (alpha) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = o[j] > 0.f ? o[j] : alpha[c + j] * o[j];
+    }
+    stv<V>(out + v * ldo + c, o);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 1: per-channel sums
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                        const float* __restrict__ shift, const float* __restrict__ res, int ldr,
+                        int cres, const float* __restrict__ alpha, const float* __restrict__ mean,
+                        const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
+                        long voxels, int C, int CB, int VPB, float* __restrict__ partial /*[cblocks][nb][3][CB]*/) {
+  __shared__ float sh[3][kThreads];
+  const int t = threadIdx.x;
+  const int cl = t % CB, vl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  float s_du = 0.f, s_dux = 0.f, s_da = 0.f;
+  if (c < C) {
+    const float sc = scale ? scale[c] : 1.f, sf = scale ? shift[c] : 0.f;
+    const float al = alpha ? alpha[c] : 1.f;
+    const float mu = mean ? mean[c] : 0.f, is = mean ? invstd[c] : 0.f;
+    const int cr = res ? (cres == C ? c : c % cres) : 0;
+    for (long v = v0 + vl; v < v1; v += VPB) {
+      float xv = x[v * ldx + c];
+      float u = fmaf(xv, sc, sf);
+      if (res) u += res[v * ldr + cr];
+      float d = dout[v * ldd + c];
+      float du = d;
+      if (alpha && !(u > 0.f)) {
+        du = al * d;
+        s_da = fmaf(d, u, s_da);
+      }
+      s_du += du;
+      s_dux = fmaf(du, (xv - mu) * is, s_dux);
+    }
+  }
+  sh[0][t] = s_du;
+  sh[1][t] = s_dux;
+  sh[2][t] = s_da;
+  __syncthreads();
+  for (int s = VPB >> 1; s > 0; s >>= 1) {
+    if (vl < s) {
+      sh[0][t] += sh[0][t + s * CB];
+      sh[1][t] += sh[1][t + s * CB];
+      sh[2][t] += sh[2][t + s * CB];
+    }
+    __syncthreads();
+  }
+  if (vl == 0) {
+    float* p = partial + ((long)blockIdx.y * nb + blockIdx.x) * 3 * CB;
+    p[cl] = sh[0][t];
+    p[CB + cl] = sh[1][t];
+    p[2 * CB + cl] = sh[2][t];
+  }
+}
+
+__global__ void sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq,
+                             float* __restrict__ sums /*[nq][C]*/, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * C) return;
+  int q = i / C, c = i % C;
+  int cb = c / CB, cl = c % CB;
+  double s = 0;
+  for (int b = 0; b < nb; ++b) s += partial[(((long)cb * nb + b) * nq + q) * CB + cl];
+  sums[i] = accumulate ? sums[i] + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 2
+// ---------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                       const float* __restrict__ shift, const float* __restrict__ res, int ldr,
+                       int cres, const float* __restrict__ alpha, const float* __restrict__ mean,
+                       const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
+                       const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx,
+                       int lddx, float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C) {
+  const int cv = C / V;
+  const long total = voxels * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / cv;
+    const int c = (int)(i - v * cv) * V;
+    float xv[V], dv[V], du[V], o[V];
+    ldv<V>(x + v * ldx + c, xv);
+    ldv<V>(dout + v * ldd + c, dv);
+    float rv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) rv[j] = 0.f;
+    if (res && alpha) {
+      if (cres == C) {
+        ldv<V>(res + v * ldr + c, rv);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) rv[j] = res[v * ldr + (c + j) % cres];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float d = dv[j];
+      if (alpha) {
+        float u = xv[j];
+        if (scale) u = fmaf(u, scale[c + j], shift[c + j]);
+        u += rv[j];
+        if (!(u > 0.f)) d *= alpha[c + j];
+      }
+      du[j] = d;
+      if (bn_mode == 1) {
+        float xh = (xv[j] - mean[c + j]) * invstd[c + j];
+        o[j] = scale[c + j] * (d - sums[c + j] * invM - xh * sums[C + c + j] * invM);
+      } else if (bn_mode == 2) {
+        o[j] = scale[c + j] * d;
+      } else {
+        o[j] = d;
+      }
+    }
+    if (dx) stv<V>(dx + v * lddx + c, o);
+    if (dres) {
+      if (dres_acc) {
+        float a[V];
+        ldv<V>(dres + v * lddr + c, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) du[j] += a[j];
+      }
+      stv<V>(dres + v * lddr + c, du);
+    }
+  }
+}
+
+__global__ void param_grads_k(int C, const float* sums, float* dgamma, float* dbeta, float* dalpha, int acc) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (acc ? dbeta[c] : 0.f) + sums[c];
+  if (dgamma) dgamma[c] = (acc ? dgamma[c] : 0.f) + sums[C + c];
+  if (dalpha) dalpha[c] = (acc ? dalpha[c] : 0.f) + sums[2 * C + c];
+}
+
+// ---------------------------------------------------------------------------
+// copy with per-(n,c) scale
+// ---------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(kThreads)
+copy_scale_k(const float* __restrict__ src, int lds_, const float* __restrict__ mask, float* __restrict__ dst,
+             int ldd, long voxels, long vox_per_n, int C, int acc) {
+  const int cv = C / V;
+  const long total = voxels * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / cv;
+    const int c = (int)(i - v * cv) * V;
+    float s[V];
+    ldv<V>(src + v * lds_ + c, s);
+    if (mask) {
+      const long n = v / vox_per_n;
+#pragma unroll
+      for (int j = 0; j < V; ++j) s[j] *= mask[n * C + c + j];
+    }
+    if (acc) {
+      float a[V];
+      ldv<V>(dst + v * ldd + c, a);
+#pragma unroll
+      for (int j = 0; j < V; ++j) s[j] += a[j];
+    }
+    stv<V>(dst + v * ldd + c, s);
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+channel_sum_partial_k(const float* __restrict__ x, int ldx, long voxels, int C, int CB, int VPB,
+                      float* __restrict__ partial /*[cblocks][nb][1][CB]*/) {
+  __shared__ float sh[kThreads];
+  const int t = threadIdx.x;
+  const int cl = t % CB, vl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  float s = 0.f;
+  if (c < C)
+    for (long v = v0 + vl; v < v1; v += VPB) s += x[v * ldx + c];
+  sh[t] = s;
+  __syncthreads();
+  for (int k = VPB >> 1; k > 0; k >>= 1) {
+    if (vl < k) sh[t] += sh[t + k * CB];
+    __syncthreads();
+  }
+  if (vl == 0) partial[((long)blockIdx.y * nb + blockIdx.x) * CB + cl] = sh[t];
+}
+
+// splitmix64-based counter RNG for Dropout3D masks
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_mask_k(uint64_t seed, uint64_t step, uint32_t site, int count, float p, float* mask) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint64_t h = splitmix64(seed ^ splitmix64(step * 0x100000001B3ull + site));
+  h = splitmix64(h + (uint64_t)i);
+  float u = (float)(h >> 40) * (1.0f / 16777216.0f);  // [0,1)
+  mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+__global__ void argmax_k(const float* __restrict__ x, int ld, long voxels, int C, int32_t* __restrict__ out) {
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (long)gridDim.x * blockDim.x) {
+    const float* p = x + v * ld;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      float q = p[c];
+      if (q > best) {  // first maximum wins (numpy/paddle argmax)
+        best = q;
+        bi = c;
+      }
+    }
+    out[v] = bi;
+  }
+}
+
+// NCDHW <-> NDHWC through a 32x32 LDS tile (voxel x channel)
+__global__ void __launch_bounds__(256)
+ncdhw_to_ndhwc_k(const float* __restrict__ src, float* __restrict__ dst, int ld, long V, int C) {
+  __shared__ float tile[32][33];
+  const long n = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // ty in [0,8)
+  for (int r = ty; r < 32; r += 8) {  // r = channel, tx = voxel
+    int c = c0 + r;
+    long v = v0 + tx;
+    tile[r][tx] = (c < C && v < V) ? src[(n * C + c) * V + v] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {  // r = voxel, tx = channel
+    long v = v0 + r;
+    int c = c0 + tx;
+    if (c < C && v < V) dst[(n * V + v) * ld + c] = tile[tx][r];
+  }
+}
+__global__ void __launch_bounds__(256)
+ndhwc_to_ncdhw_k(const float* __restrict__ src, int ld, float* __restrict__ dst, long V, int C) {
+  __shared__ float tile[32][33];
+  const long n = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+  for (int r = ty; r < 32; r += 8) {  // r = voxel, tx = channel
+    long v = v0 + r;
+    int c = c0 + tx;
+    tile[r][tx] = (c < C && v < V) ? src[(n * V + v) * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {  // r = channel, tx = voxel
+    int c = c0 + r;
+    long v = v0 + tx;
+    if (c < C && v < V) dst[(n * C + c) * V + v] = tile[tx][r];
+  }
+}
+
+inline bool vec4_ok(const msk_tensor& t) {
+  return t.p == nullptr || ((t.c % 4 == 0) && (t.ld % 4 == 0) && (((uintptr_t)t.p) % 16 == 0));
+}
+inline int ew_blocks(long total, int num_cu) {
+  long b = (total + kThreads - 1) / kThreads;
+  long cap = (long)num_cu * 16;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+inline bool same_shape(const msk_tensor& a, const msk_tensor& b) {
+  return a.n == b.n && a.d == b.d && a.h == b.h && a.w == b.w && a.c == b.c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msk_ncdhw_to_ndhwc(msk_ctx* ctx, const float* src, msk_tensor dst) {
+  long V = (long)dst.d * dst.h * dst.w;
+  msk_launch_scope ls(ctx, "layout_ncdhw_to_ndhwc");
+  dim3 grid(msk_cdiv(V, 32), msk_cdiv(dst.c, 32), dst.n);
+  hipLaunchKernelGGL(ncdhw_to_ndhwc_k, grid, dim3(256), 0, ctx->stream, src, (float*)dst.p, dst.ld, V, dst.c);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
+  long V = (long)src.d * src.h * src.w;
+  msk_launch_scope ls(ctx, "layout_ndhwc_to_ncdhw");
+  dim3 grid(msk_cdiv(V, 32), msk_cdiv(src.c, 32), src.n);
+  hipLaunchKernelGGL(ndhwc_to_ncdhw_k, grid, dim3(256), 0, ctx->stream, (const float*)src.p, src.ld, dst, V, src.c);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
+  const long voxels = msk_voxels(x);
+  MSK_REQUIRE(ctx, voxels > 0 && x.c > 0, "empty tensor");
+  ChanGeom g = chan_geom(x.c);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  size_t bytes = (size_t)g.cblocks * nb * g.CB * 3 * sizeof(float);
+  float* partial = (float*)msk_workspace(ctx, bytes);
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "bn_stats_partial");
+    hipLaunchKernelGGL(bn_stats_partial, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
+                       (const float*)x.p, voxels, x.c, x.ld, g.CB, g.VPB, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "bn_stats_merge");
+    hipLaunchKernelGGL(bn_stats_merge, dim3(msk_cdiv(x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+int msk_bn_finalize(msk_ctx* ctx, const float* gathered, int world, double count_per_rank, int C,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                    float* scale, float* shift) {
+  msk_launch_scope ls(ctx, "bn_finalize");
+  hipLaunchKernelGGL(bn_finalize_k, dim3(msk_cdiv(C, 64)), dim3(64), 0, ctx->stream, gathered, world,
+                     count_per_rank, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* save_mean, float* save_invstd,
+                       float* scale, float* shift) {
+  msk_launch_scope ls(ctx, "bn_eval_coeffs");
+  hipLaunchKernelGGL(bn_eval_coeffs_k, dim3(msk_cdiv(C, 64)), dim3(64), 0, ctx->stream, C, gamma, beta,
+                     running_mean, running_var, eps, save_mean, save_invstd, scale, shift);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                       const float* alpha, msk_tensor out) {
+  MSK_REQUIRE(ctx, same_shape(x, out), "x/out shape mismatch");
+  MSK_REQUIRE(ctx, (scale == nullptr) == (shift == nullptr), "scale and shift go together");
+  if (res.p) MSK_REQUIRE(ctx, res.c > 0 && (res.c == x.c || x.c % res.c == 0), "residual channels must tile");
+  const long voxels = msk_voxels(x);
+  const bool v4 = vec4_ok(x) && vec4_ok(out) && (res.p == nullptr || res.c != x.c || vec4_ok(res));
+  msk_launch_scope ls(ctx, "affine_act_fwd");
+  if (v4) {
+    hipLaunchKernelGGL(affine_act_fwd_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
+                       alpha, (float*)out.p, out.ld, voxels, x.c);
+  } else {
+    hipLaunchKernelGGL(affine_act_fwd_k<1>, dim3(ew_blocks(voxels * x.c, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
+                       alpha, (float*)out.p, out.ld, voxels, x.c);
+  }
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                              const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
+                              float* sums) {
+  MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
+  const long voxels = msk_voxels(x);
+  ChanGeom g = chan_geom(x.c);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  size_t bytes = (size_t)g.cblocks * nb * 3 * g.CB * sizeof(float);
+  float* partial = (float*)msk_workspace(ctx, bytes);
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "affine_act_bwd_reduce");
+    hipLaunchKernelGGL(affine_act_bwd_reduce_k, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
+                       (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean,
+                       invstd, (const float*)dout.p, dout.ld, voxels, x.c, g.CB, g.VPB, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "sums_merge");
+    hipLaunchKernelGGL(sums_merge_k, dim3(msk_cdiv(3 * x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c,
+                       g.CB, 3, sums, 0);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                             const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                             msk_tensor dout, const float* sums_total, double M_total, int bn_mode,
+                             msk_tensor dx, msk_tensor dres, int dres_acc) {
+  (void)gamma;
+  MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
+  if (dx.p) MSK_REQUIRE(ctx, same_shape(x, dx), "x/dx shape mismatch");
+  if (dres.p) MSK_REQUIRE(ctx, same_shape(x, dres), "dres must have the full channel count");
+  if (bn_mode == 1) MSK_REQUIRE(ctx, sums_total && mean && invstd && scale, "training BN backward needs sums/mean/invstd/scale");
+  if (bn_mode == 2) MSK_REQUIRE(ctx, scale != nullptr, "eval BN backward needs scale");
+  const long voxels = msk_voxels(x);
+  const bool v4 = vec4_ok(x) && vec4_ok(dout) && vec4_ok(dx) && vec4_ok(dres) &&
+                  (res.p == nullptr || res.c != x.c || vec4_ok(res));
+  const float invM = (float)(1.0 / M_total);
+  msk_launch_scope ls(ctx, "affine_act_bwd_apply");
+  if (v4) {
+    hipLaunchKernelGGL(affine_act_bwd_apply_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads),
+                       0, ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
+                       alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
+                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c);
+  } else {
+    hipLaunchKernelGGL(affine_act_bwd_apply_k<1>, dim3(ew_blocks(voxels * x.c, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
+                       alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
+                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c);
+  }
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma, float* dbeta, float* dalpha,
+                               int accumulate) {
+  msk_launch_scope ls(ctx, "affine_act_param_grads");
+  hipLaunchKernelGGL(param_grads_k, dim3(msk_cdiv(C, 64)), dim3(64), 0, ctx->stream, C, sums, dgamma, dbeta,
+                     dalpha, accumulate);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_copy_scale(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate) {
+  MSK_REQUIRE(ctx, same_shape(src, dst), "src/dst shape mismatch");
+  const long voxels = msk_voxels(src);
+  const long vpn = (long)src.d * src.h * src.w;
+  msk_launch_scope ls(ctx, "copy_scale");
+  if (vec4_ok(src) && vec4_ok(dst)) {
+    hipLaunchKernelGGL(copy_scale_k<4>, dim3(ew_blocks(voxels * src.c / 4, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)src.p, src.ld, mask, (float*)dst.p, dst.ld, voxels, vpn, src.c,
+                       accumulate);
+  } else {
+    hipLaunchKernelGGL(copy_scale_k<1>, dim3(ew_blocks(voxels * src.c, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)src.p, src.ld, mask, (float*)dst.p, dst.ld, voxels, vpn, src.c,
+                       accumulate);
+  }
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_dropout_mask(msk_ctx* ctx, uint64_t seed, uint64_t step, uint32_t site, int count, float p, float* mask) {
+  MSK_REQUIRE(ctx, p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
+  msk_launch_scope ls(ctx, "dropout_mask");
+  hipLaunchKernelGGL(dropout_mask_k, dim3(msk_cdiv(count, 256)), dim3(256), 0, ctx->stream, seed, step, site,
+                     count, p, mask);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
+  const long voxels = msk_voxels(x);
+  ChanGeom g = chan_geom(x.c);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  float* partial = (float*)msk_workspace(ctx, (size_t)g.cblocks * nb * g.CB * sizeof(float));
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "channel_sum_partial");
+    hipLaunchKernelGGL(channel_sum_partial_k, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
+                       (const float*)x.p, x.ld, voxels, x.c, g.CB, g.VPB, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "sums_merge");
+    hipLaunchKernelGGL(sums_merge_k, dim3(msk_cdiv(x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
+                       out, accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+int msk_argmax_c(msk_ctx* ctx, msk_tensor x, int32_t* out) {
+  const long voxels = msk_voxels(x);
+  msk_launch_scope ls(ctx, "argmax_c");
+  hipLaunchKernelGGL(argmax_k, dim3(ew_blocks(voxels, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
+                     (const float*)x.p, x.ld, voxels, x.c, out);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"

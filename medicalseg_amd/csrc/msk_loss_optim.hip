@@ -1,0 +1,289 @@
+// Fused CrossEntropy + Dice loss (forward statistics, backward) and the fused
+// SGD-momentum-L2 update, for gfx950.
+//
+// Thread mapping for the loss: CB = pow2ceil(C) adjacent lanes own one voxel
+// (lane = class), so the softmax max/sum are wavefront shuffles over CB lanes and the
+// per-class Dice sums are per-thread scalars.  Logits are read once per pass.
+#include "msk_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+template <typename F>
+__device__ __forceinline__ float group_reduce(float v, int CB, F op) {
+  for (int o = CB >> 1; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// mode 0: class-weight statistics (sum of softmax mass per class)
+// mode 1: loss statistics {I, S, T, ce_num, ce_den} per class
+template <int MODE>
+__global__ void __launch_bounds__(kThreads)
+loss_stats_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels,
+             const float* __restrict__ weights, int ignore_index, long voxels, int C, int CB,
+             float* __restrict__ partial /*[nb][NQ][CB]*/) {
+  constexpr int NQ = MODE == 0 ? 1 : 5;
+  __shared__ float sh[NQ][kThreads];
+  const int t = threadIdx.x;
+  const int c = t % CB, vl = t / CB, VPB = kThreads / CB;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  float acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+  const float wc = (MODE == 1 && c < C) ? weights[c] : 0.f;
+  // all CB lanes of a voxel group iterate together (trip count depends on vl only)
+  for (long v = v0 + vl; v < v1; v += VPB) {
+    const bool live = c < C;
+    const float zc = live ? z[v * ld + c] : 0.f;
+    const float zs = live ? zc + 1e-8f : -INFINITY;  // cross_entropy_loss.py:79 logit + EPS
+    const float m = group_reduce(zs, CB, [](float a, float b) { return fmaxf(a, b); });
+    const float e = live ? expf(zs - m) : 0.f;
+    const float se = group_reduce(e, CB, [](float a, float b) { return a + b; });
+    if constexpr (MODE == 0) {
+      acc[0] += e / se;
+    } else {
+      const int y = labels[v];
+      const float s = 1.f / (1.f + expf(-zc));
+      const bool hit = live && (y == c);
+      if (live) {
+        acc[1] = fmaf(s, s, acc[1]);
+        if (hit) {
+          acc[0] += s;
+          acc[2] += 1.f;
+          if (y != ignore_index) {
+            const float logp = zs - m - logf(se);
+            acc[3] = fmaf(wc, -logp, acc[3]);
+            acc[4] += wc;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) sh[q][t] = acc[q];
+  __syncthreads();
+  for (int s = VPB >> 1; s > 0; s >>= 1) {
+    if (vl < s) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) sh[q][t] += sh[q][t + s * CB];
+    }
+    __syncthreads();
+  }
+  if (vl == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) partial[((long)blockIdx.x * NQ + q) * CB + c] = sh[q][t];
+  }
+}
+
+__global__ void class_weights_final_k(const float* __restrict__ partial, int nb, int C, int CB, double voxels,
+                                      float* __restrict__ weights) {
+  int c = threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int b = 0; b < nb; ++b) s += partial[(long)b * CB + c];
+  weights[c] = (float)((voxels - s) / s);  // sum(1-p)/sum(p)
+}
+
+__global__ void loss_final_k(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ out,
+                             double* __restrict__ stats /*[3C+2]*/) {
+  __shared__ double sper[64], snum[64], sden[64];
+  int c = threadIdx.x;
+  double q[5] = {0, 0, 0, 0, 0};
+  if (c < C) {
+    for (int b = 0; b < nb; ++b)
+      for (int k = 0; k < 5; ++k) q[k] += partial[((long)b * 5 + k) * CB + c];
+    stats[c] = q[0];
+    stats[C + c] = q[1];
+    stats[2 * C + c] = q[2];
+    double den = q[1] + q[2];
+    double per = 2.0 * q[0] / (den > 1e-6 ? den : 1e-6);  // dice_loss.py:74 clip(min=1e-6)
+    out[2 + c] = (float)per;
+    sper[c] = per;
+    snum[c] = q[3];
+    sden[c] = q[4];
+  }
+  __syncthreads();
+  if (c == 0) {
+    double sp = 0, sn = 0, sd = 0;
+    for (int k = 0; k < C; ++k) {
+      sp += sper[k];
+      sn += snum[k];
+      sd += sden[k];
+    }
+    stats[3 * C] = sn;
+    stats[3 * C + 1] = sd;
+    out[0] = (float)(sd != 0 ? sn / sd : 0.0);
+    out[1] = (float)(1.0 - sp / C);
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels,
+           const float* __restrict__ weights, int ignore_index, const double* __restrict__ stats,
+           float coef_ce, float coef_dice, float* __restrict__ dz, int lddz, long voxels, int C, int CB) {
+  const int t = threadIdx.x;
+  const int c = t % CB, vl = t / CB, VPB = kThreads / CB;
+  const bool live = c < C;
+  // per-class dice constants
+  float a_t = 0.f, a_s = 0.f;
+  if (live) {
+    double I = stats[c], den = stats[C + c] + stats[2 * C + c];
+    double dc = den > 1e-6 ? den : 1e-6;
+    a_t = (float)(2.0 / dc);                                   // d per / d s  (t term)
+    a_s = (float)(den > 1e-6 ? 4.0 * I / (dc * dc) : 0.0);     // clip passes gradient only above min
+  }
+  const double cden = stats[3 * C + 1];
+  const float inv_den = cden != 0 ? (float)(1.0 / cden) : 0.f;
+  const float kd = -coef_dice / (float)C;
+  const long nvg = (voxels + VPB - 1) / VPB;  // voxel groups
+  for (long g = blockIdx.x; g < nvg; g += gridDim.x) {
+    const long v = g * VPB + vl;
+    const bool ok = v < voxels;
+    const float zc = (live && ok) ? z[v * ld + c] : 0.f;
+    const float zs = (live && ok) ? zc + 1e-8f : -INFINITY;
+    const float m = group_reduce(zs, CB, [](float a, float b) { return fmaxf(a, b); });
+    const float e = (live && ok) ? expf(zs - m) : 0.f;
+    const float se = group_reduce(e, CB, [](float a, float b) { return a + b; });
+    if (live && ok) {
+      const int y = labels[v];
+      const float p = e / se;
+      const float tt = (y == c) ? 1.f : 0.f;
+      float g_ce = 0.f;
+      if (y != ignore_index && y >= 0 && y < C) g_ce = (p - tt) * weights[y] * inv_den;
+      const float s = 1.f / (1.f + expf(-zc));
+      const float g_d = kd * (a_t * tt - a_s * s) * s * (1.f - s);
+      dz[v * lddz + c] = coef_ce * g_ce + g_d;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+sgd_momentum_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel, size_t n4,
+               size_t n, float lr, float mu, float wd, float gs) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 vv = reinterpret_cast<float4*>(vel)[i];
+    float t;
+    t = fmaf(wd, pp.x, gg.x * gs); vv.x = fmaf(mu, vv.x, t); pp.x = fmaf(-lr, vv.x, pp.x);
+    t = fmaf(wd, pp.y, gg.y * gs); vv.y = fmaf(mu, vv.y, t); pp.y = fmaf(-lr, vv.y, pp.y);
+    t = fmaf(wd, pp.z, gg.z * gs); vv.z = fmaf(mu, vv.z, t); pp.z = fmaf(-lr, vv.z, pp.z);
+    t = fmaf(wd, pp.w, gg.w * gs); vv.w = fmaf(mu, vv.w, t); pp.w = fmaf(-lr, vv.w, pp.w);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(vel)[i] = vv;
+  }
+  // tail
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float t = fmaf(wd, p[i], g[i] * gs);
+    float v = fmaf(mu, vel[i], t);
+    vel[i] = v;
+    p[i] = fmaf(-lr, v, p[i]);
+  }
+}
+
+inline int stat_blocks(long voxels, int VPB, int num_cu) {
+  long want = (voxels + (long)VPB * 32 - 1) / ((long)VPB * 32);
+  long cap = (long)num_cu * 8;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msk_class_weights(msk_ctx* ctx, msk_tensor logits, float* weights) {
+  const int C = logits.c;
+  MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
+  const int CB = pow2ceil(C);
+  const long voxels = msk_voxels(logits);
+  const int nb = stat_blocks(voxels, kThreads / CB, ctx->num_cu);
+  float* partial = (float*)msk_workspace(ctx, (size_t)nb * CB * sizeof(float));
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "loss_class_weights");
+    hipLaunchKernelGGL(loss_stats_k<0>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
+                       logits.ld, (const int32_t*)nullptr, (const float*)nullptr, 0, voxels, C, CB, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "loss_class_weights_final");
+    hipLaunchKernelGGL(class_weights_final_k, dim3(1), dim3(64), 0, ctx->stream, partial, nb, C, CB,
+                       (double)voxels, weights);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+int msk_loss_fwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, float* out, double* stats) {
+  const int C = logits.c;
+  MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
+  const int CB = pow2ceil(C);
+  const long voxels = msk_voxels(logits);
+  const int nb = stat_blocks(voxels, kThreads / CB, ctx->num_cu);
+  float* partial = (float*)msk_workspace(ctx, (size_t)nb * 5 * CB * sizeof(float));
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "loss_fwd_stats");
+    hipLaunchKernelGGL(loss_stats_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
+                       logits.ld, labels, weights, ignore_index, voxels, C, CB, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "loss_fwd_final");
+    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(64), 0, ctx->stream, partial, nb, C, CB, out, stats);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, const double* stats, float coef_ce, float coef_dice, msk_tensor dlogits) {
+  const int C = logits.c;
+  MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
+  MSK_REQUIRE(ctx, dlogits.c == C && msk_voxels(dlogits) == msk_voxels(logits), "dlogits shape mismatch");
+  const int CB = pow2ceil(C);
+  const long voxels = msk_voxels(logits);
+  const int VPB = kThreads / CB;
+  long nvg = (voxels + VPB - 1) / VPB;
+  long blocks = nvg < (long)ctx->num_cu * 16 ? nvg : (long)ctx->num_cu * 16;
+  msk_launch_scope ls(ctx, "loss_bwd");
+  hipLaunchKernelGGL(loss_bwd_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
+                     logits.ld, labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p,
+                     dlogits.ld, voxels, C, CB);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
+                     float momentum, float weight_decay, float grad_scale) {
+  if (count == 0) return 0;
+  MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
+              "arenas must be 16-byte aligned");
+  size_t n4 = count / 4;
+  long blocks = (long)((n4 + kThreads - 1) / kThreads);
+  long cap = (long)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  msk_launch_scope ls(ctx, "sgd_momentum");
+  hipLaunchKernelGGL(sgd_momentum_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, velocity, n4,
+                     count, lr, momentum, weight_decay, grad_scale);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"

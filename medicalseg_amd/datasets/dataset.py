@@ -1,0 +1,154 @@
+"""Datasets with the reference's contract (medicalseg/datasets/dataset.py:29-125):
+``__getitem__ -> (im float32 [1,D,H,W], label int32 [D,H,W], path)``; attributes
+num_classes, ignore_index, transforms.transforms, dataset_json_path, mode.
+
+``SyntheticCT`` generates the benchmark volumes of SURVEY.md section 8 d1 (no dataset can be
+downloaded here)."""
+import os
+
+import numpy as np
+
+from ..cvlibs import manager
+from ..transforms import Compose
+
+
+@manager.DATASETS.add_component
+class MedicalDataset:
+    def __init__(self, dataset_root, result_dir, transforms, num_classes, mode='train', ignore_index=255,
+                 dataset_json_path=""):
+        self.dataset_root = dataset_root
+        self.result_dir = result_dir
+        self.transforms = Compose(transforms)
+        self.file_list = list()
+        self.mode = mode.lower()
+        self.num_classes = num_classes
+        self.ignore_index = ignore_index
+        self.dataset_json_path = dataset_json_path
+        if self.dataset_root is None:
+            raise ValueError("The dataset is not Found or the folder structure is nonconfoumance.")
+        if mode == 'train':
+            file_path = os.path.join(self.dataset_root, 'train_list.txt')
+        elif mode == 'val':
+            file_path = os.path.join(self.dataset_root, 'val_list.txt')
+        elif mode == 'test':
+            file_path = os.path.join(self.dataset_root, 'test_list.txt')
+        else:
+            raise ValueError("`mode` should be 'train', 'val' or 'test', but got {}.".format(mode))
+        with open(file_path, 'r') as f:
+            for line in f:
+                items = line.strip().split()
+                if len(items) != 2:
+                    raise Exception("File list format incorrect! It should be image_name label_name\\n")
+                self.file_list.append([os.path.join(self.dataset_root, items[0]),
+                                       os.path.join(self.dataset_root, items[1])])
+        if mode == 'train':
+            self.file_list = self.file_list * 10  # reference dataset.py:110-111
+
+    def __getitem__(self, idx):
+        image_path, label_path = self.file_list[idx]
+        im, label = self.transforms(im=image_path, label=label_path)
+        return im.astype("float32"), label.astype("int32"), self.file_list[idx][0]
+
+    def save_transformed(self):
+        pass
+
+    def __len__(self):
+        return len(self.file_list)
+
+
+@manager.DATASETS.add_component
+class LungCoronavirus(MedicalDataset):
+    """COVID-19 CT scans, lung + infection masks (reference datasets/lung_coronavirus.py)."""
+
+
+@manager.DATASETS.add_component
+class MRISpineSeg(MedicalDataset):
+    """MRI spine segmentation, 20 classes (reference datasets/mri_spine_seg.py)."""
+
+
+@manager.DATASETS.add_component
+class SyntheticCT:
+    """Deterministic synthetic CT-like volumes: raw HU = clip(N(-600, 450), -2000, 2000) ->
+    HUnorm -> /max; label = background 0 plus two ellipsoids (classes 1, 2, ... cycling)."""
+
+    def __init__(self, num_samples=8, shape=(128, 128, 128), num_classes=3, seed=1234, mode='train',
+                 ignore_index=255, transforms=None, dataset_root=None, result_dir=None, dataset_json_path=""):
+        self.num_samples, self.shape = int(num_samples), tuple(int(s) for s in shape)
+        self.num_classes, self.seed, self.mode = num_classes, seed, mode
+        self.ignore_index = ignore_index
+        self.transforms = Compose(transforms or [])
+        self.dataset_json_path = dataset_json_path
+        self.file_list = [["synthetic_{}".format(i), ""] for i in range(self.num_samples)]
+
+    def __len__(self):
+        return self.num_samples
+
+    def make(self, idx):
+        rng = np.random.default_rng(self.seed + idx)
+        D, H, W = self.shape
+        hu = np.clip(rng.standard_normal(self.shape, dtype=np.float32) * 450.0 - 600.0, -2000, 2000)
+        zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+        label = np.zeros(self.shape, dtype=np.int32)
+        for c in range(1, max(2, min(self.num_classes, 3))):
+            cen = rng.uniform(0.3, 0.7, 3) * np.array(self.shape)
+            rad = rng.uniform(0.12, 0.25, 3) * np.array(self.shape)
+            m = ((zz - cen[0]) / rad[0]) ** 2 + ((yy - cen[1]) / rad[1]) ** 2 + ((xx - cen[2]) / rad[2]) ** 2 <= 1
+            label[m] = c
+            hu[m] += 300.0 * c
+        im = (hu + 1200.0) / (1800.0 / 255.0)
+        np.clip(im, 0, 255, out=im)
+        return im.astype(np.float32), label
+
+    def __getitem__(self, idx):
+        im, label = self.make(idx)
+        im, label = self.transforms(im, label)
+        return im.astype("float32"), label.astype("int32"), self.file_list[idx][0]
+
+
+class DataLoader:
+    """Minimal host loader: yields [images NCDHW float32, labels NDHW int32, paths] per batch
+    for this rank's shard (replaces paddle.io.DataLoader + DistributedBatchSampler,
+    core/train.py:87-95).  A one-batch-ahead prefetch thread hides host transforms."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, drop_last=False, num_workers=0, seed=0):
+        from ..parallel import ParallelEnv
+        env = ParallelEnv()
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        self.rank, self.world, self.seed = env.rank, env.nranks, seed
+        self.epoch = 0
+        self.num_workers = num_workers
+
+    def _batches(self):
+        from ..parallel import shard_indices
+        return shard_indices(len(self.dataset), self.batch_size, self.rank, self.world, self.shuffle, self.epoch,
+                             self.seed, self.drop_last)
+
+    def __len__(self):
+        return len(self._batches())
+
+    def _load(self, idxs):
+        items = [self.dataset[i] for i in idxs]
+        return [np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), [it[2] for it in items]]
+
+    def __iter__(self):
+        batches = self._batches()
+        self.epoch += 1
+        if self.num_workers <= 0:
+            for b in batches:
+                yield self._load(b)
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=2)
+
+        def work():
+            for b in batches:
+                q.put(self._load(b))
+            q.put(None)
+
+        threading.Thread(target=work, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            yield item

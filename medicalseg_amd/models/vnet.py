@@ -1,0 +1,302 @@
+"""V-Net on MI355X -- same classes, constructor arguments, attribute names (hence
+state-dict keys) and forward contract as the reference's medicalseg/models/vnet.py
+(:32-267), executed by fused HIP kernels in NDHWC.
+
+forward(x[N,C,D,H,W]) -> [logits]; the backward pass is explicit (VNet.backward) and is
+entered from the loss (``loss.backward()``, core/train.py:139)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import nn
+from ..cvlibs import manager
+from ..device import Tensor, get_device, to_tensor
+from ..nn import AddAct, ConvBNAct, copy_scale
+
+
+class LUConv(nn.Layer):
+    """conv5^3(p=2) -> BN -> PReLU (reference vnet.py:32-43)."""
+
+    def __init__(self, nchan, elu):
+        super(LUConv, self).__init__()
+        self.relu1 = nn.ELU() if elu else nn.PReLU(nchan)
+        self.conv1 = nn.Conv3D(nchan, nchan, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3D(nchan)
+        self._unit = ConvBNAct(self.conv1, self.bn1, self.relu1)
+
+    def forward(self, x):
+        return self._unit.forward(x)
+
+    def backward(self, dout):
+        self._unit.backward(dout)
+
+
+def _make_nConv(nchan, depth, elu):
+    return nn.Sequential(*[LUConv(nchan, elu) for _ in range(depth)])
+
+
+class InputTransition(nn.Layer):
+    """conv5^3(in->16) -> BN -> + tile(x) -> PReLU (reference vnet.py:57-79)."""
+
+    def __init__(self, in_channels, elu):
+        super(InputTransition, self).__init__()
+        self.num_features = 16
+        self.in_channels = in_channels
+        if self.num_features % in_channels:
+            raise ValueError("in_channels must divide 16 (x.tile in the reference, vnet.py:76-78)")
+        self.conv1 = nn.Conv3D(self.in_channels, self.num_features, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3D(self.num_features)
+        self.relu1 = nn.ELU() if elu else nn.PReLU(self.num_features)
+        self._unit = ConvBNAct(self.conv1, self.bn1, self.relu1)
+
+    def forward(self, x):
+        # the tiled input is the residual: channel c of the sum reads x[..., c % in_channels]
+        return self._unit.forward(x, res=x)
+
+    def backward(self, dout):
+        self._unit.backward(dout, need_dx=False, res_needs_grad=False)
+
+
+class DownTransition(nn.Layer):
+    """reference vnet.py:82-113."""
+
+    def __init__(self, inChans, nConvs, elu, dropout=False, downsample_stride=(2, 2, 2), kernel=(2, 2, 2)):
+        super(DownTransition, self).__init__()
+        outChans = 2 * inChans
+        self.if_dropout = dropout
+        self.down_conv = nn.Conv3D(inChans, outChans, kernel_size=kernel, stride=downsample_stride)
+        self.bn1 = nn.BatchNorm3D(outChans)
+        self.relu1 = nn.ELU() if elu else nn.PReLU(outChans)
+        self.relu2 = nn.ELU() if elu else nn.PReLU(outChans)
+        self.dropout = nn.Dropout3D()
+        self.ops = _make_nConv(outChans, nConvs, elu)
+        self._down = ConvBNAct(self.down_conv, self.bn1, self.relu1)
+        self._join = AddAct(self.relu2)
+
+    def forward(self, x):
+        down = self._down.forward(x)
+        self._mask = self.dropout.make_mask(down) if self.if_dropout else None
+        if self._mask is not None:
+            out = down.empty_like()
+            copy_scale(down, self._mask, out)
+        else:
+            out = down
+        self._dropped = out
+        self._t_down = down
+        for op in self.ops:
+            out = op(out)
+        self._t_ops = out
+        return self._join.forward(out, down)
+
+    def backward(self, dout):
+        down = self._t_down
+        self._join.backward(dout)  # -> ops_out.grad (write), down.grad (write)
+        for op in reversed(list(self.ops)):
+            g = op._unit.out.grad
+            op.backward(g)
+        if self._mask is not None:
+            copy_scale(self._dropped.grad, self._mask, down.grad, accumulate=True)
+        self._down.backward(down.grad)
+
+
+class UpTransition(nn.Layer):
+    """reference vnet.py:116-156."""
+
+    def __init__(self, inChans, outChans, nConvs, elu, dropout=False, dropout2=False,
+                 upsample_stride_size=(2, 2, 2), kernel=(2, 2, 2)):
+        super(UpTransition, self).__init__()
+        self.up_conv = nn.Conv3DTranspose(inChans, outChans // 2, kernel_size=kernel, stride=upsample_stride_size)
+        self.bn1 = nn.BatchNorm3D(outChans // 2)
+        self.relu1 = nn.ELU() if elu else nn.PReLU(outChans // 2)
+        self.relu2 = nn.ELU() if elu else nn.PReLU(outChans)
+        self.if_dropout = dropout
+        self.if_dropout2 = dropout2
+        self.dropout1 = nn.Dropout3D()
+        self.dropout2 = nn.Dropout3D()
+        self.ops = _make_nConv(outChans, nConvs, elu)
+        self.outChans = outChans
+        self._up = ConvBNAct(self.up_conv, self.bn1, self.relu1)
+        self._join = AddAct(self.relu2)
+
+    def forward(self, x, skipx):
+        dev = x.dev
+        self._x, self._skip = x, skipx
+        self._m1 = self.dropout1.make_mask(x) if self.if_dropout else None
+        self._m2 = self.dropout2.make_mask(skipx) if self.if_dropout2 else None
+        xin = x
+        if self._m1 is not None:
+            xin = x.empty_like()
+            copy_scale(x, self._m1, xin)
+        self._xin = xin
+        half = self.outChans // 2
+        od, oh, ow = self.up_conv.out_dims(xin)
+        if (od, oh, ow) != (skipx.d, skipx.h, skipx.w) or skipx.c != self.outChans - half:
+            raise ValueError(f"skip connection shape {skipx.shape} does not match the up-sampled "
+                             f"({x.n}, {half}, {od}, {oh}, {ow})")
+        # concat (vnet.py:152) is two channel-slice writes into one NDHWC buffer
+        xcat = Tensor.empty(dev, x.n, od, oh, ow, self.outChans)
+        self._up.forward(xin, out=xcat.channel_slice(0, half))
+        copy_scale(skipx, self._m2, xcat.channel_slice(half, self.outChans))
+        self._xcat = xcat
+        out = xcat
+        for op in self.ops:
+            out = op(out)
+        return self._join.forward(out, xcat)
+
+    def backward(self, dout):
+        xcat, half = self._xcat, self.outChans // 2
+        self._join.backward(dout)  # -> ops_out.grad, xcat.grad
+        for op in reversed(list(self.ops)):
+            op.backward(op._unit.out.grad)
+        gcat = xcat.grad
+        # skip branch
+        skip = self._skip
+        sg = skip.ensure_grad()
+        copy_scale(gcat.channel_slice(half, self.outChans), self._m2, sg, accumulate=skip.grad_written)
+        skip.grad_written = True
+        # up-conv branch
+        self._up.backward(gcat.channel_slice(0, half))
+        if self._m1 is not None:
+            x = self._x
+            xg = x.ensure_grad()
+            copy_scale(self._xin.grad, self._m1, xg, accumulate=x.grad_written)
+            x.grad_written = True
+
+
+class OutputTransition(nn.Layer):
+    """conv5^3(32->ncls) -> BN -> PReLU -> conv1^3 (reference vnet.py:159-175)."""
+
+    def __init__(self, in_channels, num_classes, elu):
+        super(OutputTransition, self).__init__()
+        self.conv1 = nn.Conv3D(in_channels, num_classes, kernel_size=5, padding=2)
+        self.bn1 = nn.BatchNorm3D(num_classes)
+        self.conv2 = nn.Conv3D(num_classes, num_classes, kernel_size=1)
+        self.relu1 = nn.ELU() if elu else nn.PReLU(num_classes)
+        self._unit = ConvBNAct(self.conv1, self.bn1, self.relu1)
+
+    def forward(self, x):
+        o = self._unit.forward(x)
+        self._o = o
+        return self.conv2.run_forward(o)
+
+    def backward(self, dlogits):
+        self.conv2.run_backward(self._o, dlogits, need_dx=True)
+        self._unit.backward(self._o.grad)
+
+
+@manager.MODELS.add_component
+class VNet(nn.Layer):
+    """Implementation of https://arxiv.org/abs/1606.04797 with the reference's
+    constructor (vnet.py:184-190)."""
+
+    def __init__(self, elu=False, in_channels=1, num_classes=4, pretrained=None,
+                 kernel_size=((2, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2)),
+                 stride_size=((2, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2))):
+        super().__init__()
+        self.best_loss = 1000000
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+
+        self.in_tr = InputTransition(in_channels, elu=elu)
+        self.down_tr32 = DownTransition(16, 1, elu, downsample_stride=stride_size[0], kernel=kernel_size[0])
+        self.down_tr64 = DownTransition(32, 2, elu, downsample_stride=stride_size[1], kernel=kernel_size[1])
+        self.down_tr128 = DownTransition(64, 3, elu, dropout=True, downsample_stride=stride_size[2],
+                                         kernel=kernel_size[2])
+        self.down_tr256 = DownTransition(128, 2, elu, dropout=True, downsample_stride=stride_size[3],
+                                         kernel=kernel_size[3])
+        self.up_tr256 = UpTransition(256, 256, 2, elu, dropout=True, dropout2=True,
+                                     upsample_stride_size=stride_size[3], kernel=kernel_size[3])
+        self.up_tr128 = UpTransition(256, 128, 2, elu, dropout=True, dropout2=True,
+                                     upsample_stride_size=stride_size[2], kernel=kernel_size[2])
+        self.up_tr64 = UpTransition(128, 64, 1, elu, upsample_stride_size=stride_size[1], kernel=kernel_size[1])
+        self.up_tr32 = UpTransition(64, 32, 1, elu, upsample_stride_size=stride_size[0], kernel=kernel_size[0])
+        self.out_tr = OutputTransition(32, num_classes, elu)
+
+        self.pretrained = pretrained
+        self._post_backward_hooks = []
+        self._build()
+        self.init_weight()
+
+    # -- device residency -----------------------------------------------------------
+    def _build(self):
+        dev = get_device()
+        params = []
+        for name, p in self.named_parameters():
+            p.name = name
+            params.append(p)
+        bufs = []
+        for name, p in self.named_buffers():
+            p.name = name
+            bufs.append(p)
+        self.arena = nn.ParamArena(dev, params, with_grad=True)
+        self.buffer_arena = nn.ParamArena(dev, bufs, with_grad=False)
+        self.dev = dev
+
+    def init_weight(self):
+        if self.pretrained is not None:
+            from ..utils import utils
+            utils.load_entire_model(self, self.pretrained)
+
+    def dropout_layers(self):
+        """site name -> Dropout3D (sites as in oracle/vnet_numpy.py)."""
+        return {"down_tr128": self.down_tr128.dropout, "down_tr256": self.down_tr256.dropout,
+                "up_tr256.x": self.up_tr256.dropout1, "up_tr256.skip": self.up_tr256.dropout2,
+                "up_tr128.x": self.up_tr128.dropout1, "up_tr128.skip": self.up_tr128.dropout2}
+
+    def set_dropout_masks(self, masks):
+        """Inject Dropout3D masks ([N, C] multipliers per site; None -> identity) -- parity
+        tests only; training uses the counter-based device RNG."""
+        for site, layer in self.dropout_layers().items():
+            if masks is None:
+                layer.injected, layer.enabled = None, True
+            elif site in masks and masks[site] is not None:
+                layer.injected, layer.enabled = np.asarray(masks[site], dtype=np.float32), True
+            else:
+                layer.injected, layer.enabled = None, False
+
+    # -- forward / backward ---------------------------------------------------------------
+    def forward(self, x):
+        if not isinstance(x, Tensor):
+            x = to_tensor(x, self.dev)
+        if x.c != self.in_channels:
+            raise ValueError(f"VNet expects {self.in_channels} input channel(s), got {x.c}")
+        self.dev.arena.reset()
+        if self.training:
+            nn.Dropout3D.step += 1
+        out16 = self.in_tr(x)
+        out32 = self.down_tr32(out16)
+        out64 = self.down_tr64(out32)
+        out128 = self.down_tr128(out64)
+        out256 = self.down_tr256(out128)
+        out = self.up_tr256(out256, out128)
+        out = self.up_tr128(out, out64)
+        out = self.up_tr64(out, out32)
+        self._feat = self.up_tr32(out, out16)
+        logits = self.out_tr(self._feat)
+        logits.producer = self
+        self._acts = (out16, out32, out64, out128, out256)
+        return [logits, ]
+
+    def backward(self, dlogits: Tensor):
+        """Adjoint of forward; accumulates parameter gradients into the flat arena."""
+        self.out_tr.backward(dlogits)
+        self.up_tr32.backward(self._feat.grad)
+        self.up_tr64.backward(self.up_tr32._x.grad)
+        self.up_tr128.backward(self.up_tr64._x.grad)
+        self.up_tr256.backward(self.up_tr128._x.grad)
+        out16, out32, out64, out128, out256 = self._acts
+        self.down_tr256.backward(out256.grad)
+        self.down_tr128.backward(out128.grad)
+        self.down_tr64.backward(out64.grad)
+        self.down_tr32.backward(out32.grad)
+        self.in_tr.backward(out16.grad)
+        for hook in self._post_backward_hooks:
+            hook(self)
+
+    def test(self):
+        np.random.seed(1)
+        a = np.random.rand(1, self.in_channels, 32, 32, 32)
+        out = self.forward(a.astype("float32"))[0]
+        assert out.shape == (1, self.num_classes, 32, 32, 32)
+        print("out", out.numpy().mean(), a.mean())
+        print("Vnet test is complete")

@@ -1,0 +1,504 @@
+"""Minimal paddle.nn-shaped layer system over libmsegk.
+
+Only what medicalseg's VNet path uses (models/vnet.py:24-26): Layer, Sequential,
+Conv3D, Conv3DTranspose, BatchNorm3D (SyncBatchNorm semantics when world > 1,
+cvlibs/config.py:322), PReLU, Dropout3D.  Parameter names and state-dict keys follow
+Paddle so reference checkpoints map one to one.
+
+Execution is fused: ``ConvBNAct`` runs conv -> BN statistics -> one elementwise kernel
+(normalise + affine + residual + PReLU); the individual BatchNorm3D/PReLU layers are
+parameter holders.  Backward is explicit (no tape): every fused unit keeps what its
+adjoint needs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from ._lib import NULL_TENSOR, MskConvDesc, MskError
+from .device import Tensor, get_device
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.9
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        if len(v) != 3:
+            raise ValueError(f"expected 3 values, got {v}")
+        return tuple(int(i) for i in v)
+    return (int(v),) * 3
+
+
+_init_rng = np.random.default_rng(0)
+
+
+def seed(s: int):
+    """Seed parameter initialisation (paddle.seed, train.py:120-123)."""
+    global _init_rng
+    _init_rng = np.random.default_rng(s)
+
+
+class Parameter:
+    """A trainable tensor or a buffer; lives in a ParamArena once the model is built."""
+
+    def __init__(self, value: np.ndarray, trainable=True):
+        self.init_value = np.ascontiguousarray(value, dtype=np.float32)
+        self.shape = tuple(self.init_value.shape)
+        self.size = int(self.init_value.size)
+        self.trainable = trainable
+        self.arena = None
+        self.offset = 0  # in floats
+        self.name = None
+
+    @property
+    def ptr(self):
+        return self.arena.value_ptr + 4 * self.offset
+
+    @property
+    def grad_ptr(self):
+        return self.arena.grad_ptr + 4 * self.offset
+
+    def numpy(self):
+        if self.arena is None:
+            return self.init_value.copy()
+        return self.arena.dev.d2h(self.ptr, self.shape, np.float32)
+
+    def grad_numpy(self):
+        return self.arena.dev.d2h(self.grad_ptr, self.shape, np.float32)
+
+    def set_value(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if tuple(v.shape) != self.shape:
+            raise ValueError(f"shape mismatch for {self.name}: {v.shape} vs {self.shape}")
+        if self.arena is None:
+            self.init_value = v
+        else:
+            self.arena.dev.h2d(self.ptr, v)
+
+
+class ParamArena:
+    """All trainable parameters of a model in ONE flat fp32 buffer (+ a parallel gradient
+    buffer), each tensor 16-byte aligned: the optimizer is a single kernel launch and the
+    data-parallel exchange a single RCCL all-reduce."""
+
+    def __init__(self, dev, params, with_grad=True):
+        self.dev = dev
+        off = 0
+        for p in params:
+            p.offset = off
+            off += (p.size + 3) & ~3
+        self.count = off
+        self.value_ptr = dev.malloc(max(off, 4) * 4)
+        dev.memset(self.value_ptr, 0, max(off, 4) * 4)
+        self.grad_ptr = None
+        if with_grad:
+            self.grad_ptr = dev.malloc(max(off, 4) * 4)
+            dev.memset(self.grad_ptr, 0, max(off, 4) * 4)
+        self.grad_scale = 1.0
+        for p in params:
+            p.arena = self
+            dev.h2d(p.ptr, p.init_value)
+        self.params = list(params)
+
+    def zero_grad(self):
+        self.dev.memset(self.grad_ptr, 0, self.count * 4)
+
+
+class Layer:
+    def __init__(self):
+        object.__setattr__(self, "_sub_layers", OrderedDict())
+        object.__setattr__(self, "_parameters", OrderedDict())
+        object.__setattr__(self, "_buffers", OrderedDict())
+        object.__setattr__(self, "training", True)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, Layer):
+            self._sub_layers[name] = value
+        elif isinstance(value, Parameter):
+            (self._parameters if value.trainable else self._buffers)[name] = value
+        object.__setattr__(self, name, value)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    # -- tree walks -------------------------------------------------------------------
+    def named_sublayers(self, prefix=""):
+        for name, layer in self._sub_layers.items():
+            full = f"{prefix}.{name}" if prefix else name
+            yield full, layer
+            yield from layer.named_sublayers(full)
+
+    def sublayers(self):
+        return [l for _, l in self.named_sublayers()]
+
+    def named_parameters(self, prefix=""):
+        for name, p in self._parameters.items():
+            yield (f"{prefix}.{name}" if prefix else name), p
+        for name, layer in self._sub_layers.items():
+            yield from layer.named_parameters(f"{prefix}.{name}" if prefix else name)
+
+    def named_buffers(self, prefix=""):
+        for name, p in self._buffers.items():
+            yield (f"{prefix}.{name}" if prefix else name), p
+        for name, layer in self._sub_layers.items():
+            yield from layer.named_buffers(f"{prefix}.{name}" if prefix else name)
+
+    def parameters(self):
+        return [p for _, p in self.named_parameters()]
+
+    def train(self):
+        self.training = True
+        for l in self.sublayers():
+            l.training = True
+
+    def eval(self):
+        self.training = False
+        for l in self.sublayers():
+            l.training = False
+
+    # -- state dict (paddle: parameters and persistable buffers, in attribute order) ----
+    def _named_state(self, prefix=""):
+        for name, p in self._parameters.items():
+            yield (f"{prefix}.{name}" if prefix else name), p
+        for name, p in self._buffers.items():
+            yield (f"{prefix}.{name}" if prefix else name), p
+        for name, layer in self._sub_layers.items():
+            yield from layer._named_state(f"{prefix}.{name}" if prefix else name)
+
+    def state_dict(self):
+        return OrderedDict((k, p.numpy()) for k, p in self._named_state())
+
+    def set_state_dict(self, state):
+        own = dict(self._named_state())
+        missing = [k for k in own if k not in state]
+        for k, v in state.items():
+            if k in own:
+                own[k].set_value(np.asarray(v))
+        return missing, [k for k in state if k not in own]
+
+    set_dict = set_state_dict
+    load_dict = set_state_dict
+
+    def clear_gradients(self):
+        arenas = {id(p.arena): p.arena for p in self.parameters() if p.arena is not None}
+        for a in arenas.values():
+            a.zero_grad()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError
+
+
+class Sequential(Layer):
+    def __init__(self, *layers):
+        super().__init__()
+        for i, l in enumerate(layers):
+            setattr(self, str(i), l)
+
+    def __iter__(self):
+        return iter(self._sub_layers.values())
+
+    def __len__(self):
+        return len(self._sub_layers)
+
+    def __getitem__(self, i):
+        return list(self._sub_layers.values())[i]
+
+    def forward(self, x):
+        for l in self._sub_layers.values():
+            x = l(x)
+        return x
+
+
+class Conv3D(Layer):
+    """paddle.nn.Conv3D: weight [Cout, Cin, kD, kH, kW], Normal(0, sqrt(2/(k^3 Cin)))
+    init, zero bias (App. B.6)."""
+
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.cin, self.cout = int(in_channels), int(out_channels)
+        self.k, self.s, self.p = _triple(kernel_size), _triple(stride), _triple(padding)
+        fan_in = self.cin * self.k[0] * self.k[1] * self.k[2]
+        self.weight = Parameter(_init_rng.standard_normal((self.cout, self.cin) + self.k) * np.sqrt(2.0 / fan_in))
+        self.bias = Parameter(np.zeros(self.cout))
+
+    def desc(self):
+        return MskConvDesc(*self.k, *self.s, *self.p)
+
+    def out_dims(self, x: Tensor):
+        return tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip((x.d, x.h, x.w), self.p, self.k, self.s))
+
+    def run_forward(self, x: Tensor, y: Tensor | None = None) -> Tensor:
+        if x.c != self.cin:
+            raise ValueError(f"Conv3D expects {self.cin} input channels, got {x.c}")
+        od, oh, ow = self.out_dims(x)
+        if y is None:
+            y = Tensor.empty(x.dev, x.n, od, oh, ow, self.cout)
+        x.dev.call("msk_conv3d_fwd", self.desc(), x.msk(), C.c_void_p(self.weight.ptr),
+                   C.c_void_p(self.bias.ptr), y.msk())
+        return y
+
+    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True):
+        dev = x.dev
+        dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                 C.c_void_p(self.bias.grad_ptr), 1)
+        if need_dx:
+            dx = x.ensure_grad()
+            dev.call("msk_conv3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
+                     1 if x.grad_written else 0)
+            x.grad_written = True
+
+    forward = run_forward
+
+
+class Conv3DTranspose(Layer):
+    """paddle.nn.Conv3DTranspose: weight [Cin, Cout, kD, kH, kW], Xavier-uniform init,
+    out = (in-1)*s + k (App. B.1, B.6)."""
+
+    transposed = True
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1):
+        super().__init__()
+        self.cin, self.cout = int(in_channels), int(out_channels)
+        self.k, self.s, self.p = _triple(kernel_size), _triple(stride), (0, 0, 0)
+        rec = self.k[0] * self.k[1] * self.k[2]
+        lim = np.sqrt(6.0 / (self.cin * rec + self.cout * rec))
+        self.weight = Parameter(_init_rng.uniform(-lim, lim, (self.cin, self.cout) + self.k))
+        self.bias = Parameter(np.zeros(self.cout))
+
+    def desc(self):
+        return MskConvDesc(*self.k, *self.s, 0, 0, 0)
+
+    def out_dims(self, x: Tensor):
+        return tuple((i - 1) * s + k for i, k, s in zip((x.d, x.h, x.w), self.k, self.s))
+
+    def run_forward(self, x: Tensor, y: Tensor | None = None) -> Tensor:
+        if x.c != self.cin:
+            raise ValueError(f"Conv3DTranspose expects {self.cin} input channels, got {x.c}")
+        od, oh, ow = self.out_dims(x)
+        if y is None:
+            y = Tensor.empty(x.dev, x.n, od, oh, ow, self.cout)
+        x.dev.call("msk_convT3d_fwd", self.desc(), x.msk(), C.c_void_p(self.weight.ptr),
+                   C.c_void_p(self.bias.ptr), y.msk())
+        return y
+
+    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True):
+        dev = x.dev
+        dev.call("msk_convT3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                 C.c_void_p(self.bias.grad_ptr), 1)
+        if need_dx:
+            dx = x.ensure_grad()
+            dev.call("msk_convT3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
+                     1 if x.grad_written else 0)
+            x.grad_written = True
+
+    forward = run_forward
+
+
+class BatchNorm3D(Layer):
+    """paddle.nn.BatchNorm3D(momentum=0.9, epsilon=1e-5); buffers `_mean`, `_variance`.
+    With world > 1 the statistics are global-batch (SyncBatchNorm), as
+    cvlibs/config.py:322 converts every BatchNorm unconditionally."""
+
+    def __init__(self, num_features, momentum=BN_MOMENTUM, epsilon=BN_EPS):
+        super().__init__()
+        self.num_features = int(num_features)
+        self.momentum, self.epsilon = float(momentum), float(epsilon)
+        self.weight = Parameter(np.ones(num_features))
+        self.bias = Parameter(np.zeros(num_features))
+        self._mean = Parameter(np.zeros(num_features), trainable=False)
+        self._variance = Parameter(np.ones(num_features), trainable=False)
+        self._scratch = None
+
+    def scratch(self, dev):
+        """Persistent device scratch: stats_local[2C] gathered[W*2C] scale shift mean invstd
+        sums[3C] sums_total[3C]."""
+        if self._scratch is None or self._scratch["world"] != dev.world:
+            Cn, W = self.num_features, dev.world
+            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn
+            base = dev.small(total)
+            o = 0
+            s = {"world": W}
+            for name, cnt in (("stats", 2 * Cn), ("gathered", W * 2 * Cn), ("scale", Cn), ("shift", Cn),
+                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn)):
+                s[name] = base + 4 * o
+                o += cnt
+            self._scratch = s
+        return self._scratch
+
+
+class SyncBatchNorm(BatchNorm3D):
+    @staticmethod
+    def convert_sync_batchnorm(layer):
+        """No-op kept for API parity (cvlibs/config.py:322): BatchNorm3D here already uses
+        cross-rank statistics whenever a communicator is initialised."""
+        return layer
+
+
+class PReLU(Layer):
+    """paddle.nn.PReLU(num_parameters=C, init=0.25); parameter name `_weight`."""
+
+    def __init__(self, num_parameters=1, init=0.25):
+        super().__init__()
+        self.num_parameters = int(num_parameters)
+        self._weight = Parameter(np.full(num_parameters, init))
+
+
+class ELU(Layer):
+    def __init__(self, alpha=1.0):
+        super().__init__()
+        raise NotImplementedError(
+            "elu=True is not built: every shipped config uses elu: False and the reference notes NaN "
+            "gradients with ELU (core/train.py:139)")
+
+
+class Dropout3D(Layer):
+    """paddle.nn.Dropout3D(p=0.5): drops whole (n, c) channels, kept ones scaled 1/(1-p)
+    (upscale_in_train); identity in eval (App. B.4).  Masks come from a counter-based RNG
+    keyed by (seed, step, site) or are injected for parity tests."""
+
+    _site_counter = 0
+    seed = 0
+    step = 0
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = float(p)
+        Dropout3D._site_counter += 1
+        self.site = Dropout3D._site_counter
+        self.injected = None  # numpy [N, C] multipliers
+        self.enabled = True
+
+    def make_mask(self, x: Tensor):
+        """Returns a device pointer to mask[N*C] or None for identity."""
+        if not self.training or not self.enabled or self.p == 0.0:
+            return None
+        dev = x.dev
+        cnt = x.n * x.c
+        ptr = dev.arena.alloc(cnt * 4)
+        if self.injected is not None:
+            m = np.ascontiguousarray(self.injected, dtype=np.float32)
+            if m.shape != (x.n, x.c):
+                raise ValueError(f"injected dropout mask must be [{x.n},{x.c}], got {m.shape}")
+            dev.h2d(ptr, m)
+        else:
+            dev.call("msk_dropout_mask", C.c_uint64(Dropout3D.seed), C.c_uint64(Dropout3D.step),
+                     C.c_uint32(self.site), cnt, C.c_float(self.p), C.c_void_p(ptr))
+        return ptr
+
+
+# ----------------------------------------------------------------------------------------
+# fused execution units
+# ----------------------------------------------------------------------------------------
+def _fp(ptr):
+    return C.c_void_p(ptr) if ptr else None
+
+
+class ConvBNAct:
+    """conv (or convT) -> BatchNorm -> (+ residual) -> PReLU, forward and adjoint.
+
+    Reference chains replaced: vnet.py:41 (LUConv), :74-79 (InputTransition),
+    :107 (down_conv/bn1/relu1), :150 (up_conv/bn1/relu1), :173 (OutputTransition)."""
+
+    def __init__(self, conv, bn: BatchNorm3D, act: PReLU | None):
+        self.conv, self.bn, self.act = conv, bn, act
+
+    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+        dev = x.dev
+        self.x, self.res = x, res
+        y = self.conv.run_forward(x)
+        self.y = y
+        bn, sc = self.bn, self.bn.scratch(dev)
+        Cn = bn.num_features
+        if bn.training:
+            dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
+            gathered = sc["stats"]
+            if dev.world > 1:
+                dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))
+                gathered = sc["gathered"]
+            dev.call("msk_bn_finalize", _fp(gathered), dev.world, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
+                     _fp(bn.bias.ptr), C.c_float(bn.epsilon), C.c_float(bn.momentum), _fp(bn._mean.ptr),
+                     _fp(bn._variance.ptr), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(sc["scale"]), _fp(sc["shift"]))
+            self.bn_mode = 1
+        else:
+            dev.call("msk_bn_eval_coeffs", Cn, _fp(bn.weight.ptr), _fp(bn.bias.ptr), _fp(bn._mean.ptr),
+                     _fp(bn._variance.ptr), C.c_float(bn.epsilon), _fp(sc["mean"]), _fp(sc["invstd"]),
+                     _fp(sc["scale"]), _fp(sc["shift"]))
+            self.bn_mode = 2
+        if out is None:
+            out = y.empty_like()
+        alpha = self.act._weight.ptr if self.act is not None else None
+        dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                 res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
+        self.out = out
+        return out
+
+    def backward(self, dout: Tensor, need_dx=True, res_needs_grad=True):
+        """dout: gradient w.r.t. the unit's output (may be a channel slice)."""
+        dev = dout.dev
+        bn, sc = self.bn, self.bn.scratch(dev)
+        Cn = bn.num_features
+        y, res = self.y, self.res
+        alpha = self.act._weight.ptr if self.act is not None else None
+        resm = res.msk() if res is not None else NULL_TENSOR
+        dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                 _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
+        sums_total, m_total = sc["sums"], float(y.voxels)
+        if self.bn_mode == 1 and dev.world > 1:
+            dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
+            dev.call("msk_dp_allreduce_sum", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
+            sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world
+        dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
+                 _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
+        dy = y.empty_like()
+        dres = NULL_TENSOR
+        dres_acc = 0
+        if res is not None and res_needs_grad and res.c == y.c:
+            g = res.ensure_grad()
+            dres, dres_acc = g.msk(), 1 if res.grad_written else 0
+            res.grad_written = True
+        dev.call("msk_affine_act_bwd_apply", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                 _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(), _fp(sums_total),
+                 C.c_double(m_total), self.bn_mode, dy.msk(), dres, dres_acc)
+        self.conv.run_backward(self.x, dy, need_dx=need_dx)
+
+
+class AddAct:
+    """out = PReLU(a + b): the residual joins of DownTransition/UpTransition
+    (vnet.py:110-111, 154)."""
+
+    def __init__(self, act: PReLU):
+        self.act = act
+        self._sums = None
+
+    def forward(self, a: Tensor, b: Tensor) -> Tensor:
+        self.a, self.b = a, b
+        out = a.empty_like()
+        a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), _fp(self.act._weight.ptr), out.msk())
+        return out
+
+    def backward(self, dout: Tensor):
+        dev = dout.dev
+        a, b = self.a, self.b
+        Cn = a.c
+        if self._sums is None:
+            self._sums = dev.small(3 * Cn)
+        alpha = _fp(self.act._weight.ptr)
+        dev.call("msk_affine_act_bwd_reduce", a.msk(), None, None, b.msk(), alpha, None, None, dout.msk(),
+                 _fp(self._sums))
+        dev.call("msk_affine_act_param_grads", Cn, _fp(self._sums), None, None, _fp(self.act._weight.grad_ptr), 1)
+        ga, gb = a.ensure_grad(), b.ensure_grad()
+        if a.grad_written:
+            raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
+        dev.call("msk_affine_act_bwd_apply", a.msk(), None, None, b.msk(), alpha, None, None, None, dout.msk(),
+                 None, C.c_double(1.0), 0, ga.msk(), gb.msk(), 1 if b.grad_written else 0)
+        a.grad_written = True
+        b.grad_written = True
+
+
+def copy_scale(src: Tensor, mask_ptr, dst: Tensor, accumulate=False):
+    src.dev.call("msk_copy_scale", src.msk(), _fp(mask_ptr), dst.msk(), 1 if accumulate else 0)

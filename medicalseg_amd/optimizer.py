@@ -1,0 +1,142 @@
+"""Optimizers and LR schedules with paddle.optimizer's surface as used by the reference
+(cvlibs/config.py:156-232, core/train.py:140-151, utils/utils.py:125)."""
+import ctypes as C
+import math
+
+import numpy as np
+
+__all__ = ["Momentum", "SGD", "lr"]
+
+
+class _LR:
+    """namespace mirroring paddle.optimizer.lr"""
+
+    class LRScheduler:
+        def __init__(self, learning_rate=0.1, last_epoch=-1):
+            self.base_lr = float(learning_rate)
+            self.last_epoch = last_epoch
+            self.last_lr = self.base_lr
+            self.step()
+
+        def __call__(self):
+            return self.last_lr
+
+        def get_lr(self):
+            raise NotImplementedError
+
+        def step(self, epoch=None):
+            self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+            self.last_lr = self.get_lr()
+
+        def state_dict(self):
+            return {"last_epoch": self.last_epoch, "last_lr": self.last_lr}
+
+        def set_state_dict(self, sd):
+            self.last_epoch = sd.get("last_epoch", self.last_epoch)
+            self.last_lr = sd.get("last_lr", self.get_lr())
+
+    class PolynomialDecay(LRScheduler):
+        """lr = (lr0 - end)*(1 - min(t,T)/T)^power + end; t advances on every step()
+        (core/train.py:150-151); first optimizer step uses lr0 (App. B.8 vi)."""
+
+        def __init__(self, learning_rate, decay_steps, end_lr=0.0001, power=1.0, cycle=False, last_epoch=-1):
+            self.decay_steps, self.end_lr, self.power, self.cycle = decay_steps, end_lr, power, cycle
+            super().__init__(learning_rate, last_epoch)
+
+        def get_lr(self):
+            t, T = self.last_epoch, self.decay_steps
+            if self.cycle:
+                div = math.ceil(t / float(T)) if t > 0 else 1
+                T = T * div
+            else:
+                t = min(t, T)
+            return (self.base_lr - self.end_lr) * ((1 - float(t) / float(T)) ** self.power) + self.end_lr
+
+    class PiecewiseDecay(LRScheduler):
+        def __init__(self, boundaries, values, last_epoch=-1):
+            self.boundaries, self.values = boundaries, values
+            super().__init__(values[0], last_epoch)
+
+        def get_lr(self):
+            for i, b in enumerate(self.boundaries):
+                if self.last_epoch < b:
+                    return self.values[i]
+            return self.values[len(self.values) - 1]
+
+    class StepDecay(LRScheduler):
+        def __init__(self, learning_rate, step_size, gamma=0.1, last_epoch=-1):
+            self.step_size, self.gamma = step_size, gamma
+            super().__init__(learning_rate, last_epoch)
+
+        def get_lr(self):
+            return self.base_lr * (self.gamma ** (self.last_epoch // self.step_size))
+
+
+lr = _LR
+
+
+class Momentum:
+    """paddle.optimizer.Momentum(lr, parameters, momentum, weight_decay: float = L2):
+    g += wd*p; v = mu*v + g; p -= lr*v on EVERY trainable tensor (BN, PReLU, biases
+    included -- App. B.8 v).  All parameters live in one flat arena, so a step is a single
+    kernel over 45.6 M floats (K10)."""
+
+    def __init__(self, learning_rate=0.001, momentum=0.9, parameters=None, weight_decay=None, **kw):
+        if not parameters:
+            raise ValueError("parameters must be a non-empty list")
+        arenas = {id(p.arena): p.arena for p in parameters}
+        if len(arenas) != 1 or None in [p.arena for p in parameters]:
+            raise ValueError("all parameters must belong to one built model (one ParamArena)")
+        self.arena = next(iter(arenas.values()))
+        self._learning_rate = learning_rate
+        self.momentum = float(momentum)
+        self.weight_decay = float(weight_decay) if weight_decay else 0.0
+        self._parameter_list = list(parameters)
+        dev = self.arena.dev
+        self.velocity_ptr = dev.malloc(max(self.arena.count, 4) * 4)
+        dev.memset(self.velocity_ptr, 0, max(self.arena.count, 4) * 4)
+
+    def get_lr(self):
+        if isinstance(self._learning_rate, _LR.LRScheduler):
+            return self._learning_rate()
+        return float(self._learning_rate)
+
+    def set_lr(self, value):
+        self._learning_rate = float(value)
+
+    def step(self):
+        a = self.arena
+        a.dev.call("msk_sgd_momentum", C.c_void_p(a.value_ptr), C.c_void_p(a.grad_ptr), C.c_void_p(self.velocity_ptr),
+                   C.c_size_t(a.count), C.c_float(self.get_lr()), C.c_float(self.momentum),
+                   C.c_float(self.weight_decay), C.c_float(a.grad_scale))
+
+    def clear_grad(self):
+        self.arena.zero_grad()
+
+    clear_gradients = clear_grad
+
+    def state_dict(self):
+        dev = self.arena.dev
+        flat = dev.d2h(self.velocity_ptr, (self.arena.count,), np.float32)
+        sd = {}
+        for p in self.arena.params:
+            sd[p.name + "_velocity_0"] = flat[p.offset:p.offset + p.size].reshape(p.shape).copy()
+        if isinstance(self._learning_rate, _LR.LRScheduler):
+            sd["LR_Scheduler"] = self._learning_rate.state_dict()
+        return sd
+
+    def set_state_dict(self, sd):
+        dev = self.arena.dev
+        flat = dev.d2h(self.velocity_ptr, (self.arena.count,), np.float32)
+        for p in self.arena.params:
+            k = p.name + "_velocity_0"
+            if k in sd:
+                flat[p.offset:p.offset + p.size] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
+        dev.h2d(self.velocity_ptr, flat)
+        if "LR_Scheduler" in sd and isinstance(self._learning_rate, _LR.LRScheduler):
+            self._learning_rate.set_state_dict(sd["LR_Scheduler"])
+
+
+class SGD(Momentum):
+    def __init__(self, learning_rate=0.001, parameters=None, weight_decay=None, **kw):
+        super().__init__(learning_rate, 0.0, parameters, weight_decay)

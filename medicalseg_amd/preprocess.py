@@ -1,0 +1,126 @@
+"""Device versions of tools/preprocess_utils (reference geometry.py:31-69, values.py:37-87):
+same function names, arguments and return values; inputs are host arrays (as the
+reference's `Prep.load_save` hands them over, tools/prepare.py:200-259), staged through
+pinned-host -> device copies, processed by HIP kernels, and returned as host arrays.
+``*_device`` variants keep data on the GPU for in-loop use."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .device import get_device
+
+
+class DeviceVolume:
+    """A 3-D float32/int32 volume on the device (persistent allocation)."""
+
+    def __init__(self, dev, ptr, shape, dtype):
+        self.dev, self.ptr, self.shape, self.dtype = dev, ptr, tuple(int(s) for s in shape), np.dtype(dtype)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def numpy(self):
+        return self.dev.d2h(self.ptr, self.shape, self.dtype)
+
+    def free(self):
+        if self.ptr:
+            self.dev.free(self.ptr)
+            self.ptr = None
+
+
+def upload(image, dev=None) -> DeviceVolume:
+    dev = dev or get_device()
+    a = np.asarray(image)
+    if a.ndim != 3:
+        raise ValueError("expected a 3-D volume, got shape {}".format(a.shape))
+    if np.issubdtype(a.dtype, np.integer):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    ptr = dev.malloc(a.nbytes)
+    dev.h2d(ptr, a)
+    return DeviceVolume(dev, ptr, a.shape, a.dtype)
+
+
+def resample_device(vol: DeviceVolume, new_shape, order=1) -> DeviceVolume:
+    dev = vol.dev
+    new_shape = tuple(int(s) for s in new_shape)
+    if order not in (0, 1):
+        raise ValueError("only order 0 and 1 are built (the orders the reference pipelines use)")
+    out = dev.malloc(int(np.prod(new_shape)) * 4)
+    dev.call("msk_resample3d", C.c_void_p(vol.ptr), *vol.shape, C.c_void_p(out), *new_shape, int(order),
+             0 if vol.dtype == np.float32 else 1)
+    return DeviceVolume(dev, out, new_shape, vol.dtype)
+
+
+def resample(image, spacing=None, new_spacing=[1.0, 1.0, 1.0], new_shape=None, order=1):
+    """reference geometry.py:31-69 -> (array, new_spacing)."""
+    image = np.asarray(image)
+    if new_shape is None:
+        spacing = np.array([spacing[0], spacing[1], spacing[2]])
+        new_shape = np.round(image.shape * spacing / new_spacing)
+    else:
+        new_shape = np.array(new_shape)
+        if spacing is not None and len(spacing) == 4:
+            spacing = spacing[1:]
+        new_spacing = tuple((image.shape / new_shape) * spacing) if spacing is not None else None
+    src_dtype = image.dtype
+    vol = upload(image)
+    out = resample_device(vol, [int(s) for s in new_shape], order)
+    res = out.numpy()
+    vol.free()
+    out.free()
+    if res.dtype != src_dtype and (np.issubdtype(src_dtype, np.integer) or src_dtype == np.float64):
+        res = res.astype(src_dtype)
+    return res, new_spacing
+
+
+def HUnorm(image, HU_min=-1200, HU_max=600, HU_nan=-2000):
+    """reference values.py:67-87."""
+    vol = upload(np.asarray(image, dtype=np.float32))
+    vol.dev.call("msk_hu_norm", C.c_void_p(vol.ptr), C.c_void_p(vol.ptr), C.c_size_t(vol.size), C.c_float(HU_min),
+                 C.c_float(HU_max), C.c_float(HU_nan))
+    out = vol.numpy()
+    vol.free()
+    return out
+
+
+def normalize(image, min_val=None, max_val=None):
+    """reference values.py:54-64."""
+    vol = upload(np.asarray(image, dtype=np.float32))
+    use = 0 if (min_val is None and max_val is None) else 1
+    vol.dev.call("msk_minmax_norm", C.c_void_p(vol.ptr), C.c_void_p(vol.ptr), C.c_size_t(vol.size), use,
+                 C.c_float(min_val or 0.0), C.c_float(max_val or 0.0))
+    out = vol.numpy()
+    vol.free()
+    return out
+
+
+def max_normalize(image):
+    """transforms/transform.py:67-69: im/im.max() if max > 0, plus the channel axis."""
+    vol = upload(np.asarray(image, dtype=np.float32))
+    vol.dev.call("msk_max_norm", C.c_void_p(vol.ptr), C.c_void_p(vol.ptr), C.c_size_t(vol.size))
+    out = vol.numpy()
+    vol.free()
+    return np.expand_dims(out, axis=0)
+
+
+def label_remap(label, map_dict=None):
+    """reference values.py:37-51 (sequential key -> value passes)."""
+    vol = upload(np.asarray(label).astype(np.int32))
+    dev = vol.dev
+    keys = np.array(list(map_dict.keys()), dtype=np.int32)
+    vals = np.array(list(map_dict.values()), dtype=np.int32)
+    kp, vp = dev.malloc(max(keys.nbytes, 4)), dev.malloc(max(vals.nbytes, 4))
+    if len(keys):
+        dev.h2d(kp, keys)
+        dev.h2d(vp, vals)
+    dev.call("msk_label_remap", C.c_void_p(vol.ptr), C.c_size_t(vol.size), C.c_void_p(kp), C.c_void_p(vp), len(keys))
+    out = vol.numpy().astype(np.asarray(label).dtype)
+    vol.free()
+    dev.free(kp)
+    dev.free(vp)
+    return out

@@ -1,0 +1,46 @@
+/* Host-only STAND-IN for libmsegk.so used by tests/test_host_dryrun.py to exercise the
+ * Python plumbing (ctypes signatures, shape logic, arena, train loop control flow) without
+ * a GPU.  It computes NOTHING: compute entry points are no-ops returning 0, memory entry
+ * points use host malloc/memcpy.  It is never built into or loaded by the product. */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { int dummy; } fake_ctx;
+static fake_ctx g_ctx;
+static long g_calls = 0;
+
+long fake_calls(void) { return g_calls; }
+int msk_version(void) { return -1; }
+int msk_device_count(int* c) { *c = 1; return 0; }
+int msk_ctx_create(int dev, void** out) { (void)dev; *out = &g_ctx; return 0; }
+int msk_ctx_destroy(void* c) { (void)c; return 0; }
+const char* msk_last_error(void* c) { (void)c; return "fake"; }
+int msk_sync(void* c) { (void)c; return 0; }
+int msk_device_name(void* c, char* buf, int n) { (void)c; strncpy(buf, "fake-host-device", n); return 0; }
+int msk_malloc(void* c, size_t b, void** out) { (void)c; *out = calloc(1, b ? b : 16); return *out ? 0 : -1; }
+int msk_free(void* c, void* p) { (void)c; free(p); return 0; }
+int msk_memset(void* c, void* p, int v, size_t b) { (void)c; memset(p, v, b); return 0; }
+int msk_h2d(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
+int msk_d2h(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
+int msk_d2d(void* c, void* d, const void* s, size_t b) { (void)c; memmove(d, s, b); return 0; }
+int msk_pinned_alloc(void* c, size_t b, void** out) { return msk_malloc(c, b, out); }
+int msk_pinned_free(void* c, void* p) { return msk_free(c, p); }
+int msk_mem_info(void* c, size_t* f, size_t* t) { (void)c; *f = *t = (size_t)1 << 38; return 0; }
+int msk_timer_start(void* c) { (void)c; return 0; }
+int msk_timer_stop(void* c, float* ms) { (void)c; *ms = 1.0f; return 0; }
+int msk_prof_enable(void* c, int on) { (void)c; (void)on; return 0; }
+int msk_prof_reset(void* c) { (void)c; return 0; }
+int msk_prof_report(void* c, char* buf, int n, int* len) { (void)c; if (buf && n > 0) buf[0] = 0; if (len) *len = 1; return 0; }
+int msk_set_option(void* c, const char* k, int v) { (void)c; (void)k; (void)v; return 0; }
+int msk_dp_unique_id(char* id) { memset(id, 7, 128); return 0; }
+#define NOOP(name) int name() { ++g_calls; return 0; }
+NOOP(msk_ncdhw_to_ndhwc) NOOP(msk_ndhwc_to_ncdhw)
+NOOP(msk_conv3d_fwd) NOOP(msk_conv3d_dgrad) NOOP(msk_conv3d_wgrad)
+NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
+NOOP(msk_bn_stats) NOOP(msk_bn_finalize) NOOP(msk_bn_eval_coeffs)
+NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)
+NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c)
+NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum)
+NOOP(msk_resample3d) NOOP(msk_hu_norm) NOOP(msk_minmax_norm) NOOP(msk_max_norm) NOOP(msk_label_remap)
+NOOP(msk_dp_init) NOOP(msk_dp_allreduce_sum) NOOP(msk_dp_allgather) NOOP(msk_dp_broadcast) NOOP(msk_dp_barrier) NOOP(msk_dp_destroy)

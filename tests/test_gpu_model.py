@@ -1,0 +1,200 @@
+"""Whole-network parity on the GPU: VNet forward, backward, loss and SGD trajectory vs the
+numpy oracle (float64) on identical inputs/weights; preprocessing vs the reference goldens.
+
+Tolerances: logits 2e-4 relative to max|logit|; parameter gradients 2e-3 relative to the
+largest gradient entry of the tensor (fp32 conv chains of depth ~30 vs float64);
+per-channel dice / mDice 1e-4 absolute (the north-star's "Dice within 1e-4")."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+from oracle import preprocess_numpy as P  # noqa: E402
+from oracle import vnet_numpy as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SITES = [("down_tr128", 128), ("down_tr256", 256), ("up_tr256.x", 256), ("up_tr256.skip", 128),
+         ("up_tr128.x", 256), ("up_tr128.skip", 64)]
+
+
+def _build(ncls, K, S, seed=1):
+    from medicalseg_amd.models import VNet
+    params = O.init_params(seed, 1, ncls, K, S)
+    model = VNet(elu=False, in_channels=1, num_classes=ncls, kernel_size=K, stride_size=S)
+    missing, unexpected = model.set_state_dict(params)
+    assert not missing and not unexpected
+    return model, params
+
+
+def _masks(rng, N):
+    return {s: (rng.random((N, c)) < 0.5).astype(np.float32) * 2.0 for s, c in SITES}
+
+
+CFGS = [
+    ((16, 16, 16), 3, ((2, 2, 2),) * 4, ((2, 2, 2),) * 4, 2),
+    ((32, 32, 12), 5, ((2, 2, 4), (2, 2, 2), (2, 2, 2), (2, 2, 2)), ((2, 2, 1), (2, 2, 1), (2, 2, 2), (2, 2, 2)), 1),
+]
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("cfg", CFGS)
+def test_vnet_forward_backward_parity(cfg, train):
+    shape, ncls, K, S, N = cfg
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(0)
+    model, params = _build(ncls, K, S)
+    x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+    masks = _masks(rng, N) if train else None
+
+    om = O.VNetOracle(params, 1, ncls, K, S)
+    lg_ref = om.forward(x, train=train, dropout_masks=masks)
+    ol = O.MixedLossOracle()
+    ll_ref, per_ref, dz = ol(lg_ref, y)
+    g_ref = om.backward(dz)
+
+    model.train() if train else model.eval()
+    model.set_dropout_masks(masks)
+    logits = model(x)
+    lg = logits[0].numpy()
+    assert lg.shape == (N, ncls) + shape
+    assert rel_err(lg, lg_ref) < 2e-4
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    loss_list, per = loss_computation(logits, to_labels(y), losses)
+    assert abs(float(loss_list[0]) - ll_ref[0]) < 1e-4 * abs(ll_ref[0])
+    assert abs(float(loss_list[1]) - ll_ref[1]) < 1e-4
+    assert np.abs(np.asarray(per) - per_ref).max() < 1e-4
+    model.clear_gradients()
+    sum(loss_list).backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        g = p.grad_numpy()
+        ref = g_ref[name]
+        scale = np.abs(ref).max()
+        if scale < 1e-9:  # conv bias ahead of a train-mode BN: exactly 0 in exact arithmetic
+            assert np.abs(g).max() < 1e-4
+            continue
+        err = np.abs(g - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    if train:  # running statistics moved like the oracle's
+        sd = model.state_dict()
+        for k in om.p:
+            if k.endswith("._mean") or k.endswith("._variance"):
+                assert np.abs(sd[k] - om.p[k]).max() < 2e-4 * (1 + np.abs(om.p[k]).max()), k
+    print("worst grad rel err", worst)
+
+
+def to_labels(y):
+    from medicalseg_amd.device import to_tensor
+    return to_tensor(y)
+
+
+def test_training_trajectory_matches_oracle():
+    """5 SGD steps (lr 1e-3 poly, momentum 0.9, L2 1e-4) in eval-mode BN like the reference's
+    intended alignment test (vnet.py:351-397), plus 3 steps in train mode."""
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    shape, ncls, K, S, N = CFGS[0]
+    for train, steps in ((False, 5), (True, 3)):
+        rng = np.random.default_rng(11)
+        model, params = _build(ncls, K, S, seed=4)
+        om = O.VNetOracle(params, 1, ncls, K, S)
+        ol, vel = O.MixedLossOracle(), {}
+        sched = optim.lr.PolynomialDecay(1e-3, decay_steps=100, end_lr=0, power=0.9)
+        opt = optim.Momentum(sched, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+        model.train() if train else model.eval()
+        for step in range(steps):
+            x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+            y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+            masks = _masks(rng, N) if train else None
+            ref_total, _, per_ref, _ = O.train_step(om, ol, vel, x, y, step, lr0=1e-3, decay_steps=100,
+                                                    train=train, dropout_masks=masks)
+            model.set_dropout_masks(masks)
+            logits = model(x)
+            loss_list, per = loss_computation(logits, to_labels(y), losses)
+            loss = sum(loss_list)
+            loss.backward()
+            assert abs(opt.get_lr() - O.poly_lr(step, 1e-3, 100, 0.0, 0.9)) < 1e-12
+            opt.step()
+            sched.step()
+            model.clear_gradients()
+            assert abs(float(loss) - ref_total) < 2e-4 * abs(ref_total), (train, step, float(loss), ref_total)
+            assert np.abs(np.asarray(per) - per_ref).max() < 1e-4
+        sd = model.state_dict()
+        for k in om.trainable:
+            assert rel_err(sd[k], om.p[k]) < 5e-4, k
+
+
+def test_eval_mdice_matches_oracle():
+    """core.val.evaluate's mDice on a synthetic validation set == oracle soft dice."""
+    from medicalseg_amd.core import evaluate
+    from medicalseg_amd.datasets import SyntheticCT
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    shape, ncls, K, S, _ = CFGS[0]
+    model, params = _build(ncls, K, S, seed=2)
+    ds = SyntheticCT(num_samples=3, shape=shape, num_classes=ncls, mode="val")
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    res = evaluate(model, ds, losses, print_detail=False)
+    om = O.VNetOracle(params, 1, ncls, K, S)
+    md = 0.0
+    for i in range(3):
+        im, lab, _ = ds[i]
+        lg = om.forward(im[None], train=False, record=False)
+        _, per, _ = O.dice(lg, lab[None])
+        md += per.mean()
+    assert abs(res["mdice"] - md / 3) < 1e-4
+
+
+def test_preprocess_matches_reference_goldens():
+    from medicalseg_amd import preprocess as pp
+    g = np.load(os.path.join(HERE, "golden", "preprocess_golden.npz"))
+    for i in range(5):
+        o1, sp = pp.resample(g[f"rs{i}_img"], spacing=[0.7, 0.8, 2.5], new_shape=list(g[f"rs{i}_shape"]), order=1)
+        assert o1.dtype == np.float32
+        assert np.abs(o1 - g[f"rs{i}_o1"]).max() <= 1e-6 * np.abs(g[f"rs{i}_o1"]).max() + 1e-6
+        assert np.allclose(sp, g[f"rs{i}_spacing"])
+        o0, _ = pp.resample(g[f"rs{i}_lab"], new_shape=list(g[f"rs{i}_shape"]), order=0)
+        assert o0.dtype == np.int32 and np.array_equal(o0, g[f"rs{i}_o0"])       # bit exact (index work)
+        of0, _ = pp.resample(g[f"rs{i}_img"], new_shape=list(g[f"rs{i}_shape"]), order=0)
+        assert np.array_equal(of0, g[f"rs{i}_of0"])
+    _, sp4 = pp.resample(np.zeros((8, 8, 8), np.float32), spacing=[9.0, 1.0, 2.0, 3.0], new_shape=[4, 4, 4])
+    assert np.allclose(sp4, g["rs_sp4"])
+    assert np.array_equal(pp.HUnorm(g["hu_in"]), g["hu_out"])
+    assert np.array_equal(pp.HUnorm(g["hu_vol_in"]), g["hu_vol_out"])
+    assert np.array_equal(pp.HUnorm(g["hu_vol_in"], -1000, 400, -1500), g["hu_vol_out_custom"])
+    assert np.array_equal(pp.normalize(g["nm_in"]), g["nm_out_auto"])
+    assert np.array_equal(pp.normalize(g["nm_in"], 0, 2650), g["nm_out_bounds"])
+    assert np.array_equal(pp.label_remap(g["lr_in"], {1: 0, 2: 1, 3: 1, 5: 2}), g["lr_out"])
+    assert np.array_equal(pp.label_remap(g["lr_in"], {1: 2, 2: 3}), g["lr_out_chain"])
+    ct, _ = pp.resample(pp.HUnorm(g["pipe_ct_in"]), new_shape=[16, 16, 16], order=1)
+    assert np.abs(ct - g["pipe_ct_out"]).max() < 2e-5 * 255
+    mr, _ = pp.resample(pp.normalize(g["pipe_mr_in"], 0, 2650), new_shape=[16, 16, 6], order=1)
+    assert np.abs(mr - g["pipe_mr_out"]).max() < 2e-6
+    v = g["nm_in"]
+    assert np.array_equal(pp.max_normalize(v), P.max_normalize(v).astype(np.float32))
+
+
+def test_preprocess_size_independent_properties():
+    """Full-size (512x512x64 -> 128^3) checks that need no oracle run: identity resample,
+    constant volumes stay constant, order-0 output values are a subset of the input's."""
+    from medicalseg_amd import preprocess as pp
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((64, 96, 80)).astype(np.float32)
+    same, _ = pp.resample(v, new_shape=list(v.shape), order=1)
+    assert np.array_equal(same, v)
+    big = np.full((128, 256, 64), 3.25, np.float32)
+    out, _ = pp.resample(big, new_shape=[128, 128, 128], order=1)
+    assert np.all(out == 3.25)
+    lab = rng.integers(0, 20, (100, 120, 12)).astype(np.int32)
+    o, _ = pp.resample(lab, new_shape=[64, 64, 12], order=0)
+    assert set(np.unique(o)) <= set(np.unique(lab))
+    # corners are preserved by the align-corner map
+    assert o[0, 0, 0] == lab[0, 0, 0] and o[-1, -1, -1] == lab[-1, -1, -1]

@@ -1,0 +1,311 @@
+"""Per-op parity: HIP kernels (through the C ABI) vs the numpy oracle, on the GPU.
+
+Tolerances (fp32 kernels vs float64 oracle, stated per the north-star's "fp32 tolerance"):
+  convolutions: max abs err <= 2e-5 * max|ref| * sqrt(K/1000 + 1)   (K = reduction length)
+  elementwise / BN / loss: 1e-5 relative to max|ref|.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import dev, rel_err, t_empty, t_from_ncdhw, t_to_ncdhw, vec, vec_back, vp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vnet_numpy as O  # noqa: E402
+
+
+def _desc(k, s, p):
+    from medicalseg_amd._lib import MskConvDesc
+    return MskConvDesc(*k, *s, *p)
+
+
+CONV_CASES = [
+    # (Cin, Cout, k, s, p, (N, D, H, W))
+    (32, 32, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 6, 9, 35)),     # halo MFMA, TW=32, ragged tiles
+    (64, 64, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 5, 10, 16)),    # TW=16
+    (128, 96, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 4, 8, 8)),     # TW=8, Cout not multiple of 64
+    (1, 16, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 8, 8, 12)),      # in_tr: Cin=1
+    (32, 3, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 6, 8, 33)),      # out_tr: Cout=3
+    (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),      # out_tr.conv2
+    (3, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),
+    (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
+    (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
+    (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
+    (5, 7, (3, 2, 1), (2, 1, 1), (1, 0, 0), (1, 7, 6, 5)),        # odd everything -> reference kernels
+]
+
+
+def _conv_tol(K):
+    return 2e-5 * np.sqrt(K / 1000.0 + 1.0)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_dgrad_wgrad(case, impl):
+    cin, cout, k, s, p, (N, D, H, W) = case
+    d = dev()
+    d.set_option("conv_impl", impl)
+    try:
+        rng = np.random.default_rng(hash((cin, cout, k, s)) % 2**31)
+        x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * np.prod(k))).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, p)
+        od, oh, ow = y_ref.shape[2:]
+        xt, yt = t_from_ncdhw(x), t_empty(N, cout, od, oh, ow, fill=7.0)
+        wp, bp = vec(w.ravel()), vec(b)
+        d.call("msk_conv3d_fwd", _desc(k, s, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        K = cin * int(np.prod(k))
+        assert rel_err(t_to_ncdhw(yt), y_ref) < _conv_tol(K)
+
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        dx_ref = O.conv3d_dgrad(dy.astype(np.float64), w.astype(np.float64), x.shape, s, p)
+        dw_ref, db_ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s, p)
+        dyt = t_from_ncdhw(dy)
+        dxt = t_empty(N, cin, D, H, W, fill=3.0)
+        d.call("msk_conv3d_dgrad", _desc(k, s, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+        assert rel_err(t_to_ncdhw(dxt), dx_ref) < _conv_tol(cout * int(np.prod(k)))
+        # accumulate semantics
+        d.call("msk_conv3d_dgrad", _desc(k, s, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+        assert rel_err(t_to_ncdhw(dxt), 2 * dx_ref) < _conv_tol(cout * int(np.prod(k)))
+
+        dwp, dbp = vec(np.full(w.size, 0.5, np.float32)), vec(np.full(cout, 0.25, np.float32))
+        d.call("msk_conv3d_wgrad", _desc(k, s, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        M = N * od * oh * ow
+        assert rel_err(vec_back(dwp, w.size).reshape(w.shape), dw_ref) < _conv_tol(M) * 2
+        assert rel_err(vec_back(dbp, cout), db_ref) < 1e-5 * np.sqrt(M / 1000 + 1)
+        d.call("msk_conv3d_wgrad", _desc(k, s, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
+        assert rel_err(vec_back(dwp, w.size).reshape(w.shape), 2 * dw_ref) < _conv_tol(M) * 2
+    finally:
+        d.set_option("conv_impl", 0)
+
+
+CONVT_CASES = [
+    (32, 16, (2, 2, 2), (2, 2, 2), (2, 4, 4, 4)),
+    (64, 16, (2, 2, 4), (2, 2, 1), (1, 4, 4, 9)),     # MRI up conv (overlap-add along W)
+    (6, 5, (3, 2, 2), (2, 2, 1), (1, 3, 4, 5)),
+]
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convT3d_fwd_dgrad_wgrad(case, impl):
+    cin, cout, k, s, (N, D, H, W) = case
+    d = dev()
+    d.set_option("conv_impl", impl)
+    try:
+        rng = np.random.default_rng(cin * 131 + cout)
+        x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout) + k) / np.sqrt(cin * np.prod(k))).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        x64, w64 = x.astype(np.float64), w.astype(np.float64)
+        y_ref = O.conv_transpose3d(x64, w64, b.astype(np.float64), s)
+        od, oh, ow = y_ref.shape[2:]
+        xt, yt = t_from_ncdhw(x), t_empty(N, cout, od, oh, ow, fill=-1.0)
+        wp, bp = vec(w.ravel()), vec(b)
+        d.call("msk_convT3d_fwd", _desc(k, s, (0, 0, 0)), xt.msk(), vp(wp), vp(bp), yt.msk())
+        assert rel_err(t_to_ncdhw(yt), y_ref) < 3e-5
+        dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        dx_ref = O.conv_transpose3d_dgrad(dy.astype(np.float64), w64, s)
+        dw_ref, db_ref = O.conv_transpose3d_wgrad(dy.astype(np.float64), x64, k, s)
+        dyt, dxt = t_from_ncdhw(dy), t_empty(N, cin, D, H, W, fill=9.0)
+        d.call("msk_convT3d_dgrad", _desc(k, s, (0, 0, 0)), dyt.msk(), vp(wp), dxt.msk(), 0)
+        assert rel_err(t_to_ncdhw(dxt), dx_ref) < 3e-5
+        dwp, dbp = vec(np.zeros(w.size, np.float32)), vec(np.zeros(cout, np.float32))
+        d.call("msk_convT3d_wgrad", _desc(k, s, (0, 0, 0)), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        assert rel_err(vec_back(dwp, w.size).reshape(w.shape), dw_ref) < 5e-5
+        assert rel_err(vec_back(dbp, cout), db_ref) < 2e-5
+    finally:
+        d.set_option("conv_impl", 0)
+
+
+def test_conv_strided_channel_slice():
+    """Tensors that are channel slices of wider buffers (zero-copy concat) work for convs."""
+    d = dev()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 32, 4, 6, 33)).astype(np.float32)
+    w = (rng.standard_normal((32, 32, 5, 5, 5)) / 60).astype(np.float32)
+    y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), None, 1, 2)
+    xt = t_from_ncdhw(x, ld=48)
+    yt = t_empty(1, 32, 4, 6, 33, ld=40, fill=0.0)
+    d.call("msk_conv3d_fwd", _desc((5,) * 3, (1,) * 3, (2,) * 3), xt.msk(), vp(vec(w.ravel())), None, yt.msk())
+    assert rel_err(yt.numpy(), y_ref) < 5e-5
+
+
+@pytest.mark.parametrize("C_,shape", [(16, (2, 9, 10, 11)), (3, (1, 7, 8, 9)), (256, (2, 4, 4, 4)), (20, (1, 5, 6, 7))])
+def test_bn_stats_and_affine_act(C_, shape):
+    d = dev()
+    N, D, H, W = shape
+    rng = np.random.default_rng(C_)
+    x = (rng.standard_normal((N, C_, D, H, W)) * 3 + 50.0).astype(np.float32)  # large mean: cancellation test
+    gamma, beta = rng.uniform(0.5, 1.5, C_).astype(np.float32), rng.standard_normal(C_).astype(np.float32)
+    alpha = rng.uniform(0.1, 0.4, C_).astype(np.float32)
+    res = rng.standard_normal(x.shape).astype(np.float32)
+    rm, rv = rng.standard_normal(C_).astype(np.float32), rng.uniform(0.5, 2, C_).astype(np.float32)
+    x64 = x.astype(np.float64)
+    y_ref, xhat, mean, var, invstd = O.bn_train(x64, gamma.astype(np.float64), beta.astype(np.float64))
+    out_ref = O.prelu(y_ref + res, alpha.astype(np.float64))
+
+    xt, rt, ot = t_from_ncdhw(x), t_from_ncdhw(res), t_empty(N, C_, D, H, W)
+    stats = vec(np.zeros(2 * C_))
+    d.call("msk_bn_stats", xt.msk(), vp(stats))
+    st = vec_back(stats, 2 * C_)
+    M = N * D * H * W
+    assert np.abs(st[:C_] - mean).max() < 1e-5 * 50
+    assert rel_err(st[C_:] / M, var) < 2e-5
+    g, b_, rmp, rvp = vec(gamma), vec(beta), vec(rm), vec(rv)
+    sm, si, sc, sh = vec(np.zeros(C_)), vec(np.zeros(C_)), vec(np.zeros(C_)), vec(np.zeros(C_))
+    d.call("msk_bn_finalize", vp(stats), 1, C.c_double(M), C_, vp(g), vp(b_), C.c_float(1e-5), C.c_float(0.9),
+           vp(rmp), vp(rvp), vp(sm), vp(si), vp(sc), vp(sh))
+    assert rel_err(vec_back(si, C_), invstd) < 2e-5
+    assert rel_err(vec_back(rmp, C_), 0.9 * rm + 0.1 * mean) < 1e-5
+    assert rel_err(vec_back(rvp, C_), 0.9 * rv + 0.1 * var) < 2e-5
+    al = vec(alpha)
+    d.call("msk_affine_act_fwd", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), ot.msk())
+    assert np.abs(t_to_ncdhw(ot) - out_ref).max() < 2e-4  # values O(10) after (x-50)/3 scaling
+
+    # backward
+    dout = rng.standard_normal(x.shape).astype(np.float32)
+    u = y_ref + res
+    du, dalpha = O.prelu_bwd(dout.astype(np.float64), u, alpha.astype(np.float64))
+    dx_ref, dg_ref, db_ref = O.bn_train_bwd(du, xhat, gamma.astype(np.float64), invstd)
+    dt = t_from_ncdhw(dout)
+    sums = vec(np.zeros(3 * C_))
+    d.call("msk_affine_act_bwd_reduce", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), vp(sm), vp(si), dt.msk(), vp(sums))
+    s_ = vec_back(sums, 3 * C_)
+    assert rel_err(s_[:C_], db_ref) < 1e-4
+    assert rel_err(s_[C_:2 * C_], dg_ref) < 1e-4
+    assert rel_err(s_[2 * C_:], dalpha) < 1e-4
+    dxt, drt = t_empty(N, C_, D, H, W), t_empty(N, C_, D, H, W, fill=1.0)
+    d.call("msk_affine_act_bwd_apply", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), vp(sm), vp(si), vp(g), dt.msk(),
+           vp(sums), C.c_double(M), 1, dxt.msk(), drt.msk(), 1)
+    assert rel_err(t_to_ncdhw(dxt), dx_ref) < 2e-4
+    assert rel_err(t_to_ncdhw(drt), du + 1.0) < 1e-5
+    # eval-mode coefficients
+    d.call("msk_bn_eval_coeffs", C_, vp(g), vp(b_), vp(rmp), vp(rvp), C.c_float(1e-5), vp(sm), vp(si), vp(sc), vp(sh))
+    d.call("msk_affine_act_fwd", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), ot.msk())
+    ev = O.prelu(O.bn_eval(x64, gamma, beta, vec_back(rmp, C_).astype(np.float64), vec_back(rvp, C_).astype(np.float64)) + res, alpha)
+    assert rel_err(t_to_ncdhw(ot), ev) < 2e-5
+
+
+def test_affine_act_tiled_residual_and_slices():
+    """InputTransition's x.tile residual (res.c=1) and channel-slice outputs."""
+    d = dev()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 16, 3, 4, 5)).astype(np.float32)
+    r = rng.standard_normal((2, 1, 3, 4, 5)).astype(np.float32)
+    alpha = rng.uniform(0.1, 0.4, 16).astype(np.float32)
+    xt, rt = t_from_ncdhw(x), t_from_ncdhw(r)
+    wide = t_empty(2, 32, 3, 4, 5, fill=0.0)
+    d.call("msk_affine_act_fwd", xt.msk(), None, None, rt.msk(), vp(vec(alpha)), wide.channel_slice(16, 32).msk())
+    got = wide.numpy()
+    assert np.all(got[:, :16] == 0)
+    assert rel_err(got[:, 16:], O.prelu((x + r).astype(np.float64), alpha.astype(np.float64))) < 1e-6
+
+
+def test_copy_scale_channel_sum_argmax_layout():
+    d = dev()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 20, 3, 5, 4)).astype(np.float32)
+    xt = t_from_ncdhw(x)
+    mask = (rng.random((2, 20)) < 0.5).astype(np.float32) * 2
+    dst = t_empty(2, 20, 3, 5, 4, fill=1.0)
+    d.call("msk_copy_scale", xt.msk(), vp(vec(mask.ravel())), dst.msk(), 1)
+    assert rel_err(t_to_ncdhw(dst), x * mask[:, :, None, None, None] + 1.0) < 1e-6
+    out = vec(np.ones(20))
+    d.call("msk_channel_sum", xt.msk(), vp(out), 1)
+    assert rel_err(vec_back(out, 20), x.sum(axis=(0, 2, 3, 4)) + 1.0) < 1e-5
+    am = d.malloc(2 * 3 * 5 * 4 * 4)
+    d.call("msk_argmax_c", xt.msk(), vp(am))
+    assert np.array_equal(d.d2h(am, (2, 3, 5, 4), np.int32), x.argmax(axis=1))
+    assert np.array_equal(xt.numpy(), x)  # NDHWC -> NCDHW round trip
+    from medicalseg_amd.device import to_tensor
+    assert np.array_equal(to_tensor(x).numpy(), x)  # NCDHW -> NDHWC -> NCDHW
+
+
+@pytest.mark.parametrize("ncls,shape", [(3, (2, 6, 7, 8)), (20, (1, 5, 6, 12)), (2, (1, 4, 4, 4))])
+def test_loss_fwd_bwd(ncls, shape):
+    d = dev()
+    N, D, H, W = shape
+    rng = np.random.default_rng(ncls)
+    z = (rng.standard_normal((N, ncls, D, H, W)) * 2).astype(np.float32)
+    y = rng.integers(0, ncls, (N, D, H, W)).astype(np.int32)
+    y[0, 0, 0, :2] = 255  # ignore_index voxels (CE only)
+    zt = t_from_ncdhw(z)
+    yp = d.malloc(y.nbytes)
+    d.h2d(yp, y)
+    wv = vec(np.zeros(ncls))
+    d.call("msk_class_weights", zt.msk(), vp(wv))
+    w_ref = O.class_weights(z.astype(np.float64))
+    assert rel_err(vec_back(wv, ncls), w_ref) < 1e-5
+    out, stats = vec(np.zeros(2 + ncls)), d.malloc((3 * ncls + 2) * 8)
+    d.call("msk_loss_fwd", zt.msk(), vp(yp), vp(wv), 255, vp(out), vp(stats))
+    ce_ref, dce = O.cross_entropy(z.astype(np.float64), y, w_ref, 255)
+    ysafe = np.where(y == 255, 0, y)
+    # dice of the oracle one-hots every voxel; mask the ignored ones out of t by hand
+    C_ = ncls
+    s = 1 / (1 + np.exp(-z.astype(np.float64)))
+    t = np.moveaxis(np.eye(C_)[ysafe], -1, 1) * (y != 255)[:, None]
+    inter, den = (s * t).sum((0, 2, 3, 4)), (s * s).sum((0, 2, 3, 4)) + (t * t).sum((0, 2, 3, 4))
+    per = 2 * inter / np.maximum(den, 1e-6)
+    o = vec_back(out, 2 + ncls)
+    assert abs(o[0] - ce_ref) < 2e-5 * abs(ce_ref)
+    assert abs(o[1] - (1 - per.mean())) < 2e-6
+    assert rel_err(o[2:], per) < 2e-6
+    dz = t_empty(N, ncls, D, H, W)
+    d.call("msk_loss_bwd", zt.msk(), vp(yp), vp(wv), 255, vp(stats), C.c_float(0.7), C.c_float(1.3), dz.msk())
+    ddice = -(1.0 / C_) * (2 * t / np.maximum(den, 1e-6).reshape(1, -1, 1, 1, 1)
+                           - (2 * inter / np.maximum(den, 1e-6) ** 2).reshape(1, -1, 1, 1, 1) * 2 * s) * s * (1 - s)
+    assert rel_err(t_to_ncdhw(dz), 0.7 * dce + 1.3 * ddice) < 2e-5
+
+
+def test_loss_known_answer():
+    """SURVEY.md Appendix C known-answer vector, through the device kernels."""
+    d = dev()
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((1, 3, 2, 3, 4)).astype(np.float32)
+    y = rng.integers(0, 3, (1, 2, 3, 4)).astype(np.int32)
+    zt = t_from_ncdhw(z)
+    yp = d.malloc(y.nbytes)
+    d.h2d(yp, y)
+    wv = vec(np.zeros(3))
+    d.call("msk_class_weights", zt.msk(), vp(wv))
+    assert np.allclose(vec_back(wv, 3), [2.47594326, 1.75639001, 1.86110799], rtol=2e-6)
+    out, stats = vec(np.zeros(5)), d.malloc(11 * 8)
+    d.call("msk_loss_fwd", zt.msk(), vp(yp), vp(wv), 255, vp(out), vp(stats))
+    o = vec_back(out, 5)
+    assert abs(o[0] - 1.4261519761109072) < 3e-6
+    assert abs(o[1] - 0.5177017349991624) < 1e-6
+    assert np.allclose(o[2:], [0.33488489, 0.69615749, 0.41585241], atol=1e-6)
+    dz = t_empty(1, 3, 2, 3, 4)
+    d.call("msk_loss_bwd", zt.msk(), vp(yp), vp(wv), 255, vp(stats), C.c_float(1.0), C.c_float(1.0), dz.msk())
+    assert np.allclose(dz.numpy()[0, :, 0, 0, 0], [0.00738261, -0.0318339, 0.02601402], atol=2e-7)
+
+
+def test_sgd_momentum():
+    d = dev()
+    rng = np.random.default_rng(3)
+    n = 10007
+    p, g, v = [rng.standard_normal(n).astype(np.float32) for _ in range(3)]
+    pp, gp, vp_ = vec(p), vec(g), vec(v)
+    d.call("msk_sgd_momentum", vp(pp), vp(gp), vp(vp_), C.c_size_t(n), C.c_float(0.01), C.c_float(0.9),
+           C.c_float(1e-4), C.c_float(0.5))
+    g2 = 0.5 * g.astype(np.float64) + 1e-4 * p
+    v2 = 0.9 * v + g2
+    assert rel_err(vec_back(vp_, n), v2) < 1e-6
+    assert rel_err(vec_back(pp, n), p - 0.01 * v2) < 1e-6
+
+
+def test_dropout_mask_statistics():
+    d = dev()
+    m = vec(np.zeros(4096))
+    d.call("msk_dropout_mask", C.c_uint64(7), C.c_uint64(3), C.c_uint32(2), 4096, C.c_float(0.5), vp(m))
+    a = vec_back(m, 4096)
+    assert set(np.unique(a)) <= {0.0, 2.0}
+    assert 0.45 < (a == 0).mean() < 0.55
+    d.call("msk_dropout_mask", C.c_uint64(7), C.c_uint64(3), C.c_uint32(2), 4096, C.c_float(0.5), vp(m))
+    assert np.array_equal(vec_back(m, 4096), a)  # deterministic in (seed, step, site)
+    d.call("msk_dropout_mask", C.c_uint64(7), C.c_uint64(4), C.c_uint32(2), 4096, C.c_float(0.5), vp(m))
+    assert not np.array_equal(vec_back(m, 4096), a)
