@@ -38,7 +38,8 @@ struct msk_ctx {
   std::vector<msk_pending_event> prof_pending;
   std::vector<hipEvent_t> event_pool;
   // options
-  int conv_impl = 0;  // 0 auto, 1 direct, 2 mfma
+  int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
+  int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
   // data parallel
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;

@@ -190,7 +190,7 @@ int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& i
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
 int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
   const int taps = g.kd * g.kh * g.kw;
-  if (ctx->conv_impl != 1) {
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 4) {
     int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
@@ -212,7 +212,7 @@ int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* d
   if (db) {
     if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
   }
-  if (ctx->conv_impl != 1) {
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3) {
     int r = msk_wgrad_mfma(ctx, g);
     if (r < 0) return r;
     if (r == 1) return 0;

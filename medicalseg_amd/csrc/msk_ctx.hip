@@ -27,6 +27,7 @@ static void* grow(msk_ctx* ctx, void** p, size_t* cur, size_t bytes) {
     return nullptr;
   }
   *cur = want;
+  if (ctx->poison >= 0) hipMemsetAsync(*p, ctx->poison, want, ctx->stream);  // debug: make stale-scratch reads visible
   return *p;
 }
 void* msk_workspace(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes); }
@@ -220,6 +221,15 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len) {
 int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   if (strcmp(key, "conv_impl") == 0) {
     ctx->conv_impl = value;
+    return 0;
+  }
+  if (strcmp(key, "poison_scratch") == 0) {  // debug: fill (re)allocated scratch with this byte; -1 = off
+    ctx->poison = value;
+    if (value >= 0) {
+      hipStreamSynchronize(ctx->stream);
+      if (ctx->ws) hipMemsetAsync(ctx->ws, value, ctx->ws_bytes, ctx->stream);
+      if (ctx->ws2) hipMemsetAsync(ctx->ws2, value, ctx->ws2_bytes, ctx->stream);
+    }
     return 0;
   }
   return msk_fail(ctx, __FILE__, __LINE__, "msk_set_option", "unknown key");

@@ -464,6 +464,7 @@ class ConvBNAct:
         dev.call("msk_affine_act_bwd_apply", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                  _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(), _fp(sums_total),
                  C.c_double(m_total), self.bn_mode, dy.msk(), dres, dres_acc)
+        self.dy = dy  # kept for introspection (tests); freed with the arena
         self.conv.run_backward(self.x, dy, need_dx=need_dx)
 
 

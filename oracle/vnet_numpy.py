@@ -436,10 +436,13 @@ class VNetOracle:
         out64 = self._down("down_tr64", out32, 2, K[1], S[1], False)
         out128 = self._down("down_tr128", out64, 3, K[2], S[2], True)
         out256 = self._down("down_tr256", out128, 2, K[3], S[3], True)
-        out = self._up("up_tr256", out256, out128, 2, K[3], S[3], True)
-        out = self._up("up_tr128", out, out64, 2, K[2], S[2], True)
-        out = self._up("up_tr64", out, out32, 1, K[1], S[1], False)
-        out = self._up("up_tr32", out, out16, 1, K[0], S[0], False)
+        up256 = self._up("up_tr256", out256, out128, 2, K[3], S[3], True)
+        up128 = self._up("up_tr128", up256, out64, 2, K[2], S[2], True)
+        up64 = self._up("up_tr64", up128, out32, 1, K[1], S[1], False)
+        out = self._up("up_tr32", up64, out16, 1, K[0], S[0], False)
+        # named activations (value .v, and gradient .g after backward) for debugging/tests
+        self.acts = {"out16": out16, "out32": out32, "out64": out64, "out128": out128, "out256": out256,
+                     "up256": up256, "up128": up128, "up64": up64, "up32": out}
         # OutputTransition vnet.py:172-175
         o = self._prelu("out_tr.relu1", self._bn("out_tr.bn1", self._conv("out_tr.conv1", out, 1, 2)))
         logits = self._conv("out_tr.conv2", o, 1, 0)
