@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: 3D voxels/s of the VNet training step (fwd + loss + bwd + grad
+all-reduce + SGD-momentum update), 128^3 fp32, batch 2 per GPU, synthetic CT volumes
+already resident in HBM (BASELINE.json configs[1]; configs[2] at --gpus 8).
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is
+not imported).  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- the dominant kernel (conv_halo_mfma_k5: all 5x5x5 convs and their data
+                  gradients), HIP-event time over the timed region, algorithmic FLOPs;
+  cpu_baseline -- the CPU oracle timed on the host cores on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def vnet_conv5_flops(n, d, h, w, ncls):
+    """Algorithmic FLOPs (2*k^3*Cin*Cout*voxels, real channel counts) of every launch of the
+    halo kernel in one training step: the 5^3 convs forward + their data gradients
+    (in_tr has no data gradient)."""
+    layers = []  # (cin, cout, voxels_per_sample)
+    v = d * h * w
+    layers.append((1, 16, v, False))                       # in_tr.conv1 (no dgrad)
+    lv = [v // 8, v // 64, v // 512, v // 4096]
+    for c, nconv, vv in ((32, 1, lv[0]), (64, 2, lv[1]), (128, 3, lv[2]), (256, 2, lv[3])):
+        layers += [(c, c, vv, True)] * nconv               # down_tr*.ops
+    for c, nconv, vv in ((256, 2, lv[2]), (128, 2, lv[1]), (64, 1, lv[0]), (32, 1, v)):
+        layers += [(c, c, vv, True)] * nconv               # up_tr*.ops
+    layers.append((32, ncls, v, True))                     # out_tr.conv1
+    fwd = sum(2.0 * 125 * ci * co * vv for ci, co, vv, _ in layers) * n
+    dgrad = sum(2.0 * 125 * ci * co * vv for ci, co, vv, dg in layers if dg) * n
+    return fwd + dgrad
+
+
+def step_flops_per_sample():
+    return 4431.2e9  # fwd 1479.9 + bwd 2951.3 GFLOP per 128^3 sample, ncls 3
+
+
+def cpu_baseline(sample_edge=32):
+    """The CPU oracle (numpy restatement, float32, BLAS threads = host cores) on one
+    fwd+bwd+SGD step of a batch-1 sample_edge^3 volume; reported as voxels/s."""
+    from oracle import vnet_numpy as O  # baseline only
+    ncls = 3
+    params = O.init_params(0, 1, ncls, perturb=False)
+    om = O.VNetOracle(params, 1, ncls, dtype=np.float32)
+    ol, vel = O.MixedLossOracle(dtype=np.float32), {}
+    rng = np.random.default_rng(0)
+    shp = (sample_edge,) * 3
+    x = rng.random((1, 1) + shp).astype(np.float32)
+    y = rng.integers(0, ncls, (1,) + shp).astype(np.int32)
+    t0 = time.time()
+    O.train_step(om, ol, vel, x, y, 0, train=True, dropout_masks={})
+    dt = time.time() - t0
+    return {"value": float(np.prod(shp) / dt), "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "numpy-oracle (float32, BLAS threads) 1 train step, batch 1, %d^3 volume: %.1f s" % (sample_edge, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="samples per GPU")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--num-classes", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="tag conv kernels with their problem shapes in the profile")
+    ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile here")
+    args = ap.parse_args()
+
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd import parallel
+    from medicalseg_amd.datasets import SyntheticCT
+    from medicalseg_amd.device import get_device, to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation
+
+    env = parallel.ParallelEnv()
+    world, rank = env.nranks, env.rank
+    if world != args.gpus:
+        if args.gpus == 1 and world == 1:
+            pass
+        else:
+            raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); "
+                             "got WORLD_SIZE=%d" % (args.gpus, args.gpus, world))
+    dev = get_device()
+    if world > 1:
+        parallel.init_parallel_env()
+
+    S, B, ncls = args.size, args.batch, args.num_classes
+    ds = SyntheticCT(num_samples=B, shape=(S, S, S), num_classes=ncls, seed=1234 + 1000 * rank)
+    items = [ds[i] for i in range(B)]
+    images = to_tensor(np.stack([it[0] for it in items]), dev)   # resident in HBM before timing
+    labels = to_tensor(np.stack([it[1] for it in items]), dev)
+
+    from medicalseg_amd import nn
+    nn.seed(0)
+    model = VNet(elu=False, in_channels=1, num_classes=ncls)
+    sched = optim.lr.PolynomialDecay(1e-3, decay_steps=15000, end_lr=0, power=0.9)
+    opt = optim.Momentum(sched, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    net = parallel.DataParallel(model) if world > 1 else model
+    model.train()
+
+    def step():
+        logits_list = net(images)
+        loss_list, per = loss_computation(logits_list, labels, losses)
+        loss = sum(loss_list)
+        loss.backward()
+        opt.step()
+        sched.step()
+        model.clear_gradients()
+        return loss
+
+    for _ in range(args.warmup):
+        last = step()
+    parallel.barrier()
+    dev.sync()
+    dev.prof_reset()
+    if args.shapes:
+        dev.set_option("prof_shapes", 1)
+    dev.prof_enable(True)       # HIP events around every launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    dev.sync()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    dev.prof_enable(False)
+    prof = dev.prof_report()
+    loss_val = float(last)
+
+    # max over ranks
+    if world > 1:
+        import ctypes as C
+        sp, rp = dev.small(1), dev.small(world)
+        dev.h2d(sp, np.array([elapsed], np.float32))
+        dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(1))
+        elapsed = float(dev.d2h(rp, (world,), np.float32).max())
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    voxels_per_step = world * B * S ** 3
+    value = voxels_per_step / (elapsed / args.steps)
+
+    calls = sum(v[0] for k, v in prof.items() if k.startswith("conv_halo_mfma_k5"))
+    kms = sum(v[1] for k, v in prof.items() if k.startswith("conv_halo_mfma_k5"))
+    conv_flops = vnet_conv5_flops(B, S, S, S, ncls) * args.steps
+    achieved = conv_flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    total_kernel_ms = sum(v[1] for v in prof.values())
+    roofline = {"bound": "mfma", "kernel": "conv_halo_mfma_k5", "achieved": round(achieved, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches": calls, "avg_launch_ms": round(kms / max(calls, 1), 4),
+                "kernel_share_of_step": round(kms / max(total_kernel_ms, 1e-9), 4),
+                "step_frac_of_fp32_roofline": round(step_flops_per_sample() * B * (S / 128.0) ** 3 / (ms_per_step * 1e-3)
+                                                    / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    out = {"metric": "3D-voxels/sec fwd+bwd, VNet 128^3 fp32", "value": round(value, 1), "unit": "voxels/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes (BASELINE configs[%d])"
+                      % (S, S, S, B, 1 if world == 1 else 2),
+                      "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
+                      "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": True},
+           "final_loss": round(loss_val, 6), "roofline": roofline}
+    if args.profile_out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)) or ".", exist_ok=True)
+        with open(args.profile_out, "w") as f:
+            f.write("# per-kernel HIP-event time over the timed region (%d steps)\n# tag\tcalls\ttotal_ms\tavg_ms\tshare\n"
+                    % args.steps)
+            for tag, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+                f.write("%s\t%d\t%.3f\t%.4f\t%.4f\n" % (tag, c, ms, ms / max(c, 1), ms / max(total_kernel_ms, 1e-9)))
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

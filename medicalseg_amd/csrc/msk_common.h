@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,8 @@ struct msk_ctx {
   std::map<std::string, msk_prof_entry> prof_map;
   std::vector<msk_pending_event> prof_pending;
   std::vector<hipEvent_t> event_pool;
+  std::set<std::string> tag_pool;  // interned dynamic tags (pointers stay valid)
+  bool prof_shapes = false;        // append problem shapes to conv tags
   // options
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
@@ -53,6 +56,7 @@ void* msk_workspace(msk_ctx* ctx, size_t bytes);   // returns nullptr on failure
 void* msk_workspace2(msk_ctx* ctx, size_t bytes);
 void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
+const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 
 #define MSK_CHECK_HIP(ctx, expr)                                                        \
   do {                                                                                  \

@@ -146,17 +146,37 @@ wgrad_direct_k(WGrad g, int splits, float* __restrict__ partial /*[split][tap][C
 __global__ void __launch_bounds__(kThreads)
 wgrad_reduce_k(const float* __restrict__ partial, int splits, int taps, int CA, int CB, float* __restrict__ dw,
                int accumulate) {
+  // block = 64 consecutive outputs x 4 split slices: coalesced 256-byte reads of every slab,
+  // 4-way split parallelism + 4 independent accumulators per thread (fixed order: deterministic)
+  __shared__ double sh[4][64];
   const long per = (long)taps * CA * CB;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (long)gridDim.x * blockDim.x) {
-    // idx = (tap*CA + ca)*CB + cb  (cb fastest: coalesced reads of the partial slabs)
-    const int cb = (int)(idx % CB);
-    const long r = idx / CB;
-    const int ca = (int)(r % CA);
-    const int tap = (int)(r / CA);
-    double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += partial[(long)k * per + idx];
-    float* o = dw + ((long)cb * CA + ca) * taps + tap;
-    *o = accumulate ? *o + (float)s : (float)s;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  for (long base = (long)blockIdx.x * 64; base < per; base += (long)gridDim.x * 64) {
+    const long idx = base + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (idx < per) {
+      int k = slice;
+      for (; k + 12 < splits; k += 16) {
+        s0 += partial[(long)k * per + idx];
+        s1 += partial[(long)(k + 4) * per + idx];
+        s2 += partial[(long)(k + 8) * per + idx];
+        s3 += partial[(long)(k + 12) * per + idx];
+      }
+      for (; k < splits; k += 4) s0 += partial[(long)k * per + idx];
+    }
+    sh[slice][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && idx < per) {
+      const double s = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+      // idx = (tap*CA + ca)*CB + cb
+      const int cb = (int)(idx % CB);
+      const long r = idx / CB;
+      const int ca = (int)(r % CA);
+      const int tap = (int)(r / CA);
+      float* o = dw + ((long)cb * CA + ca) * taps + tap;
+      *o = accumulate ? *o + (float)s : (float)s;
+    }
+    __syncthreads();
   }
 }
 
@@ -202,6 +222,11 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
   if (!wp) return -1;
   if (msk_pack_weights(ctx, w, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 0, g.CK, g.CN, 0, 0, wp) != 0) return -1;
   const long total = (long)g.N * g.DD * g.DH * g.DW * g.CN;
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,k=%dx%dx%d,dst=%dx%dx%dx%d]", tag, g.CK, g.CN, g.kd, g.kh, g.kw, g.N, g.DD, g.DH, g.DW);
+    tag = msk_intern_tag(ctx, buf);
+  }
   msk_launch_scope ls(ctx, tag);
   hipLaunchKernelGGL(gconv_direct_k, dim3(grid_for(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp);
   MSK_LAUNCH_CHECK(ctx);
@@ -252,7 +277,9 @@ int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, i
                      int accumulate) {
   const long per = (long)taps * CA * CB;
   msk_launch_scope ls(ctx, "wgrad_reduce");
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3(grid_for(per, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, partial, splits,
+  long rblocks = (per + 63) / 64;
+  if (rblocks > (long)ctx->num_cu * 32) rblocks = (long)ctx->num_cu * 32;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)rblocks), dim3(kThreads), 0, ctx->stream, partial, splits,
                      taps, CA, CB, dw, accumulate);
   MSK_LAUNCH_CHECK(ctx);
   return 0;

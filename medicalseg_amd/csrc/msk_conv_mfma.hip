@@ -162,6 +162,125 @@ __global__ void __launch_bounds__(256, 2) conv_halo_mfma_k(HaloArgs a) {
   }
 }
 
+// Same halo staging, VALU inner loop: for layers with a tiny channel count on one side
+// (in_tr 1->16, out_tr 32->ncls and its data gradient ncls->32) a 32x32 MFMA tile would be
+// mostly padding (10x waste at ncls=3).  fp32 VALU FMA has the same 64 FLOP/clk/SIMD peak as
+// the fp32 MFMA, so one thread per output voxel with CN accumulators, the input quad from LDS
+// (conflict-free ds_read_b128) and the weights as wave-uniform scalar loads runs these layers
+// at their useful FLOP count.
+template <int TD, int TH, int TW, int KS, int CK, int CN>
+__global__ void __launch_bounds__(256, 2) conv_halo_valu_k(HaloArgs a, const float* __restrict__ wp /*[tap][CK][CN]*/) {
+  constexpr int P = KS / 2;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
+  constexpr int NV = HD * HH * HW;
+  constexpr int NVP = NV | 1;
+  constexpr int KC = (CK + 7) / 8;
+  static_assert(TD * TH * TW == 256, "one thread per output voxel");
+  __shared__ float4 lds[2 * NVP];
+
+  const int tid = threadIdx.x;
+  int tile = xcd_remap(blockIdx.x, a.nblk);
+  const int twi = tile % a.tiles_w;
+  tile /= a.tiles_w;
+  const int thi = tile % a.tiles_h;
+  tile /= a.tiles_h;
+  const int tdi = tile % a.tiles_d;
+  const int n = tile / a.tiles_d;
+  const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+  const int dz = tid / (TH * TW), hy = (tid / TW) % TH, wx = tid % TW;
+  const int base = (dz * HH + hy) * HW + wx;
+
+  float acc[CN];
+#pragma unroll
+  for (int j = 0; j < CN; ++j) acc[j] = 0.f;
+
+#pragma unroll 1
+  for (int kc = 0; kc < KC; ++kc) {
+    __syncthreads();
+    for (int it = tid; it < NV * 2; it += 256) {
+      const int hv = it >> 1, q = it & 1;
+      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c0 = kc * 8 + q * 4;
+      if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < CK) {
+        const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+        if (a.vec) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (c0 + 1 < CK) v.y = p[1];
+          if (c0 + 2 < CK) v.z = p[2];
+          if (c0 + 3 < CK) v.w = p[3];
+        }
+      }
+      lds[q * NVP + hv] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c0 = kc * 8 + q * 4;
+      if (c0 >= CK) break;
+#pragma unroll 1
+      for (int rr = 0; rr < KS * KS; ++rr) {
+        const int rowoff = ((rr / KS) * HH + (rr % KS)) * HW;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const float4 av = lds[q * NVP + base + rowoff + kw];
+          const float* w = wp + ((long)(rr * KS + kw) * CK + c0) * CN;  // wave-uniform -> scalar loads
+          const float xs[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c0 + c < CK) {
+#pragma unroll
+              for (int j = 0; j < CN; ++j) acc[j] = fmaf(xs[c], w[c * CN + j], acc[j]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const int gd = d0 + dz, gh = h0 + hy, gw = w0 + wx;
+  if (gd < a.D && gh < a.H && gw < a.W) {
+    float* o = a.dst + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.dld;
+#pragma unroll
+    for (int j = 0; j < CN; ++j) {
+      float v = acc[j] + (a.bias ? a.bias[j] : 0.f);
+      if (a.accumulate) v += o[j];
+      o[j] = v;
+    }
+  }
+}
+
+template <int KS, int CK, int CN>
+int launch_halo_valu(msk_ctx* ctx, HaloArgs& a, const float* wp) {
+  // one thread per voxel: tiles of 256 voxels
+  const int TW = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : 8);
+  const int TD = TW == 8 ? 4 : 2, TH = TW == 32 ? 4 : 8;
+  a.tiles_d = msk_cdiv(a.D, TD);
+  a.tiles_h = msk_cdiv(a.H, TH);
+  a.tiles_w = msk_cdiv(a.W, TW);
+  const long nblk = (long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+  if (nblk > 0x7fffffff) return msk_fail(ctx, __FILE__, __LINE__, "conv_halo_valu", "grid too large");
+  a.nblk = (int)nblk;
+  const char* tag = "conv_halo_valu";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "conv_halo_valu[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", CK, CN, a.N, a.D, a.H, a.W, a.accumulate);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
+  if (TW == 32)
+    hipLaunchKernelGGL((conv_halo_valu_k<2, 4, 32, KS, CK, CN>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, a, wp);
+  else if (TW == 16)
+    hipLaunchKernelGGL((conv_halo_valu_k<2, 8, 16, KS, CK, CN>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, a, wp);
+  else
+    hipLaunchKernelGGL((conv_halo_valu_k<4, 8, 8, KS, CK, CN>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, a, wp);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 template <int TD, int TH, int TW, int KS>
 int launch_halo(msk_ctx* ctx, HaloArgs& a, int ntiles_n) {
   a.tiles_d = msk_cdiv(a.D, TD);
@@ -170,7 +289,13 @@ int launch_halo(msk_ctx* ctx, HaloArgs& a, int ntiles_n) {
   const long nblk = (long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
   if (nblk > 0x7fffffff) return msk_fail(ctx, __FILE__, __LINE__, "conv_halo", "grid too large");
   a.nblk = (int)nblk;
-  msk_launch_scope ls(ctx, KS == 5 ? "conv_halo_mfma_k5" : "conv_halo_mfma_k3");
+  const char* tag = KS == 5 ? "conv_halo_mfma_k5" : "conv_halo_mfma_k3";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", tag, a.CK, a.CN, a.N, a.D, a.H, a.W, a.accumulate);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
   hipLaunchKernelGGL((conv_halo_mfma_k<TD, TH, TW, KS>), dim3((unsigned)nblk, ntiles_n), dim3(256), 0, ctx->stream, a);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
@@ -179,8 +304,45 @@ int launch_halo(msk_ctx* ctx, HaloArgs& a, int ntiles_n) {
 // ---------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------
-template <int KW>
-__global__ void __launch_bounds__(256, 2) wgrad_mfma_k(WGrad g, int splits, float* __restrict__ partial) {
+// All operand loads are raw buffer loads: a 32-bit byte offset per lane and the hardware
+// range check (offset >= num_records -> 0) replace every bounds branch, so the K loop is
+// straight-line code: offsets -> loads (next step) -> MFMAs (this step).
+constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+struct VoxCursor {  // (n, d, h, w) of a linear voxel index, advanced without divisions
+  int n, d, h, w;
+  __device__ __forceinline__ void init(long m, int D, int H, int W) {
+    w = (int)(m % W);
+    h = (int)((m / W) % H);
+    d = (int)((m / ((long)W * H)) % D);
+    n = (int)(m / ((long)W * H * D));
+  }
+  __device__ __forceinline__ void wrap(int D, int H, int W) {
+    if (w >= W) {
+      w -= W;
+      if (++h >= H) {
+        h = 0;
+        if (++d >= D) {
+          d = 0;
+          ++n;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void advance2(int D, int H, int W) {
+    w += 2;
+    wrap(D, H, W);
+    wrap(D, H, W);  // W == 1 needs two carries
+  }
+};
+
+template <int KW, int U>
+__global__ void __launch_bounds__(256, 2)
+wgrad_mfma_k(WGrad g, int splits, float* __restrict__ partial, unsigned a_bytes, unsigned b_bytes) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int ca_tiles = (g.CA + 31) >> 5, cb_tiles = (g.CB + 31) >> 5;
@@ -202,6 +364,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_k(WGrad g, int splits, floa
 
   const int ca = cat * 32 + li, cb = cbt * 32 + li;
   const bool ca_ok = ca < g.CA, cb_ok = cb < g.CB;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
 
   f32x16 acc[KW];
 #pragma unroll
@@ -209,49 +373,48 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_k(WGrad g, int splits, floa
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-  // coordinates of this lane-half's first voxel
+  VoxCursor c;
   long m = m0 + lh;
-  int ow = (int)(m % g.BW);
-  int oh = (int)((m / g.BW) % g.BH);
-  int od = (int)((m / ((long)g.BW * g.BH)) % g.BD);
-  int n = (int)(m / ((long)g.BW * g.BH * g.BD));
+  c.init(m, g.BD, g.BH, g.BW);
 
-  // software pipeline: operands of step s+1 are in flight while step s's MFMAs issue
-  float av_n[KW], bv_n;
-  auto load_step = [&](long mm) {
-    const bool live = mm < m1;
-    const int id = od * g.sd - g.pd + kd, ih = oh * g.sh - g.ph + kh;
-    const bool rowok = live && id >= 0 && id < g.AD && ih >= 0 && ih < g.AH;
-    const float* arow = g.A + ((((long)n * g.AD + id) * g.AH + ih) * g.AW) * g.ald + ca;
-    const int iw0 = ow * g.sw - g.pw;
+  // Batches of U steps: all (KW+1)*U loads of the NEXT batch are issued before the KW*U MFMAs
+  // of the current one, so each wave has U*KW*64 cycles of matrix work per memory round trip
+  // (with U = 1 the loop ran at min(1, 4 waves * 320 cycles / load latency) ~ 45% of peak).
+  float av_n[U][KW], bv_n[U];
+  auto load_batch = [&](long mm) {  // loads steps mm, mm+2, ...; leaves the cursor after the batch
 #pragma unroll
-    for (int k = 0; k < KW; ++k) {
-      const int iw = iw0 + k;
-      av_n[k] = (rowok && ca_ok && iw >= 0 && iw < g.AW) ? arow[(long)iw * g.ald] : 0.f;
-    }
-    bv_n = (live && cb_ok) ? g.B[mm * g.bld + cb] : 0.f;
-  };
-  load_step(m);
-  for (; m - lh < m1; m += 2) {  // uniform trip count across the wave
-    float av[KW];
+    for (int u = 0; u < U; ++u) {
+      const long mu = mm + 2 * u;
+      const bool live = mu < m1;
+      const int id = c.d * g.sd - g.pd + kd, ih = c.h * g.sh - g.ph + kh;
+      const bool rowok = live && ca_ok && (unsigned)id < (unsigned)g.AD && (unsigned)ih < (unsigned)g.AH;
+      const int rowbase = ((c.n * g.AD + id) * g.AH + ih) * g.AW;  // voxel index of (n, id, ih, 0)
+      const int iw0 = c.w * g.sw - g.pw;
 #pragma unroll
-    for (int k = 0; k < KW; ++k) av[k] = av_n[k];
-    const float bv = bv_n;
-    // advance two voxels and issue the next step's loads
-    ow += 2;
-    while (ow >= g.BW) {
-      ow -= g.BW;
-      if (++oh >= g.BH) {
-        oh = 0;
-        if (++od >= g.BD) {
-          od = 0;
-          ++n;
-        }
+      for (int k = 0; k < KW; ++k) {
+        const int iw = iw0 + k;
+        const unsigned off = ((unsigned)(rowbase + iw) * (unsigned)g.ald + (unsigned)ca) * 4u;
+        av_n[u][k] = buf_load(ra, (rowok && (unsigned)iw < (unsigned)g.AW) ? off : kOOB);
       }
+      const unsigned offb = ((unsigned)mu * (unsigned)g.bld + (unsigned)cb) * 4u;
+      bv_n[u] = buf_load(rb, (live && cb_ok) ? offb : kOOB);
+      c.advance2(g.BD, g.BH, g.BW);
     }
-    load_step(m + 2);
+  };
+  load_batch(m);
+  for (; m - lh < m1; m += 2 * U) {  // uniform trip count across the wave
+    float av[U][KW], bv[U];
 #pragma unroll
-    for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv, acc[k], 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int k = 0; k < KW; ++k) av[u][k] = av_n[u][k];
+      bv[u] = bv_n[u];
+    }
+    load_batch(m + 2 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < KW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][k], bv[u], acc[k], 0, 0, 0);
   }
 
   const int taps = g.kd * g.kh * g.kw;
@@ -269,15 +432,157 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_k(WGrad g, int splits, floa
   }
 }
 
+// Folded-taps variant for layers with a tiny channel count on one side (stride 1, same grid):
+//   FOLD_ROWS (in_tr, CA small): MFMA rows = (tap, ca) pairs, cols = cb.
+//        dW[cb][ca][tap] = sum_m A[m + tap - p][ca] * B[m][cb]     (A gathered, B streamed)
+//   !FOLD_ROWS (out_tr, CB small): rows = ca, MFMA cols = (tap, cb) pairs.
+//        dW[cb][ca][tap] = sum_u A[u][ca] * B[u - tap + p][cb]     (A streamed, B gathered)
+// so the padded MFMA dimension holds useful (tap, channel) pairs instead of zeros.
+template <bool FOLD_ROWS, int NT>
+__global__ void __launch_bounds__(256, 2)
+wgrad_fold_mfma_k(WGrad g, int splits, float* __restrict__ partial, unsigned a_bytes, unsigned b_bytes, int groups) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int CF = FOLD_ROWS ? g.CA : g.CB;  // folded (small) channel count
+  const int CS = FOLD_ROWS ? g.CB : g.CA;  // streamed channel count
+  const int taps = g.kd * g.kh * g.kw;
+  const int Q = taps * CF;
+  int b = blockIdx.x;
+  const int grp = b % groups;  // group of NT folded tiles
+  const int st = b / groups;   // tile of 32 streamed channels
+  const int split = blockIdx.y * 4 + wave;
+  if (split >= splits) return;
+
+  // stride-1 same-size grids: one voxel index space for both tensors
+  const int D = g.BD, H = g.BH, W = g.BW;
+  const long M = (long)g.N * D * H * W;
+  long per = (M + splits - 1) / splits;
+  per = (per + 1) & ~1L;
+  const long m0 = (long)split * per;
+  long m1 = m0 + per;
+  if (m1 > M) m1 = M;
+
+  const int cs = st * 32 + li;
+  const bool cs_ok = cs < CS;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = FOLD_ROWS ? ra : rb;   // gathered tensor
+  const __amdgpu_buffer_rsrc_t rs = FOLD_ROWS ? rb : ra;   // streamed tensor
+  const int ldf = FOLD_ROWS ? g.ald : g.bld, lds_ = FOLD_ROWS ? g.bld : g.ald;
+
+  // per-lane folded pairs: voxel displacement (ed, eh, ew), linear delta, channel
+  int ed[NT], eh[NT], ew[NT], delta[NT], cf[NT];
+  bool qok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int q = (grp * NT + t) * 32 + li;
+    qok[t] = q < Q;
+    const int tap = qok[t] ? q / CF : 0;
+    cf[t] = qok[t] ? q % CF : 0;
+    const int sgn = FOLD_ROWS ? 1 : -1;
+    ed[t] = sgn * (tap / (g.kh * g.kw) - g.pd);
+    eh[t] = sgn * ((tap / g.kw) % g.kh - g.ph);
+    ew[t] = sgn * (tap % g.kw - g.pw);
+    delta[t] = (ed[t] * H + eh[t]) * W + ew[t];
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  VoxCursor c;
+  long m = m0 + lh;
+  c.init(m, D, H, W);
+  float fv_n[NT], sv_n;
+  auto load_step = [&](long mm) {
+    const bool live = mm < m1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bool ok = live && qok[t] && (unsigned)(c.d + ed[t]) < (unsigned)D &&
+                      (unsigned)(c.h + eh[t]) < (unsigned)H && (unsigned)(c.w + ew[t]) < (unsigned)W;
+      const unsigned off = ((unsigned)((int)mm + delta[t]) * (unsigned)ldf + (unsigned)cf[t]) * 4u;
+      fv_n[t] = buf_load(rf, ok ? off : kOOB);
+    }
+    const unsigned offs = ((unsigned)mm * (unsigned)lds_ + (unsigned)cs) * 4u;
+    sv_n = buf_load(rs, (live && cs_ok) ? offs : kOOB);
+  };
+  load_step(m);
+  for (; m - lh < m1; m += 2) {
+    float fv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fv[t] = fv_n[t];
+    const float sv = sv_n;
+    c.advance2(D, H, W);
+    load_step(m + 2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (FOLD_ROWS)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fv[t], sv, acc[t], 0, 0, 0);  // rows = pairs, cols = cb
+      else
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, fv[t], acc[t], 0, 0, 0);  // rows = ca, cols = pairs
+    }
+  }
+
+  // D[row][col]: row = (j&3) + 8*(j>>2) + 4*lh, col = li
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
+      int q, cstream;
+      if constexpr (FOLD_ROWS) {
+        q = (grp * NT + t) * 32 + row;
+        cstream = st * 32 + li;
+      } else {
+        q = (grp * NT + t) * 32 + li;
+        cstream = st * 32 + row;
+      }
+      if (q < Q && cstream < CS) {
+        const int tap = q / CF, cfold = q % CF;
+        const int oca = FOLD_ROWS ? cfold : cstream, ocb = FOLD_ROWS ? cstream : cfold;
+        partial[(((long)split * taps + tap) * g.CA + oca) * g.CB + ocb] = acc[t][j];
+      }
+    }
+  }
+}
+
+const char* wgrad_tag(msk_ctx* ctx, const char* base, const WGrad& g, int splits) {
+  if (!(ctx->prof && ctx->prof_shapes)) return base;
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%s[ca=%d,cb=%d,k=%dx%dx%d,M=%ld,splits=%d]", base, g.CA, g.CB, g.kd, g.kh, g.kw,
+           (long)g.N * g.BD * g.BH * g.BW, splits);
+  return msk_intern_tag(ctx, buf);
+}
+
 template <int KW>
-int launch_wgrad(msk_ctx* ctx, const WGrad& g, int splits, float* partial) {
+int launch_wgrad(msk_ctx* ctx, const WGrad& g, int splits, float* partial, unsigned a_bytes, unsigned b_bytes) {
   const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
   const int rows = g.kd * g.kh;
-  msk_launch_scope ls(ctx, "wgrad_mfma");
-  hipLaunchKernelGGL((wgrad_mfma_k<KW>), dim3(rows * ca_tiles * cb_tiles, (splits + 3) / 4), dim3(256), 0, ctx->stream,
-                     g, splits, partial);
+  msk_launch_scope ls(ctx, wgrad_tag(ctx, "wgrad_mfma", g, splits));
+  hipLaunchKernelGGL((wgrad_mfma_k<KW, (KW >= 4 ? 4 : 8)>), dim3(rows * ca_tiles * cb_tiles, (splits + 3) / 4), dim3(256), 0, ctx->stream,
+                     g, splits, partial, a_bytes, b_bytes);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+long pick_splits(long tasks, long M, size_t per_bytes) {
+  // ~3 rounds of (256 CUs x 16 resident waves): short waves keep the last-round tail small
+  // (exactly 1025 blocks on 1024 slots doubled the kernel time in the first measurement)
+  long splits = (12288 + tasks - 1) / tasks;
+  const long maxs = M / 256 > 0 ? M / 256 : 1;
+  if (splits > maxs) splits = maxs;
+  if (splits < 1) splits = 1;
+  splits = (splits + 3) & ~3L;
+  while (splits > 4 && splits * per_bytes > ((size_t)1 << 30)) splits -= 4;  // partial slab <= 1 GiB
+  return splits;
+}
+
+int used_splits(long M, long splits) {
+  long per_vox = (M + splits - 1) / splits;
+  per_vox = (per_vox + 1) & ~1L;
+  return (int)((M + per_vox - 1) / per_vox);
 }
 
 }  // namespace
@@ -292,6 +597,41 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   // With stride 1 and p = k/2 the transposed gather equals a forward gather with flipped taps.
   const int flip = g.transposed ? 1 : 0;
   const int taps = ks * ks * ks;
+
+  // tiny-channel 5^3 layers of VNet: VALU halo kernel (useful FLOPs only)
+  const bool valu_in = ks == 5 && g.CK == 1 && g.CN == 16;                 // in_tr.conv1 forward
+  const bool valu_out = ks == 5 && g.CK == 32 && g.CN >= 1 && g.CN <= 4;   // out_tr.conv1 forward
+  const bool valu_outT = ks == 5 && g.CN == 32 && g.CK >= 1 && g.CK <= 4;  // out_tr.conv1 data gradient
+  if (valu_in || valu_out || valu_outT) {
+    float* wp = (float*)msk_workspace2(ctx, (size_t)taps * g.CK * g.CN * sizeof(float));
+    if (!wp) return -1;
+    if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, flip, ks, ks, ks, 0, g.CK, g.CN, 0, 0, wp) != 0) return -1;
+    HaloArgs a{};
+    a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
+    a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW;
+    a.CK = g.CK; a.CN = g.CN;
+    a.bias = g.bias; a.accumulate = g.accumulate;
+    a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
+    int rc = 0;
+    if (valu_in) rc = launch_halo_valu<5, 1, 16>(ctx, a, wp);
+    else if (valu_out) {
+      switch (g.CN) {
+        case 1: rc = launch_halo_valu<5, 32, 1>(ctx, a, wp); break;
+        case 2: rc = launch_halo_valu<5, 32, 2>(ctx, a, wp); break;
+        case 3: rc = launch_halo_valu<5, 32, 3>(ctx, a, wp); break;
+        default: rc = launch_halo_valu<5, 32, 4>(ctx, a, wp); break;
+      }
+    } else {
+      switch (g.CK) {
+        case 1: rc = launch_halo_valu<5, 1, 32>(ctx, a, wp); break;
+        case 2: rc = launch_halo_valu<5, 2, 32>(ctx, a, wp); break;
+        case 3: rc = launch_halo_valu<5, 3, 32>(ctx, a, wp); break;
+        default: rc = launch_halo_valu<5, 4, 32>(ctx, a, wp); break;
+      }
+    }
+    return rc == 0 ? 1 : rc;
+  }
+
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
   const size_t wbytes = (size_t)taps * KC * 2 * npad * 4 * sizeof(float);
@@ -322,34 +662,56 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
 }
 
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g) {
-  if (g.kw < 1 || g.kw > 5) return 0;
   const int taps = g.kd * g.kh * g.kw;
   const long M = (long)g.N * g.BD * g.BH * g.BW;
-  const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
-  const long tasks = (long)g.kd * g.kh * ca_tiles * cb_tiles;
-  long splits = (4096 + tasks - 1) / tasks;
-  const long maxs = M / 256 > 0 ? M / 256 : 1;
-  if (splits > maxs) splits = maxs;
-  if (splits < 1) splits = 1;
-  splits = (splits + 3) & ~3L;
-  // keep the partial slab below 1 GiB
+  // 32-bit byte offsets inside the kernels: both tensors must stay below 4 GiB
+  const size_t abytes = (size_t)g.N * g.AD * g.AH * g.AW * g.ald * sizeof(float);
+  const size_t bbytes = (size_t)M * g.bld * sizeof(float);
+  if (abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull) return 0;
   const size_t per = (size_t)taps * g.CA * g.CB * sizeof(float);
-  while (splits > 4 && splits * per > ((size_t)1 << 30)) splits -= 4;
+
+  // tiny channel count on one side + stride-1 same grid -> fold the taps into the MFMA tile
+  const bool same_grid = g.sd == 1 && g.sh == 1 && g.sw == 1 && g.AD == g.BD && g.AH == g.BH && g.AW == g.BW;
+  const bool fold_rows = same_grid && taps > 1 && g.CA <= 8 && g.CA < g.CB;
+  const bool fold_cols = same_grid && taps > 1 && g.CB <= 8 && !fold_rows;
+  if (fold_rows || fold_cols) {
+    constexpr int NT = 4;
+    const int CF = fold_rows ? g.CA : g.CB, CS = fold_rows ? g.CB : g.CA;
+    const int tiles = (taps * CF + 31) / 32;
+    const int groups = (tiles + NT - 1) / NT;
+    const int stiles = (CS + 31) / 32;
+    const long splits = pick_splits((long)groups * stiles, M, per);
+    float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
+    if (!partial) return -1;
+    {
+      msk_launch_scope ls(ctx, wgrad_tag(ctx, fold_rows ? "wgrad_fold_rows_mfma" : "wgrad_fold_cols_mfma", g, (int)splits));
+      dim3 grid(groups * stiles, (unsigned)((splits + 3) / 4));
+      if (fold_rows)
+        hipLaunchKernelGGL((wgrad_fold_mfma_k<true, NT>), grid, dim3(256), 0, ctx->stream, g, (int)splits, partial,
+                           (unsigned)abytes, (unsigned)bbytes, groups);
+      else
+        hipLaunchKernelGGL((wgrad_fold_mfma_k<false, NT>), grid, dim3(256), 0, ctx->stream, g, (int)splits, partial,
+                           (unsigned)abytes, (unsigned)bbytes, groups);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    int rc = msk_wgrad_reduce(ctx, partial, used_splits(M, splits), taps, g.CA, g.CB, g.dw, g.accumulate);
+    return rc == 0 ? 1 : rc;
+  }
+
+  if (g.kw < 1 || g.kw > 5) return 0;
+  const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
+  const long splits = pick_splits((long)g.kd * g.kh * ca_tiles * cb_tiles, M, per);
   float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
   if (!partial) return -1;
   int rc;
   switch (g.kw) {
-    case 1: rc = launch_wgrad<1>(ctx, g, (int)splits, partial); break;
-    case 2: rc = launch_wgrad<2>(ctx, g, (int)splits, partial); break;
-    case 3: rc = launch_wgrad<3>(ctx, g, (int)splits, partial); break;
-    case 4: rc = launch_wgrad<4>(ctx, g, (int)splits, partial); break;
-    default: rc = launch_wgrad<5>(ctx, g, (int)splits, partial); break;
+    case 1: rc = launch_wgrad<1>(ctx, g, (int)splits, partial, (unsigned)abytes, (unsigned)bbytes); break;
+    case 2: rc = launch_wgrad<2>(ctx, g, (int)splits, partial, (unsigned)abytes, (unsigned)bbytes); break;
+    case 3: rc = launch_wgrad<3>(ctx, g, (int)splits, partial, (unsigned)abytes, (unsigned)bbytes); break;
+    case 4: rc = launch_wgrad<4>(ctx, g, (int)splits, partial, (unsigned)abytes, (unsigned)bbytes); break;
+    default: rc = launch_wgrad<5>(ctx, g, (int)splits, partial, (unsigned)abytes, (unsigned)bbytes); break;
   }
   if (rc != 0) return rc;
-  // splits whose voxel range is empty wrote nothing: count only the populated ones
-  long per_vox = (M + splits - 1) / splits;
-  per_vox = (per_vox + 1) & ~1L;
-  const int used = (int)((M + per_vox - 1) / per_vox);
-  rc = msk_wgrad_reduce(ctx, partial, used, taps, g.CA, g.CB, g.dw, g.accumulate);
+  rc = msk_wgrad_reduce(ctx, partial, used_splits(M, splits), taps, g.CA, g.CB, g.dw, g.accumulate);
   return rc == 0 ? 1 : rc;
 }

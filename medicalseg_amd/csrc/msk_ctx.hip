@@ -58,6 +58,8 @@ static void drain_prof(msk_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+const char* msk_intern_tag(msk_ctx* ctx, const std::string& s) { return ctx->tag_pool.insert(s).first->c_str(); }
+
 void msk_prof_begin(msk_ctx* ctx, const char* tag) {
   msk_pending_event pe;
   pe.a = get_event(ctx);
@@ -221,6 +223,10 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len) {
 int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   if (strcmp(key, "conv_impl") == 0) {
     ctx->conv_impl = value;
+    return 0;
+  }
+  if (strcmp(key, "prof_shapes") == 0) {
+    ctx->prof_shapes = value != 0;
     return 0;
   }
   if (strcmp(key, "poison_scratch") == 0) {  // debug: fill (re)allocated scratch with this byte; -1 = off

@@ -96,25 +96,38 @@ bn_stats_partial(const float* __restrict__ x, long voxels, int C, int ld, int CB
   }
 }
 
-__global__ void bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB,
-                               float* __restrict__ stats /*[2C]*/) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  int cb = c / CB, cl = c % CB;
+// One block per channel: 64 lanes stride over the nb block partials (Chan merge in double),
+// then a fixed-order tree over the 64 lane results -> deterministic and ~nb/64 serial steps.
+__global__ void __launch_bounds__(64)
+bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ stats /*[2C]*/) {
+  __shared__ double sn[64], sm[64], s2[64];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int cb = c / CB, cl = c % CB;
   double n = 0, mean = 0, m2 = 0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = t; b < nb; b += 64) {
     const float* p = partial + (((long)cb * nb + b) * CB + cl) * 3;
-    double bn = p[0];
+    const double bn = p[0];
     if (bn == 0) continue;
-    double d = (double)p[1] - mean;
-    double tot = n + bn;
-    double f = bn / tot;
+    const double d = (double)p[1] - mean, tot = n + bn, f = bn / tot;
     m2 = m2 + (double)p[2] + d * d * n * f;
     mean = mean + d * f;
     n = tot;
   }
-  stats[c] = (float)mean;
-  stats[C + c] = (float)m2;
+  sn[t] = n; sm[t] = mean; s2[t] = m2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (t < s && sn[t + s] > 0) {
+      const double bn = sn[t + s], d = sm[t + s] - sm[t], tot = sn[t] + bn, f = bn / tot;
+      s2[t] = s2[t] + s2[t + s] + d * d * sn[t] * f;
+      sm[t] = sm[t] + d * f;
+      sn[t] = tot;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    stats[c] = (float)sm[0];
+    stats[C + c] = (float)s2[0];
+  }
 }
 
 __global__ void bn_finalize_k(const float* __restrict__ gathered, int world, double cnt, int C,
@@ -279,15 +292,24 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
   }
 }
 
-__global__ void sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq,
-                             float* __restrict__ sums /*[nq][C]*/, int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq * C) return;
-  int q = i / C, c = i % C;
-  int cb = c / CB, cl = c % CB;
+// One block per output (q, c): 64 lanes stride over the nb block partials in double, fixed-order
+// tree over the lanes (deterministic).
+__global__ void __launch_bounds__(64)
+sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq, float* __restrict__ sums /*[nq][C]*/,
+             int accumulate) {
+  __shared__ double sh[64];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int q = i / C, c = i % C;
+  const int cb = c / CB, cl = c % CB;
   double s = 0;
-  for (int b = 0; b < nb; ++b) s += partial[(((long)cb * nb + b) * nq + q) * CB + cl];
-  sums[i] = accumulate ? sums[i] + (float)s : (float)s;
+  for (int b = t; b < nb; b += 64) s += partial[(((long)cb * nb + b) * nq + q) * CB + cl];
+  sh[t] = s;
+  __syncthreads();
+  for (int k = 32; k > 0; k >>= 1) {
+    if (t < k) sh[t] += sh[t + k];
+    __syncthreads();
+  }
+  if (t == 0) sums[i] = accumulate ? sums[i] + (float)sh[0] : (float)sh[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -536,7 +558,7 @@ int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
   }
   {
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(msk_cdiv(x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local);
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 0;
@@ -604,7 +626,7 @@ int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, co
   }
   {
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(msk_cdiv(3 * x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c,
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c,
                        g.CB, 3, sums, 0);
     MSK_LAUNCH_CHECK(ctx);
   }
@@ -691,7 +713,7 @@ int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
   }
   {
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(msk_cdiv(x.c, 64)), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
+    hipLaunchKernelGGL(sums_merge_k, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
                        out, accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
