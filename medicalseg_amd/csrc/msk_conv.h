@@ -44,6 +44,7 @@ int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int s
 // MFMA kernels (msk_conv_mfma.hip).  Return 1 if the problem was handled, 0 if not eligible,
 // <0 on error.
 int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
 
 // split-K reducer shared by both wgrad implementations:

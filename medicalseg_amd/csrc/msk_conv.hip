@@ -214,6 +214,9 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
     int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
+    r = msk_gconv_gather_mfma(ctx, g, w, A, B, swap);
+    if (r < 0) return r;
+    if (r == 1) return 0;
   }
   // reference path
   g.flip = 0;

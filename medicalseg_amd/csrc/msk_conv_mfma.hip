@@ -432,6 +432,313 @@ wgrad_mfma_k(WGrad g, int splits, float* __restrict__ partial, unsigned a_bytes,
   }
 }
 
+// ---------------------------------------------------------------------------
+// General gather convolution on MFMA, operands straight from global memory.
+// Used for the strided 2x2x2 (or anisotropic) down/up convolutions and the 1x1x1 head:
+// HBM-bound layers (arithmetic intensity ~13-20 flop/B) where an LDS halo buys nothing --
+// every input voxel is used by exactly one output voxel when k == s.
+//   forward mode    spos = dpos*s - p + k
+//   transposed mode spos = (dpos + p - k)/s when divisible: dst voxels are tiled per PARITY
+//                   CLASS (dpos mod s), so inside a tile the set of contributing taps is
+//                   uniform and no MFMA work is spent on masked taps.
+// M = 32 dst voxels per wave, N = NR x 32 output channels in registers, K = taps x channels
+// in chunks of 8 with the same packed weights as the halo kernel.
+template <int NR>
+__global__ void __launch_bounds__(256)
+gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned src_bytes, int vec,
+                    int tiles_max) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  // parity class of this block (forward mode: a single class with "stride" 1)
+  const int cs_d = g.transposed ? g.sd : 1, cs_h = g.transposed ? g.sh : 1, cs_w = g.transposed ? g.sw : 1;
+  int cls = blockIdx.y;
+  const int rw = cls % cs_w;
+  cls /= cs_w;
+  const int rh = cls % cs_h;
+  const int rd = cls / cs_h;
+  // coarse grid of this class: dpos = q*cs + r
+  const int QD = (g.DD - rd + cs_d - 1) / cs_d, QH = (g.DH - rh + cs_h - 1) / cs_h, QW = (g.DW - rw + cs_w - 1) / cs_w;
+  const long Mq = (long)g.N * QD * QH * QW;
+  const long m = ((long)blockIdx.x * 4 + wave) * 32 + li;
+  if (((long)blockIdx.x * 4 + wave) * 32 >= Mq || QD <= 0 || QH <= 0 || QW <= 0) return;
+  const bool mok = m < Mq;
+  const long mm = mok ? m : 0;
+  const int qw = (int)(mm % QW), qh = (int)((mm / QW) % QH), qd = (int)((mm / ((long)QW * QH)) % QD);
+  const int n = (int)(mm / ((long)QW * QH * QD));
+  const int od = qd * cs_d + rd, oh = qh * cs_h + rh, ow = qw * cs_w + rw;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, src_bytes, 0x00020000);
+  const int nt0 = blockIdx.z * NR;
+
+  f32x16 acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+
+  const long tapstride = (long)KC * 2 * npad;
+  const float4* wlane = wm + ((long)lh * npad + nt0 * 32 + li);
+  for (int a = 0; a < g.kd; ++a) {
+    int id;
+    if (!g.transposed) {
+      id = od * g.sd - g.pd + a;
+    } else {
+      const int t = od + g.pd - a;
+      if ((rd + g.pd - a) % g.sd != 0) continue;  // uniform over the class
+      id = t >= 0 ? t / g.sd : -1;
+    }
+    for (int b = 0; b < g.kh; ++b) {
+      int ih;
+      if (!g.transposed) {
+        ih = oh * g.sh - g.ph + b;
+      } else {
+        const int t = oh + g.ph - b;
+        if ((rh + g.ph - b) % g.sh != 0) continue;
+        ih = t >= 0 ? t / g.sh : -1;
+      }
+      for (int c = 0; c < g.kw; ++c) {
+        int iw;
+        if (!g.transposed) {
+          iw = ow * g.sw - g.pw + c;
+        } else {
+          const int t = ow + g.pw - c;
+          if ((rw + g.pw - c) % g.sw != 0) continue;
+          iw = t >= 0 ? t / g.sw : -1;
+        }
+        const bool ok = mok && (unsigned)id < (unsigned)g.SD && (unsigned)ih < (unsigned)g.SH && (unsigned)iw < (unsigned)g.SW;
+        const unsigned vbase = (unsigned)(((n * g.SD + id) * g.SH + ih) * g.SW + iw) * (unsigned)g.sld;
+        const int tap = (a * g.kh + b) * g.kw + c;
+        const float4* wt = wlane + (long)tap * tapstride;
+        for (int kc = 0; kc < KC; ++kc) {
+          const int c0 = kc * 8 + lh * 4;
+          float av[4];
+          if (vec) {  // CK % 4 == 0: one validity test per quad (the compiler merges the 4 dwords)
+            const unsigned off = (ok && c0 < g.CK) ? (vbase + (unsigned)c0) * 4u : kOOB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = buf_load(rs, off == kOOB ? kOOB : off + 4u * q);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              av[q] = buf_load(rs, (ok && c0 + q < g.CK) ? (vbase + (unsigned)(c0 + q)) * 4u : kOOB);
+          }
+          float4 bv[NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) bv[r] = wt[(long)kc * 2 * npad + r * 32];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[r].x, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[r].y, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[r].z, acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[r].w, acc[r], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: rows = the tile's 32 dst voxels (decoded per row), cols = output channels
+  const long mbase = ((long)blockIdx.x * 4 + wave) * 32;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int co = (nt0 + r) * 32 + li;
+    if (co >= g.CN) continue;
+    const float bvs = g.bias ? g.bias[co] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
+      const long mr = mbase + row;
+      if (mr < Mq) {
+        const int w_ = (int)(mr % QW), h_ = (int)((mr / QW) % QH), d_ = (int)((mr / ((long)QW * QH)) % QD);
+        const int n_ = (int)(mr / ((long)QW * QH * QD));
+        float* o = g.dst + ((((long)n_ * g.DD + d_ * cs_d + rd) * g.DH + h_ * cs_h + rh) * g.DW + w_ * cs_w + rw) * g.dld + co;
+        float v = acc[r][j] + bvs;
+        if (g.accumulate) v += *o;
+        *o = v;
+      }
+    }
+  }
+  (void)tiles_max;
+}
+
+const char* wgrad_tag(msk_ctx* ctx, const char* base, const WGrad& g, int splits);
+
+// LDS-staged weight gradient for stride-1 'same' convolutions (all 5x5x5 LUConv layers).
+// The global-direct kernel above re-reads every x row 5x per tap-row and thrashes the 32 KiB L1
+// (PMC: MFMA pipe 42% busy, TCP pending-stall dominant).  Here a workgroup of KS waves owns one
+// kd plane of taps (wave = kh, registers = kw): per chunk of R output rows x WS columns it stages
+// the (R+2P) x (WS+2P) x-halo rows and the R x WS dy rows ONCE with coalesced float4 loads, then
+// every MFMA operand is a conflict-free ds_read_b32 (32 lanes = 32 consecutive channels).
+template <int KS, int R, int WS>
+__global__ void __launch_bounds__(256, 3)
+wgrad_lds_mfma_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial) {
+  constexpr int P = KS / 2;
+  constexpr int XR = R + 2 * P, XW = WS + 2 * P;
+  constexpr int NT = 256;
+  // 4 waves (one per SIMD: odd wave counts leave the doubly-loaded SIMD as the occupancy
+  // limiter -- measured 1.2 waves/SIMD with 5-wave workgroups).  The KS*KS taps of the kd plane
+  // are dealt round-robin: wave w owns taps w, w+4, ... (7/6/6/6 for 5x5).
+  constexpr int TPW = (KS * KS + 3) / 4;
+  __shared__ float xs[XR * XW * 32];
+  __shared__ float dys[R * WS * 32];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int ca_tiles = (g.CA + 31) >> 5, cb_tiles = (g.CB + 31) >> 5;
+  int b = blockIdx.x;
+  const int cbt = b % cb_tiles;
+  b /= cb_tiles;
+  const int cat = b % ca_tiles;
+  const int kd = b / ca_tiles;
+  const int split = blockIdx.y;
+  const int D = g.BD, H = g.BH, W = g.BW;
+  const int hblocks = (H + R - 1) / R, wblocks = (W + WS - 1) / WS;
+
+  int toff[TPW];  // LDS float offset of tap j relative to (row r, col 2p)
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = wave + 4 * j;
+    toff[j] = t < KS * KS ? ((t / KS) * XW + (t % KS)) * 32 : 0;
+  }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int k = 0; k < TPW; ++k)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+  const int c_begin = split * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > chunks_total) c_end = chunks_total;
+
+  // Staging: groups of 4 float4 loads in flight per thread, written straight to LDS (the 7x16
+  // accumulator registers leave no room for a whole-chunk register prefetch without spills;
+  // with 3 workgroups per CU another workgroup's MFMAs cover this phase).
+  constexpr int XITEMS = XR * XW * 8, DITEMS = R * WS * 8;
+  auto next_valid = [&](int ch) {  // first chunk >= ch whose input depth d + kd - P is inside the volume
+    while (ch < c_end) {
+      const int d = (ch / (wblocks * hblocks)) % D;
+      if ((unsigned)(d + kd - P) < (unsigned)D) break;
+      ++ch;
+    }
+    return ch;
+  };
+  auto stage = [&](int ch) {
+    int t = ch;
+    const int wb = t % wblocks;
+    t /= wblocks;
+    const int hb = t % hblocks;
+    t /= hblocks;
+    const int d = t % D;
+    const int n = t / D;
+    const int id = d + kd - P;
+    const int h0 = hb * R, w0 = wb * WS;
+    for (int base = 0; base < XITEMS; base += 4 * NT) {
+      float4 tmp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        const int q = it & 7, v = it >> 3;
+        const int row = v / XW, col = v % XW;
+        const int ih = h0 - P + row, iw = w0 - P + col;
+        const int c0 = cat * 32 + q * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
+          val = *reinterpret_cast<const float4*>(g.A + ((((long)n * D + id) * H + ih) * W + iw) * g.ald + c0);
+        tmp[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        if (it < XITEMS) *reinterpret_cast<float4*>(&xs[it * 4]) = tmp[i];  // (v*32 + q*4) == it*4
+      }
+    }
+    for (int base = 0; base < DITEMS; base += 4 * NT) {
+      float4 tmp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        const int q = it & 7, v = it >> 3;
+        const int row = v / WS, col = v % WS;
+        const int oh = h0 + row, ow = w0 + col;
+        const int c0 = cbt * 32 + q * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
+          val = *reinterpret_cast<const float4*>(g.B + ((((long)n * D + d) * H + oh) * W + ow) * g.bld + c0);
+        tmp[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        if (it < DITEMS) *reinterpret_cast<float4*>(&dys[it * 4]) = tmp[i];
+      }
+    }
+  };
+
+  int ch = next_valid(c_begin);
+  while (ch < c_end) {
+    __syncthreads();  // every wave finished reading the previous chunk
+    stage(ch);
+    __syncthreads();
+    const int nxt = next_valid(ch + 1);
+    // ---- MFMA: K runs over the chunk's voxels, 2 per instruction (lane half) ----
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      const float* xrow = &xs[(r * XW + lh) * 32 + li];
+      const float* drow = &dys[(r * WS + lh) * 32 + li];
+#pragma unroll 2
+      for (int p = 0; p < WS / 2; ++p) {
+        const float bv = drow[p * 64];
+        float av[TPW];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) av[k] = xrow[p * 64 + toff[k]];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv, acc[k], 0, 0, 0);
+      }
+    }
+    ch = nxt;
+  }
+
+  const int taps = KS * KS * KS;
+  const int cb = cbt * 32 + li;
+  if (cb < g.CB) {
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int t = wave + 4 * k;
+      if (t >= KS * KS) continue;
+      const int tap = kd * KS * KS + t;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
+        const int oca = cat * 32 + row;
+        if (oca < g.CA) partial[(((long)split * taps + tap) * g.CA + oca) * g.CB + cb] = acc[k][j];
+      }
+    }
+  }
+}
+
+template <int KS, int R, int WS>
+int launch_wgrad_lds(msk_ctx* ctx, const WGrad& g, int num_cu) {
+  const int taps = KS * KS * KS;
+  const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
+  const long chunks = (long)g.N * g.BD * ((g.BH + R - 1) / R) * ((g.BW + WS - 1) / WS);
+  const long tasks = (long)KS * ca_tiles * cb_tiles;
+  // ~3 rounds of 2-3 resident workgroups per CU
+  long splits = ((long)num_cu * 8 + tasks - 1) / tasks;
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  const size_t per = (size_t)taps * g.CA * g.CB * sizeof(float);
+  while (splits > 1 && splits * per > ((size_t)1 << 30)) --splits;
+  const int cps = (int)((chunks + splits - 1) / splits);
+  splits = (chunks + cps - 1) / cps;  // no empty splits
+  float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, wgrad_tag(ctx, "wgrad_lds_mfma", g, (int)splits));
+    hipLaunchKernelGGL((wgrad_lds_mfma_k<KS, R, WS>), dim3((unsigned)tasks, (unsigned)splits), dim3(256), 0,
+                       ctx->stream, g, (int)splits, (int)chunks, cps, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return msk_wgrad_reduce(ctx, partial, (int)splits, taps, g.CA, g.CB, g.dw, g.accumulate);
+}
+
 // Folded-taps variant for layers with a tiny channel count on one side (stride 1, same grid):
 //   FOLD_ROWS (in_tr, CA small): MFMA rows = (tap, ca) pairs, cols = cb.
 //        dW[cb][ca][tap] = sum_m A[m + tap - p][ca] * B[m][cb]     (A gathered, B streamed)
@@ -661,6 +968,48 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   return rc == 0 ? 1 : rc;
 }
 
+int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+  const size_t sbytes = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
+  if (sbytes >= 0xFFFFFFF0ull) return 0;  // 32-bit byte offsets in the kernel
+  const int taps = g.kd * g.kh * g.kw;
+  const int KC = (g.CK + 7) / 8;
+  const int npad = ((g.CN + 31) / 32) * 32;
+  float* wm = (float*)msk_workspace2(ctx, (size_t)taps * KC * 2 * npad * 4 * sizeof(float));
+  if (!wm) return -1;
+  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
+  const int ntn = npad / 32;
+  const int NR = (ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8) ? ntn : 1;
+  const int cs_d = g.transposed ? g.sd : 1, cs_h = g.transposed ? g.sh : 1, cs_w = g.transposed ? g.sw : 1;
+  long tiles_max = 1;
+  for (int rd = 0; rd < cs_d; ++rd)
+    for (int rh = 0; rh < cs_h; ++rh)
+      for (int rw = 0; rw < cs_w; ++rw) {
+        const long QD = (g.DD - rd + cs_d - 1) / cs_d, QH = (g.DH - rh + cs_h - 1) / cs_h, QW = (g.DW - rw + cs_w - 1) / cs_w;
+        if (QD <= 0 || QH <= 0 || QW <= 0) continue;
+        const long t = ((long)g.N * QD * QH * QW + 127) / 128;
+        if (t > tiles_max) tiles_max = t;
+      }
+  const int vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
+  const char* tag = "gconv_gather_mfma";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "gconv_gather_mfma[ck=%d,cn=%d,k=%dx%dx%d,T=%d,dst=%dx%dx%dx%d]", g.CK, g.CN, g.kd, g.kh,
+             g.kw, g.transposed, g.N, g.DD, g.DH, g.DW);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
+  dim3 grid((unsigned)tiles_max, cs_d * cs_h * cs_w, ntn / NR);
+  const float4* w4 = reinterpret_cast<const float4*>(wm);
+  switch (NR) {
+    case 8: hipLaunchKernelGGL((gconv_gather_mfma_k<8>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
+    case 4: hipLaunchKernelGGL((gconv_gather_mfma_k<4>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
+    case 2: hipLaunchKernelGGL((gconv_gather_mfma_k<2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
+    default: hipLaunchKernelGGL((gconv_gather_mfma_k<1>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
+  }
+  MSK_LAUNCH_CHECK(ctx);
+  return 1;
+}
+
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g) {
   const int taps = g.kd * g.kh * g.kw;
   const long M = (long)g.N * g.BD * g.BH * g.BW;
@@ -695,6 +1044,25 @@ int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g) {
       MSK_LAUNCH_CHECK(ctx);
     }
     int rc = msk_wgrad_reduce(ctx, partial, used_splits(M, splits), taps, g.CA, g.CB, g.dw, g.accumulate);
+    return rc == 0 ? 1 : rc;
+  }
+
+  // stride-1 'same' cubic 3^3 / 5^3 with vector-friendly channels: LDS-staged kernel
+  const bool cubic = g.kd == g.kh && g.kh == g.kw && (g.kd == 3 || g.kd == 5) && g.pd == g.kd / 2 &&
+                     g.ph == g.kd / 2 && g.pw == g.kd / 2;
+  const bool vec_ok = g.ald % 4 == 0 && g.bld % 4 == 0 && g.CA % 4 == 0 && g.CB % 4 == 0 &&
+                      ((uintptr_t)g.A) % 16 == 0 && ((uintptr_t)g.B) % 16 == 0;
+  if (same_grid && cubic && vec_ok && ctx->conv_impl != 5) {
+    int rc;
+    if (g.kd == 5) {
+      if (g.BW >= 32) rc = launch_wgrad_lds<5, 4, 32>(ctx, g, ctx->num_cu);
+      else if (g.BW >= 16) rc = launch_wgrad_lds<5, 8, 16>(ctx, g, ctx->num_cu);
+      else rc = launch_wgrad_lds<5, 16, 8>(ctx, g, ctx->num_cu);
+    } else {
+      if (g.BW >= 32) rc = launch_wgrad_lds<3, 4, 32>(ctx, g, ctx->num_cu);
+      else if (g.BW >= 16) rc = launch_wgrad_lds<3, 8, 16>(ctx, g, ctx->num_cu);
+      else rc = launch_wgrad_lds<3, 16, 8>(ctx, g, ctx->num_cu);
+    }
     return rc == 0 ? 1 : rc;
   }
 
