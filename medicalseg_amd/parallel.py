@@ -192,11 +192,17 @@ def shard_indices(n_items: int, batch_size: int, rank: int, world: int, shuffle:
     per = (n_items + world - 1) // world
     total = per * world
     idx += idx[:total - len(idx)]
-    # paddle subsamples by interleaved batches: [rank*bs : rank*bs+bs] of every world*bs block
+    # full blocks of world*bs indices are dealt batch-wise (rank r takes the r-th batch of each
+    # block); the ragged tail (< world*bs indices, a multiple of world) is cut into `world` equal
+    # contiguous pieces -- every rank ends up with exactly `per` samples
+    block = batch_size * world
+    tail = total % block
     mine = []
-    for start in range(rank * batch_size, total, batch_size * world):
+    for start in range(rank * batch_size, total - tail, block):
         mine.extend(idx[start:start + batch_size])
-    mine = mine[:per] if len(mine) > per else mine
+    tail_idx = idx[total - tail:]
+    piece = tail // world
+    mine.extend(tail_idx[rank * piece:(rank + 1) * piece])
     batches = [mine[i:i + batch_size] for i in range(0, len(mine), batch_size)]
     if drop_last and batches and len(batches[-1]) < batch_size:
         batches.pop()

@@ -1,0 +1,199 @@
+"""Host-side logic that needs neither GPU nor the fake library: registries, YAML config
+semantics (the drop-in boundary), LR schedule, sampler sharding, timers."""
+import os
+import textwrap
+
+import numpy as np
+import pytest
+
+from oracle import vnet_numpy as O
+
+
+def _write(tmp, name, text):
+    p = os.path.join(tmp, name)
+    os.makedirs(os.path.dirname(p), exist_ok=True)
+    with open(p, "w") as f:
+        f.write(textwrap.dedent(text))
+    return p
+
+
+# A config tree in the REFERENCE's format (same keys/values as
+# configs/lung_coronavirus/{lung_coronavirus,vnet_lung_coronavirus_128_128_128_15k}.yml)
+BASE = """
+    data_root: data/
+"""
+LUNG = """
+    _base_: '../_base_/global_configs.yml'
+    batch_size: 6
+    iters: 15000
+    train_dataset:
+      type: LungCoronavirus
+      dataset_root: lung_coronavirus/lung_coronavirus_phase0
+      result_dir: lung_coronavirus/lung_coronavirus_phase1
+      transforms:
+        - type: RandomResizedCrop3D
+          size: 128
+          scale: [0.8, 1.2]
+        - type: RandomRotation3D
+          degrees: 90
+        - type: RandomFlip3D
+      mode: train
+      num_classes: 3
+    val_dataset:
+      type: LungCoronavirus
+      dataset_root: lung_coronavirus/lung_coronavirus_phase0
+      result_dir: lung_coronavirus/lung_coronavirus_phase1
+      num_classes: 3
+      transforms: []
+      mode: val
+      dataset_json_path: "data/lung_coronavirus/lung_coronavirus_raw/dataset.json"
+    optimizer:
+      type: sgd
+      momentum: 0.9
+      weight_decay: 1.0e-4
+    lr_scheduler:
+      type: PolynomialDecay
+      decay_steps: 15000
+      learning_rate: 0.001
+      end_lr: 0
+      power: 0.9
+    loss:
+      types:
+        - type: MixedLoss
+          losses:
+            - type: CrossEntropyLoss
+              weight: Null
+            - type: DiceLoss
+          coef: [1, 1]
+      coef: [1]
+"""
+VNET = """
+    _base_: 'lung_coronavirus.yml'
+    model:
+      type: VNet
+      elu: False
+      in_channels: 1
+      num_classes: 3
+      pretrained: null
+"""
+
+
+@pytest.fixture()
+def cfg_tree(tmp_path):
+    t = str(tmp_path)
+    _write(t, "configs/_base_/global_configs.yml", BASE)
+    _write(t, "configs/lung_coronavirus/lung_coronavirus.yml", LUNG)
+    return _write(t, "configs/lung_coronavirus/vnet_lung.yml", VNET)
+
+
+def test_config_inheritance_and_resolved_values(cfg_tree):
+    from medicalseg_amd.cvlibs import Config
+    with pytest.warns(UserWarning):  # data_root == 'data/' warning, like the reference
+        cfg = Config(cfg_tree)
+    assert cfg.batch_size == 6 and cfg.iters == 15000
+    assert cfg.dic["data_root"] == "data/"                       # from the 2-levels-up base
+    assert cfg.dic["model"] == {"type": "VNet", "elu": False, "in_channels": 1, "num_classes": 3, "pretrained": None}
+    assert cfg.optimizer_args == {"type": "sgd", "momentum": 0.9, "weight_decay": 1.0e-4}
+    sched = cfg.lr_scheduler
+    assert abs(sched() - 1e-3) < 1e-15 and sched.decay_steps == 15000 and sched.power == 0.9
+    assert cfg.train_dataset_config["dataset_root"] == "data/lung_coronavirus/lung_coronavirus_phase0"
+    losses = cfg.dic["loss"]
+    assert losses["coef"] == [1] and losses["types"][0]["coef"] == [1, 1]
+    # CLI overrides (train.py:138-142)
+    with pytest.warns(UserWarning):
+        cfg2 = Config(cfg_tree, learning_rate=0.01, batch_size=2, iters=100)
+    assert cfg2.batch_size == 2 and cfg2.iters == 100 and abs(cfg2.lr_scheduler() - 0.01) < 1e-15
+
+
+def test_config_inherited_false_cuts_subtree(tmp_path):
+    from medicalseg_amd.cvlibs import Config
+    t = str(tmp_path)
+    _write(t, "a.yml", "data_root: d/\niters: 5\noptimizer:\n  type: sgd\n  momentum: 0.5\n  weight_decay: 0.1\n")
+    p = _write(t, "b.yml", "_base_: 'a.yml'\noptimizer:\n  _inherited_: False\n  type: sgd\n")
+    cfg = Config(p)
+    assert cfg.dic["optimizer"] == {"type": "sgd"} and cfg.optimizer_args == {"type": "sgd", "momentum": 0.9}
+    with pytest.raises(FileNotFoundError):
+        Config(os.path.join(t, "missing.yml"))
+    with pytest.raises(RuntimeError):
+        Config(_write(t, "c.txt", "x: 1"))
+    q = _write(t, "d.yml", "data_root: d/\n")
+    with pytest.raises(RuntimeError):
+        Config(q).iters
+
+
+def test_registries_and_component_lookup():
+    from medicalseg_amd.cvlibs import manager
+    assert "VNet" in manager.MODELS.components_dict
+    for n in ("CrossEntropyLoss", "DiceLoss", "MixedLoss"):
+        assert n in manager.LOSSES.components_dict
+    for n in ("LungCoronavirus", "MRISpineSeg", "MedicalDataset"):
+        assert n in manager.DATASETS.components_dict
+    for n in ("RandomResizedCrop3D", "RandomRotation3D", "RandomFlip3D", "Resize3D"):
+        assert n in manager.TRANSFORMS.components_dict
+    m = manager.ComponentManager("t")
+
+    @m.add_component
+    class A:
+        pass
+
+    def f():
+        pass
+    m.add_component([f])
+    assert len(m) == 2 and m["A"] is A and m["f"] is f
+    with pytest.warns(UserWarning):
+        m.add_component(A)
+    with pytest.raises(TypeError):
+        m.add_component(3)
+    with pytest.raises(KeyError):
+        m["nope"]
+
+
+def test_polynomial_decay_matches_oracle():
+    from medicalseg_amd.optimizer import lr
+    s = lr.PolynomialDecay(1e-3, decay_steps=15000, end_lr=0, power=0.9)
+    for step in range(0, 20000, 777):
+        assert abs(s.get_lr() - O.poly_lr(step, 1e-3, 15000, 0.0, 0.9)) < 1e-18 or s.last_epoch != step
+        while s.last_epoch < step:
+            s.step()
+        assert abs(s() - O.poly_lr(step, 1e-3, 15000, 0.0, 0.9)) < 1e-18
+    pw = lr.PiecewiseDecay([3, 6], [1.0, 0.5, 0.1])
+    vals = []
+    for _ in range(8):
+        vals.append(pw())
+        pw.step()
+    assert vals == [1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 0.1, 0.1]
+
+
+def test_shard_indices_partition():
+    from medicalseg_amd.parallel import shard_indices
+    for n, bs, world in ((20, 2, 4), (7, 3, 2), (200, 6, 8), (5, 2, 1)):
+        per_rank = [shard_indices(n, bs, r, world, shuffle=True, epoch=3, seed=1) for r in range(world)]
+        counts = [sum(len(b) for b in br) for br in per_rank]
+        assert len(set(counts)) == 1 and counts[0] == (n + world - 1) // world      # equal work per rank
+        seen = [i for br in per_rank for b in br for i in b]
+        assert set(seen) == set(range(n))                                           # full coverage (with padding)
+        assert all(len(b) <= bs for br in per_rank for b in br)
+        again = shard_indices(n, bs, 0, world, shuffle=True, epoch=3, seed=1)
+        assert again == per_rank[0]                                                 # same seed -> same shard
+    a = shard_indices(50, 5, 0, 2, shuffle=True, epoch=0)
+    b = shard_indices(50, 5, 0, 2, shuffle=True, epoch=1)
+    assert a != b
+
+
+def test_time_averager_ips_definition():
+    from medicalseg_amd.utils import TimeAverager, calculate_eta
+    t = TimeAverager()
+    t.record(0.5, num_samples=2)
+    t.record(1.5, num_samples=2)
+    assert t.get_average() == 1.0 and t.get_ips_average() == 2.0       # samples / time, per process
+    assert calculate_eta(3661, 1.0) == "01:01:01"
+
+
+def test_synthetic_dataset_contract():
+    from medicalseg_amd.datasets import SyntheticCT
+    ds = SyntheticCT(num_samples=2, shape=(8, 10, 12), num_classes=3)
+    im, lab, path = ds[1]
+    assert im.shape == (1, 8, 10, 12) and im.dtype == np.float32 and lab.shape == (8, 10, 12) and lab.dtype == np.int32
+    assert 0.0 <= im.min() and im.max() == 1.0 and set(np.unique(lab)) <= {0, 1, 2} and isinstance(path, str)
+    im2, lab2, _ = ds[1]
+    assert np.array_equal(im, im2) and np.array_equal(lab, lab2)
