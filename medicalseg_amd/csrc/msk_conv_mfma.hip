@@ -37,6 +37,11 @@ struct HaloArgs {
   int tiles_d, tiles_h, tiles_w;
   int nblk;
   int vec;
+  // deterministic split-K over the 8-channel chunks (small-M layers: 256ch @ 8^3 has only 32
+  // (M,N) tiles for 256 CUs): blockIdx.z owns chunks [z*kc_per, (z+1)*kc_per) and writes an
+  // fp32 slab partial[z][voxel][CN]; splitk_reduce_k adds the slabs in fixed order.
+  int ksplit, kc_per;
+  float* partial;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
@@ -84,7 +89,9 @@ __global__ void __launch_bounds__(256, 2) conv_halo_mfma_k(HaloArgs a) {
   const long tapstride = (long)a.KC * 2 * a.npad;  // float4 units
   const float4* wlane = a.wm + ((long)lh * a.npad + nt * 32 + li);
 
-  for (int kc = 0; kc < a.KC; ++kc) {
+  const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
+  const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
     __syncthreads();
     // ---- stage the halo tile for channels [8kc, 8kc+8) ----
     for (int it = tid; it < NV * 2; it += 256) {
@@ -152,13 +159,32 @@ __global__ void __launch_bounds__(256, 2) conv_halo_mfma_k(HaloArgs a) {
         const int dz = l / (TH * TW), hy = (l / TW) % TH, wx = l % TW;
         const int gd = d0 + dz, gh = h0 + hy, gw = w0 + wx;
         if (gd < a.D && gh < a.H && gw < a.W) {
-          float* o = a.dst + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.dld + co;
-          float v = acc[r][j] + bv;
-          if (a.accumulate) v += *o;
-          *o = v;
+          const long vox = (((long)n * a.D + gd) * a.H + gh) * a.W + gw;
+          if (a.ksplit > 1) {
+            a.partial[((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox) * a.CN + co] = acc[r][j];
+          } else {
+            float* o = a.dst + vox * a.dld + co;
+            float v = acc[r][j] + bv;
+            if (a.accumulate) v += *o;
+            *o = v;
+          }
         }
       }
     }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int CN, const float* __restrict__ bias,
+                float* __restrict__ dst, int dld, int accumulate) {
+  const long total = voxels * CN;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / CN;
+    const int c = (int)(i - v * CN);
+    float s = bias ? bias[c] : 0.f;
+    for (int z = 0; z < ksplit; ++z) s += partial[(long)z * total + i];  // fixed order
+    float* o = dst + v * dld + c;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -295,9 +321,36 @@ int launch_halo(msk_ctx* ctx, HaloArgs& a, int ntiles_n) {
     snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", tag, a.CK, a.CN, a.N, a.D, a.H, a.W, a.accumulate);
     tag = msk_intern_tag(ctx, buf);
   }
-  msk_launch_scope ls(ctx, tag);
-  hipLaunchKernelGGL((conv_halo_mfma_k<TD, TH, TW, KS>), dim3((unsigned)nblk, ntiles_n), dim3(256), 0, ctx->stream, a);
-  MSK_LAUNCH_CHECK(ctx);
+  // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted)
+  a.ksplit = 1;
+  a.kc_per = a.KC;
+  a.partial = nullptr;
+  const long mn_blocks = nblk * ntiles_n;
+  if (mn_blocks < 2L * ctx->num_cu && a.KC >= 2) {
+    long want = (4L * ctx->num_cu + mn_blocks - 1) / mn_blocks;
+    if (want > a.KC) want = a.KC;
+    a.kc_per = (int)((a.KC + want - 1) / want);
+    a.ksplit = (a.KC + a.kc_per - 1) / a.kc_per;
+  }
+  const long voxels = (long)a.N * a.D * a.H * a.W;
+  if (a.ksplit > 1) {
+    a.partial = (float*)msk_workspace(ctx, (size_t)a.ksplit * voxels * a.CN * sizeof(float));
+    if (!a.partial) return -1;
+  }
+  {
+    msk_launch_scope ls(ctx, tag);
+    hipLaunchKernelGGL((conv_halo_mfma_k<TD, TH, TW, KS>), dim3((unsigned)nblk, ntiles_n, a.ksplit), dim3(256), 0,
+                       ctx->stream, a);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  if (a.ksplit > 1) {
+    msk_launch_scope ls(ctx, "conv_splitk_reduce");
+    long blocks = (voxels * a.CN + 255) / 256;
+    if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
+    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.partial,
+                       a.ksplit, voxels, a.CN, a.bias, a.dst, a.dld, a.accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
   return 0;
 }
 
