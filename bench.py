@@ -27,45 +27,68 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_HBM_GBS = 8000.0
 
 
-def vnet_conv5_flops(n, d, h, w, ncls):
-    """Algorithmic FLOPs (2*k^3*Cin*Cout*voxels, real channel counts) of every launch of the
-    halo kernel in one training step: the 5^3 convs forward + their data gradients
-    (in_tr has no data gradient)."""
-    layers = []  # (cin, cout, voxels_per_sample)
+def vnet_lu_layers(d, h, w):
+    """(cin, cout, voxels_per_sample, W) of every 5x5x5 LUConv-type layer that runs on the MFMA halo
+    kernel, forward AND data gradient (in_tr/out_tr use the VALU halo kernel)."""
     v = d * h * w
-    layers.append((1, 16, v, False))                       # in_tr.conv1 (no dgrad)
-    lv = [v // 8, v // 64, v // 512, v // 4096]
-    for c, nconv, vv in ((32, 1, lv[0]), (64, 2, lv[1]), (128, 3, lv[2]), (256, 2, lv[3])):
-        layers += [(c, c, vv, True)] * nconv               # down_tr*.ops
-    for c, nconv, vv in ((256, 2, lv[2]), (128, 2, lv[1]), (64, 1, lv[0]), (32, 1, v)):
-        layers += [(c, c, vv, True)] * nconv               # up_tr*.ops
-    layers.append((32, ncls, v, True))                     # out_tr.conv1
-    fwd = sum(2.0 * 125 * ci * co * vv for ci, co, vv, _ in layers) * n
-    dgrad = sum(2.0 * 125 * ci * co * vv for ci, co, vv, dg in layers if dg) * n
-    return fwd + dgrad
+    layers = []
+    lv = [(v // 8, w // 2), (v // 64, w // 4), (v // 512, w // 8), (v // 4096, w // 16)]
+    for c, nconv, (vv, ww) in ((32, 1, lv[0]), (64, 2, lv[1]), (128, 3, lv[2]), (256, 2, lv[3])):
+        layers += [(c, c, vv, ww)] * nconv               # down_tr*.ops
+    for c, nconv, (vv, ww) in ((256, 2, lv[2]), (128, 2, lv[1]), (64, 1, lv[0]), (32, 1, (v, w))):
+        layers += [(c, c, vv, ww)] * nconv               # up_tr*.ops
+    return layers
+
+
+def halo_variant_work(n, d, h, w):
+    """Algorithmic FLOPs (2*125*Cin*Cout per output voxel) and algorithmic HBM bytes (input + output
+    + weights, each once) summed over the launches of conv_halo_mfma_k<2, 4, 32, 5> (layers with
+    W >= 32) in ONE training step: forward + data gradient of each layer."""
+    flops = bytes_ = 0.0
+    launches = 0
+    for ci, co, vv, ww in vnet_lu_layers(d, h, w):
+        if ww >= 32:
+            flops += 2 * (2.0 * 125 * ci * co * vv * n)
+            bytes_ += 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co))
+            launches += 2
+    return flops, bytes_, launches
 
 
 def step_flops_per_sample():
     return 4431.2e9  # SURVEY.md section 8 d3: fwd 1479.9 + bwd 2951.3 GFLOP per 128^3 sample, ncls 3
 
 
-def cpu_baseline(sample_edge=32):
-    """The CPU oracle (numpy restatement, float32, BLAS threads = host cores) on one
-    fwd+bwd+SGD step of a batch-1 sample_edge^3 volume; reported as voxels/s."""
-    from oracle import vnet_numpy as O  # baseline only
-    ncls = 3
-    params = O.init_params(0, 1, ncls, perturb=False)
-    om = O.VNetOracle(params, 1, ncls, dtype=np.float32)
-    ol, vel = O.MixedLossOracle(dtype=np.float32), {}
+def cpu_baseline(size=128, ncls=3):
+    """CPU baseline (kind "port"): the torch-CPU/oneDNN restatement of the SAME step
+    (oracle/vnet_torch.py: VNet forward + CE/Dice loss + backward + SGD-momentum-L2), one
+    batch-1 step of a size^3 volume on all host cores after one untimed warm-up step."""
+    import torch
+    from oracle.vnet_torch import TorchVNet, torch_mixed_loss  # baseline only
+    # oneDNN's 3D convolutions stop scaling (and regress) beyond a few dozen threads: 256 threads on
+    # the GPU box's host took 90 s for the step that 8 threads do in 15 s -> cap at 32 and report it
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(0)
+    m = TorchVNet(1, ncls)
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     rng = np.random.default_rng(0)
-    shp = (sample_edge,) * 3
-    x = rng.random((1, 1) + shp).astype(np.float32)
-    y = rng.integers(0, ncls, (1,) + shp).astype(np.int32)
+    x = torch.tensor(rng.random((1, 1, size, size, size)).astype(np.float32))
+    y = torch.tensor(rng.integers(0, ncls, (1, size, size, size)).astype(np.int64))
+    w = torch.ones(ncls)
+
+    def step(xx, yy):
+        opt.zero_grad()
+        ce, dl, _ = torch_mixed_loss(m(xx), yy, w)
+        (ce + dl).backward()
+        opt.step()
+
+    step(x[:, :, :32, :32, :32].contiguous(), y[:, :32, :32, :32].contiguous())  # warm-up (thread pool, primitives)
     t0 = time.time()
-    O.train_step(om, ol, vel, x, y, 0, train=True, dropout_masks={})
+    step(x, y)
     dt = time.time() - t0
-    return {"value": float(np.prod(shp) / dt), "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "numpy-oracle (float32, BLAS threads) 1 train step, batch 1, %d^3 volume: %.1f s" % (sample_edge, dt)}
+    return {"value": float(size ** 3 / dt), "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "torch-CPU/oneDNN restatement (oracle/vnet_torch.py), 1 train step, batch 1, %d^3 fp32: %.1f s"
+                      % (size, dt)}
 
 
 def main():
@@ -157,14 +180,24 @@ def main():
     voxels_per_step = world * B * S ** 3
     value = voxels_per_step / (elapsed / args.steps)
 
-    calls = sum(v[0] for k, v in prof.items() if k.startswith("conv_halo_mfma_k5"))
-    kms = sum(v[1] for k, v in prof.items() if k.startswith("conv_halo_mfma_k5"))
-    conv_flops = vnet_conv5_flops(B, S, S, S, ncls) * args.steps
-    achieved = conv_flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    DOM = "conv_halo_mfma_k<2, 4, 32, 5>"   # dominant kernel: same name as in rocprofv3's kernel stats
+    calls = sum(v[0] for k, v in prof.items() if k.startswith(DOM))
+    kms = sum(v[1] for k, v in prof.items() if k.startswith(DOM))
+    flops_step, bytes_step, launches_step = halo_variant_work(B, S, S, S)
+    achieved = flops_step * args.steps / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     total_kernel_ms = sum(v[1] for v in prof.values())
-    roofline = {"bound": "mfma", "kernel": "conv_halo_mfma_k5", "achieved": round(achieved, 2),
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath) and S == 128 and B == 2:   # PMC pass of this exact workload (tools/summarize_rocprof.py)
+        try:
+            traffic = json.load(open(tpath)).get(DOM, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": DOM, "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches": calls, "avg_launch_ms": round(kms / max(calls, 1), 4),
+                "traffic": traffic, "launches": calls, "avg_launch_ms": round(kms / max(calls, 1), 4),
+                "algorithmic_flop_per_launch": round(flops_step / max(launches_step, 1), 1),
+                "algorithmic_bytes_per_launch": round(bytes_step / max(launches_step, 1), 1),
                 "kernel_share_of_step": round(kms / max(total_kernel_ms, 1e-9), 4),
                 "step_frac_of_fp32_roofline": round(step_flops_per_sample() * B * (S / 128.0) ** 3 / (ms_per_step * 1e-3)
                                                     / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}

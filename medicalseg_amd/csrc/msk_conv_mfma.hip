@@ -315,10 +315,12 @@ int launch_halo(msk_ctx* ctx, HaloArgs& a, int ntiles_n) {
   const long nblk = (long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
   if (nblk > 0x7fffffff) return msk_fail(ctx, __FILE__, __LINE__, "conv_halo", "grid too large");
   a.nblk = (int)nblk;
-  const char* tag = KS == 5 ? "conv_halo_mfma_k5" : "conv_halo_mfma_k3";
-  if (ctx->prof && ctx->prof_shapes) {
-    char buf[160];
-    snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", tag, a.CK, a.CN, a.N, a.D, a.H, a.W, a.accumulate);
+  const char* tag = "conv_halo_mfma_k";
+  if (ctx->prof) {  // same spelling as the demangled kernel name in rocprofv3's kernel stats
+    char buf[200];
+    int n = snprintf(buf, sizeof(buf), "conv_halo_mfma_k<%d, %d, %d, %d>", TD, TH, TW, KS);
+    if (ctx->prof_shapes)
+      snprintf(buf + n, sizeof(buf) - n, "[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", a.CK, a.CN, a.N, a.D, a.H, a.W, a.accumulate);
     tag = msk_intern_tag(ctx, buf);
   }
   // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted)

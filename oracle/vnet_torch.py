@@ -1,6 +1,10 @@
-"""torch-CPU restatement of the reference VNet (test helper, build-container and
-GPU-box safe: uses only torch CPU ops).  Used ONLY to cross-check oracle/ --
-the reference itself was ported from a torch implementation (vnet.py:1-3).
+"""torch-CPU restatement of the reference VNet (oracle, test-only; CPU ops only).
+
+Two uses: (1) independent cross-check of oracle/vnet_numpy.py (the reference itself was
+ported from a torch implementation and aligned against it, vnet.py:1-3,285-294);
+(2) the timed `cpu_baseline` of bench.py -- torch's oneDNN convolutions are the strongest
+CPU implementation of this step available in the image (the numpy oracle reaches only
+~9 GFLOP/s and would flatter the GPU/CPU ratio).  Never imported by the product.
 
 Differences Paddle<->torch handled here: BN momentum
 0.9 <-> 0.1, PReLU parameter name, running-var biased (we overwrite the buffer

@@ -13,7 +13,7 @@ import torch
 
 from oracle import preprocess_numpy as P
 from oracle import vnet_numpy as O
-from torch_ref import TorchVNet, torch_mixed_loss
+from oracle.vnet_torch import TorchVNet, torch_mixed_loss
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SITES = [("down_tr128", 128), ("down_tr256", 256), ("up_tr256.x", 256), ("up_tr256.skip", 128),

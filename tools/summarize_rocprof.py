@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 output directories (gpurun_out/prof_{stats,fetch,write}) into the small tracked
+summaries under profiles/:  <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats),
+<tag>_hbm_traffic.json (FETCH_SIZE / WRITE_SIZE per launch for the MFMA kernels, with the
+gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md section HBM).
+
+    python tools/summarize_rocprof.py r01
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def agg(path, counter):
+    d = collections.defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                d[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+                d[r["Kernel_Name"]][1] += 1
+    return d
+
+
+def main(tag):
+    go = os.path.join(ROOT, "gpurun_out")
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = os.path.join(go, "prof_stats", "r01_kernel_stats.csv")
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
+        bj = os.path.join(go, "prof_stats", "bench.json")
+        if os.path.exists(bj):
+            shutil.copy(bj, os.path.join(out, f"{tag}_rocprofv3_kernel_stats_bench_line.json"))
+    fe_p = os.path.join(go, "prof_fetch", "r01_counter_collection.csv")
+    wr_p = os.path.join(go, "prof_write", "r01_counter_collection.csv")
+    if os.path.exists(fe_p) and os.path.exists(wr_p):
+        fe, wr = agg(fe_p, "FETCH_SIZE"), agg(wr_p, "WRITE_SIZE")
+        res = {"_note": "per-launch averages over one training step; FETCH_SIZE/WRITE_SIZE are in KiB; "
+                        "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 rocprofv3 reports half of a wide "
+                        "coalesced read stream, MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)"}
+        for k in fe:
+            if "mfma" in k or "valu" in k:
+                n = fe[k][1]
+                f_kb, w_kb = fe[k][0] / n, wr[k][0] / max(wr[k][1], 1)
+                name = k.split("(")[1].split("::")[-1] if "::" in k else k
+                short = k.replace("void (anonymous namespace)::", "").split("(")[0]
+                res[short] = {"launches": n, "FETCH_SIZE_KiB": round(f_kb, 1), "WRITE_SIZE_KiB": round(w_kb, 1),
+                              "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
+        with open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+    print("wrote summaries to", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
