@@ -172,7 +172,7 @@ def main():
         sp, rp = dev.small(1), dev.small(world)
         dev.h2d(sp, np.array([elapsed], np.float32))
         dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(1))
-        elapsed = float(dev.d2h(rp, (world,), np.float32).max())
+        elapsed = max(elapsed, float(dev.d2h(rp, (world,), np.float32).max()))
 
     if rank != 0:
         return

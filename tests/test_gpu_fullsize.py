@@ -1,0 +1,132 @@
+"""Full-size (BASELINE.json configs) checks on the GPU through properties that need no full
+oracle run: sampled-voxel comparison against direct numpy dot products, linearity of the
+convolution, bitwise run-to-run determinism of a whole training step, finite losses and shapes
+for VNet 128^3 batch 2 and the anisotropic MRI slab 512x512x12 with 20 classes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import dev, t_empty, t_from_ncdhw, vec, vec_back, vp
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc(k, s, p):
+    from medicalseg_amd._lib import MskConvDesc
+    return MskConvDesc(*k, *s, *p)
+
+
+def test_conv5_128cubed_sampled_and_linear():
+    d = dev()
+    rng = np.random.default_rng(0)
+    S, Cc = 128, 32
+    x1 = rng.standard_normal((1, Cc, S, S, S), dtype=np.float32)
+    x2 = rng.standard_normal((1, Cc, S, S, S), dtype=np.float32)
+    w = (rng.standard_normal((Cc, Cc, 5, 5, 5)) / np.sqrt(Cc * 125)).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    wp, bp = vec(w.ravel()), vec(b)
+    desc = _desc((5,) * 3, (1,) * 3, (2,) * 3)
+
+    def conv(x, bias=True):
+        xt, yt = t_from_ncdhw(x), t_empty(1, Cc, S, S, S)
+        d.call("msk_conv3d_fwd", desc, xt.msk(), vp(wp), vp(bp) if bias else None, yt.msk())
+        out = yt.numpy()
+        d.free(xt.ptr)
+        d.free(yt.ptr)
+        return out
+
+    y1 = conv(x1)
+    # sampled voxels (corners/edges included) against float64 dot products
+    xp = np.pad(x1[0].astype(np.float64), ((0, 0), (2, 2), (2, 2), (2, 2)))
+    pts = [(0, 0, 0), (127, 127, 127), (0, 127, 5), (64, 0, 127)] + [tuple(rng.integers(0, S, 3)) for _ in range(40)]
+    w64 = w.astype(np.float64)
+    for (z, yy, xx) in pts:
+        patch = xp[:, z:z + 5, yy:yy + 5, xx:xx + 5]
+        ref = np.tensordot(w64, patch, axes=([1, 2, 3, 4], [0, 1, 2, 3])) + b
+        assert np.abs(y1[0, :, z, yy, xx] - ref).max() < 5e-5 * (np.abs(ref).max() + 1)
+    # linearity: conv(2*x1 - 3*x2) == 2*conv(x1) - 3*conv(x2)   (bias-free)
+    ya, yb = conv(x1, False), conv(x2, False)
+    yc = conv(2 * x1 - 3 * x2, False)
+    assert np.abs(yc - (2 * ya - 3 * yb)).max() < 2e-4 * np.abs(yc).max()
+
+
+def test_wgrad_128cubed_sampled():
+    d = dev()
+    rng = np.random.default_rng(1)
+    S, Cc = 128, 32
+    x = rng.standard_normal((1, Cc, S, S, S), dtype=np.float32)
+    dy = rng.standard_normal((1, Cc, S, S, S), dtype=np.float32)
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    dw, db = vec(np.zeros(Cc * Cc * 125)), vec(np.zeros(Cc))
+    d.call("msk_conv3d_wgrad", _desc((5,) * 3, (1,) * 3, (2,) * 3), xt.msk(), dyt.msk(), vp(dw), vp(db), 0)
+    got = vec_back(dw, Cc * Cc * 125).reshape(Cc, Cc, 5, 5, 5)
+    xp = np.pad(x[0], ((0, 0), (2, 2), (2, 2), (2, 2)))
+    for _ in range(12):
+        co, ci = rng.integers(0, Cc, 2)
+        a, b_, c = rng.integers(0, 5, 3)
+        ref = np.dot(dy[0, co].astype(np.float64).ravel(), xp[ci, a:a + S, b_:b_ + S, c:c + S].astype(np.float64).ravel())
+        assert abs(got[co, ci, a, b_, c] - ref) < 2e-4 * np.sqrt(S ** 3), (co, ci, a, b_, c)
+    assert np.abs(vec_back(db, Cc) - dy.sum(axis=(0, 2, 3, 4))).max() < 1e-3 * np.sqrt(S ** 3)
+
+
+def _train_step(model, opt, losses, x, y):
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.utils import loss_computation
+    ll, per = loss_computation(model(x), to_tensor(y), losses)
+    loss = sum(ll)
+    loss.backward()
+    opt.step()
+    model.clear_gradients()
+    return float(loss), np.asarray(per).copy()
+
+
+def test_vnet_128_batch2_step_is_finite_and_bitwise_deterministic():
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.datasets import SyntheticCT
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    ds = SyntheticCT(num_samples=2, shape=(128, 128, 128), num_classes=3)
+    items = [ds[i] for i in range(2)]
+    x, y = np.stack([i[0] for i in items]), np.stack([i[1] for i in items])
+    results = []
+    for run in range(2):
+        nn.seed(0)
+        nn.Dropout3D.step, nn.Dropout3D.seed = 0, 0
+        model = VNet(num_classes=3)
+        model.train()
+        opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+        sites = {k: l.site for k, l in model.dropout_layers().items()}
+        base = min(sites.values())
+        for k, l in model.dropout_layers().items():      # same RNG sites in both runs
+            l.site = l.site - base + 1
+        l1, per1 = _train_step(model, opt, losses, x, y)
+        l2, per2 = _train_step(model, opt, losses, x, y)
+        sd = model.state_dict()
+        results.append((l1, l2, per1, sd["up_tr32.ops.0.conv1.weight"], sd["in_tr.bn1._mean"], sd["down_tr256.ops.1.conv1.weight"]))
+        assert np.isfinite(l1) and np.isfinite(l2) and 0 < l1 < 10 and per1.shape == (3,)
+        assert np.all(per1 >= 0) and np.all(per1 <= 1)
+        assert np.abs(sd["in_tr.bn1._mean"]).max() > 0          # running stats moved
+    a, b = results
+    assert a[0] == b[0] and a[1] == b[1]
+    for u, v in zip(a[2:], b[2:]):
+        assert np.array_equal(u, v)                              # bitwise reproducible step
+
+
+def test_vnet_mri_512x512x12_20_classes_runs():
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    K = [[2, 2, 4], [2, 2, 2], [2, 2, 2], [2, 2, 2]]
+    S = [[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]
+    model = VNet(num_classes=20, kernel_size=K, stride_size=S)
+    model.train()
+    opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    rng = np.random.default_rng(0)
+    x = rng.random((1, 1, 512, 512, 12), dtype=np.float32)
+    y = rng.integers(0, 20, (1, 512, 512, 12)).astype(np.int32)
+    loss, per = _train_step(model, opt, losses, x, y)
+    assert [a.shape for a in model._acts] == [(1, 16, 512, 512, 12), (1, 32, 256, 256, 9), (1, 64, 128, 128, 8),
+                                              (1, 128, 64, 64, 4), (1, 256, 32, 32, 2)]
+    assert np.isfinite(loss) and per.shape == (20,) and np.all(np.isfinite(per))
