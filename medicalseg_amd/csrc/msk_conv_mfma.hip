@@ -93,25 +93,37 @@ __global__ void __launch_bounds__(256, 2) conv_halo_mfma_k(HaloArgs a) {
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     __syncthreads();
-    // ---- stage the halo tile for channels [8kc, 8kc+8) ----
-    for (int it = tid; it < NV * 2; it += 256) {
-      const int hv = it >> 1, q = it & 1;
-      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int c0 = kc * 8 + q * 4;
-      if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
-        const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
-        if (a.vec) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          v.x = p[0];
-          if (c0 + 1 < a.CK) v.y = p[1];
-          if (c0 + 2 < a.CK) v.z = p[2];
-          if (c0 + 3 < a.CK) v.w = p[3];
+    // ---- stage the halo tile for channels [8kc, 8kc+8): groups of 7 independent float4 loads in
+    // flight per thread (a plain load->store loop serialises ~14 global round trips per chunk) ----
+    constexpr int SG = 7;
+    for (int base = 0; base < NV * 2; base += SG * 256) {
+      float4 tmp[SG];
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        const int hv = it >> 1, q = it & 1;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = kc * 8 + q * 4;
+        if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
+          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          if (a.vec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c0 + 1 < a.CK) v.y = p[1];
+            if (c0 + 2 < a.CK) v.z = p[2];
+            if (c0 + 3 < a.CK) v.w = p[3];
+          }
         }
+        tmp[i] = v;
       }
-      lds[q * NVP + hv] = v;
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        if (it < NV * 2) lds[(it & 1) * NVP + (it >> 1)] = tmp[i];
+      }
     }
     __syncthreads();
 
@@ -630,13 +642,17 @@ wgrad_lds_mfma_k(WGrad g, int splits, int chunks_total, int chunks_per_split, fl
   constexpr int NT = 256;
   // 4 waves (one per SIMD: odd wave counts leave the doubly-loaded SIMD as the occupancy
   // limiter -- measured 1.2 waves/SIMD with 5-wave workgroups).  The KS*KS taps of the kd plane
-  // are dealt round-robin: wave w owns taps w, w+4, ... (7/6/6/6 for 5x5).
-  constexpr int TPW = (KS * KS + 3) / 4;
+  // are dealt round-robin: wave w owns taps w, w+4, ... (6 each for 5x5) and the LAST tap is
+  // shared -- each wave accumulates it for a quarter of the voxel pairs and the four partial
+  // accumulators are summed through LDS in a fixed order at the end (7/6/6/6 -> 6.25 each).
+  static_assert((KS * KS - 1) % 4 == 0, "own taps must divide evenly over 4 waves");
+  constexpr int TPW = (KS * KS - 1) / 4;
+  constexpr int SHARED_OFF = ((KS - 1) * XW + (KS - 1)) * 32;  // tap (kh, kw) = (KS-1, KS-1)
   __shared__ float xs[XR * XW * 32];
   __shared__ float dys[R * WS * 32];
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int ca_tiles = (g.CA + 31) >> 5, cb_tiles = (g.CB + 31) >> 5;
   int b = blockIdx.x;
   const int cbt = b % cb_tiles;
@@ -651,13 +667,15 @@ wgrad_lds_mfma_k(WGrad g, int splits, int chunks_total, int chunks_per_split, fl
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
     const int t = wave + 4 * j;
-    toff[j] = t < KS * KS ? ((t / KS) * XW + (t % KS)) * 32 : 0;
+    toff[j] = ((t / KS) * XW + (t % KS)) * 32;
   }
-  f32x16 acc[TPW];
+  f32x16 acc[TPW], acc_sh;
 #pragma unroll
   for (int k = 0; k < TPW; ++k)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc_sh[j] = 0.f;
 
   const int c_begin = split * chunks_per_split;
   int c_end = c_begin + chunks_per_split;
@@ -738,32 +756,52 @@ wgrad_lds_mfma_k(WGrad g, int splits, int chunks_total, int chunks_per_split, fl
     for (int r = 0; r < R; ++r) {
       const float* xrow = &xs[(r * XW + lh) * 32 + li];
       const float* drow = &dys[(r * WS + lh) * 32 + li];
-#pragma unroll 2
-      for (int p = 0; p < WS / 2; ++p) {
-        const float bv = drow[p * 64];
-        float av[TPW];
+      for (int p4 = 0; p4 < WS / 2; p4 += 4) {
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) av[k] = xrow[p * 64 + toff[k]];
+        for (int u = 0; u < 4; ++u) {
+          const int p = p4 + u;
+          const float bv = drow[p * 64];
+          float av[TPW];
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv, acc[k], 0, 0, 0);
+          for (int k = 0; k < TPW; ++k) av[k] = xrow[p * 64 + toff[k]];
+#pragma unroll
+          for (int k = 0; k < TPW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv, acc[k], 0, 0, 0);
+          if (u == wave)  // wave-uniform: this wave's quarter of the shared tap
+            acc_sh = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[p * 64 + SHARED_OFF], bv, acc_sh, 0, 0, 0);
+        }
       }
     }
     ch = nxt;
   }
+  // ---- shared tap: sum the four waves' partial accumulators in a fixed order through LDS ----
+  __syncthreads();
+  float* red = xs;  // 4 waves x 16 regs x 64 lanes floats = 16 KiB <= sizeof(xs)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) red[(wave * 16 + j) * 64 + lane] = acc_sh[j];
+  __syncthreads();
 
   const int taps = KS * KS * KS;
   const int cb = cbt * 32 + li;
   if (cb < g.CB) {
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      const int t = wave + 4 * k;
-      if (t >= KS * KS) continue;
-      const int tap = kd * KS * KS + t;
+      const int tap = kd * KS * KS + wave + 4 * k;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
         const int oca = cat * 32 + row;
         if (oca < g.CA) partial[(((long)split * taps + tap) * g.CA + oca) * g.CB + cb] = acc[k][j];
+      }
+    }
+    if (wave == 0) {
+      const int tap = kd * KS * KS + KS * KS - 1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
+        const int oca = cat * 32 + row;
+        const float v = ((red[(0 * 16 + j) * 64 + lane] + red[(1 * 16 + j) * 64 + lane]) +
+                         (red[(2 * 16 + j) * 64 + lane] + red[(3 * 16 + j) * 64 + lane]));
+        if (oca < g.CA) partial[(((long)split * taps + tap) * g.CA + oca) * g.CB + cb] = v;
       }
     }
   }
