@@ -51,6 +51,10 @@ int msk_ctx_create(int device, msk_ctx** out);
 int msk_ctx_destroy(msk_ctx* ctx);
 const char* msk_last_error(msk_ctx* ctx);        /* ctx may be NULL (global error) */
 int msk_sync(msk_ctx* ctx);
+/* Weight-gradient kernels run on an internal side stream (option "wgrad_async"); msk_join_side makes
+ * the main stream wait for them -- call it before consuming weight gradients (optimizer, all-reduce).
+ * msk_sync and msk_d2h join implicitly. */
+int msk_join_side(msk_ctx* ctx);
 int msk_device_name(msk_ctx* ctx, char* buf, int buflen);
 int msk_malloc(msk_ctx* ctx, size_t bytes, void** out);
 int msk_free(msk_ctx* ctx, void* p);
@@ -71,7 +75,8 @@ int msk_prof_enable(msk_ctx* ctx, int on);
 int msk_prof_reset(msk_ctx* ctx);
 /* writes "tag\tcalls\ttotal_ms\n" lines into buf (NUL terminated); returns needed size via *len */
 int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
-/* knobs: "conv_impl" 0=auto 1=direct(VALU reference kernels) 2=mfma */
+/* knobs: "conv_impl" 0=auto 1=VALU reference kernels 3=reference wgrad only 4=reference gather-conv only;
+ * "wgrad_async" 0|1; "prof_shapes" 0|1; "poison_scratch" byte|-1 (debug) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);
 
 /* ---- layout at the boundary ------------------------------------------------ */

@@ -42,6 +42,7 @@ SIGNATURES = {
     "msk_ctx_destroy": (_i, [_vp]),
     "msk_last_error": (C.c_char_p, [_vp]),
     "msk_sync": (_i, [_vp]),
+    "msk_join_side": (_i, [_vp]),
     "msk_device_name": (_i, [_vp, C.c_char_p, _i]),
     "msk_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "msk_free": (_i, [_vp, _vp]),

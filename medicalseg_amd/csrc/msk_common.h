@@ -8,6 +8,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "msegk.h"
@@ -43,6 +44,14 @@ struct msk_ctx {
   // options
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
+  // side stream: weight gradients run concurrently with the data-gradient chain (they only share
+  // inputs), so HBM-bound elementwise backward kernels hide behind MFMA-bound wgrad kernels
+  hipStream_t side = nullptr;
+  void* ws_side = nullptr;
+  size_t ws_side_bytes = 0;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool wgrad_async = false;
+  bool side_dirty = false;
   // data parallel
   void* comm = nullptr;  // ncclComm_t
   int rank = 0, world = 1;
@@ -57,6 +66,29 @@ void* msk_workspace2(msk_ctx* ctx, size_t bytes);
 void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
+int msk_join_side_impl(msk_ctx* ctx);
+
+// Redirect launches of the enclosed scope to the side stream (with its own scratch) after making
+// it wait for everything enqueued so far on the main stream.
+struct msk_side_scope {
+  msk_ctx* ctx;
+  bool active;
+  explicit msk_side_scope(msk_ctx* c) : ctx(c), active(c->wgrad_async && c->side != nullptr) {
+    if (!active) return;
+    hipEventRecord(ctx->ev_fork, ctx->stream);
+    hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+    std::swap(ctx->stream, ctx->side);
+    std::swap(ctx->ws, ctx->ws_side);
+    std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+    ctx->side_dirty = true;
+  }
+  ~msk_side_scope() {
+    if (!active) return;
+    std::swap(ctx->stream, ctx->side);
+    std::swap(ctx->ws, ctx->ws_side);
+    std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+  }
+};
 
 #define MSK_CHECK_HIP(ctx, expr)                                                        \
   do {                                                                                  \

@@ -180,6 +180,37 @@ wgrad_reduce_k(const float* __restrict__ partial, int splits, int taps, int CA, 
   }
 }
 
+// 1x1x1 convolution with few channels (out_tr.conv2, ncls -> ncls, vnet.py:169) and its data
+// gradient: pure HBM streaming -- one thread per voxel, the CK x CN weight block in LDS.
+__global__ void __launch_bounds__(kThreads)
+pointwise_small_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
+  __shared__ float ws[8 * 8];
+  __shared__ float bs[8];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    const int k = i / 8, n = i % 8;
+    ws[i] = (k < g.CK && n < g.CN) ? wp[k * g.CN + n] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 8; i += blockDim.x) bs[i] = (g.bias && i < g.CN) ? g.bias[i] : 0.f;
+  __syncthreads();
+  const long M = (long)g.N * g.DD * g.DH * g.DW;
+  for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+    float x[8];
+    const float* sp = g.src + m * g.sld;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = k < g.CK ? sp[k] : 0.f;
+    float* dp = g.dst + m * g.dld;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      if (n < g.CN) {
+        float acc = bs[n];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = fmaf(x[k], ws[k * 8 + n], acc);
+        dp[n] = g.accumulate ? dp[n] + acc : acc;
+      }
+    }
+  }
+}
+
 inline int grid_for(long total, int num_cu) {
   long b = (total + kThreads - 1) / kThreads;
   long cap = (long)num_cu * 32;
@@ -210,6 +241,17 @@ int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& i
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
 int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
   const int taps = g.kd * g.kh * g.kw;
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 &&
+      g.ph == 0 && g.pw == 0 && g.CK <= 8 && g.CN <= 8) {
+    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    if (!wp1) return -1;
+    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
+    const long M = (long)g.N * g.DD * g.DH * g.DW;
+    msk_launch_scope ls(ctx, "pointwise_small");
+    hipLaunchKernelGGL(pointwise_small_k, dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4) {
     int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
@@ -318,6 +360,7 @@ int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float*
 
 int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
+  msk_side_scope side(ctx);
   WGrad g{};
   g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
   g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
@@ -356,6 +399,7 @@ int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float
 
 int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, true) != 0) return -1;
+  msk_side_scope side(ctx);
   // dWT[ci][co][tap] = sum_ipos x[ipos][ci] * dy[ipos*s + k][co]: conv wgrad with A = dy, B = x
   WGrad g{};
   g.A = (const float*)dy.p; g.ald = dy.ld; g.B = (const float*)x.p; g.bld = x.ld;

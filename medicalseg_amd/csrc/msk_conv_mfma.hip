@@ -575,27 +575,39 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
         const unsigned vbase = (unsigned)(((n * g.SD + id) * g.SH + ih) * g.SW + iw) * (unsigned)g.sld;
         const int tap = (a * g.kh + b) * g.kw + c;
         const float4* wt = wlane + (long)tap * tapstride;
-        for (int kc = 0; kc < KC; ++kc) {
-          const int c0 = kc * 8 + lh * 4;
-          float av[4];
-          if (vec) {  // CK % 4 == 0: one validity test per quad (the compiler merges the 4 dwords)
-            const unsigned off = (ok && c0 < g.CK) ? (vbase + (unsigned)c0) * 4u : kOOB;
+        // K chunks in batches of KB: every load of the batch is issued before its MFMAs (these
+        // layers have only a handful of MFMAs per wave; a load->MFMA chain per chunk was pure latency)
+        constexpr int KB = NR >= 4 ? 2 : 4;
+        for (int kc0 = 0; kc0 < KC; kc0 += KB) {
+          float av[KB][4];
+          float4 bv[KB][NR];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = buf_load(rs, off == kOOB ? kOOB : off + 4u * q);
-          } else {
+          for (int u = 0; u < KB; ++u) {
+            const int kc = kc0 + u;
+            const int c0 = kc * 8 + lh * 4;
+            const bool kin = kc < KC;
+            if (vec) {  // CK % 4 == 0: one validity test per quad (the compiler merges the 4 dwords)
+              const unsigned off = (ok && kin && c0 < g.CK) ? (vbase + (unsigned)c0) * 4u : kOOB;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              av[q] = buf_load(rs, (ok && c0 + q < g.CK) ? (vbase + (unsigned)(c0 + q)) * 4u : kOOB);
+              for (int q = 0; q < 4; ++q) av[u][q] = buf_load(rs, off == kOOB ? kOOB : off + 4u * q);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                av[u][q] = buf_load(rs, (ok && kin && c0 + q < g.CK) ? (vbase + (unsigned)(c0 + q)) * 4u : kOOB);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+              bv[u][r] = kin ? wt[(long)kc * 2 * npad + r * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
           }
-          float4 bv[NR];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) bv[r] = wt[(long)kc * 2 * npad + r * 32];
+          for (int u = 0; u < KB; ++u) {
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[r].x, acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[r].y, acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[r].z, acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[r].w, acc[r], 0, 0, 0);
+            for (int r = 0; r < NR; ++r) {
+              acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u][r].x, acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][r].y, acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][2], bv[u][r].z, acc[r], 0, 0, 0);
+              acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][3], bv[u][r].w, acc[r], 0, 0, 0);
+            }
           }
         }
       }
@@ -1082,6 +1094,9 @@ int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, in
         const long t = ((long)g.N * QD * QH * QW + 127) / 128;
         if (t > tiles_max) tiles_max = t;
       }
+  // deep levels have few dst voxels: trade A re-reads (tiny tensors) for parallelism over N
+  int NRsel = NR;
+  while (NRsel > 1 && tiles_max * cs_d * cs_h * cs_w * (ntn / NRsel) < 2L * ctx->num_cu) NRsel >>= 1;
   const int vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   const char* tag = "gconv_gather_mfma";
   if (ctx->prof && ctx->prof_shapes) {
@@ -1091,9 +1106,9 @@ int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, in
     tag = msk_intern_tag(ctx, buf);
   }
   msk_launch_scope ls(ctx, tag);
-  dim3 grid((unsigned)tiles_max, cs_d * cs_h * cs_w, ntn / NR);
+  dim3 grid((unsigned)tiles_max, cs_d * cs_h * cs_w, ntn / NRsel);
   const float4* w4 = reinterpret_cast<const float4*>(wm);
-  switch (NR) {
+  switch (NRsel) {
     case 8: hipLaunchKernelGGL((gconv_gather_mfma_k<8>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
     case 4: hipLaunchKernelGGL((gconv_gather_mfma_k<4>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;
     case 2: hipLaunchKernelGGL((gconv_gather_mfma_k<2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, vec, (int)tiles_max); break;

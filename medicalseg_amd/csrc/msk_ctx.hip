@@ -73,6 +73,15 @@ void msk_prof_end(msk_ctx* ctx) {
   if (ctx->prof_pending.size() > 4096) drain_prof(ctx);
 }
 
+int msk_join_side_impl(msk_ctx* ctx) {
+  if (ctx->side_dirty) {
+    MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    ctx->side_dirty = false;
+  }
+  return 0;
+}
+
 extern "C" {
 
 int msk_version(void) { return 100; }
@@ -95,8 +104,12 @@ int msk_ctx_create(int device, msk_ctx** out) {
   if (device < 0 || device >= n) return msk_fail(nullptr, __FILE__, __LINE__, "msk_ctx_create", "bad device index");
   msk_ctx* ctx = new msk_ctx();
   ctx->device = device;
+  ctx->wgrad_async = true;
   MSK_CHECK_HIP(ctx, hipSetDevice(device));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t0));
   MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t1));
   hipDeviceProp_t prop;
@@ -114,6 +127,10 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
+  if (ctx->ws_side) hipFree(ctx->ws_side);
+  if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   hipEventDestroy(ctx->t0);
   hipEventDestroy(ctx->t1);
   hipStreamDestroy(ctx->stream);
@@ -124,9 +141,12 @@ int msk_ctx_destroy(msk_ctx* ctx) {
 const char* msk_last_error(msk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_msk_global_err.c_str(); }
 
 int msk_sync(msk_ctx* ctx) {
+  if (msk_join_side_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
+
+int msk_join_side(msk_ctx* ctx) { return msk_join_side_impl(ctx); }
 
 int msk_device_name(msk_ctx* ctx, char* buf, int buflen) {
   hipDeviceProp_t prop;
@@ -143,12 +163,14 @@ int msk_malloc(msk_ctx* ctx, size_t bytes, void** out) {
 }
 int msk_free(msk_ctx* ctx, void* p) {
   if (!p) return 0;
+  if (msk_join_side_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MSK_CHECK_HIP(ctx, hipFree(p));
   return 0;
 }
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes) {
   if (bytes == 0) return 0;
+  if (msk_join_side_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipMemsetAsync(p, value, bytes, ctx->stream));
   return 0;
 }
@@ -161,6 +183,7 @@ int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return 0;
+  if (msk_join_side_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
@@ -223,6 +246,11 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len) {
 int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   if (strcmp(key, "conv_impl") == 0) {
     ctx->conv_impl = value;
+    return 0;
+  }
+  if (strcmp(key, "wgrad_async") == 0) {  // weight gradients on the side stream (default on)
+    if (msk_join_side_impl(ctx) != 0) return -1;
+    ctx->wgrad_async = value != 0;
     return 0;
   }
   if (strcmp(key, "prof_shapes") == 0) {

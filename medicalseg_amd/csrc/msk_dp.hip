@@ -40,6 +40,7 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
 
 int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  if (msk_join_side_impl(ctx) != 0) return -1;  // the gradient arena includes side-stream weight gradients
   msk_launch_scope ls(ctx, "rccl_allreduce");
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;

@@ -272,6 +272,7 @@ int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
 int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
                      float momentum, float weight_decay, float grad_scale) {
   if (count == 0) return 0;
+  if (msk_join_side_impl(ctx) != 0) return -1;  // weight gradients may still be running on the side stream
   MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
               "arenas must be 16-byte aligned");
   size_t n4 = count / 4;

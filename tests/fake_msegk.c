@@ -17,6 +17,7 @@ int msk_ctx_create(int dev, void** out) { (void)dev; *out = &g_ctx; return 0; }
 int msk_ctx_destroy(void* c) { (void)c; return 0; }
 const char* msk_last_error(void* c) { (void)c; return "fake"; }
 int msk_sync(void* c) { (void)c; return 0; }
+int msk_join_side(void* c) { (void)c; return 0; }
 int msk_device_name(void* c, char* buf, int n) { (void)c; strncpy(buf, "fake-host-device", n); return 0; }
 int msk_malloc(void* c, size_t b, void** out) { (void)c; *out = calloc(1, b ? b : 16); return *out ? 0 : -1; }
 int msk_free(void* c, void* p) { (void)c; free(p); return 0; }
