@@ -61,6 +61,9 @@ int msk_free(msk_ctx* ctx, void* p);
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes);
 int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* blocking for pageable src */
 int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* synchronises the stream */
+/* asynchronous host->device copy from PINNED memory (msk_pinned_alloc): returns immediately, the
+ * source must stay untouched until the stream passes the copy (tools/prepare.py:200-259 loader path) */
+int msk_h2d_async(msk_ctx* ctx, void* dst, const void* pinned_src, size_t bytes);
 int msk_d2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);
 int msk_pinned_alloc(msk_ctx* ctx, size_t bytes, void** out);
 int msk_pinned_free(msk_ctx* ctx, void* p);

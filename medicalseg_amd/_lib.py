@@ -49,6 +49,7 @@ SIGNATURES = {
     "msk_memset": (_i, [_vp, _vp, _i, _sz]),
     "msk_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "msk_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "msk_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
     "msk_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "msk_pinned_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "msk_pinned_free": (_i, [_vp, _vp]),

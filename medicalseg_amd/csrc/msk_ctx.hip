@@ -181,6 +181,11 @@ int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
+int msk_h2d_async(msk_ctx* ctx, void* dst, const void* pinned_src, size_t bytes) {
+  if (bytes == 0) return 0;
+  MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
 int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return 0;
   if (msk_join_side_impl(ctx) != 0) return -1;

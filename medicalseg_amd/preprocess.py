@@ -124,3 +124,88 @@ def label_remap(label, map_dict=None):
     dev.free(kp)
     dev.free(vp)
     return out
+
+
+class DevicePipeline:
+    """In-loop preprocessing that never returns to the host: raw volume -> pinned staging buffer ->
+    asynchronous H2D copy -> HIP kernels -> model input tensor.
+
+    Mirrors the op lists of the reference's prepare scripts
+    (tools/prepare_lung_coronavirus.py:81-90: [HUnorm, resample(128^3, order 1)];
+    tools/prepare_mri_spine_seg.py:71-80: [normalize(0, 2650), resample([512,512,12], 1)]) followed by
+    Compose's max-normalisation (transforms/transform.py:67-69).  Labels take `resample(order=0)`.
+
+        pipe = DevicePipeline()
+        x = pipe.image(raw).HUnorm().resample([128, 128, 128], 1).max_normalize().tensor()
+        y = pipe.label(raw_label).resample([128, 128, 128], 0).int_tensor()
+    """
+
+    def __init__(self, dev=None):
+        self.dev = dev or get_device()
+        self._pinned = [None, 0]
+
+    def _stage(self, a: np.ndarray) -> DeviceVolume:
+        dev = self.dev
+        a = np.ascontiguousarray(a)
+        if self._pinned[1] < a.nbytes:
+            if self._pinned[0]:
+                dev.sync()
+                dev.call("msk_pinned_free", C.c_void_p(self._pinned[0]))
+            p = C.c_void_p()
+            dev.call("msk_pinned_alloc", C.c_size_t(a.nbytes), C.byref(p))
+            self._pinned = [p.value, a.nbytes]
+        else:
+            dev.sync()  # the previous copy out of the staging buffer must have drained
+        C.memmove(self._pinned[0], a.ctypes.data, a.nbytes)
+        ptr = dev.malloc(a.nbytes)
+        dev.call("msk_h2d_async", C.c_void_p(ptr), C.c_void_p(self._pinned[0]), C.c_size_t(a.nbytes))
+        return DeviceVolume(dev, ptr, a.shape, a.dtype)
+
+    def image(self, raw) -> "_Chain":
+        return _Chain(self, self._stage(np.asarray(raw, dtype=np.float32)))
+
+    def label(self, raw) -> "_Chain":
+        return _Chain(self, self._stage(np.asarray(raw).astype(np.int32)))
+
+
+class _Chain:
+    def __init__(self, pipe, vol):
+        self.pipe, self.vol = pipe, vol
+
+    def HUnorm(self, HU_min=-1200, HU_max=600, HU_nan=-2000):
+        v = self.vol
+        v.dev.call("msk_hu_norm", C.c_void_p(v.ptr), C.c_void_p(v.ptr), C.c_size_t(v.size), C.c_float(HU_min),
+                   C.c_float(HU_max), C.c_float(HU_nan))
+        return self
+
+    def normalize(self, min_val=None, max_val=None):
+        v = self.vol
+        use = 0 if (min_val is None and max_val is None) else 1
+        v.dev.call("msk_minmax_norm", C.c_void_p(v.ptr), C.c_void_p(v.ptr), C.c_size_t(v.size), use,
+                   C.c_float(min_val or 0.0), C.c_float(max_val or 0.0))
+        return self
+
+    def resample(self, new_shape, order=1):
+        out = resample_device(self.vol, new_shape, order)
+        old, self.vol = self.vol, out
+        # the source is still being read by the enqueued kernel: free() synchronises first
+        old.free()
+        return self
+
+    def max_normalize(self):
+        v = self.vol
+        v.dev.call("msk_max_norm", C.c_void_p(v.ptr), C.c_void_p(v.ptr), C.c_size_t(v.size))
+        return self
+
+    def tensor(self):
+        """[1, 1, D, H, W] model input (one channel: NDHWC and NCDHW coincide); keeps the buffer."""
+        from .device import Tensor
+        d, h, w = self.vol.shape
+        return Tensor(self.vol.dev, self.vol.ptr, 1, d, h, w, 1, 1, None)
+
+    def int_tensor(self):
+        from .device import IntTensor
+        return IntTensor(self.vol.dev, self.vol.ptr, (1,) + tuple(self.vol.shape))
+
+    def numpy(self):
+        return self.vol.numpy()

@@ -24,6 +24,7 @@ int msk_free(void* c, void* p) { (void)c; free(p); return 0; }
 int msk_memset(void* c, void* p, int v, size_t b) { (void)c; memset(p, v, b); return 0; }
 int msk_h2d(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
 int msk_d2h(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
+int msk_h2d_async(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
 int msk_d2d(void* c, void* d, const void* s, size_t b) { (void)c; memmove(d, s, b); return 0; }
 int msk_pinned_alloc(void* c, size_t b, void** out) { return msk_malloc(c, b, out); }
 int msk_pinned_free(void* c, void* p) { return msk_free(c, p); }

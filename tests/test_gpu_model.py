@@ -248,3 +248,29 @@ def test_preprocess_size_independent_properties():
     assert set(np.unique(o)) <= set(np.unique(lab))
     # corners are preserved by the align-corner map
     assert o[0, 0, 0] == lab[0, 0, 0] and o[-1, -1, -1] == lab[-1, -1, -1]
+
+
+def test_in_loop_device_preprocessing_feeds_the_model():
+    """BASELINE configs[4] flow: raw MRI slab -> pinned H2D -> normalize(0,2650) -> resample(order 1)
+    -> max-normalise on the device -> VNet (20 classes, anisotropic kernels), no host round trip;
+    values equal the oracle's preprocessing, logits equal a forward on the oracle-preprocessed input."""
+    from medicalseg_amd.models import VNet
+    from medicalseg_amd.preprocess import DevicePipeline
+    rng = np.random.default_rng(3)
+    raw = (rng.random((60, 60, 12)) * 2650).astype(np.float32)
+    raw_lab = rng.integers(0, 20, (60, 60, 12)).astype(np.int32)
+    pipe = DevicePipeline()
+    chain = pipe.image(raw).normalize(0, 2650).resample([32, 32, 12], 1).max_normalize()
+    lab = pipe.label(raw_lab).resample([32, 32, 12], 0)
+    ref, _ = P.resample(P.normalize(raw.copy(), 0, 2650), [32, 32, 12], 1)
+    ref = P.max_normalize(ref)[None].astype(np.float32)
+    assert np.abs(chain.numpy() - ref[0, 0]).max() < 2e-6
+    assert np.array_equal(lab.numpy(), P.resample(raw_lab, [32, 32, 12], 0)[0])
+    K = [[2, 2, 4], [2, 2, 2], [2, 2, 2], [2, 2, 2]]
+    S = [[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]
+    model = VNet(num_classes=20, kernel_size=K, stride_size=S)
+    model.eval()
+    a = model(chain.tensor())[0].numpy()
+    b = model(ref)[0].numpy()
+    assert a.shape == (1, 20, 32, 32, 12) and rel_err(a, b) < 1e-5
+    assert lab.int_tensor().shape == (1, 32, 32, 12)
