@@ -207,14 +207,16 @@ splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int 
 // (conflict-free ds_read_b128) and the weights as wave-uniform scalar loads runs these layers
 // at their useful FLOP count.
 template <int TD, int TH, int TW, int KS, int CK, int CN>
-__global__ void __launch_bounds__(256, 2) conv_halo_valu_k(HaloArgs a, const float* __restrict__ wp /*[tap][CK][CN]*/) {
+__global__ void __launch_bounds__(256) conv_halo_valu_k(HaloArgs a, const float* __restrict__ wp /*[tap][CK][CN]*/) {
   constexpr int P = KS / 2;
   constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
   constexpr int NV = HD * HH * HW;
-  constexpr int NVP = NV | 1;
-  constexpr int KC = (CK + 7) / 8;
+  // ONE channel quad per staged chunk: 27.7 KiB of LDS per workgroup -> 5 workgroups per CU, so the
+  // scalar-load latency of the wave-uniform weights is covered by occupancy (with 8-channel chunks
+  // and 2 workgroups per CU the kernel ran 5.6x off its VALU bound)
+  constexpr int QC = (CK + 3) / 4;
   static_assert(TD * TH * TW == 256, "one thread per output voxel");
-  __shared__ float4 lds[2 * NVP];
+  __shared__ float4 lds[NV];
 
   const int tid = threadIdx.x;
   int tile = xcd_remap(blockIdx.x, a.nblk);
@@ -233,46 +235,51 @@ __global__ void __launch_bounds__(256, 2) conv_halo_valu_k(HaloArgs a, const flo
   for (int j = 0; j < CN; ++j) acc[j] = 0.f;
 
 #pragma unroll 1
-  for (int kc = 0; kc < KC; ++kc) {
+  for (int qc = 0; qc < QC; ++qc) {
+    const int c0 = qc * 4;
     __syncthreads();
-    for (int it = tid; it < NV * 2; it += 256) {
-      const int hv = it >> 1, q = it & 1;
-      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int c0 = kc * 8 + q * 4;
-      if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < CK) {
-        const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
-        if (a.vec) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          v.x = p[0];
-          if (c0 + 1 < CK) v.y = p[1];
-          if (c0 + 2 < CK) v.z = p[2];
-          if (c0 + 3 < CK) v.w = p[3];
+    constexpr int SG = 7;
+    for (int sb = 0; sb < NV; sb += SG * 256) {
+      float4 tmp[SG];
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int hv = sb + tid + i * 256;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hv < NV && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          if (a.vec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c0 + 1 < CK) v.y = p[1];
+            if (c0 + 2 < CK) v.z = p[2];
+            if (c0 + 3 < CK) v.w = p[3];
+          }
         }
+        tmp[i] = v;
       }
-      lds[q * NVP + hv] = v;
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int hv = sb + tid + i * 256;
+        if (hv < NV) lds[hv] = tmp[i];
+      }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c0 = kc * 8 + q * 4;
-      if (c0 >= CK) break;
 #pragma unroll 1
-      for (int rr = 0; rr < KS * KS; ++rr) {
-        const int rowoff = ((rr / KS) * HH + (rr % KS)) * HW;
+    for (int rr = 0; rr < KS * KS; ++rr) {
+      const int rowoff = ((rr / KS) * HH + (rr % KS)) * HW;
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          const float4 av = lds[q * NVP + base + rowoff + kw];
-          const float* w = wp + ((long)(rr * KS + kw) * CK + c0) * CN;  // wave-uniform -> scalar loads
-          const float xs[4] = {av.x, av.y, av.z, av.w};
+      for (int kw = 0; kw < KS; ++kw) {
+        const float4 av = lds[base + rowoff + kw];
+        const float* w = wp + ((long)(rr * KS + kw) * CK + c0) * CN;  // wave-uniform -> scalar loads
+        const float xs[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (c0 + c < CK) {
+        for (int c = 0; c < 4; ++c) {
+          if (c0 + c < CK) {
 #pragma unroll
-              for (int j = 0; j < CN; ++j) acc[j] = fmaf(xs[c], w[c * CN + j], acc[j]);
-            }
+            for (int j = 0; j < CN; ++j) acc[j] = fmaf(xs[c], w[c * CN + j], acc[j]);
           }
         }
       }
