@@ -204,6 +204,18 @@ int msk_max_norm(msk_ctx* ctx, const float* src, float* dst, size_t count);
 int msk_label_remap(msk_ctx* ctx, int32_t* label, size_t count, const int32_t* keys,
                     const int32_t* vals, int npairs);
 
+/* ---- deep supervision (models/vnet_deepsup.py:266-277) -------------- */
+/* F.interpolate(d, size=x.shape[2:], mode='trilinear') of a conv3^3 head: align_corners=
+ * False, align_mode=0 [PADDLE]: per axis ratio = in/out, src = max(ratio*(o+0.5)-0.5, 0),
+ * i0 = floor(src), i1 = min(i0+1, in-1).  src/dst: NDHWC with equal n and c.         */
+int msk_interp_trilinear_fwd(msk_ctx* ctx, msk_tensor src, msk_tensor dst);
+/* Adjoint: ddst (gradient at the resized size) -> dsrc (head resolution); separable
+ * gather passes, deterministic.  scratch: device buffer of >= msk_interp_scratch_bytes
+ * (may be NULL when only the depth axis is resized).                                  */
+int msk_interp_scratch_bytes(msk_ctx* ctx, msk_tensor src, msk_tensor dst, size_t* bytes);
+int msk_interp_trilinear_bwd(msk_ctx* ctx, msk_tensor ddst, msk_tensor dsrc, int accumulate,
+                             void* scratch, size_t scratch_bytes);
+
 /* ---- data parallel (RCCL over xGMI; core/train.py:81-85 fleet DataParallel) ---- */
 #define MSK_UNIQUE_ID_BYTES 128
 int msk_dp_unique_id(char* id128);                       /* rank 0 */

@@ -88,6 +88,9 @@ SIGNATURES = {
     "msk_minmax_norm": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f]),
     "msk_max_norm": (_i, [_vp, _vp, _vp, _sz]),
     "msk_label_remap": (_i, [_vp, _vp, _sz, _vp, _vp, _i]),
+    "msk_interp_trilinear_fwd": (_i, [_vp, _T, _T]),
+    "msk_interp_scratch_bytes": (_i, [_vp, _T, _T, C.POINTER(_sz)]),
+    "msk_interp_trilinear_bwd": (_i, [_vp, _T, _T, _i, _vp, _sz]),
     "msk_dp_unique_id": (_i, [C.c_char_p]),
     "msk_dp_init": (_i, [_vp, C.c_char_p, _i, _i]),
     "msk_dp_allreduce_sum": (_i, [_vp, _vp, _sz]),

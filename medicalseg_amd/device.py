@@ -173,7 +173,7 @@ class Tensor:
     ``shape`` reports the reference's logical NCDHW order so code written against the
     reference (``_, c, d, h, w = images.shape``; core/train.py:266) keeps working."""
 
-    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer")
+    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index")
 
     def __init__(self, dev, ptr, n, d, h, w, c, ld=None, gen=None):
         self.dev, self.ptr = dev, ptr
@@ -183,6 +183,7 @@ class Tensor:
         self.grad = None
         self.grad_written = False
         self.producer = None
+        self.out_index = 0
 
     # -- construction ------------------------------------------------------------------
     @staticmethod

@@ -1,2 +1,3 @@
 from .losses import *
 from .vnet import VNet
+from .vnet_deepsup import VNetDeepSup

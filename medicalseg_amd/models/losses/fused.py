@@ -51,11 +51,8 @@ class LossNode:
         dev.call("msk_loss_bwd", self.logits.msk(), C.c_void_p(self.labels.ptr), C.c_void_p(w),
                  int(self.ignore_index), C.c_void_p(self.stats_ptr), C.c_float(coef_ce), C.c_float(coef_dice),
                  dz.msk())
-        if self.logits.producer is None:
-            self.logits.grad = dz
-            self.logits.grad_written = True
-            return dz
-        self.logits.producer.backward(dz)
+        self.logits.grad = dz
+        self.logits.grad_written = True
         return dz
 
 
@@ -125,8 +122,20 @@ class Scalar:
                 g[1] += c
             else:
                 g[2] += c
+        # dL/dlogits per evaluated output, then ONE backward per producing model: a
+        # multi-output model (VNetDeepSup.num_outputs = 4) receives the list in forward order
+        producers = {}
         for node, cce, cdice in groups.values():
-            node.backward(cce, cdice)
+            dz = node.backward(cce, cdice)
+            prod = node.logits.producer
+            if prod is not None:
+                producers.setdefault(id(prod), (prod, {}))[1][getattr(node.logits, "out_index", 0)] = dz
+        for prod, grads in producers.values():
+            n_out = getattr(prod, "num_outputs", 1)
+            if n_out == 1:
+                prod.backward(grads[0])
+            else:
+                prod.backward([grads.get(i) for i in range(n_out)])
 
     def detach(self):
         return self

@@ -220,16 +220,18 @@ class VNet(nn.Layer):
     # -- device residency -----------------------------------------------------------
     def _build(self):
         dev = get_device()
-        params = []
+        params, frozen = [], []
         for name, p in self.named_parameters():
             p.name = name
-            params.append(p)
+            (frozen if getattr(p, "frozen", False) else params).append(p)
         bufs = []
         for name, p in self.named_buffers():
             p.name = name
             bufs.append(p)
         self.arena = nn.ParamArena(dev, params, with_grad=True)
         self.buffer_arena = nn.ParamArena(dev, bufs, with_grad=False)
+        # parameters no forward path reaches (VNetDeepSup.out_tr_all): stored, never updated
+        self.frozen_arena = nn.ParamArena(dev, frozen, with_grad=False) if frozen else None
         self.dev = dev
 
     def init_weight(self):

@@ -183,7 +183,8 @@ class Layer:
     load_dict = set_state_dict
 
     def clear_gradients(self):
-        arenas = {id(p.arena): p.arena for p in self.parameters() if p.arena is not None}
+        arenas = {id(p.arena): p.arena for p in self.parameters()
+                  if p.arena is not None and p.arena.grad_ptr is not None}
         for a in arenas.values():
             a.zero_grad()
 

@@ -84,6 +84,8 @@ class Momentum:
     def __init__(self, learning_rate=0.001, momentum=0.9, parameters=None, weight_decay=None, **kw):
         if not parameters:
             raise ValueError("parameters must be a non-empty list")
+        # tensors no forward path reaches get no gradient and are skipped by paddle's optimizer
+        parameters = [p for p in parameters if not getattr(p, "frozen", False)]
         arenas = {id(p.arena): p.arena for p in parameters}
         if len(arenas) != 1 or None in [p.arena for p in parameters]:
             raise ValueError("all parameters must belong to one built model (one ParamArena)")

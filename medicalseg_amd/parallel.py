@@ -165,6 +165,9 @@ class DataParallel:
             if model.buffer_arena.count:
                 dev.call("msk_dp_broadcast", C.c_void_p(model.buffer_arena.value_ptr),
                          C.c_size_t(model.buffer_arena.count), 0)
+            fa = getattr(model, "frozen_arena", None)
+            if fa is not None and fa.count:
+                dev.call("msk_dp_broadcast", C.c_void_p(fa.value_ptr), C.c_size_t(fa.count), 0)
             model.arena.grad_scale = 1.0 / dev.world
             model._post_backward_hooks.append(self._allreduce)
 

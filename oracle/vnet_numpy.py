@@ -251,9 +251,13 @@ def init_params(seed=0, in_channels=1, num_classes=4, kernel_size=DEFAULT_K,
     """Deterministic initialisation (App. B.6 distributions).  With ``perturb``
     BN gamma/beta, PReLU alpha, biases and running stats get non-trivial values so
     that parity tests exercise every term."""
+    return _init_from_specs(param_specs(in_channels, num_classes, kernel_size, stride_size), seed, dtype, perturb)
+
+
+def _init_from_specs(specs, seed, dtype, perturb):
     rng = np.random.default_rng(seed)
     out = {}
-    for name, shape, kind in param_specs(in_channels, num_classes, kernel_size, stride_size):
+    for name, shape, kind in specs:
         if kind == "conv_w":
             fan_in = shape[1] * shape[2] * shape[3] * shape[4]
             v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
@@ -419,14 +423,18 @@ class VNetOracle:
         return self._prelu(name + ".relu2", self._add(out, xcat))
 
     # ---- public --------------------------------------------------------
-    def forward(self, x, train=True, dropout_masks=None, record=True):
+    def _begin(self, x, train, dropout_masks, record):
         self.training = train
         self.masks = dropout_masks or {}
         self.tape = Tape() if record else None
         self.grads = {}
-        K, S = self.kernel_size, self.stride_size
         xin = Var(np.asarray(x, dtype=self.dtype))
         self._xin = xin
+        return xin
+
+    def _trunk(self, xin):
+        """in_tr .. up_tr32 (vnet.py:255-265); fills self.acts."""
+        K, S = self.kernel_size, self.stride_size
         # InputTransition vnet.py:74-79
         c = self._bn("in_tr.bn1", self._conv("in_tr.conv1", xin, 1, 2))
         rep = 16 // self.in_channels
@@ -443,14 +451,125 @@ class VNetOracle:
         # named activations (value .v, and gradient .g after backward) for debugging/tests
         self.acts = {"out16": out16, "out32": out32, "out64": out64, "out128": out128, "out256": out256,
                      "up256": up256, "up128": up128, "up64": up64, "up32": out}
-        # OutputTransition vnet.py:172-175
-        o = self._prelu("out_tr.relu1", self._bn("out_tr.bn1", self._conv("out_tr.conv1", out, 1, 2)))
-        logits = self._conv("out_tr.conv2", o, 1, 0)
+        return out
+
+    def _out_transition(self, name, x):  # OutputTransition vnet.py:172-175
+        o = self._prelu(name + ".relu1", self._bn(name + ".bn1", self._conv(name + ".conv1", x, 1, 2)))
+        return self._conv(name + ".conv2", o, 1, 0)
+
+    def forward(self, x, train=True, dropout_masks=None, record=True):
+        xin = self._begin(x, train, dropout_masks, record)
+        logits = self._out_transition("out_tr", self._trunk(xin))
         self._logits = logits
         return logits.v
 
     def backward(self, dlogits):
         self._logits.g = np.asarray(dlogits, dtype=self.dtype)
+        self.tape.backward()
+        return self.grads
+
+
+# --------------------------------------------------------------------------
+# VNetDeepSup (models/vnet_deepsup.py:178-281)
+# --------------------------------------------------------------------------
+def trilinear_matrix(n_in, n_out, dtype=np.float64):
+    """[n_out, n_in] interpolation matrix of one axis of paddle F.interpolate(mode=
+    'trilinear', align_corners=False, align_mode=0) with an explicit output size
+    (vnet_deepsup.py:268-277; [PADDLE] interpolate kernel): ratio = n_in/n_out,
+    src = max(ratio*(o+0.5)-0.5, 0), i0 = floor(src), i1 = min(i0+1, n_in-1),
+    out = (1-lam)*x[i0] + lam*x[i1] with lam = src - i0."""
+    m = np.zeros((n_out, n_in), dtype=dtype)
+    ratio = n_in / n_out
+    for o in range(n_out):
+        src = max(ratio * (o + 0.5) - 0.5, 0.0)
+        i0 = min(int(np.floor(src)), n_in - 1)
+        i1 = min(i0 + 1, n_in - 1)
+        lam = src - i0
+        m[o, i0] += 1.0 - lam
+        m[o, i1] += lam
+    return m
+
+
+def trilinear_resize(x, size):
+    """x [N,C,D,H,W] -> [N,C,*size] (separable form of the 8-corner sum)."""
+    md, mh, mw = (trilinear_matrix(i, o, x.dtype) for i, o in zip(x.shape[2:], size))
+    y = np.einsum("od,ncdhw->ncohw", md, x)
+    y = np.einsum("ph,ncohw->ncopw", mh, y)
+    return np.einsum("qw,ncopw->ncopq", mw, y)
+
+
+def trilinear_resize_bwd(g, in_size):
+    """Adjoint of trilinear_resize: g [N,C,*out] -> [N,C,*in_size]."""
+    md, mh, mw = (trilinear_matrix(i, o, g.dtype) for i, o in zip(in_size, g.shape[2:]))
+    y = np.einsum("qw,ncopq->ncopw", mw, g)
+    y = np.einsum("ph,ncopw->ncohw", mh, y)
+    return np.einsum("od,ncohw->ncdhw", md, y)
+
+
+def param_specs_deepsup(in_channels=1, num_classes=4, kernel_size=DEFAULT_K, stride_size=DEFAULT_S):
+    """State-dict names of VNetDeepSup in attribute order (vnet_deepsup.py:210-251): the
+    VNet trunk, out_tr32 (= VNet's out_tr), three conv3^3 heads and the never-called
+    out_tr_all (:251; its parameters exist, receive no gradient and are skipped by the
+    optimizer [PADDLE])."""
+    specs = [(n.replace("out_tr.", "out_tr32."), s, k)
+             for n, s, k in param_specs(in_channels, num_classes, kernel_size, stride_size)]
+    for name, cin in (("out_tr64", 64), ("out_tr128", 128), ("out_tr256", 256)):
+        specs.append((name + ".weight", (num_classes, cin, 3, 3, 3), "conv_w"))
+        specs.append((name + ".bias", (num_classes,), "bias"))
+    n = "out_tr_all"
+    specs += [(n + ".conv1.weight", (num_classes, 4 * num_classes, 5, 5, 5), "conv_w"),
+              (n + ".conv1.bias", (num_classes,), "bias"),
+              (n + ".bn1.weight", (num_classes,), "bn_w"), (n + ".bn1.bias", (num_classes,), "bn_b"),
+              (n + ".bn1._mean", (num_classes,), "bn_mean"), (n + ".bn1._variance", (num_classes,), "bn_var"),
+              (n + ".conv2.weight", (num_classes, num_classes, 1, 1, 1), "conv_w"),
+              (n + ".conv2.bias", (num_classes,), "bias"),
+              (n + ".relu1._weight", (num_classes,), "prelu")]
+    return specs
+
+
+def init_params_deepsup(seed=0, in_channels=1, num_classes=4, kernel_size=DEFAULT_K, stride_size=DEFAULT_S,
+                        dtype=np.float32, perturb=True):
+    return _init_from_specs(param_specs_deepsup(in_channels, num_classes, kernel_size, stride_size), seed, dtype,
+                            perturb)
+
+
+class VNetDeepSupOracle(VNetOracle):
+    """forward -> [out, d1, d2, d3] (vnet_deepsup.py:257-281): d1/d2/d3 are conv3^3(p=1)
+    heads on the up_tr256/up_tr128/up_tr64 outputs, trilinearly resized to the input
+    size.  backward takes the list of the four logit gradients."""
+
+    def __init__(self, params, in_channels=1, num_classes=4, kernel_size=DEFAULT_K, stride_size=DEFAULT_S,
+                 dtype=np.float64):
+        super().__init__(params, in_channels, num_classes, kernel_size, stride_size, dtype)
+        self.specs = param_specs_deepsup(in_channels, num_classes, kernel_size, stride_size)
+        self.unused = [n for n, _, _ in self.specs if n.startswith("out_tr_all.")]
+        self.trainable = [n for n, _, k in self.specs if k in TRAINABLE_KINDS and n not in self.unused]
+
+    def _resize(self, x, size):
+        y = Var(trilinear_resize(x.v, size))
+        if self.tape is not None:
+            self.tape.record(lambda: x.acc(trilinear_resize_bwd(y.g, x.v.shape[2:])))
+        return y
+
+    def forward(self, x, train=True, dropout_masks=None, record=True):
+        xin = self._begin(x, train, dropout_masks, record)
+        size = xin.v.shape[2:]
+        feat = self._trunk(xin)
+        outs = [self._out_transition("out_tr32", feat)]
+        for head, act in (("out_tr256", "up256"), ("out_tr128", "up128"), ("out_tr64", "up64")):
+            d = self._conv(head, self.acts[act], 1, 1)
+            self.acts[head] = d
+            outs.append(self._resize(d, size))
+        self._outs = outs
+        return [o.v for o in outs]
+
+    def backward(self, dlogits_list):
+        for o, g in zip(self._outs, dlogits_list):
+            o.g = None if g is None else np.asarray(g, dtype=self.dtype)
+        # a head without a gradient contributes nothing
+        for o in self._outs:
+            if o.g is None:
+                o.g = np.zeros_like(o.v)
         self.tape.backward()
         return self.grads
 

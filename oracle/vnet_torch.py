@@ -122,6 +122,24 @@ class TorchVNet(nn.Module):
         out = self.up_tr32(out, o16)
         return self.out_tr(out)
 
+    def trunk(self, x, masks=None):
+        """(up_tr256, up_tr128, up_tr64, up_tr32) outputs -- shared with TorchVNetDeepSup."""
+        m = masks or {}
+
+        def g(k):
+            v = m.get(k)
+            return None if v is None else torch.as_tensor(v, dtype=x.dtype)[:, :, None, None, None]
+
+        o16 = self.in_tr(x)
+        o32 = self.down_tr32(o16)
+        o64 = self.down_tr64(o32)
+        o128 = self.down_tr128(o64, g("down_tr128"))
+        o256 = self.down_tr256(o128, g("down_tr256"))
+        u256 = self.up_tr256(o256, o128, g("up_tr256.x"), g("up_tr256.skip"))
+        u128 = self.up_tr128(u256, o64, g("up_tr128.x"), g("up_tr128.skip"))
+        u64 = self.up_tr64(u128, o32)
+        return u256, u128, u64, self.up_tr32(u64, o16)
+
     def load_oracle_params(self, params):
         sd = {}
         for k, v in params.items():
@@ -135,6 +153,38 @@ class TorchVNet(nn.Module):
     def named_oracle_grads(self):
         out = {}
         for k, p in self.named_parameters():
+            parts = k.split(".")
+            if parts[-2].startswith("relu"):
+                k = ".".join(parts[:-1]) + "._weight"
+            out[k] = p.grad.detach().numpy().copy()
+        return out
+
+
+class TorchVNetDeepSup(TorchVNet):
+    """vnet_deepsup.py:178-281: VNet trunk, out_tr32, three conv3^3 heads resized with
+    F.interpolate(mode='trilinear', align_corners=False) (same half-pixel convention as
+    paddle's default align_mode=0), and the never-called out_tr_all."""
+
+    def __init__(self, in_channels=1, num_classes=4, kernel_size=((2, 2, 2),) * 4, stride_size=((2, 2, 2),) * 4):
+        super().__init__(in_channels, num_classes, kernel_size, stride_size)
+        self.out_tr32 = self.out_tr
+        del self.out_tr
+        self.out_tr64 = nn.Conv3d(64, num_classes, 3, padding=1)
+        self.out_tr128 = nn.Conv3d(128, num_classes, 3, padding=1)
+        self.out_tr256 = nn.Conv3d(256, num_classes, 3, padding=1)
+        self.out_tr_all = OutTr(4 * num_classes, num_classes)
+
+    def forward(self, x, masks=None):
+        u256, u128, u64, feat = self.trunk(x, masks)
+        size = x.shape[2:]
+        r = lambda t: F.interpolate(t, size=size, mode="trilinear", align_corners=False)
+        return [self.out_tr32(feat), r(self.out_tr256(u256)), r(self.out_tr128(u128)), r(self.out_tr64(u64))]
+
+    def named_oracle_grads(self):
+        out = {}
+        for k, p in self.named_parameters():
+            if p.grad is None:
+                continue
             parts = k.split(".")
             if parts[-2].startswith("relu"):
                 k = ".".join(parts[:-1]) + "._weight"

@@ -45,4 +45,9 @@ NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd
 NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c)
 NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum)
 NOOP(msk_resample3d) NOOP(msk_hu_norm) NOOP(msk_minmax_norm) NOOP(msk_max_norm) NOOP(msk_label_remap)
+NOOP(msk_interp_trilinear_fwd) NOOP(msk_interp_trilinear_bwd)
+typedef struct { void* p; int32_t n, d, h, w, c, ld; } fake_tensor;
+int msk_interp_scratch_bytes(void* c, fake_tensor s, fake_tensor d, size_t* b) {
+  (void)c; *b = ((size_t)d.n * d.d * d.h * s.w + (size_t)d.n * d.d * s.h * s.w) * s.c * 4; return 0;
+}
 NOOP(msk_dp_init) NOOP(msk_dp_allreduce_sum) NOOP(msk_dp_allgather) NOOP(msk_dp_broadcast) NOOP(msk_dp_barrier) NOOP(msk_dp_destroy)

@@ -1,0 +1,112 @@
+"""VNetDeepSup (reference models/vnet_deepsup.py:178-281) on the GPU vs the
+float64 oracle: four outputs, per-output MixedLoss with coef 0.25, multi-output backward,
+optimizer step that must leave the never-called out_tr_all untouched.
+
+Tolerances as in test_gpu_model.py (calibrated against the same oracle run in float32)."""
+import numpy as np
+import pytest
+
+from helpers import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vnet_numpy as O  # noqa: E402
+
+SITES = [("down_tr128", 128), ("down_tr256", 256), ("up_tr256.x", 256), ("up_tr256.skip", 128),
+         ("up_tr128.x", 256), ("up_tr128.skip", 64)]
+
+CFGS = [
+    ((16, 16, 16), 3, ((2, 2, 2),) * 4, ((2, 2, 2),) * 4, 2),
+    # MRI: vnetdeepsup_mri_spine_seg_512_512_12_15k.yml:17-18
+    ((32, 32, 12), 5, ((2, 2, 4), (2, 2, 2), (2, 2, 2), (2, 2, 2)), ((2, 2, 1), (2, 2, 1), (2, 2, 2), (2, 2, 2)), 1),
+]
+
+
+def _l2(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _oracle(params, ncls, K, S, x, y, masks, dtype):
+    om = O.VNetDeepSupOracle(params, 1, ncls, K, S, dtype=dtype)
+    outs = om.forward(x, train=True, dropout_masks=masks)
+    Ls = [O.MixedLossOracle(outer_coef=0.25, dtype=dtype) for _ in outs]
+    res = [L(o, y) for L, o in zip(Ls, outs)]
+    return om, outs, res, om.backward([r[2] for r in res])
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_deepsup_forward_backward_step(cfg):
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNetDeepSup
+    from medicalseg_amd.utils import loss_computation
+    shape, ncls, K, S, N = cfg
+    rng = np.random.default_rng(5)
+    params = O.init_params_deepsup(4, 1, ncls, K, S)
+    model = VNetDeepSup(elu=False, in_channels=1, num_classes=ncls, kernel_size=K, stride_size=S)
+    missing, unexpected = model.set_state_dict(params)
+    assert not missing and not unexpected
+    assert list(model.state_dict().keys()) == [n for n, _, _ in O.param_specs_deepsup(1, ncls, K, S)]
+    x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+    masks = {s: (rng.random((N, c)) < 0.5).astype(np.float32) * 2.0 for s, c in SITES}
+
+    om, outs_ref, res_ref, g_ref = _oracle(params, ncls, K, S, x, y, masks, np.float64)
+    _, outs32, _, g32 = _oracle(params, ncls, K, S, x, y, masks, np.float32)
+    noise = {k: np.abs(g32[k] - g_ref[k]).max() / (np.abs(g_ref[k]).max() + 1e-30) for k in g_ref}
+    noise_l2 = {k: _l2(g32[k], g_ref[k]) for k in g_ref}
+
+    model.train()
+    model.set_dropout_masks(masks)
+    outs = model(x)
+    assert len(outs) == 4
+    for o, ref, o32 in zip(outs, outs_ref, outs32):
+        assert o.shape == (N, ncls) + shape
+        assert rel_err(o.numpy(), ref) < max(2e-4, 4 * rel_err(o32, ref))
+
+    # one MixedLoss per output, coef 0.25 each (yml :12-20; Config replicates the single type)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1]) for _ in range(4)], "coef": [0.25] * 4}
+    loss_list, per = loss_computation(outs, to_tensor(y), losses)
+    assert len(loss_list) == 8
+    for i, r in enumerate(res_ref):
+        assert abs(float(loss_list[2 * i]) - r[0][0]) < 1e-4 * abs(r[0][0])
+        assert abs(float(loss_list[2 * i + 1]) - r[0][1]) < 1e-4
+    assert np.abs(np.asarray(per) - res_ref[-1][1]).max() < 1e-4  # the LAST output's dice survives (loss_utils.py:41)
+
+    model.clear_gradients()
+    sum(loss_list).backward()
+    l2s = []
+    frozen = {n for n, p in model.named_parameters() if getattr(p, "frozen", False)}
+    assert frozen == {n for n in om.unused if not n.endswith(("._mean", "._variance"))}
+    for name, p in model.named_parameters():
+        if name in frozen:
+            continue
+        g, ref = p.grad_numpy(), g_ref[name]
+        scale = np.abs(ref).max()
+        if scale < 1e-9:
+            assert np.abs(g).max() < 1e-4
+            continue
+        err, l2 = np.abs(g - ref).max() / scale, _l2(g, ref)
+        l2s.append(l2)
+        assert l2 < max(2e-2, 6 * noise_l2[name]), (name, l2, noise_l2[name])
+        assert err < max(1e-1, 6 * noise[name]), (name, err, noise[name])
+    assert float(np.median(l2s)) < max(3e-3, 3 * float(np.median(list(noise_l2.values()))))
+    # the three heads are shallow: their gradients must be tight
+    for head in ("out_tr64", "out_tr128", "out_tr256"):
+        assert _l2(dict(model.named_parameters())[head + ".weight"].grad_numpy(), g_ref[head + ".weight"]) < \
+            max(2e-3, 6 * noise_l2[head + ".weight"])
+
+    # optimizer step: trainable tensors move like the oracle's, out_tr_all does not move at all
+    before = {n: p.numpy() for n, p in model.named_parameters() if n in frozen}
+    opt = optim.Momentum(learning_rate=1e-2, momentum=0.9, parameters=model.parameters(), weight_decay=1e-4)
+    opt.step()
+    vel = {}
+    O.sgd_momentum_step(om.p, g_ref, vel, 1e-2, 0.9, 1e-4, names=om.trainable)
+    after = dict(model.named_parameters())
+    for n in frozen:
+        assert np.array_equal(after[n].numpy(), before[n]), n
+    for n in ("out_tr64.weight", "out_tr256.bias", "out_tr32.conv2.weight", "in_tr.conv1.weight"):
+        assert np.abs(after[n].numpy() - om.p[n]).max() < 1e-4 * (np.abs(om.p[n]).max() + 1e-3), n
+    dev().sync()

@@ -33,6 +33,9 @@ CONV_CASES = [
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
+    (64, 3, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 6, 9, 34)),      # VNetDeepSup out_tr64 (lung, ncls 3)
+    (128, 20, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 5, 9, 12)),    # VNetDeepSup out_tr128 (MRI, ncls 20)
+    (256, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 6, 6)),      # VNetDeepSup out_tr256
     (5, 7, (3, 2, 1), (2, 1, 1), (1, 0, 0), (1, 7, 6, 5)),        # odd everything -> reference kernels
 ]
 
@@ -309,3 +312,56 @@ def test_dropout_mask_statistics():
     assert np.array_equal(vec_back(m, 4096), a)  # deterministic in (seed, step, site)
     d.call("msk_dropout_mask", C.c_uint64(7), C.c_uint64(4), C.c_uint32(2), 4096, C.c_float(0.5), vp(m))
     assert not np.array_equal(vec_back(m, 4096), a)
+
+
+INTERP_CASES = [
+    # (C, (N, d, h, w) head resolution, (D, H, W) input resolution)
+    (3, (2, 4, 4, 4), (32, 32, 32)),      # lung d1: x8 per axis
+    (3, (1, 8, 8, 8), (32, 32, 32)),      # lung d2: x4
+    (3, (1, 16, 16, 16), (32, 32, 32)),   # lung d3: x2
+    (20, (1, 8, 8, 6), (64, 64, 12)),     # MRI d1: (8, 8, 2)
+    (20, (1, 16, 16, 12), (32, 32, 12)),  # MRI d2/d3 class: last axis identity
+    (5, (2, 5, 7, 3), (13, 9, 8)),        # ragged: non-integer ratios, one axis SHRINKS (7 -> 9, 5 -> 13)
+    (4, (1, 6, 5, 4), (6, 5, 4)),         # identity
+    (2, (1, 1, 1, 1), (5, 4, 3)),         # single source voxel
+]
+
+
+@pytest.mark.parametrize("case", INTERP_CASES)
+def test_interp_trilinear_fwd_bwd(case):
+    """msk_interp_trilinear_{fwd,bwd} vs the oracle's restatement of F.interpolate(mode='trilinear')
+    (vnet_deepsup.py:268-277); 1e-5 of max|ref| (fp32 coordinates and weights vs float64)."""
+    Cn, (N, sd, sh, sw), size = case
+    d = dev()
+    rng = np.random.default_rng(Cn * 1000 + sd * 7 + size[0])
+    x = rng.standard_normal((N, Cn, sd, sh, sw)).astype(np.float32)
+    y_ref = O.trilinear_resize(x.astype(np.float64), size)
+    xt, yt = t_from_ncdhw(x), t_empty(N, Cn, *size, fill=9.0)
+    d.call("msk_interp_trilinear_fwd", xt.msk(), yt.msk())
+    assert rel_err(t_to_ncdhw(yt), y_ref) < 1e-5
+    # a constant volume resizes to the same constant (weights sum to one)
+    ct = t_from_ncdhw(np.full_like(x, 2.5))
+    d.call("msk_interp_trilinear_fwd", ct.msk(), yt.msk())
+    assert np.abs(t_to_ncdhw(yt) - 2.5).max() < 1e-5
+
+    g = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.trilinear_resize_bwd(g.astype(np.float64), (sd, sh, sw))
+    gt = t_from_ncdhw(g, ld=Cn + 3)  # gradient arriving as a channel slice of a wider buffer
+    dxt = t_empty(N, Cn, sd, sh, sw, fill=1.0)
+    need = C.c_size_t(0)
+    d.call("msk_interp_scratch_bytes", dxt.msk(), gt.msk(), C.byref(need))
+    scratch = d.malloc(max(need.value, 16))
+    d.call("msk_interp_trilinear_bwd", gt.msk(), dxt.msk(), 0, vp(scratch), C.c_size_t(need.value))
+    assert rel_err(t_to_ncdhw(dxt), dx_ref) < 1e-5
+    d.call("msk_interp_trilinear_bwd", gt.msk(), dxt.msk(), 1, vp(scratch), C.c_size_t(need.value))
+    assert rel_err(t_to_ncdhw(dxt), 2 * dx_ref) < 1e-5
+    # adjoint identity <resize(x), g> == <x, resize^T(g)> with the device results
+    d.call("msk_interp_trilinear_fwd", xt.msk(), yt.msk())
+    d.call("msk_interp_trilinear_bwd", gt.msk(), dxt.msk(), 0, vp(scratch), C.c_size_t(need.value))
+    lhs = float((t_to_ncdhw(yt).astype(np.float64) * g).sum())
+    rhs = float((t_to_ncdhw(dxt).astype(np.float64) * x).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    if sh != size[1] or sw != size[2]:  # H/W passes need the scratch: too small must fail loudly
+        from medicalseg_amd._lib import MskError
+        with pytest.raises(MskError):
+            d.call("msk_interp_trilinear_bwd", gt.msk(), dxt.msk(), 0, vp(scratch), C.c_size_t(4))

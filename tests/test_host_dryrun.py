@@ -77,6 +77,43 @@ def test_mri_config_shapes(fake_pkg):
         model(np.zeros((1, 2, 64, 64, 12), np.float32))
 
 
+def test_deepsup_control_flow_and_config(fake_pkg, tmp_path):
+    """VNetDeepSup (vnet_deepsup.py:178-281): four outputs at input size, state-dict keys in the
+    reference's attribute order, out_tr_all kept out of the optimizer, and the shipped config
+    (one loss type x four coefs) trains through core.train."""
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.core import train
+    from medicalseg_amd.cvlibs import Config
+    from medicalseg_amd.models import VNetDeepSup
+    from oracle import vnet_numpy as O
+    cfg = Config(os.path.join(os.path.dirname(HERE), "configs", "synthetic", "vnetdeepsup_synthetic_mri_512_512_12.yml"))
+    assert cfg.dic["model"]["type"] == "VNetDeepSup"
+    losses = cfg.loss
+    assert len(losses["types"]) == 4 and losses["coef"] == [0.25] * 4
+    assert len({id(t) for t in losses["types"]}) == 4          # separate instances -> separate CE class weights
+    K, S = cfg.dic["model"]["kernel_size"], cfg.dic["model"]["stride_size"]
+    model = VNetDeepSup(num_classes=20, kernel_size=K, stride_size=S)
+    assert list(model.state_dict().keys()) == [n for n, _, _ in O.param_specs_deepsup(1, 20, K, S)]
+    frozen = [p for p in model.parameters() if getattr(p, "frozen", False)]
+    assert len(frozen) == 7 and all(p.name.startswith("out_tr_all.") for p in frozen)
+    assert len(model.parameters()) == 130 + 6 + 7
+    opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+    assert len(opt._parameter_list) == 136 and opt.arena is model.arena
+    outs = model(np.zeros((1, 1, 64, 64, 12), np.float32))
+    assert [o.shape for o in outs] == [(1, 20, 64, 64, 12)] * 4
+    assert [h.shape for h in model._heads] == [(1, 20, 8, 8, 4), (1, 20, 16, 16, 8), (1, 20, 32, 32, 9)]
+    from medicalseg_amd.datasets import SyntheticCT
+    ds = SyntheticCT(num_samples=2, shape=(32, 32, 12), num_classes=20)
+    train(model, ds, optimizer=opt, save_dir=str(tmp_path / "o"), iters=2, batch_size=1, save_interval=2, log_iters=1,
+          losses=losses)
+    assert os.path.exists(tmp_path / "o" / "iter_2" / "model.pdparams")
+    import pickle
+    sd = pickle.load(open(tmp_path / "o" / "iter_2" / "model.pdparams", "rb"))
+    assert "out_tr_all.conv1.weight" in sd and "out_tr256.weight" in sd
+    od = pickle.load(open(tmp_path / "o" / "iter_2" / "model.pdopt", "rb"))
+    assert "out_tr64.weight_velocity_0" in od and not any(k.startswith("out_tr_all") for k in od)
+
+
 def test_stale_activation_is_detected(fake_pkg):
     from medicalseg_amd._lib import MskError
     from medicalseg_amd.models import VNet

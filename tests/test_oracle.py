@@ -13,7 +13,7 @@ import torch
 
 from oracle import preprocess_numpy as P
 from oracle import vnet_numpy as O
-from oracle.vnet_torch import TorchVNet, torch_mixed_loss
+from oracle.vnet_torch import TorchVNet, TorchVNetDeepSup, torch_mixed_loss
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SITES = [("down_tr128", 128), ("down_tr256", 256), ("up_tr256.x", 256), ("up_tr256.skip", 128),
@@ -79,6 +79,46 @@ def test_oracle_anisotropic_mri_config_vs_torch():
     with torch.no_grad():
         tl = tm(torch.tensor(x, dtype=torch.float64))
     assert np.abs(tl.numpy() - lg).max() < 1e-10
+
+
+def test_deepsup_oracle_vs_torch_autograd():
+    """VNetDeepSup (vnet_deepsup.py:257-281): four outputs, loss coef 0.25 each
+    (vnetdeepsup_mri_spine_seg_512_512_12_15k.yml:20), anisotropic MRI kernels."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    K = ((2, 2, 4), (2, 2, 2), (2, 2, 2), (2, 2, 2))
+    Sd = ((2, 2, 1), (2, 2, 1), (2, 2, 2), (2, 2, 2))
+    S, ncls, N = (16, 16, 12), 5, 2
+    rng = np.random.default_rng(3)
+    params = O.init_params_deepsup(2, 1, ncls, K, Sd)
+    specs = O.param_specs_deepsup(1, ncls, K, Sd)
+    # 130 trunk tensors + 3 heads x (w, b) + the 7 never-used out_tr_all tensors
+    assert len([s for s in specs if s[2] in O.TRAINABLE_KINDS]) == 130 + 6 + 7
+    x = rng.standard_normal((N, 1) + S).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + S).astype(np.int32)
+    masks = {s: (rng.random((N, c)) < 0.5).astype(np.float32) * 2.0 for s, c in SITES}
+    m = O.VNetDeepSupOracle(params, 1, ncls, K, Sd)
+    outs = m.forward(x, train=True, dropout_masks=masks)
+    assert [o.shape for o in outs] == [(N, ncls) + S] * 4
+    Ls = [O.MixedLossOracle(outer_coef=0.25) for _ in outs]
+    res = [L(o, y) for L, o in zip(Ls, outs)]
+    g = m.backward([r[2] for r in res])
+    tm = TorchVNetDeepSup(1, ncls, K, Sd).double()
+    tm.load_oracle_params({k: np.asarray(v, dtype=np.float64) for k, v in params.items()})
+    tm.train(True)
+    touts = tm(torch.tensor(x, dtype=torch.float64), masks)
+    total = 0
+    for o, to, L, r in zip(outs, touts, Ls, res):
+        assert np.abs(to.detach().numpy() - o).max() < 1e-10
+        ce, dl, _ = torch_mixed_loss(to, torch.tensor(y), torch.tensor(L.weight))
+        assert abs(0.25 * float(ce.detach()) - r[0][0]) < 1e-10 and abs(0.25 * float(dl.detach()) - r[0][1]) < 1e-10
+        total = total + 0.25 * (ce + dl)
+    total.backward()
+    tg = tm.named_oracle_grads()
+    assert not any(k.startswith("out_tr_all") for k in tg) and not any(k.startswith("out_tr_all") for k in g)
+    assert set(tg) == set(m.trainable)
+    gmax = max(np.abs(v).max() for v in g.values())
+    for k, v in tg.items():
+        assert np.abs(v - g[k]).max() < 1e-9 * gmax + 1e-12 * np.abs(v).max(), k
 
 
 def test_sgd_and_poly_lr_vs_torch():
