@@ -771,22 +771,29 @@ wgrad_lds_mfma_k(WGrad g, int splits, int chunks_total, int chunks_per_split, fl
     __syncthreads();
     const int nxt = next_valid(ch + 1);
     // ---- MFMA: K runs over the chunk's voxels, 2 per instruction (lane half) ----
+    // voxel pairs are consumed in groups of 4 (one shared-tap quarter per wave); rows narrower
+    // than 4 pairs (WS = 4, 2: the MRI slabs' W = 12, 9, 4, 2) take their group from 2 or 4 rows
+    constexpr int PP = WS / 2;
+    constexpr int RSTEP = PP >= 4 ? 1 : 4 / PP;
+    static_assert(R % RSTEP == 0 && (PP >= 4 ? PP % 4 == 0 : 4 % PP == 0), "pair groups must tile the chunk");
 #pragma unroll 1
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < R; r += RSTEP) {
       const float* xrow = &xs[(r * XW + lh) * 32 + li];
       const float* drow = &dys[(r * WS + lh) * 32 + li];
-      for (int p4 = 0; p4 < WS / 2; p4 += 4) {
+      for (int p4 = 0; p4 < (PP >= 4 ? PP : 4); p4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int p = p4 + u;
-          const float bv = drow[p * 64];
+          const int e = p4 + u;
+          const int xo = PP >= 4 ? e * 64 : (e / PP) * XW * 32 + (e % PP) * 64;
+          const int yo = PP >= 4 ? e * 64 : (e / PP) * WS * 32 + (e % PP) * 64;
+          const float bv = drow[yo];
           float av[TPW];
 #pragma unroll
-          for (int k = 0; k < TPW; ++k) av[k] = xrow[p * 64 + toff[k]];
+          for (int k = 0; k < TPW; ++k) av[k] = xrow[xo + toff[k]];
 #pragma unroll
           for (int k = 0; k < TPW; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k], bv, acc[k], 0, 0, 0);
           if (u == wave)  // wave-uniform: this wave's quarter of the shared tap
-            acc_sh = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[p * 64 + SHARED_OFF], bv, acc_sh, 0, 0, 0);
+            acc_sh = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[xo + SHARED_OFF], bv, acc_sh, 0, 0, 0);
         }
       }
     }
@@ -1067,15 +1074,35 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.bias = g.bias; a.accumulate = g.accumulate;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   const int ntn = npad / 32;
+  // 256-voxel tile shape: the one that wastes the fewest padded voxels on this volume (the MRI
+  // slabs have W = 12, 9, 8, 4, 2: a W=8 tile is 56% full at W=9, 50% at W=4); ties go to the
+  // widest W (longest contiguous runs in the staging loads).
+  static const int kTiles[5][3] = {{2, 4, 32}, {2, 8, 16}, {4, 8, 8}, {4, 16, 4}, {8, 16, 2}};
+  int best = 0;
+  double best_util = -1.0;
+  for (int i = 0; i < 5; ++i) {
+    const double padded = (double)msk_cdiv(g.DD, kTiles[i][0]) * kTiles[i][0] * msk_cdiv(g.DH, kTiles[i][1]) * kTiles[i][1] *
+                          msk_cdiv(g.DW, kTiles[i][2]) * kTiles[i][2];
+    const double util = (double)g.DD * g.DH * g.DW / padded;
+    if (util > best_util * 1.02) { best_util = util; best = i; }
+  }
   int rc;
   if (ks == 5) {
-    if (g.DW >= 32) rc = launch_halo<2, 4, 32, 5>(ctx, a, ntn);
-    else if (g.DW >= 16) rc = launch_halo<2, 8, 16, 5>(ctx, a, ntn);
-    else rc = launch_halo<4, 8, 8, 5>(ctx, a, ntn);
+    switch (best) {
+      case 0: rc = launch_halo<2, 4, 32, 5>(ctx, a, ntn); break;
+      case 1: rc = launch_halo<2, 8, 16, 5>(ctx, a, ntn); break;
+      case 2: rc = launch_halo<4, 8, 8, 5>(ctx, a, ntn); break;
+      case 3: rc = launch_halo<4, 16, 4, 5>(ctx, a, ntn); break;
+      default: rc = launch_halo<8, 16, 2, 5>(ctx, a, ntn); break;
+    }
   } else {
-    if (g.DW >= 32) rc = launch_halo<2, 4, 32, 3>(ctx, a, ntn);
-    else if (g.DW >= 16) rc = launch_halo<2, 8, 16, 3>(ctx, a, ntn);
-    else rc = launch_halo<4, 8, 8, 3>(ctx, a, ntn);
+    switch (best) {
+      case 0: rc = launch_halo<2, 4, 32, 3>(ctx, a, ntn); break;
+      case 1: rc = launch_halo<2, 8, 16, 3>(ctx, a, ntn); break;
+      case 2: rc = launch_halo<4, 8, 8, 3>(ctx, a, ntn); break;
+      case 3: rc = launch_halo<4, 16, 4, 3>(ctx, a, ntn); break;
+      default: rc = launch_halo<8, 16, 2, 3>(ctx, a, ntn); break;
+    }
   }
   return rc == 0 ? 1 : rc;
 }
@@ -1168,15 +1195,32 @@ int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g) {
   const bool vec_ok = g.ald % 4 == 0 && g.bld % 4 == 0 && g.CA % 4 == 0 && g.CB % 4 == 0 &&
                       ((uintptr_t)g.A) % 16 == 0 && ((uintptr_t)g.B) % 16 == 0;
   if (same_grid && cubic && vec_ok && ctx->conv_impl != 5) {
+    // chunk shape (R rows x WS columns) with the fewest padded voxels on this plane; ties -> widest
+    static const int kChunks[5][2] = {{4, 32}, {8, 16}, {16, 8}, {32, 4}, {32, 2}};
+    int best = 0;
+    double best_util = -1.0;
+    for (int i = 0; i < 5; ++i) {
+      const double padded = (double)msk_cdiv(g.BH, kChunks[i][0]) * kChunks[i][0] * msk_cdiv(g.BW, kChunks[i][1]) * kChunks[i][1];
+      const double util = (double)g.BH * g.BW / padded;
+      if (util > best_util * 1.02) { best_util = util; best = i; }
+    }
     int rc;
     if (g.kd == 5) {
-      if (g.BW >= 32) rc = launch_wgrad_lds<5, 4, 32>(ctx, g, ctx->num_cu);
-      else if (g.BW >= 16) rc = launch_wgrad_lds<5, 8, 16>(ctx, g, ctx->num_cu);
-      else rc = launch_wgrad_lds<5, 16, 8>(ctx, g, ctx->num_cu);
+      switch (best) {
+        case 0: rc = launch_wgrad_lds<5, 4, 32>(ctx, g, ctx->num_cu); break;
+        case 1: rc = launch_wgrad_lds<5, 8, 16>(ctx, g, ctx->num_cu); break;
+        case 2: rc = launch_wgrad_lds<5, 16, 8>(ctx, g, ctx->num_cu); break;
+        case 3: rc = launch_wgrad_lds<5, 32, 4>(ctx, g, ctx->num_cu); break;
+        default: rc = launch_wgrad_lds<5, 32, 2>(ctx, g, ctx->num_cu); break;
+      }
     } else {
-      if (g.BW >= 32) rc = launch_wgrad_lds<3, 4, 32>(ctx, g, ctx->num_cu);
-      else if (g.BW >= 16) rc = launch_wgrad_lds<3, 8, 16>(ctx, g, ctx->num_cu);
-      else rc = launch_wgrad_lds<3, 16, 8>(ctx, g, ctx->num_cu);
+      switch (best) {
+        case 0: rc = launch_wgrad_lds<3, 4, 32>(ctx, g, ctx->num_cu); break;
+        case 1: rc = launch_wgrad_lds<3, 8, 16>(ctx, g, ctx->num_cu); break;
+        case 2: rc = launch_wgrad_lds<3, 16, 8>(ctx, g, ctx->num_cu); break;
+        case 3: rc = launch_wgrad_lds<3, 32, 4>(ctx, g, ctx->num_cu); break;
+        default: rc = launch_wgrad_lds<3, 32, 2>(ctx, g, ctx->num_cu); break;
+      }
     }
     return rc == 0 ? 1 : rc;
   }

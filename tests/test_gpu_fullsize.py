@@ -130,3 +130,37 @@ def test_vnet_mri_512x512x12_20_classes_runs():
     assert [a.shape for a in model._acts] == [(1, 16, 512, 512, 12), (1, 32, 256, 256, 9), (1, 64, 128, 128, 8),
                                               (1, 128, 64, 64, 4), (1, 256, 32, 32, 2)]
     assert np.isfinite(loss) and per.shape == (20,) and np.all(np.isfinite(per))
+
+
+def test_vnetdeepsup_mri_512x512x12_step_deterministic():
+    """BASELINE's VNetDeepSup config at full size (vnetdeepsup_mri_spine_seg_512_512_12_15k.yml):
+    four 20-class outputs at 512x512x12; the step must be finite and bitwise reproducible
+    (the resize adjoint is a fixed-order gather, no atomics)."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNetDeepSup
+    K = [[2, 2, 4], [2, 2, 2], [2, 2, 2], [2, 2, 2]]
+    S = [[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]
+    rng = np.random.default_rng(0)
+    x = rng.random((1, 1, 512, 512, 12), dtype=np.float32)
+    y = rng.integers(0, 20, (1, 512, 512, 12)).astype(np.int32)
+    runs = []
+    for run in range(2):
+        nn.seed(0)
+        nn.Dropout3D.step, nn.Dropout3D.seed = 0, 0
+        model = VNetDeepSup(num_classes=20, kernel_size=K, stride_size=S)
+        model.train()
+        base = min(l.site for l in model.dropout_layers().values())
+        for l in model.dropout_layers().values():
+            l.site = l.site - base + 1
+        opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1]) for _ in range(4)], "coef": [0.25] * 4}
+        l1, per = _train_step(model, opt, losses, x, y)
+        l2, _ = _train_step(model, opt, losses, x, y)
+        assert [h.shape for h in model._heads] == [(1, 20, 64, 64, 4), (1, 20, 128, 128, 8), (1, 20, 256, 256, 9)]
+        assert np.isfinite(l1) and np.isfinite(l2) and per.shape == (20,)
+        sd = model.state_dict()
+        runs.append((l1, l2, sd["out_tr256.weight"], sd["out_tr64.weight"], sd["up_tr256.ops.0.conv1.weight"]))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
+    for u, v in zip(runs[0][2:], runs[1][2:]):
+        assert np.array_equal(u, v)

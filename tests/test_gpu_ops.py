@@ -33,6 +33,10 @@ CONV_CASES = [
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
+    (32, 40, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 7, 30, 4)),     # MRI slab depth 4 -> halo tile <4,16,4>
+    (24, 32, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 15, 31, 2)),    # MRI slab depth 2 -> halo tile <8,16,2>
+    (64, 64, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 8, 16, 9)),     # MRI level 2 (W = 9)
+    (16, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 7, 30, 4)),     # 3^3 on the narrow tiles
     (64, 3, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 6, 9, 34)),      # VNetDeepSup out_tr64 (lung, ncls 3)
     (128, 20, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 5, 9, 12)),    # VNetDeepSup out_tr128 (MRI, ncls 20)
     (256, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 6, 6)),      # VNetDeepSup out_tr256
