@@ -192,6 +192,21 @@ int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* veloc
  * dtype: 0 = float32, 1 = int32 (labels).                                       */
 int msk_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, void* dst,
                    int dd, int dh, int dw, int order, int dtype);
+/* ---- loader augmentations on the device (medicalseg/transforms) ------- */
+/* functional.py:103-110 resized_crop_3d: crop box (i,j,k)+(cd,ch,cw) of a (sd,sh,sw) volume,
+ * zoomed to (dd,dh,dw) with msk_resample3d's coordinate map (order 1 image / 0 label,
+ * transform.py:334-339).                                                              */
+int msk_crop_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, int i, int j,
+                        int k, int cd, int ch, int cw, void* dst, int dd, int dh, int dw,
+                        int order, int dtype);
+/* functional.py:80-88 flip_3d (np.flip along axis 0|1|2); out of place               */
+int msk_flip3d(msk_ctx* ctx, const void* src, void* dst, int d, int h, int w, int axis,
+               int dtype);
+/* functional.py:91-100 rotate_3d == scipy.ndimage.rotate(angle, axes=(axis_a, axis_b),
+ * order, mode='constant', cval, reshape=False): affine map about the plane centre in
+ * double, no interpolation beyond the edges, int32 rounds half away from zero.       */
+int msk_rotate3d(msk_ctx* ctx, const void* src, void* dst, int d, int h, int w, int axis_a,
+                 int axis_b, double angle_deg, int order, double cval, int dtype);
 /* values.py:67-87 HUnorm */
 int msk_hu_norm(msk_ctx* ctx, const float* src, float* dst, size_t count, float hu_min,
                 float hu_max, float hu_nan);

@@ -84,6 +84,9 @@ SIGNATURES = {
     "msk_loss_bwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _f, _f, _T]),
     "msk_sgd_momentum": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f]),
     "msk_resample3d": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
+    "msk_crop_resample3d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
+    "msk_flip3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "msk_rotate3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _d, _i]),
     "msk_hu_norm": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f]),
     "msk_minmax_norm": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f]),
     "msk_max_norm": (_i, [_vp, _vp, _vp, _sz]),

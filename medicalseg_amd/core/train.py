@@ -63,7 +63,8 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
                 break
             reader_cost_averager.record(time.time() - batch_start)
             images = to_tensor(data[0], dev)
-            labels = to_tensor(np.asarray(data[1]).astype('int32'), dev)
+            # device-augmented batches arrive as device tensors already (datasets.DataLoader._stack_device)
+            labels = data[1] if hasattr(data[1], 'ptr') else to_tensor(np.asarray(data[1]).astype('int32'), dev)
 
             logits_list = ddp_model(images)
             loss_list, per_channel_dice = loss_computation(logits_list=logits_list, labels=labels, losses=losses)

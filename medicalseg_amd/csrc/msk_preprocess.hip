@@ -25,7 +25,10 @@ __device__ __forceinline__ double axis_coord(int o, int n_in, int n_out) {
 
 template <typename T, int ORDER>
 __global__ void __launch_bounds__(kThreads)
-resample_k(const T* __restrict__ src, int sd, int sh, int sw, T* __restrict__ dst, int dd, int dh, int dw) {
+resample_k(const T* __restrict__ src_full, int fh, int fw, int ci, int cj, int ck, int sd, int sh, int sw,
+           T* __restrict__ dst, int dd, int dh, int dw) {
+  // the source is the crop box [ci, ci+sd) x [cj, cj+sh) x [ck, ck+sw) of a volume with row pitches (fh, fw):
+  // functional.py:103-110 resized_crop_3d = crop_3d + resize_3d; the plain resample is the full box
   const size_t total = (size_t)dd * dh * dw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ow = (int)(i % dw);
@@ -37,13 +40,13 @@ resample_k(const T* __restrict__ src, int sd, int sh, int sw, T* __restrict__ ds
       id = min(max(id, 0), sd - 1);
       ih = min(max(ih, 0), sh - 1);
       iw = min(max(iw, 0), sw - 1);
-      dst[i] = src[((size_t)id * sh + ih) * sw + iw];
+      dst[i] = src_full[((size_t)(id + ci) * fh + (ih + cj)) * fw + (iw + ck)];
     } else {
       int d0 = min(max((int)floor(cd), 0), sd - 1), h0 = min(max((int)floor(ch), 0), sh - 1),
           w0 = min(max((int)floor(cw), 0), sw - 1);
       const int d1 = min(d0 + 1, sd - 1), h1 = min(h0 + 1, sh - 1), w1 = min(w0 + 1, sw - 1);
       const double td = cd - d0, th = ch - h0, tw = cw - w0;
-      auto at = [&](int a, int b, int c) { return (double)src[((size_t)a * sh + b) * sw + c]; };
+      auto at = [&](int a, int b, int c) { return (double)src_full[((size_t)(a + ci) * fh + (b + cj)) * fw + (c + ck)]; };
       // separable: d, then h, then w (matches oracle/preprocess_numpy.py)
       const double v00 = at(d0, h0, w0) * (1.0 - td) + at(d1, h0, w0) * td;
       const double v01 = at(d0, h0, w1) * (1.0 - td) + at(d1, h0, w1) * td;
@@ -57,6 +60,65 @@ resample_k(const T* __restrict__ src, int sd, int sh, int sw, T* __restrict__ ds
       } else {
         dst[i] = (T)v;
       }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+flip3d_k(const T* __restrict__ src, T* __restrict__ dst, int d, int h, int w, int axis) {
+  const size_t total = (size_t)d * h * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int ow = (int)(i % w), oh = (int)((i / w) % h), od = (int)(i / ((size_t)w * h));
+    if (axis == 0) od = d - 1 - od;
+    else if (axis == 1) oh = h - 1 - oh;
+    else ow = w - 1 - ow;
+    dst[i] = src[((size_t)od * h + oh) * w + ow];
+  }
+}
+
+// scipy.ndimage.rotate(order 0|1, mode='constant', reshape=False) on the (a0, a1) plane:
+// in = M @ out + shift in double like scipy's NI_GeometricTransform (no FMA contraction so that
+// right-angle rotations stay on the grid); coordinates outside [0, n-1] -> cval, no interpolation
+// beyond the edges; integer outputs round half away from zero.
+template <typename T, int ORDER>
+__global__ void __launch_bounds__(kThreads)
+rotate3d_k(const T* __restrict__ src, T* __restrict__ dst, int d, int h, int w, int a0, int a1, double m00, double m01,
+           double m10, double m11, double s0, double s1, double cval) {
+  const size_t total = (size_t)d * h * w;
+  const int dims[3] = {d, h, w};
+  const int n0 = dims[a0], n1 = dims[a1];
+  const size_t strides[3] = {(size_t)h * w, (size_t)w, 1};
+  const size_t st0 = strides[a0], st1 = strides[a1];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int idx[3];
+    idx[2] = (int)(i % w);
+    idx[1] = (int)((i / w) % h);
+    idx[0] = (int)(i / ((size_t)w * h));
+    const double o0 = (double)idx[a0], o1 = (double)idx[a1];
+    const double c0 = __dadd_rn(__dadd_rn(s0, __dmul_rn(o0, m00)), __dmul_rn(o1, m01));
+    const double c1 = __dadd_rn(__dadd_rn(s1, __dmul_rn(o0, m10)), __dmul_rn(o1, m11));
+    double v = cval;
+    if (!(c0 < 0.0 || c0 > (double)(n0 - 1) || c1 < 0.0 || c1 > (double)(n1 - 1))) {
+      const size_t base = i - (size_t)idx[a0] * st0 - (size_t)idx[a1] * st1;  // the other axis' offset
+      if constexpr (ORDER == 0) {
+        const int i0 = min(max((int)floor(c0 + 0.5), 0), n0 - 1), i1 = min(max((int)floor(c1 + 0.5), 0), n1 - 1);
+        v = (double)src[base + i0 * st0 + i1 * st1];
+      } else {
+        const int f0 = (int)floor(c0), f1 = (int)floor(c1);
+        const double t0 = c0 - f0, t1 = c1 - f1;
+        const int g0 = min(f0 + 1, n0 - 1), g1 = min(f1 + 1, n1 - 1);  // weight 0 when clamped
+        auto at = [&](int p, int q) { return (double)src[base + p * st0 + q * st1]; };
+        v = __dmul_rn(at(f0, f1), __dmul_rn(1.0 - t0, 1.0 - t1));
+        v = __dadd_rn(v, __dmul_rn(at(f0, g1), __dmul_rn(1.0 - t0, t1)));
+        v = __dadd_rn(v, __dmul_rn(at(g0, f1), __dmul_rn(t0, 1.0 - t1)));
+        v = __dadd_rn(v, __dmul_rn(at(g0, g1), __dmul_rn(t0, t1)));
+      }
+    }
+    if constexpr (!std::is_same<T, float>::value) {
+      dst[i] = (T)(v > 0.0 ? floor(v + 0.5) : ceil(v - 0.5));
+    } else {
+      dst[i] = (T)v;
     }
   }
 }
@@ -145,24 +207,94 @@ label_remap_k(int32_t* __restrict__ label, size_t n, const int32_t* __restrict__
 
 extern "C" {
 
-int msk_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, void* dst, int dd, int dh, int dw,
-                   int order, int dtype) {
+static int crop_resample(msk_ctx* ctx, const void* src, int fd, int fh, int fw, int ci, int cj, int ck, int sd, int sh,
+                         int sw, void* dst, int dd, int dh, int dw, int order, int dtype) {
   MSK_REQUIRE(ctx, order == 0 || order == 1, "order must be 0 or 1");
   MSK_REQUIRE(ctx, dtype == 0 || dtype == 1, "dtype must be 0 (float32) or 1 (int32)");
   MSK_REQUIRE(ctx, sd > 0 && sh > 0 && sw > 0 && dd > 0 && dh > 0 && dw > 0, "empty volume");
+  MSK_REQUIRE(ctx, ci >= 0 && cj >= 0 && ck >= 0 && ci + sd <= fd && cj + sh <= fh && ck + sw <= fw,
+              "crop box outside the volume");
   const size_t total = (size_t)dd * dh * dw;
   const int nb = ew_blocks(total, ctx->num_cu);
   msk_launch_scope ls(ctx, order == 0 ? "resample3d_order0" : "resample3d_order1");
   if (dtype == 0) {
     if (order == 0)
-      hipLaunchKernelGGL((resample_k<float, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, sd, sh, sw, (float*)dst, dd, dh, dw);
+      hipLaunchKernelGGL((resample_k<float, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, fh, fw, ci, cj, ck, sd, sh, sw, (float*)dst, dd, dh, dw);
     else
-      hipLaunchKernelGGL((resample_k<float, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, sd, sh, sw, (float*)dst, dd, dh, dw);
+      hipLaunchKernelGGL((resample_k<float, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, fh, fw, ci, cj, ck, sd, sh, sw, (float*)dst, dd, dh, dw);
   } else {
     if (order == 0)
-      hipLaunchKernelGGL((resample_k<int32_t, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, sd, sh, sw, (int32_t*)dst, dd, dh, dw);
+      hipLaunchKernelGGL((resample_k<int32_t, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, fh, fw, ci, cj, ck, sd, sh, sw, (int32_t*)dst, dd, dh, dw);
     else
-      hipLaunchKernelGGL((resample_k<int32_t, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, sd, sh, sw, (int32_t*)dst, dd, dh, dw);
+      hipLaunchKernelGGL((resample_k<int32_t, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, fh, fw, ci, cj, ck, sd, sh, sw, (int32_t*)dst, dd, dh, dw);
+  }
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, void* dst, int dd, int dh, int dw,
+                   int order, int dtype) {
+  return crop_resample(ctx, src, sd, sh, sw, 0, 0, 0, sd, sh, sw, dst, dd, dh, dw, order, dtype);
+}
+
+int msk_crop_resample3d(msk_ctx* ctx, const void* src, int sd, int sh, int sw, int i, int j, int k, int cd, int ch,
+                        int cw, void* dst, int dd, int dh, int dw, int order, int dtype) {
+  return crop_resample(ctx, src, sd, sh, sw, i, j, k, cd, ch, cw, dst, dd, dh, dw, order, dtype);
+}
+
+int msk_flip3d(msk_ctx* ctx, const void* src, void* dst, int d, int h, int w, int axis, int dtype) {
+  MSK_REQUIRE(ctx, axis >= 0 && axis <= 2, "axis must be 0, 1 or 2");
+  MSK_REQUIRE(ctx, dtype == 0 || dtype == 1, "dtype must be 0 (float32) or 1 (int32)");
+  MSK_REQUIRE(ctx, src != dst, "flip is out of place");
+  const size_t total = (size_t)d * h * w;
+  if (total == 0) return 0;
+  msk_launch_scope ls(ctx, "flip3d");
+  // float32 and int32 are both 4-byte moves
+  hipLaunchKernelGGL((flip3d_k<uint32_t>), dim3(ew_blocks(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
+                     (const uint32_t*)src, (uint32_t*)dst, d, h, w, axis);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_rotate3d(msk_ctx* ctx, const void* src, void* dst, int d, int h, int w, int axis_a, int axis_b, double angle_deg,
+                 int order, double cval, int dtype) {
+  MSK_REQUIRE(ctx, order == 0 || order == 1, "order must be 0 or 1");
+  MSK_REQUIRE(ctx, dtype == 0 || dtype == 1, "dtype must be 0 (float32) or 1 (int32)");
+  MSK_REQUIRE(ctx, axis_a >= 0 && axis_a <= 2 && axis_b >= 0 && axis_b <= 2 && axis_a != axis_b, "bad rotation plane");
+  MSK_REQUIRE(ctx, src != dst, "rotate is out of place");
+  MSK_REQUIRE(ctx, d > 0 && h > 0 && w > 0, "empty volume");
+  const int a0 = axis_a < axis_b ? axis_a : axis_b, a1 = axis_a < axis_b ? axis_b : axis_a;  // scipy sorts the axes
+  // scipy.special.cosdg / sindg: exact at multiples of 90 degrees
+  double c, s;
+  double am = fmod(angle_deg, 360.0);
+  if (am < 0) am += 360.0;
+  if (fmod(am, 90.0) == 0.0) {
+    static const double kc[4] = {1.0, 0.0, -1.0, 0.0}, ks[4] = {0.0, 1.0, 0.0, -1.0};
+    const int q = ((int)(am / 90.0)) & 3;
+    c = kc[q];
+    s = ks[q];
+  } else {
+    const double r = angle_deg * (M_PI / 180.0);
+    c = cos(r);
+    s = sin(r);
+  }
+  const int dims[3] = {d, h, w};
+  const double c0 = (dims[a0] - 1) / 2.0, c1 = (dims[a1] - 1) / 2.0;
+  const double m00 = c, m01 = s, m10 = -s, m11 = c;
+  const double s0 = c0 - (m00 * c0 + m01 * c1), s1 = c1 - (m10 * c0 + m11 * c1);
+  const size_t total = (size_t)d * h * w;
+  const int nb = ew_blocks(total, ctx->num_cu);
+  msk_launch_scope ls(ctx, "rotate3d");
+  if (dtype == 0) {
+    if (order == 0)
+      hipLaunchKernelGGL((rotate3d_k<float, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, (float*)dst, d, h, w, a0, a1, m00, m01, m10, m11, s0, s1, cval);
+    else
+      hipLaunchKernelGGL((rotate3d_k<float, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)src, (float*)dst, d, h, w, a0, a1, m00, m01, m10, m11, s0, s1, cval);
+  } else {
+    if (order == 0)
+      hipLaunchKernelGGL((rotate3d_k<int32_t, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, (int32_t*)dst, d, h, w, a0, a1, m00, m01, m10, m11, s0, s1, cval);
+    else
+      hipLaunchKernelGGL((rotate3d_k<int32_t, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const int32_t*)src, (int32_t*)dst, d, h, w, a0, a1, m00, m01, m10, m11, s0, s1, cval);
   }
   MSK_LAUNCH_CHECK(ctx);
   return 0;

@@ -12,13 +12,22 @@ from ..cvlibs import manager
 from ..transforms import Compose
 
 
+def _as_item(im, label, path):
+    from ..preprocess import DeviceVolume
+    if isinstance(im, DeviceVolume):
+        return im, label, path
+    return im.astype("float32"), label.astype("int32"), path
+
+
 @manager.DATASETS.add_component
 class MedicalDataset:
     def __init__(self, dataset_root, result_dir, transforms, num_classes, mode='train', ignore_index=255,
-                 dataset_json_path=""):
+                 dataset_json_path="", device_aug=False):
         self.dataset_root = dataset_root
         self.result_dir = result_dir
-        self.transforms = Compose(transforms)
+        # device_aug: run the transform list as HIP kernels on device volumes;
+        # __getitem__ then yields device volumes that DataLoader batches without a host round trip
+        self.transforms = Compose(transforms, device=device_aug)
         self.file_list = list()
         self.mode = mode.lower()
         self.num_classes = num_classes
@@ -47,7 +56,7 @@ class MedicalDataset:
     def __getitem__(self, idx):
         image_path, label_path = self.file_list[idx]
         im, label = self.transforms(im=image_path, label=label_path)
-        return im.astype("float32"), label.astype("int32"), self.file_list[idx][0]
+        return _as_item(im, label, self.file_list[idx][0])
 
     def save_transformed(self):
         pass
@@ -72,11 +81,12 @@ class SyntheticCT:
     HUnorm -> /max; label = background 0 plus two ellipsoids (classes 1, 2, ... cycling)."""
 
     def __init__(self, num_samples=8, shape=(128, 128, 128), num_classes=3, seed=1234, mode='train',
-                 ignore_index=255, transforms=None, dataset_root=None, result_dir=None, dataset_json_path=""):
+                 ignore_index=255, transforms=None, dataset_root=None, result_dir=None, dataset_json_path="",
+                 device_aug=False):
         self.num_samples, self.shape = int(num_samples), tuple(int(s) for s in shape)
         self.num_classes, self.seed, self.mode = num_classes, seed, mode
         self.ignore_index = ignore_index
-        self.transforms = Compose(transforms or [])
+        self.transforms = Compose(transforms or [], device=device_aug)
         self.dataset_json_path = dataset_json_path
         self.file_list = [["synthetic_{}".format(i), ""] for i in range(self.num_samples)]
 
@@ -102,7 +112,7 @@ class SyntheticCT:
     def __getitem__(self, idx):
         im, label = self.make(idx)
         im, label = self.transforms(im, label)
-        return im.astype("float32"), label.astype("int32"), self.file_list[idx][0]
+        return _as_item(im, label, self.file_list[idx][0])
 
 
 class DataLoader:
@@ -128,12 +138,43 @@ class DataLoader:
 
     def _load(self, idxs):
         items = [self.dataset[i] for i in idxs]
+        from ..preprocess import DeviceVolume
+        if isinstance(items[0][0], DeviceVolume):
+            return self._stack_device(items)
         return [np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), [it[2] for it in items]]
+
+    @staticmethod
+    def _stack_device(items):
+        """Device-augmented samples -> one [N,1,D,H,W] Tensor and one [N,D,H,W] IntTensor, device-to-device
+        (one channel: NDHWC == NCDHW).  The batch buffers rotate over two slots, so the batch handed out
+        one iteration ago stays valid while the next one is assembled."""
+        from ..device import IntTensor, Tensor
+        ims, labs = [it[0] for it in items], [it[1] for it in items]
+        dev, shape = ims[0].dev, ims[0].shape
+        if any(v.shape != shape for v in ims + labs):
+            raise ValueError("device batching needs equal sample shapes, got {}".format([v.shape for v in ims]))
+        n, vox = len(ims), int(np.prod(shape))
+        slots = DataLoader._slots.setdefault((id(dev), n, shape), {"bufs": [], "next": 0})
+        if len(slots["bufs"]) < 2:
+            slots["bufs"].append((dev.malloc(n * vox * 4), dev.malloc(n * vox * 4)))
+            xb, yb = slots["bufs"][-1]
+        else:
+            xb, yb = slots["bufs"][slots["next"]]
+            slots["next"] ^= 1
+        for i, (x, y) in enumerate(zip(ims, labs)):
+            dev.d2d(xb + i * vox * 4, x.ptr, vox * 4)
+            dev.d2d(yb + i * vox * 4, y.ptr, vox * 4)
+            x.free()
+            y.free()
+        d, h, w = shape
+        return [Tensor(dev, xb, n, d, h, w, 1, 1, None), IntTensor(dev, yb, (n, d, h, w)), [it[2] for it in items]]
+
+    _slots = {}
 
     def __iter__(self):
         batches = self._batches()
         self.epoch += 1
-        if self.num_workers <= 0:
+        if self.num_workers <= 0 or getattr(getattr(self.dataset, "transforms", None), "device", False):
             for b in batches:
                 yield self._load(b)
             return

@@ -17,6 +17,7 @@ class DeviceVolume:
 
     def __init__(self, dev, ptr, shape, dtype):
         self.dev, self.ptr, self.shape, self.dtype = dev, ptr, tuple(int(s) for s in shape), np.dtype(dtype)
+        self.pooled = False
 
     @property
     def size(self):
@@ -27,8 +28,78 @@ class DeviceVolume:
 
     def free(self):
         if self.ptr:
-            self.dev.free(self.ptr)
+            if self.pooled:
+                _pool_release(self.dev, self.ptr, self.size * 4)
+            else:
+                self.dev.free(self.ptr)
             self.ptr = None
+
+
+# Stream-ordered recycling of augmentation buffers: every op is enqueued on the context's single
+# stream, so a buffer released by one op can be handed to a later op without synchronising
+# (hipFree would stall the loader on the whole training stream).
+_POOL = {}
+
+
+def _pool_alloc(dev, nbytes):
+    free = _POOL.setdefault(id(dev), {}).setdefault(int(nbytes), [])
+    return free.pop() if free else dev.malloc(nbytes)
+
+
+def _pool_release(dev, ptr, nbytes):
+    _POOL.setdefault(id(dev), {}).setdefault(int(nbytes), []).append(ptr)
+
+
+def _pooled_volume(dev, shape, dtype) -> DeviceVolume:
+    shape = tuple(int(v) for v in shape)
+    v = DeviceVolume(dev, _pool_alloc(dev, int(np.prod(shape)) * 4), shape, dtype)
+    v.pooled = True
+    return v
+
+
+def _dt(vol):
+    return 0 if vol.dtype == np.float32 else 1
+
+
+def flip_device(vol: DeviceVolume, axis: int) -> DeviceVolume:
+    """functional.py:80-88 flip_3d on the device."""
+    out = _pooled_volume(vol.dev, vol.shape, vol.dtype)
+    vol.dev.call("msk_flip3d", C.c_void_p(vol.ptr), C.c_void_p(out.ptr), *vol.shape, int(axis), _dt(vol))
+    return out
+
+
+def rotate_device(vol: DeviceVolume, r_plane, angle, order=1, cval=0) -> DeviceVolume:
+    """functional.py:91-100 rotate_3d (scipy.ndimage.rotate, reshape=False) on the device."""
+    out = _pooled_volume(vol.dev, vol.shape, vol.dtype)
+    vol.dev.call("msk_rotate3d", C.c_void_p(vol.ptr), C.c_void_p(out.ptr), *vol.shape, int(r_plane[0]), int(r_plane[1]),
+                 C.c_double(float(angle)), int(order), C.c_double(float(cval)), _dt(vol))
+    return out
+
+
+def resized_crop_device(vol: DeviceVolume, i, j, k, d, h, w, size, order) -> DeviceVolume:
+    """functional.py:103-110 resized_crop_3d (crop box, then zoom to `size`) on the device."""
+    out = _pooled_volume(vol.dev, size, vol.dtype)
+    vol.dev.call("msk_crop_resample3d", C.c_void_p(vol.ptr), *vol.shape, int(i), int(j), int(k), int(d), int(h), int(w),
+                 C.c_void_p(out.ptr), *out.shape, int(order), _dt(vol))
+    return out
+
+
+def max_normalize_device(vol: DeviceVolume) -> DeviceVolume:
+    """transforms/transform.py:67-69 in place: im / im.max() when the maximum is positive."""
+    vol.dev.call("msk_max_norm", C.c_void_p(vol.ptr), C.c_void_p(vol.ptr), C.c_size_t(vol.size))
+    return vol
+
+
+def upload_pooled(image, dev=None) -> DeviceVolume:
+    """Host volume -> pooled device buffer (loader path of the device augmentations)."""
+    dev = dev or get_device()
+    a = np.asarray(image)
+    if a.ndim != 3:
+        raise ValueError("expected a 3-D volume, got shape {}".format(a.shape))
+    a = np.ascontiguousarray(a, dtype=np.int32 if np.issubdtype(a.dtype, np.integer) else np.float32)
+    v = _pooled_volume(dev, a.shape, a.dtype)
+    dev.h2d(v.ptr, a)
+    return v
 
 
 def upload(image, dev=None) -> DeviceVolume:

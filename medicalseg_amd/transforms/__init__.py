@@ -1,1 +1,2 @@
-from .transform import Compose, RandomFlip3D, RandomResizedCrop3D, RandomRotation3D, Resize3D
+from .transform import (BinaryMaskToConnectComponent, Compose, RandomFlip3D, RandomResizedCrop3D, RandomRotation3D,
+                        Resize3D, TopkLargestConnectComponent)

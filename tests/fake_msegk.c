@@ -45,6 +45,7 @@ NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd
 NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c)
 NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum)
 NOOP(msk_resample3d) NOOP(msk_hu_norm) NOOP(msk_minmax_norm) NOOP(msk_max_norm) NOOP(msk_label_remap)
+NOOP(msk_crop_resample3d) NOOP(msk_flip3d) NOOP(msk_rotate3d)
 NOOP(msk_interp_trilinear_fwd) NOOP(msk_interp_trilinear_bwd)
 typedef struct { void* p; int32_t n, d, h, w, c, ld; } fake_tensor;
 int msk_interp_scratch_bytes(void* c, fake_tensor s, fake_tensor d, size_t* b) {

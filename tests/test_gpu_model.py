@@ -274,3 +274,71 @@ def test_in_loop_device_preprocessing_feeds_the_model():
     b = model(ref)[0].numpy()
     assert a.shape == (1, 20, 32, 32, 12) and rel_err(a, b) < 1e-5
     assert lab.int_tensor().shape == (1, 32, 32, 12)
+
+
+def test_checkpoint_resume_continues_bitwise(tmp_path):
+    """SURVEY 8 f2 (core/train.py:230-254, utils/utils.py:115-135): iter_N/model.pdparams +
+    model.pdopt written through utils.save, loaded by utils.resume into a FRESH model/optimizer;
+    the continued trajectory must equal the uninterrupted one bit for bit (weights, BN buffers,
+    velocity and the LR-scheduler position all travel)."""
+    import pickle
+
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation, resume, save
+    shape, ncls, N = (16, 16, 16), 3, 2
+    rng = np.random.default_rng(11)
+    xs = [rng.standard_normal((N, 1) + shape).astype(np.float32) for _ in range(4)]
+    ys = [rng.integers(0, ncls, (N,) + shape).astype(np.int32) for _ in range(4)]
+    w = [1.0, 2.0, 0.5]  # explicit CE weights: the cached first-batch weights are not checkpointed (F8)
+
+    def make():
+        nn.seed(3)
+        model = VNet(num_classes=ncls)
+        model.train()
+        model.set_dropout_masks({})  # dropout RNG state is not checkpointed either
+        sched = optim.lr.PolynomialDecay(1e-2, decay_steps=10, end_lr=0, power=0.9)
+        opt = optim.Momentum(sched, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(weight=w), DiceLoss()], [1, 1])], "coef": [1]}
+        return model, opt, sched, losses
+
+    def step(model, opt, sched, losses, i):
+        ll, _ = loss_computation(model(xs[i]), to_labels(ys[i]), losses)
+        sum(ll).backward()
+        opt.step()
+        sched.step()
+        model.clear_gradients()
+
+    model, opt, sched, losses = make()
+    for i in range(2):
+        step(model, opt, sched, losses, i)
+    ck = tmp_path / "iter_2"
+    save(model.state_dict(), str(ck / "model.pdparams"))
+    save(opt.state_dict(), str(ck / "model.pdopt"))
+    for i in range(2, 4):
+        step(model, opt, sched, losses, i)
+    ref_sd, ref_opt = model.state_dict(), opt.state_dict()
+
+    # the files are plain pickles of {name: ndarray} with the reference's key names
+    sd = pickle.load(open(ck / "model.pdparams", "rb"))
+    assert list(sd.keys()) == [n for n, _, _ in O.param_specs(1, ncls)]
+    assert all(isinstance(v, np.ndarray) and v.dtype == np.float32 for v in sd.values())
+    od = pickle.load(open(ck / "model.pdopt", "rb"))
+    assert "in_tr.conv1.weight_velocity_0" in od and "LR_Scheduler" in od
+
+    model2, opt2, sched2, losses2 = make()
+    # a paddle-written file also carries this name table; it must be ignored
+    sd["StructuredToParameterName@@"] = {k: "param_%d" % i for i, k in enumerate(sd)}
+    save(sd, str(ck / "model.pdparams"))
+    assert resume(model2, opt2, str(ck)) == 2
+    assert sched2.last_epoch == sched.last_epoch - 2
+    for i in range(2, 4):
+        step(model2, opt2, sched2, losses2, i)
+    sd2, opt_sd2 = model2.state_dict(), opt2.state_dict()
+    for k in ref_sd:
+        assert np.array_equal(ref_sd[k], sd2[k]), k
+    for k in ref_opt:
+        if k != "LR_Scheduler":
+            assert np.array_equal(ref_opt[k], opt_sd2[k]), k
+    assert ref_opt["LR_Scheduler"] == opt_sd2["LR_Scheduler"]

@@ -197,3 +197,104 @@ def test_synthetic_dataset_contract():
     assert 0.0 <= im.min() and im.max() == 1.0 and set(np.unique(lab)) <= {0, 1, 2} and isinstance(path, str)
     im2, lab2, _ = ds[1]
     assert np.array_equal(im, im2) and np.array_equal(lab, lab2)
+
+
+# ---------------------------------------------------------------------------------------
+# loader augmentations vs goldens captured from the reference's own classes
+# ---------------------------------------------------------------------------------------
+def _tg():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms_golden.npz"))
+
+
+def test_transform_random_streams_match_reference():
+    """Same `random`/`np.random` seed -> same crop boxes, angles, planes, flip axes as
+    medicalseg/transforms/transform.py (goldens: tests/golden/make_transforms_golden.py)."""
+    import random
+
+    from medicalseg_amd import transforms as T
+    g = _tg()
+    img, lab = g["cls_img"], g["cls_lab"]
+    for tag, kw in (("rrc_default", {}), ("rrc_small", {"scale": (0.3, 0.6), "ratio": (0.5, 2.0)})):
+        t = T.RandomResizedCrop3D(size=(8, 8, 8), **kw)
+        for seed, want in enumerate(g[tag + "_params"]):
+            random.seed(seed)
+            assert list(t.get_params(img, t.scale, t.ratio)) == list(want), (tag, seed)
+    t = T.RandomRotation3D(degrees=30)
+    for seed, (a, p0, p1) in enumerate(g["rot_params"]):
+        random.seed(seed)
+        angle, plane = t.get_params(t.degrees)
+        assert angle == a and list(plane) == [int(p0), int(p1)]
+    t = T.RandomFlip3D(prob=0.5)
+    for seed, (want,) in enumerate(g["flip_axes"]):
+        random.seed(seed)
+        o, _ = t(img, lab)
+        got = -1 if np.array_equal(o, img) else [a for a in range(3) if np.array_equal(o, np.flip(img, a))][0]
+        assert got == want, seed
+
+
+def test_transform_classes_end_to_end_match_reference():
+    import random
+
+    from medicalseg_amd import transforms as T
+    g = _tg()
+    img, lab = g["cls_img"], g["cls_lab"]
+    random.seed(5)
+    np.random.seed(5)
+    o = T.RandomResizedCrop3D(size=(10, 9, 8), scale=(0.3, 0.6))(img, lab)
+    assert np.array_equal(o[0], g["rrc_call_img"]) and np.array_equal(o[1], g["rrc_call_lab"])
+    random.seed(9)
+    np.random.seed(9)
+    o = T.RandomResizedCrop3D(size=(8, 8, 6), scale=(0.8, 1.2), pre_crop=True)(img, lab)
+    assert np.array_equal(o[0], g["rrc_precrop_img"]) and np.array_equal(o[1], g["rrc_precrop_lab"])
+    random.seed(10)
+    np.random.seed(10)
+    o = T.RandomResizedCrop3D(size=(6, 6, 4), scale=(0.8, 1.2), pre_crop=True, nonzero_mask=True)(img, g["cls_lab2"])
+    assert np.array_equal(o[0], g["rrc_nonzero_img"]) and np.array_equal(o[1], g["rrc_nonzero_lab"])
+    random.seed(3)
+    o = T.RandomRotation3D(degrees=(-10, 50), rotate_planes=[[0, 1], [1, 2]])(img, lab)
+    assert np.array_equal(o[0], g["rot_call_img"]) and np.array_equal(o[1], g["rot_call_lab"])  # label: order 1 too
+    o = T.Resize3D(6)(img, lab)
+    assert np.array_equal(o[0], g["resize_int_img"]) and np.array_equal(o[1], g["resize_int_lab"])
+    o = T.Resize3D([9, 10, 11])(img, lab)
+    assert np.array_equal(o[0], g["resize_tuple_img"]) and np.array_equal(o[1], g["resize_tuple_lab"])
+    random.seed(1)
+    o = T.Compose([T.RandomFlip3D(prob=1.0, flip_axis=1)])(img.copy(), lab.copy())
+    assert o[0].shape == (1,) + img.shape and np.array_equal(o[0], g["compose_img"]) and np.array_equal(o[1], g["compose_lab"])
+
+
+def test_connected_component_transforms():
+    """functional.py:117-131 restated with scipy (SimpleITK absent): components ordered by size."""
+    from medicalseg_amd import transforms as T
+    m = np.zeros((6, 6, 6), np.uint8)
+    m[0:2, 0:2, 0:2] = 1      # 8 voxels
+    m[3:6, 3:6, 3:6] = 1      # 27 voxels
+    m[0, 5, 5] = 1            # 1 voxel
+    out, _ = T.BinaryMaskToConnectComponent()(m)
+    assert out[4, 4, 4] == 1 and out[0, 0, 0] == 2 and out[0, 5, 5] == 3 and out.max() == 3
+    out, _ = T.BinaryMaskToConnectComponent(minimum_volume=5)(m)
+    assert out.max() == 2 and out[0, 5, 5] == 0
+    out, _ = T.TopkLargestConnectComponent(k=1)(m)
+    assert set(np.unique(out)) == {0, 1} and out.sum() == 27
+    with pytest.raises(AssertionError):
+        T.BinaryMaskToConnectComponent()(np.arange(27).reshape(3, 3, 3))
+
+
+def test_augmentation_oracle_matches_reference_goldens():
+    """oracle/preprocess_numpy.py {flip3d, rotate3d, resized_crop3d} vs outputs of the reference's
+    functional.py: bit-exact labels, images within one float32 ulp."""
+    from oracle import preprocess_numpy as P
+    g = _tg()
+    for si in range(3):
+        img, lab = g[f"s{si}_img"], g[f"s{si}_lab"]
+        for ax in range(3):
+            assert np.array_equal(P.flip3d(img, ax), g[f"s{si}_flip{ax}_img"])
+            assert np.array_equal(P.flip3d(lab, ax), g[f"s{si}_flip{ax}_lab"])
+        for ri, (a0, a1, ang) in enumerate(g[f"s{si}_rot_params"]):
+            r = P.rotate3d(img, [int(a0), int(a1)], ang)
+            assert np.abs(r - g[f"s{si}_rot{ri}_img"]).max() <= 2e-5, (si, ri)
+            assert np.array_equal(P.rotate3d(lab, [int(a0), int(a1)], ang), g[f"s{si}_rot{ri}_lab"]), (si, ri)
+        for ci, p in enumerate(g[f"s{si}_crop_params"]):
+            i, j, k, d, h, w = (int(v) for v in p[:6])
+            size = [int(v) for v in p[6:]]
+            assert np.abs(P.resized_crop3d(img, i, j, k, d, h, w, size, 1) - g[f"s{si}_crop{ci}_img"]).max() <= 2e-5
+            assert np.array_equal(P.resized_crop3d(lab, i, j, k, d, h, w, size, 0), g[f"s{si}_crop{ci}_lab"])
