@@ -4,29 +4,28 @@ from ...cvlibs import manager
 
 @manager.LOSSES.add_component
 class MixedLoss(nn.Layer):
-    """Weighted list of losses (reference losses/mixes_losses.py:23-60); dispatch on the
-    class NAME 'DiceLoss' to pick up its side output, like the reference (:57)."""
+    """sum_i coef_i * loss_i over ONE logits tensor (reference losses/mixes_losses.py:23-60).
+
+    forward returns ``(loss_list, per_channel_dice)``: the weighted terms stay separate so that
+    the train loop can log them individually; a member whose class is NAMED ``DiceLoss`` also
+    returns its per-class dice, which is passed through (the reference dispatches on the class
+    name too, :57).  Here every term is a device-side ``Scalar`` of the fused loss node."""
 
     def __init__(self, losses, coef):
-        super(MixedLoss, self).__init__()
-        if not isinstance(losses, list):
-            raise TypeError('`losses` must be a list!')
-        if not isinstance(coef, list):
-            raise TypeError('`coef` must be a list!')
-        len_losses = len(losses)
-        len_coef = len(coef)
-        if len_losses != len_coef:
+        super().__init__()
+        for what, value in (("losses", losses), ("coef", coef)):
+            if not isinstance(value, list):
+                raise TypeError('`{}` must be a list!'.format(what))
+        if len(losses) != len(coef):
             raise ValueError('The length of `losses` should equal to `coef`, but they are {} and {}.'
-                             .format(len_losses, len_coef))
-        self.losses = losses
-        self.coef = coef
+                             .format(len(losses), len(coef)))
+        self.losses, self.coef = losses, coef
 
     def forward(self, logits, labels):
-        loss_list = []
-        per_channel_dice = None
-        for i, loss in enumerate(self.losses):
-            output = loss(logits, labels)
-            if type(loss).__name__ == "DiceLoss":
-                output, per_channel_dice = output
-            loss_list.append(output * self.coef[i])
-        return loss_list, per_channel_dice
+        terms, dice_per_class = [], None
+        for weight, member in zip(self.coef, self.losses):
+            value = member(logits, labels)
+            if type(member).__name__ == "DiceLoss":
+                value, dice_per_class = value
+            terms.append(value * weight)
+        return terms, dice_per_class

@@ -1,36 +1,35 @@
-"""Rank-0 level logger (reference medicalseg/utils/logger.py:20-48 behaviour: prints
-`time [LEVEL]\tmessage` on the local master only)."""
+"""Console logger of the train/eval loops: `YYYY-mm-dd HH:MM:SS [LEVEL]<TAB>message`, printed by
+the master rank only and filtered by `log_level` -- the line format and the four entry points
+(debug/info/warning/error) of the reference's utils/logger.py, which the reference's log
+parsers and users' grep patterns rely on.  The rank comes from the launcher's environment
+(torch.distributed.run exports RANK) instead of paddle's ParallelEnv."""
 import os
 import sys
-import time
+from datetime import datetime
 
-levels = {0: 'ERROR', 1: 'WARNING', 2: 'INFO', 3: 'DEBUG'}
-log_level = 2
-
-
-def _is_master():
-    return int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0"))) == 0
+ERROR, WARNING, INFO, DEBUG = range(4)
+levels = {ERROR: 'ERROR', WARNING: 'WARNING', INFO: 'INFO', DEBUG: 'DEBUG'}
+log_level = INFO  # messages above this verbosity are dropped
 
 
-def log(level=2, message=""):
-    if not _is_master() or log_level < level:
+def _master_rank() -> bool:
+    env = os.environ
+    return int(env.get("RANK", env.get("LOCAL_RANK", "0"))) == 0
+
+
+def log(level=INFO, message=""):
+    if level > log_level or not _master_rank():
         return
-    stamp = time.strftime("%Y-%m-%d %H:%M:%S", time.localtime())
-    print("{} [{}]\t{}".format(stamp, levels[level], message).encode("utf-8").decode("latin1"))
+    stamp = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
+    sys.stdout.write("%s [%s]\t%s\n" % (stamp, levels[level], message))
     sys.stdout.flush()
 
 
-def debug(message=""):
-    log(level=3, message=message)
+def _at(level):
+    def emit(message=""):
+        log(level, message)
+    emit.__name__ = levels[level].lower()
+    return emit
 
 
-def info(message=""):
-    log(level=2, message=message)
-
-
-def warning(message=""):
-    log(level=1, message=message)
-
-
-def error(message=""):
-    log(level=0, message=message)
+debug, info, warning, error = _at(DEBUG), _at(INFO), _at(WARNING), _at(ERROR)
