@@ -219,6 +219,13 @@ int msk_max_norm(msk_ctx* ctx, const float* src, float* dst, size_t count);
 int msk_label_remap(msk_ctx* ctx, int32_t* label, size_t count, const int32_t* keys,
                     const int32_t* vals, int npairs);
 
+/* Adjoint of the residual join out = prelu(a + b, alpha) (vnet.py:110-111,154) in ONE pass:
+ * da = dout * prelu'(a+b); db (+)= the same; dalpha[c] += sum dout*(a+b) over a+b <= 0.
+ * (A join has no BatchNorm, so its data gradient needs no reduction first.)  float4-aligned
+ * tensors with C % 4 == 0.                                                              */
+int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha, msk_tensor dout,
+                    msk_tensor da, msk_tensor db, int db_accumulate, float* dalpha);
+
 /* ---- deep supervision (models/vnet_deepsup.py:266-277) -------------- */
 /* F.interpolate(d, size=x.shape[2:], mode='trilinear') of a conv3^3 head: align_corners=
  * False, align_mode=0 [PADDLE]: per axis ratio = in/out, src = max(ratio*(o+0.5)-0.5, 0),

@@ -96,6 +96,71 @@ bn_stats_partial(const float* __restrict__ x, long voxels, int C, int ld, int CB
   }
 }
 
+// float4 variant: one channel quad per thread, two voxels in flight (the scalar kernel reached 3.2 TB/s)
+__global__ void __launch_bounds__(kThreads)
+bn_stats_partial_v4(const float* __restrict__ x, long voxels, int C, int ld, int QCB, int VL,
+                    float* __restrict__ partial /*[nb][4*QCB][3]*/) {
+  __shared__ WF sh[4][kThreads];
+  const int t = threadIdx.x;
+  const int cq = t % QCB, vl = t / QCB;
+  const int c = cq * 4;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  WF w[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  if (c < C && v0 + vl < v1) {
+    const float4 K = *reinterpret_cast<const float4*>(x + (v0 + vl) * ld + c);
+    const float k[4] = {K.x, K.y, K.z, K.w};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float n = 0.f;
+    auto acc = [&](const float4 q) {
+      const float xv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = xv[j] - k[j];
+        s1[j] += d;
+        s2[j] = fmaf(d, d, s2[j]);
+      }
+      n += 1.f;
+    };
+    long v = v0 + vl;
+    for (; v + VL < v1; v += 2 * VL) {
+      const float4 a = *reinterpret_cast<const float4*>(x + v * ld + c);
+      const float4 b = *reinterpret_cast<const float4*>(x + (v + VL) * ld + c);
+      acc(a);
+      acc(b);
+    }
+    if (v < v1) acc(*reinterpret_cast<const float4*>(x + v * ld + c));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j].n = n;
+      w[j].mean = k[j] + s1[j] / n;
+      w[j].m2 = fmaxf(s2[j] - s1[j] * s1[j] / n, 0.f);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sh[j][t] = w[j];
+  __syncthreads();
+  for (int s = VL >> 1; s > 0; s >>= 1) {
+    if (vl < s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sh[j][t] = wf_merge(sh[j][t], sh[j][t + s * QCB]);
+    }
+    __syncthreads();
+  }
+  if (vl == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* p = partial + (((long)blockIdx.x) * 4 * QCB + c + j) * 3;
+      p[0] = sh[j][t].n;
+      p[1] = sh[j][t].mean;
+      p[2] = sh[j][t].m2;
+    }
+  }
+}
+
 // One block per channel: 64 lanes stride over the nb block partials (Chan merge in double),
 // then a fixed-order tree over the 64 lane results -> deterministic and ~nb/64 serial steps.
 __global__ void __launch_bounds__(64)
@@ -197,16 +262,31 @@ __device__ __forceinline__ void stv(float* p, const float (&o)[V]) {
   }
 }
 
+// element index -> (voxel, channel group): shift/mask when the group count is a power of two (every VNet
+// layer), a 64-bit division per element otherwise -- the division was a visible cost in these HBM-bound loops
+__device__ __forceinline__ void split_vc(long i, int cv, int cshift, long& v, int& cg) {
+  if (cshift >= 0) {
+    v = i >> cshift;
+    cg = (int)(i & (long)(cv - 1));
+  } else {
+    v = i / cv;
+    cg = (int)(i - v * cv);
+  }
+}
+
 template <int V>
 __global__ void __launch_bounds__(kThreads)
 affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                  const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                  const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C) {
   const int cv = C / V;
+  const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / cv;
-    const int c = (int)(i - v * cv) * V;
+    long v;
+    int cg;
+    split_vc(i, cv, cshift, v, cg);
+    const int c = cg * V;
     float xv[V], o[V];
     ldv<V>(x + v * ldx + c, xv);
 #pragma unroll
@@ -232,6 +312,51 @@ affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__
     }
     stv<V>(out + v * ldo + c, o);
   }
+}
+
+// Channel-stationary float4 variants (C/4 a power of two, i.e. every VNet trunk layer): a thread keeps
+// ONE channel quad and strides over voxels, so the per-channel coefficients are loaded once into
+// registers instead of 3-7 cached loads per element (the element-indexed kernels were bound by the
+// texture-address path: 2.3 TB/s for bwd_apply vs 5 TB/s for a plain copy), two voxels in flight.
+__global__ void __launch_bounds__(kThreads)
+affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
+                    const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift) {
+  const long g = (long)blockIdx.x * kThreads + threadIdx.x;
+  const int c = (int)(g & ((C >> 2) - 1)) * 4;
+  const long vstride = ((long)gridDim.x * kThreads) >> cshift;
+  float sc[4], sf[4], al[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = scale ? scale[c + j] : 1.f;
+    sf[j] = scale ? shift[c + j] : 0.f;
+    al[j] = alpha ? alpha[c + j] : 1.f;
+  }
+  auto load_res = [&](long v) {
+    if (!res) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
+    const float* r = res + v * ldr;
+    return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
+  };
+  auto body = [&](long v, const float4 xq, const float4 rq) {
+    const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = fmaf(xv[j], sc[j], sf[j]) + rv[j];
+      o[j] = (alpha && !(u > 0.f)) ? al[j] * u : u;
+    }
+    *reinterpret_cast<float4*>(out + v * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  long v = g >> cshift;
+  for (; v + vstride < voxels; v += 2 * vstride) {
+    const float4 xa = *reinterpret_cast<const float4*>(x + v * ldx + c);
+    const float4 xb = *reinterpret_cast<const float4*>(x + (v + vstride) * ldx + c);
+    const float4 ra = load_res(v), rb = load_res(v + vstride);
+    body(v, xa, ra);
+    body(v + vstride, xb, rb);
+  }
+  if (v < voxels) body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), load_res(v));
 }
 
 // ---------------------------------------------------------------------------
@@ -292,6 +417,119 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
   }
 }
 
+// float4 variant: a thread owns one channel QUAD and every VL-th voxel (a wavefront reads 1 KiB
+// contiguous), two voxels in flight per iteration.  The scalar kernel above moved 4 bytes per
+// lane per load and reached ~1.2 TB/s on the 128^3 layers.
+//   JOIN = false: the three BatchNorm/PReLU sums of a ConvBNAct unit
+//   JOIN = true : the residual join out = prelu(a + b) in ONE pass: writes da (and db, optionally
+//                 accumulating) while reducing the alpha-gradient sum -- the data gradient of a
+//                 join does not depend on any sum, so the separate reduce pass is not needed.
+template <bool JOIN>
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                           const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
+                           const float* __restrict__ alpha, const float* __restrict__ mean,
+                           const float* __restrict__ invstd, const float* __restrict__ dout, int ldd, long voxels,
+                           int C, int QCB, int VL, float* __restrict__ da, int ldda, float* __restrict__ db,
+                           int lddb, int db_acc, float* __restrict__ partial /*[nb][NQ][4*QCB]*/) {
+  constexpr int NQ = JOIN ? 1 : 3;
+  __shared__ float sh[NQ * 4][kThreads];
+  const int t = threadIdx.x;
+  const int cq = t % QCB, vl = t / QCB;
+  const int c = cq * 4;
+  const int nb = gridDim.x;
+  const long per = (voxels + nb - 1) / nb;
+  const long v0 = (long)blockIdx.x * per;
+  long v1 = v0 + per;
+  if (v1 > voxels) v1 = voxels;
+  float s_du[4] = {0.f, 0.f, 0.f, 0.f}, s_dux[4] = {0.f, 0.f, 0.f, 0.f}, s_da[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    float sc[4], sf[4], al[4], mu[4], is[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = scale ? scale[c + j] : 1.f;
+      sf[j] = scale ? shift[c + j] : 0.f;
+      al[j] = alpha ? alpha[c + j] : 1.f;
+      mu[j] = mean ? mean[c + j] : 0.f;
+      is[j] = mean ? invstd[c + j] : 0.f;
+    }
+    auto body = [&](long v, const float4 xq, const float4 dq, const float4 rq) {
+      const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
+      const float rv[4] = {rq.x, rq.y, rq.z, rq.w};
+      float du[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = fmaf(xv[j], sc[j], sf[j]) + rv[j];
+        float g = dv[j];
+        if (alpha && !(u > 0.f)) {
+          g = al[j] * dv[j];
+          s_da[j] = fmaf(dv[j], u, s_da[j]);
+        }
+        du[j] = g;
+        if (!JOIN) {
+          s_du[j] += g;
+          s_dux[j] = fmaf(g, (xv[j] - mu[j]) * is[j], s_dux[j]);
+        }
+      }
+      if (JOIN) {
+        const float4 o = make_float4(du[0], du[1], du[2], du[3]);
+        *reinterpret_cast<float4*>(da + v * ldda + c) = o;
+        float4* bp = reinterpret_cast<float4*>(db + v * lddb + c);
+        if (db_acc) {
+          const float4 old = *bp;
+          *bp = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+        } else {
+          *bp = o;
+        }
+      }
+    };
+    auto load_res = [&](long v) {
+      if (!res) return make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
+      const float* r = res + v * ldr;
+      return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
+    };
+    long v = v0 + vl;
+    for (; v + VL < v1; v += 2 * VL) {
+      const float4 xa = *reinterpret_cast<const float4*>(x + v * ldx + c);
+      const float4 xb = *reinterpret_cast<const float4*>(x + (v + VL) * ldx + c);
+      const float4 ga = *reinterpret_cast<const float4*>(dout + v * ldd + c);
+      const float4 gb = *reinterpret_cast<const float4*>(dout + (v + VL) * ldd + c);
+      const float4 ra = load_res(v), rb = load_res(v + VL);
+      body(v, xa, ga, ra);
+      body(v + VL, xb, gb, rb);
+    }
+    if (v < v1)
+      body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
+           load_res(v));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (JOIN) {
+      sh[j][t] = s_da[j];
+    } else {
+      sh[j][t] = s_du[j];
+      sh[4 + j][t] = s_dux[j];
+      sh[8 + j][t] = s_da[j];
+    }
+  }
+  __syncthreads();
+  for (int s = VL >> 1; s > 0; s >>= 1) {
+    if (vl < s) {
+#pragma unroll
+      for (int k = 0; k < NQ * 4; ++k) sh[k][t] += sh[k][t + s * QCB];
+    }
+    __syncthreads();
+  }
+  if (vl == 0) {
+    float* p = partial + (long)blockIdx.x * NQ * 4 * QCB;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[q * 4 * QCB + c + j] = sh[q * 4 + j][t];
+  }
+}
+
 // One block per output (q, c): 64 lanes stride over the nb block partials in double, fixed-order
 // tree over the lanes (deterministic).
 __global__ void __launch_bounds__(64)
@@ -324,10 +562,13 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
                        const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx,
                        int lddx, float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C) {
   const int cv = C / V;
+  const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / cv;
-    const int c = (int)(i - v * cv) * V;
+    long v;
+    int cg;
+    split_vc(i, cv, cshift, v, cg);
+    const int c = cg * V;
     float xv[V], dv[V], du[V], o[V];
     ldv<V>(x + v * ldx + c, xv);
     ldv<V>(dout + v * ldd + c, dv);
@@ -374,6 +615,80 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
   }
 }
 
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                          const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
+                          const float* __restrict__ alpha, const float* __restrict__ mean,
+                          const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
+                          const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx, int lddx,
+                          float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C, int cshift) {
+  const long g = (long)blockIdx.x * kThreads + threadIdx.x;
+  const int c = (int)(g & ((C >> 2) - 1)) * 4;
+  const long vstride = ((long)gridDim.x * kThreads) >> cshift;
+  float sc[4], sf[4], al[4], mu[4], is[4], s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = scale ? scale[c + j] : 1.f;
+    sf[j] = scale ? shift[c + j] : 0.f;
+    al[j] = alpha ? alpha[c + j] : 1.f;
+    mu[j] = bn_mode == 1 ? mean[c + j] : 0.f;
+    is[j] = bn_mode == 1 ? invstd[c + j] : 0.f;
+    s1[j] = bn_mode == 1 ? sums[c + j] * invM : 0.f;
+    s2[j] = bn_mode == 1 ? sums[C + c + j] * invM : 0.f;
+  }
+  const bool need_res = res && alpha;
+  auto load_res = [&](long v) {
+    if (!need_res) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
+    const float* r = res + v * ldr;
+    return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
+  };
+  auto body = [&](long v, const float4 xq, const float4 dq, const float4 rq) {
+    const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w}, rv[4] = {rq.x, rq.y, rq.z, rq.w};
+    float du[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = dv[j];
+      if (alpha) {
+        const float u = fmaf(xv[j], sc[j], sf[j]) + rv[j];
+        if (!(u > 0.f)) d *= al[j];
+      }
+      du[j] = d;
+      if (bn_mode == 1) {
+        const float xh = (xv[j] - mu[j]) * is[j];
+        o[j] = sc[j] * (d - s1[j] - xh * s2[j]);
+      } else if (bn_mode == 2) {
+        o[j] = sc[j] * d;
+      } else {
+        o[j] = d;
+      }
+    }
+    if (dx) *reinterpret_cast<float4*>(dx + v * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) {
+      float4* rp = reinterpret_cast<float4*>(dres + v * lddr + c);
+      float4 w = make_float4(du[0], du[1], du[2], du[3]);
+      if (dres_acc) {
+        const float4 old = *rp;
+        w = make_float4(w.x + old.x, w.y + old.y, w.z + old.z, w.w + old.w);
+      }
+      *rp = w;
+    }
+  };
+  long v = g >> cshift;
+  for (; v + vstride < voxels; v += 2 * vstride) {
+    const float4 xa = *reinterpret_cast<const float4*>(x + v * ldx + c);
+    const float4 xb = *reinterpret_cast<const float4*>(x + (v + vstride) * ldx + c);
+    const float4 ga = *reinterpret_cast<const float4*>(dout + v * ldd + c);
+    const float4 gb = *reinterpret_cast<const float4*>(dout + (v + vstride) * ldd + c);
+    const float4 ra = load_res(v), rb = load_res(v + vstride);
+    body(v, xa, ga, ra);
+    body(v + vstride, xb, gb, rb);
+  }
+  if (v < voxels)
+    body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
+         load_res(v));
+}
+
 __global__ void param_grads_k(int C, const float* sums, float* dgamma, float* dbeta, float* dalpha, int acc) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -390,10 +705,13 @@ __global__ void __launch_bounds__(kThreads)
 copy_scale_k(const float* __restrict__ src, int lds_, const float* __restrict__ mask, float* __restrict__ dst,
              int ldd, long voxels, long vox_per_n, int C, int acc) {
   const int cv = C / V;
+  const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / cv;
-    const int c = (int)(i - v * cv) * V;
+    long v;
+    int cg;
+    split_vc(i, cv, cshift, v, cg);
+    const int c = cg * V;
     float s[V];
     ldv<V>(src + v * lds_ + c, s);
     if (mask) {
@@ -512,7 +830,7 @@ inline bool vec4_ok(const msk_tensor& t) {
 }
 inline int ew_blocks(long total, int num_cu) {
   long b = (total + kThreads - 1) / kThreads;
-  long cap = (long)num_cu * 16;
+  long cap = (long)num_cu * 32;  // 8 waves per SIMD
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
@@ -545,6 +863,22 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
 int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
   const long voxels = msk_voxels(x);
   MSK_REQUIRE(ctx, voxels > 0 && x.c > 0, "empty tensor");
+  if (x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x)) {
+    const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
+    const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+    float* partial = (float*)msk_workspace(ctx, (size_t)nb * 4 * QCB * 3 * sizeof(float));
+    if (!partial) return -1;
+    {
+      msk_launch_scope ls(ctx, "bn_stats_partial");
+      hipLaunchKernelGGL(bn_stats_partial_v4, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)x.p, voxels, x.c,
+                         x.ld, QCB, VL, partial);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "bn_stats_merge");
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   ChanGeom g = chan_geom(x.c);
   int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
   size_t bytes = (size_t)g.cblocks * nb * g.CB * 3 * sizeof(float);
@@ -594,7 +928,14 @@ int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const flo
   const long voxels = msk_voxels(x);
   const bool v4 = vec4_ok(x) && vec4_ok(out) && (res.p == nullptr || res.c != x.c || vec4_ok(res));
   msk_launch_scope ls(ctx, "affine_act_fwd");
-  if (v4) {
+  const int cq = x.c / 4;
+  if (v4 && cq >= 1 && (cq & (cq - 1)) == 0 && cq <= kThreads) {
+    int cshift = 0;
+    while ((1 << cshift) < cq) ++cshift;
+    hipLaunchKernelGGL(affine_act_fwd_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
+                       (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, (float*)out.p,
+                       out.ld, voxels, x.c, cshift);
+  } else if (v4) {
     hipLaunchKernelGGL(affine_act_fwd_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
                        alpha, (float*)out.p, out.ld, voxels, x.c);
@@ -612,6 +953,26 @@ int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, co
                               float* sums) {
   MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
   const long voxels = msk_voxels(x);
+  const bool v4 = x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x) && vec4_ok(dout) &&
+                  (res.p == nullptr || res.c != x.c || vec4_ok(res));
+  if (v4) {
+    const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
+    const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+    float* partial = (float*)msk_workspace(ctx, (size_t)nb * 3 * 4 * QCB * sizeof(float));
+    if (!partial) return -1;
+    {
+      msk_launch_scope ls(ctx, "affine_act_bwd_reduce");
+      hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<false>, dim3(nb), dim3(kThreads), 0, ctx->stream,
+                         (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean, invstd,
+                         (const float*)dout.p, dout.ld, voxels, x.c, QCB, VL, (float*)nullptr, 0, (float*)nullptr, 0, 0,
+                         partial);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "sums_merge");
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   ChanGeom g = chan_geom(x.c);
   int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
   size_t bytes = (size_t)g.cblocks * nb * 3 * g.CB * sizeof(float);
@@ -648,7 +1009,15 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
                   (res.p == nullptr || res.c != x.c || vec4_ok(res));
   const float invM = (float)(1.0 / M_total);
   msk_launch_scope ls(ctx, "affine_act_bwd_apply");
-  if (v4) {
+  const int cq = x.c / 4;
+  if (v4 && cq >= 1 && (cq & (cq - 1)) == 0 && cq <= kThreads) {
+    int cshift = 0;
+    while ((1 << cshift) < cq) ++cshift;
+    hipLaunchKernelGGL(affine_act_bwd_apply_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0,
+                       ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean,
+                       invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode, (float*)dx.p, dx.ld,
+                       (float*)dres.p, dres.ld, dres_acc, voxels, x.c, cshift);
+  } else if (v4) {
     hipLaunchKernelGGL(affine_act_bwd_apply_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads),
                        0, ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
                        alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
@@ -659,6 +1028,31 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
                        alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
                        (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c);
   }
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da,
+                    msk_tensor db, int db_accumulate, float* dalpha) {
+  MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && same_shape(a, db), "shape mismatch");
+  MSK_REQUIRE(ctx, alpha != nullptr && dalpha != nullptr, "join needs alpha and its gradient");
+  MSK_REQUIRE(ctx, a.c % 4 == 0 && a.c / 4 <= kThreads && vec4_ok(a) && vec4_ok(b) && vec4_ok(dout) && vec4_ok(da) &&
+                       vec4_ok(db), "join backward needs float4-aligned tensors with C % 4 == 0");
+  const long voxels = msk_voxels(a);
+  const int QCB = pow2ceil(a.c / 4), VL = kThreads / QCB;
+  const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+  float* partial = (float*)msk_workspace(ctx, (size_t)nb * 4 * QCB * sizeof(float));
+  if (!partial) return -1;
+  {
+    msk_launch_scope ls(ctx, "add_act_bwd");
+    hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<true>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p,
+                       a.ld, (const float*)nullptr, (const float*)nullptr, (const float*)b.p, b.ld, b.c, alpha,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)dout.p, dout.ld, voxels, a.c, QCB, VL,
+                       (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  msk_launch_scope ls(ctx, "sums_merge");
+  hipLaunchKernelGGL(sums_merge_k, dim3(a.c), dim3(64), 0, ctx->stream, partial, nb, a.c, 4 * QCB, 1, dalpha, 1);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -490,14 +490,19 @@ class AddAct:
         if self._sums is None:
             self._sums = dev.small(3 * Cn)
         alpha = _fp(self.act._weight.ptr)
-        dev.call("msk_affine_act_bwd_reduce", a.msk(), None, None, b.msk(), alpha, None, None, dout.msk(),
-                 _fp(self._sums))
-        dev.call("msk_affine_act_param_grads", Cn, _fp(self._sums), None, None, _fp(self.act._weight.grad_ptr), 1)
         ga, gb = a.ensure_grad(), b.ensure_grad()
         if a.grad_written:
             raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
-        dev.call("msk_affine_act_bwd_apply", a.msk(), None, None, b.msk(), alpha, None, None, None, dout.msk(),
-                 None, C.c_double(1.0), 0, ga.msk(), gb.msk(), 1 if b.grad_written else 0)
+        if Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
+            # one pass: both data gradients and the alpha-gradient sum (a join has no BatchNorm)
+            dev.call("msk_add_act_bwd", a.msk(), b.msk(), alpha, dout.msk(), ga.msk(), gb.msk(),
+                     1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr))
+        else:
+            dev.call("msk_affine_act_bwd_reduce", a.msk(), None, None, b.msk(), alpha, None, None, dout.msk(),
+                     _fp(self._sums))
+            dev.call("msk_affine_act_param_grads", Cn, _fp(self._sums), None, None, _fp(self.act._weight.grad_ptr), 1)
+            dev.call("msk_affine_act_bwd_apply", a.msk(), None, None, b.msk(), alpha, None, None, None, dout.msk(),
+                     None, C.c_double(1.0), 0, ga.msk(), gb.msk(), 1 if b.grad_written else 0)
         a.grad_written = True
         b.grad_written = True
 
