@@ -8,8 +8,8 @@ already resident in HBM (BASELINE.json configs[1]; configs[2] at --gpus 8).
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is
 not imported).  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (conv_halo_mfma_k5: all 5x5x5 convs and their data
-                  gradients), HIP-event time over the timed region, algorithmic FLOPs;
+  roofline     -- the dominant kernel (the conv_halo_mfma_k<..., 5> variant with the largest time: the 5x5x5
+                  convs and their data gradients), HIP-event time over the timed region, algorithmic FLOPs;
   cpu_baseline -- the CPU oracle timed on the host cores on a bounded sample (rank 0, N=1).
 """
 import argparse
@@ -40,18 +40,34 @@ def vnet_lu_layers(d, h, w):
     return layers
 
 
+HALO_TILES = ((2, 4, 32), (2, 8, 16), (4, 8, 8), (4, 16, 4), (8, 16, 2))
+HALO_ORDER = (2, 1, 0, 3, 4)
+
+
+def halo_tile_for(d, h, w):
+    """Mirror of the tile choice in msk_gconv_halo_mfma (msk_conv_mfma.hip): fewest padded voxels,
+    ties to the first in HALO_ORDER."""
+    best, best_util = 0, -1.0
+    for i in HALO_ORDER:
+        td, th, tw = HALO_TILES[i]
+        padded = -(-d // td) * td * (-(-h // th)) * th * (-(-w // tw)) * tw
+        util = d * h * w / padded
+        if util > best_util * 1.02:
+            best, best_util = i, util
+    return best
+
+
 def halo_variant_work(n, d, h, w):
-    """Algorithmic FLOPs (2*125*Cin*Cout per output voxel) and algorithmic HBM bytes (input + output
-    + weights, each once) summed over the launches of conv_halo_mfma_k<2, 4, 32, 5> (layers with
-    W >= 32) in ONE training step: forward + data gradient of each layer."""
-    flops = bytes_ = 0.0
-    launches = 0
+    """{kernel name: (algorithmic FLOPs, algorithmic HBM bytes, launches)} per training step for every
+    conv_halo_mfma_k<TD, TH, TW, 5> variant: 2*125*Cin*Cout FLOPs per output voxel and input + output +
+    weights once, forward + data gradient of each 5^3 LUConv layer (cubic volumes: level dims = w)."""
+    work = {}
     for ci, co, vv, ww in vnet_lu_layers(d, h, w):
-        if ww >= 32:
-            flops += 2 * (2.0 * 125 * ci * co * vv * n)
-            bytes_ += 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co))
-            launches += 2
-    return flops, bytes_, launches
+        td, th, tw = HALO_TILES[halo_tile_for(ww, ww, ww)]
+        name = "conv_halo_mfma_k<%d, %d, %d, 5>" % (td, th, tw)
+        f, b, l = work.get(name, (0.0, 0.0, 0))
+        work[name] = (f + 2 * (2.0 * 125 * ci * co * vv * n), b + 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co)), l + 2)
+    return work
 
 
 def step_flops_per_sample():
@@ -102,6 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="tag conv kernels with their problem shapes in the profile")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile here")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="msk_set_option knob for experiments, e.g. --opt wgrad_async=0 (not for the headline run)")
     args = ap.parse_args()
 
     from medicalseg_amd import optimizer as optim
@@ -148,6 +166,9 @@ def main():
         model.clear_gradients()
         return loss
 
+    for kv in args.opt:
+        k, v = kv.split("=")
+        dev.set_option(k, int(v))
     for _ in range(args.warmup):
         last = step()
     parallel.barrier()
@@ -180,10 +201,14 @@ def main():
     voxels_per_step = world * B * S ** 3
     value = voxels_per_step / (elapsed / args.steps)
 
-    DOM = "conv_halo_mfma_k<2, 4, 32, 5>"   # dominant kernel: same name as in rocprofv3's kernel stats
-    calls = sum(v[0] for k, v in prof.items() if k.startswith(DOM))
-    kms = sum(v[1] for k, v in prof.items() if k.startswith(DOM))
-    flops_step, bytes_step, launches_step = halo_variant_work(B, S, S, S)
+    # dominant kernel = the MFMA halo-conv variant with the largest HIP-event time (kernel names are spelled
+    # as in rocprofv3's kernel stats)
+    work = halo_variant_work(B, S, S, S)
+    by_variant = {name: (sum(v[0] for k, v in prof.items() if k.startswith(name)),
+                         sum(v[1] for k, v in prof.items() if k.startswith(name))) for name in work}
+    DOM = max(by_variant, key=lambda k: by_variant[k][1])
+    calls, kms = by_variant[DOM]
+    flops_step, bytes_step, launches_step = work[DOM]
     achieved = flops_step * args.steps / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic = None

@@ -43,6 +43,9 @@ struct msk_ctx {
   bool prof_shapes = false;        // append problem shapes to conv tags
   // options
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
+  int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
+  int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
+  int wgrad_rounds = 8;  // LDS wgrad: target workgroups per CU (split-K granularity)
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
   // side stream: weight gradients run concurrently with the data-gradient chain (they only share
   // inputs), so HBM-bound elementwise backward kernels hide behind MFMA-bound wgrad kernels

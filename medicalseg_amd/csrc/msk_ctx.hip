@@ -253,6 +253,18 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->conv_impl = value;
     return 0;
   }
+  if (strcmp(key, "halo_tile") == 0) {
+    ctx->halo_tile = value;
+    return 0;
+  }
+  if (strcmp(key, "wgrad_rounds") == 0) {
+    ctx->wgrad_rounds = value > 0 ? value : 8;
+    return 0;
+  }
+  if (strcmp(key, "wgrad_chunk") == 0) {
+    ctx->wgrad_chunk = value;
+    return 0;
+  }
   if (strcmp(key, "wgrad_async") == 0) {  // weight gradients on the side stream (default on)
     if (msk_join_side_impl(ctx) != 0) return -1;
     ctx->wgrad_async = value != 0;

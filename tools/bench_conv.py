@@ -1,0 +1,58 @@
+"""Micro-benchmark of one 'same' 5^3 convolution (forward, data gradient, weight gradient) through the C ABI,
+with the tile/chunk tuning knobs:  python tools/bench_conv.py --c 32 --size 128 --halo-tile 1 --wgrad-chunk 1"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c", type=int, default=32)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--n", type=int, default=2)
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--halo-tile", type=int, default=-1)
+    ap.add_argument("--wgrad-chunk", type=int, default=-1)
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    from medicalseg_amd._lib import MskConvDesc
+    from medicalseg_amd.device import Tensor, get_device
+    dev = get_device()
+    dev.set_option("halo_tile", a.halo_tile)
+    dev.set_option("wgrad_chunk", a.wgrad_chunk)
+    dev.set_option("wgrad_async", 0)
+    n, s, c, k = a.n, a.size, a.c, a.k
+    vox = n * s ** 3
+    mk = lambda: Tensor(dev, dev.malloc(vox * c * 4), n, s, s, s, c, c, None)
+    x, y, dy, dx = mk(), mk(), mk(), mk()
+    rng = np.random.default_rng(0)
+    for t in (x, dy):
+        dev.h2d(t.ptr, rng.standard_normal(vox * c, dtype=np.float32))
+    w = dev.malloc(c * c * k ** 3 * 4)
+    dev.h2d(w, (rng.standard_normal(c * c * k ** 3) * 0.01).astype(np.float32))
+    dw, b, db = dev.malloc(c * c * k ** 3 * 4), dev.small(c), dev.small(c)
+    cd = MskConvDesc(k, k, k, 1, 1, 1, k // 2, k // 2, k // 2)
+    vp = C.c_void_p
+    gf = 2.0 * k ** 3 * c * c * vox / 1e9
+    cases = {
+        "fwd": lambda: dev.call("msk_conv3d_fwd", cd, x.msk(), vp(w), vp(b), y.msk()),
+        "dgrad": lambda: dev.call("msk_conv3d_dgrad", cd, dy.msk(), vp(w), dx.msk(), 0),
+        "wgrad": lambda: dev.call("msk_conv3d_wgrad", cd, x.msk(), dy.msk(), vp(dw), vp(db), 0),
+    }
+    for name, fn in cases.items():
+        fn()
+        dev.sync()
+        dev.timer_start()
+        for _ in range(a.iters):
+            fn()
+        ms = dev.timer_stop() / a.iters
+        print(f"c={c} {n}x{s}^3 k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
