@@ -53,6 +53,23 @@ def main(tag):
                               "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
         with open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
+    sq_p = os.path.join(go, "prof_sq", "r01_counter_collection.csv")
+    if os.path.exists(sq_p):
+        # MFMA-pipe utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs,
+        # GRBM_GUI_ACTIVE over the 8 XCDs (pass run with wgrad_async=0 so that kernels do not overlap)
+        tot = collections.defaultdict(lambda: collections.defaultdict(float))
+        with open(sq_p) as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+                tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        res = {"_note": "mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), summed over "
+                        "all launches of one training step, weight gradients on the main stream (--opt wgrad_async=0)"}
+        for k, v in tot.items():
+            if "mfma" in k and v.get("GRBM_GUI_ACTIVE"):
+                res[k] = {"mfma_busy_frac": round((v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (v["GRBM_GUI_ACTIVE"] / 8), 4),
+                          "gui_active_cycles_per_xcd": int(v["GRBM_GUI_ACTIVE"] / 8)}
+        with open(os.path.join(out, f"{tag}_mfma_busy.json"), "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
     print("wrote summaries to", out)
 
 
