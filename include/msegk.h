@@ -219,6 +219,12 @@ int msk_max_norm(msk_ctx* ctx, const float* src, float* dst, size_t count);
 int msk_label_remap(msk_ctx* ctx, int32_t* label, size_t count, const int32_t* keys,
                     const int32_t* vals, int npairs);
 
+/* Bias gradient of a convolution that feeds a BatchNorm, from the sums msk_affine_act_bwd_reduce
+ * already produced (no extra pass over dy): with batch statistics sum_v dy[v][c] is identically 0
+ * (the BN backward removes the mean) -- callers skip db there; with running statistics (eval-mode
+ * BN, vnet.py:351-397 alignment runs) it is scale[c] * sums[c].                          */
+int msk_bn_bias_grad(msk_ctx* ctx, int C, const float* sums, const float* scale, float* dbias,
+                     int accumulate);
 /* Adjoint of the residual join out = prelu(a + b, alpha) (vnet.py:110-111,154) in ONE pass:
  * da = dout * prelu'(a+b); db (+)= the same; dalpha[c] += sum dout*(a+b) over a+b <= 0.
  * (A join has no BatchNorm, so its data gradient needs no reduction first.)  float4-aligned

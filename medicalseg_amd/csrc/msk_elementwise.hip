@@ -697,6 +697,11 @@ __global__ void param_grads_k(int C, const float* sums, float* dgamma, float* db
   if (dalpha) dalpha[c] = (acc ? dalpha[c] : 0.f) + sums[2 * C + c];
 }
 
+__global__ void bias_grad_from_sums_k(int C, const float* sums, const float* scale, float* dbias, int acc) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) dbias[c] = (acc ? dbias[c] : 0.f) + scale[c] * sums[c];
+}
+
 // ---------------------------------------------------------------------------
 // copy with per-(n,c) scale
 // ---------------------------------------------------------------------------
@@ -1062,6 +1067,15 @@ int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dg
   msk_launch_scope ls(ctx, "affine_act_param_grads");
   hipLaunchKernelGGL(param_grads_k, dim3(msk_cdiv(C, 64)), dim3(64), 0, ctx->stream, C, sums, dgamma, dbeta,
                      dalpha, accumulate);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_bn_bias_grad(msk_ctx* ctx, int C, const float* sums, const float* scale, float* dbias, int accumulate) {
+  MSK_REQUIRE(ctx, sums && scale && dbias, "null pointer");
+  msk_launch_scope ls(ctx, "bn_bias_grad");
+  hipLaunchKernelGGL(bias_grad_from_sums_k, dim3(msk_cdiv(C, 64)), dim3(64), 0, ctx->stream, C, sums, scale, dbias,
+                     accumulate);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }

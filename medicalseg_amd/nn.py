@@ -243,10 +243,10 @@ class Conv3D(Layer):
                    C.c_void_p(self.bias.ptr), y.msk())
         return y
 
-    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True):
+    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True, bias_grad=True):
         dev = x.dev
         dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
-                 C.c_void_p(self.bias.grad_ptr), 1)
+                 C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
         if need_dx:
             dx = x.ensure_grad()
             dev.call("msk_conv3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
@@ -287,10 +287,10 @@ class Conv3DTranspose(Layer):
                    C.c_void_p(self.bias.ptr), y.msk())
         return y
 
-    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True):
+    def run_backward(self, x: Tensor, dy: Tensor, need_dx=True, bias_grad=True):
         dev = x.dev
         dev.call("msk_convT3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
-                 C.c_void_p(self.bias.grad_ptr), 1)
+                 C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
         if need_dx:
             dx = x.ensure_grad()
             dev.call("msk_convT3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
@@ -466,7 +466,12 @@ class ConvBNAct:
                  _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(), _fp(sums_total),
                  C.c_double(m_total), self.bn_mode, dy.msk(), dres, dres_acc)
         self.dy = dy  # kept for introspection (tests); freed with the arena
-        self.conv.run_backward(self.x, dy, need_dx=need_dx)
+        # conv bias gradient = sum_v dy[v][c]: identically zero behind a batch-statistics BN (its backward
+        # removes the mean), scale * sum(dout * prelu') behind a running-statistics BN -- either way no
+        # extra pass over dy (was 0.8 ms of channel-sum reads per step)
+        if self.bn_mode == 2:
+            dev.call("msk_bn_bias_grad", Cn, _fp(sc["sums"]), _fp(sc["scale"]), _fp(self.conv.bias.grad_ptr), 1)
+        self.conv.run_backward(self.x, dy, need_dx=need_dx, bias_grad=False)
 
 
 class AddAct:
