@@ -78,8 +78,10 @@ int msk_prof_enable(msk_ctx* ctx, int on);
 int msk_prof_reset(msk_ctx* ctx);
 /* writes "tag\tcalls\ttotal_ms\n" lines into buf (NUL terminated); returns needed size via *len */
 int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
-/* knobs: "conv_impl" 0=auto 1=VALU reference kernels 3=reference wgrad only 4=reference gather-conv only;
- * "wgrad_async" 0|1; "prof_shapes" 0|1; "poison_scratch" byte|-1 (debug) */
+/* knobs: "conv_impl" 0=auto 1=VALU reference kernels 3=reference wgrad only 4=reference gather-conv only
+ * 5=no LDS wgrad 6=no k==s scatter kernel 7=scatter kernel at any size; "wgrad_async" 0|1; "prof_shapes" 0|1;
+ * "poison_scratch" byte|-1 (debug); tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index),
+ * "wgrad_rounds" (workgroups per CU targeted by the LDS wgrad split-K) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);
 
 /* ---- layout at the boundary ------------------------------------------------ */

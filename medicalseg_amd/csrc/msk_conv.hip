@@ -256,6 +256,11 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
     int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
+    if (ctx->conv_impl != 6) {  // 6 = skip the scatter kernel (A/B against the parity-class gather kernel)
+      r = msk_gconv_scatter_mfma(ctx, g, w, A, B, swap);
+      if (r < 0) return r;
+      if (r == 1) return 0;
+    }
     r = msk_gconv_gather_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;

@@ -48,7 +48,7 @@ def _conv_tol(K):
     return 2e-5 * np.sqrt(K / 1000.0 + 1.0)
 
 
-@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("impl", [0, 1, 7])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_fwd_dgrad_wgrad(case, impl):
     cin, cout, k, s, p, (N, D, H, W) = case
@@ -93,10 +93,16 @@ CONVT_CASES = [
     (32, 16, (2, 2, 2), (2, 2, 2), (2, 4, 4, 4)),
     (64, 16, (2, 2, 4), (2, 2, 1), (1, 4, 4, 9)),     # MRI up conv (overlap-add along W)
     (6, 5, (3, 2, 2), (2, 2, 1), (1, 3, 4, 5)),
+    # kernel == stride: taps-folded scatter kernel (msk_conv_scatter.hip)
+    (64, 16, (2, 2, 2), (2, 2, 2), (1, 4, 8, 32)),    # up_tr32.up_conv class
+    (128, 32, (2, 2, 2), (2, 2, 2), (1, 3, 5, 7)),    # two N groups, ragged M, two K passes
+    (12, 5, (2, 2, 2), (2, 2, 2), (2, 3, 3, 5)),      # CK % 8 != 0, taps*CN % 32 != 0
+    (16, 8, (2, 2, 1), (2, 2, 1), (1, 4, 4, 6)),      # anisotropic k == s
+    (40, 24, (1, 2, 2), (1, 2, 2), (2, 5, 4, 3)),
 ]
 
 
-@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("impl", [0, 1, 7])
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_convT3d_fwd_dgrad_wgrad(case, impl):
     cin, cout, k, s, (N, D, H, W) = case
