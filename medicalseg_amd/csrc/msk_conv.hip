@@ -253,7 +253,10 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
     return 0;
   }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4) {
-    int r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
+    int r = ctx->conv_impl == 8 ? 0 : msk_gconv_halo_tightk(ctx, g, w, A, B, swap);  // 8 = A/B: skip the tight-K kernel
+    if (r < 0) return r;
+    if (r == 1) return 0;
+    r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
     if (ctx->conv_impl != 6) {  // 6 = skip the scatter kernel (A/B against the parity-class gather kernel)
