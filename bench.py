@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="tag conv kernels with their problem shapes in the profile")
     ap.add_argument("--profile-out", default=None, help="write the per-kernel HIP-event profile here")
+    ap.add_argument("--no-sync-bn", action="store_true",
+                    help="rank-local BatchNorm statistics: a documented deviation (the reference uses SyncBatchNorm); "
+                         "reported in config.sync_bn, never the default")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msk_set_option knob for experiments, e.g. --opt wgrad_async=0 (not for the headline run)")
     args = ap.parse_args()
@@ -166,6 +169,9 @@ def main():
         model.clear_gradients()
         return loss
 
+    if args.no_sync_bn:
+        from medicalseg_amd import nn as _nn
+        _nn.BatchNorm3D.sync = False
     for kv in args.opt:
         k, v = kv.split("=")
         dev.set_option(k, int(v))
@@ -232,7 +238,7 @@ def main():
            "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes (BASELINE configs[%d])"
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
-                      "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": True},
+                      "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn},
            "final_loss": round(loss_val, 6), "roofline": roofline}
     if args.profile_out:
         os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)) or ".", exist_ok=True)

@@ -303,7 +303,13 @@ class Conv3DTranspose(Layer):
 class BatchNorm3D(Layer):
     """paddle.nn.BatchNorm3D(momentum=0.9, epsilon=1e-5); buffers `_mean`, `_variance`.
     With world > 1 the statistics are global-batch (SyncBatchNorm), as
-    cvlibs/config.py:322 converts every BatchNorm unconditionally."""
+    cvlibs/config.py:322 converts every BatchNorm unconditionally.
+
+    ``BatchNorm3D.sync = False`` (train.py/bench.py ``--no_sync_bn``) is a DOCUMENTED DEVIATION from
+    the reference: rank-local statistics, which removes the 24 + 24 latency-bound
+    collectives per step and leaves the single gradient all-reduce."""
+
+    sync = True
 
     def __init__(self, num_features, momentum=BN_MOMENTUM, epsilon=BN_EPS):
         super().__init__()
@@ -417,11 +423,11 @@ class ConvBNAct:
         Cn = bn.num_features
         if bn.training:
             dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
-            gathered = sc["stats"]
-            if dev.world > 1:
+            gathered, nstat = sc["stats"], 1
+            if dev.world > 1 and BatchNorm3D.sync:
                 dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))
-                gathered = sc["gathered"]
-            dev.call("msk_bn_finalize", _fp(gathered), dev.world, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
+                gathered, nstat = sc["gathered"], dev.world
+            dev.call("msk_bn_finalize", _fp(gathered), nstat, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
                      _fp(bn.bias.ptr), C.c_float(bn.epsilon), C.c_float(bn.momentum), _fp(bn._mean.ptr),
                      _fp(bn._variance.ptr), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(sc["scale"]), _fp(sc["shift"]))
             self.bn_mode = 1
@@ -449,7 +455,7 @@ class ConvBNAct:
         dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                  _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
         sums_total, m_total = sc["sums"], float(y.voxels)
-        if self.bn_mode == 1 and dev.world > 1:
+        if self.bn_mode == 1 and dev.world > 1 and BatchNorm3D.sync:
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
             dev.call("msk_dp_allreduce_sum", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world

@@ -37,6 +37,9 @@ def parse_args():
     p.add_argument('--use_vdl', dest='use_vdl', help='Whether to record the data to VisualDL during training',
                    action='store_true')
     p.add_argument('--seed', dest='seed', help='Set the random seed during training.', default=None, type=int)
+    p.add_argument('--no_sync_bn', dest='no_sync_bn', action='store_true',
+                   help='rank-local BatchNorm statistics (documented deviation from the reference, which converts every '
+                        'BatchNorm to SyncBatchNorm: cvlibs/config.py:322)')
     p.add_argument('--data_format', dest='data_format', type=str, default='NCHW',
                    help='Kept for CLI compatibility; the device layout is always NDHWC internally.')
     p.add_argument('--profiler_options', type=str, default=None,
@@ -56,6 +59,8 @@ def main(args):
     if args.seed is not None:
         nn.seed(args.seed)
         nn.Dropout3D.seed = args.seed
+    if args.no_sync_bn:
+        nn.BatchNorm3D.sync = False
     if not args.cfg:
         raise RuntimeError('No configuration file specified.')
     cfg = Config(args.cfg, learning_rate=args.learning_rate, iters=args.iters, batch_size=args.batch_size)
