@@ -250,7 +250,10 @@ int msk_interp_trilinear_bwd(msk_ctx* ctx, msk_tensor ddst, msk_tensor dsrc, int
 #define MSK_UNIQUE_ID_BYTES 128
 int msk_dp_unique_id(char* id128);                       /* rank 0 */
 int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world);
-int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);
+int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);   /* joins the weight-gradient side stream first */
+/* SyncBatchNorm backward sums (2*C floats, produced on the main stream): same reduction WITHOUT the join,
+ * so the 24 per-step statistics exchanges do not serialise the side stream */
+int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count);
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank);
 int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root);
 int msk_dp_barrier(msk_ctx* ctx);

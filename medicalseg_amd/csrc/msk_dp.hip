@@ -46,6 +46,15 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   return 0;
 }
 
+int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
+  // per-channel BatchNorm-backward sums: produced on the main stream, so the weight-gradient side stream
+  // keeps running (msk_dp_allreduce_sum would join it 24 times per step and undo the overlap)
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_launch_scope ls(ctx, "rccl_allreduce_stats");
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  return 0;
+}
+
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   msk_launch_scope ls(ctx, "rccl_allgather");

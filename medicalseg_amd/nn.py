@@ -457,7 +457,7 @@ class ConvBNAct:
         sums_total, m_total = sc["sums"], float(y.voxels)
         if self.bn_mode == 1 and dev.world > 1 and BatchNorm3D.sync:
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
-            dev.call("msk_dp_allreduce_sum", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
+            dev.call("msk_dp_allreduce_stats", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world
         dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
                  _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)

@@ -23,6 +23,8 @@ def test_rccl_world1_collectives():
         p = vec(x)
         d.call("msk_dp_allreduce_sum", vp(p), C.c_size_t(1000))
         assert np.array_equal(vec_back(p, 1000), x)
+        d.call("msk_dp_allreduce_stats", vp(p), C.c_size_t(512))      # SyncBN sums: no side-stream join
+        assert np.array_equal(vec_back(p, 1000), x)
         q = vec(np.zeros(1000))
         d.call("msk_dp_allgather", vp(p), vp(q), C.c_size_t(1000))
         assert np.array_equal(vec_back(q, 1000), x)
