@@ -239,7 +239,7 @@ int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& i
 }
 
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
-int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
+int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
   const int taps = g.kd * g.kh * g.kw;
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 &&
       g.ph == 0 && g.pw == 0 && g.CK <= 8 && g.CN <= 8) {
@@ -286,10 +286,7 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
   return 0;
 }
 
-int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* db, int accumulate) {
-  if (db) {
-    if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
-  }
+int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
   if (ctx->conv_impl != 1 && ctx->conv_impl != 3) {
     int r = msk_wgrad_mfma(ctx, g);
     if (r < 0) return r;
@@ -335,6 +332,50 @@ int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, i
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)rblocks), dim3(kThreads), 0, ctx->stream, partial, splits,
                      taps, CA, CB, dw, accumulate);
   MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+// Several kernels address a tensor with 32-bit byte offsets (raw buffer loads), i.e. need every tensor below
+// 4 GiB.  288 GB of HBM invites batches beyond that (32ch @ 128^3 crosses it at N = 17), so the batch is cut
+// into chunks of whole samples here: forward / data-gradient chunks are independent, weight-gradient chunks
+// accumulate in order (deterministic).
+constexpr size_t kChunkBytes = (size_t)3900 << 20;
+
+int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
+  const size_t sper = (size_t)g.SD * g.SH * g.SW * g.sld * sizeof(float), dper = (size_t)g.DD * g.DH * g.DW * g.dld * sizeof(float);
+  const size_t per = sper > dper ? sper : dper;
+  long nmax = per > 0 ? (long)(kChunkBytes / per) : g.N;
+  if (nmax < 1) nmax = 1;
+  if (g.N <= nmax) return run_gconv_one(ctx, g, w, A, B, swap, tag);
+  const int total = g.N;
+  for (int n0 = 0; n0 < total; n0 += (int)nmax) {
+    GConv c = g;
+    c.N = total - n0 < nmax ? total - n0 : (int)nmax;
+    c.src = g.src + (size_t)n0 * (sper / sizeof(float));
+    c.dst = g.dst + (size_t)n0 * (dper / sizeof(float));
+    if (int rc = run_gconv_one(ctx, c, w, A, B, swap, tag)) return rc;
+  }
+  return 0;
+}
+
+int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* db, int accumulate) {
+  if (db) {
+    if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
+  }
+  const size_t aper = (size_t)g.AD * g.AH * g.AW * g.ald * sizeof(float), bper = (size_t)g.BD * g.BH * g.BW * g.bld * sizeof(float);
+  const size_t per = aper > bper ? aper : bper;
+  long nmax = per > 0 ? (long)(kChunkBytes / per) : g.N;
+  if (nmax < 1) nmax = 1;
+  if (g.N <= nmax) return run_wgrad_one(ctx, g);
+  const int total = g.N;
+  for (int n0 = 0; n0 < total; n0 += (int)nmax) {
+    WGrad c = g;
+    c.N = total - n0 < nmax ? total - n0 : (int)nmax;
+    c.A = g.A + (size_t)n0 * (aper / sizeof(float));
+    c.B = g.B + (size_t)n0 * (bper / sizeof(float));
+    if (n0 > 0) c.accumulate = 1;
+    if (int rc = run_wgrad_one(ctx, c)) return rc;
+  }
   return 0;
 }
 

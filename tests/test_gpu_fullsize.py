@@ -164,3 +164,57 @@ def test_vnetdeepsup_mri_512x512x12_step_deterministic():
     assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1]
     for u, v in zip(runs[0][2:], runs[1][2:]):
         assert np.array_equal(u, v)
+
+
+def test_conv_beyond_4gib_tensors_is_chunked_per_sample():
+    """288 GB of HBM invites batches whose activations exceed 4 GiB (32ch @ 128^3: N >= 17), beyond the 32-bit byte
+    offsets some kernels use: the dispatch cuts the batch into whole-sample chunks.  Every sample carries the SAME
+    volume here, so every output sample must equal sample 0 bit for bit (also across the chunk boundary), sample 0 is
+    spot-checked against numpy, and the weight gradient must be N x the single-sample one."""
+    from medicalseg_amd.device import Tensor
+    d = dev()
+    S, Cc, N = 128, 32, 17
+    vox = S ** 3
+    assert N * vox * Cc * 4 > (1 << 32)
+    rng = np.random.default_rng(7)
+    x1 = rng.standard_normal((vox, Cc), dtype=np.float32)          # NDHWC sample
+    g1 = rng.standard_normal((vox, Cc), dtype=np.float32)
+    w = (rng.standard_normal((Cc, Cc, 5, 5, 5)) / np.sqrt(Cc * 125)).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    mk = lambda n: Tensor(d, d.malloc(n * vox * Cc * 4), n, S, S, S, Cc, Cc, None)
+    x, y, dy, dx = mk(N), mk(N), mk(N), mk(N)
+    xs, gs = mk(1), mk(1)
+    d.h2d(xs.ptr, x1)
+    d.h2d(gs.ptr, g1)
+    for n in range(N):
+        d.d2d(x.ptr + n * vox * Cc * 4, xs.ptr, vox * Cc * 4)
+        d.d2d(dy.ptr + n * vox * Cc * 4, gs.ptr, vox * Cc * 4)
+    wp, bp = vec(w.ravel()), vec(b)
+    cd = _desc((5,) * 3, (1,) * 3, (2,) * 3)
+    d.call("msk_conv3d_fwd", cd, x.msk(), vp(wp), vp(bp), y.msk())
+    d.call("msk_conv3d_dgrad", cd, dy.msk(), vp(wp), dx.msk(), 0)
+
+    def sample(t, n):
+        return d.d2h(t.ptr + n * vox * Cc * 4, (S, S, S, Cc), np.float32)
+
+    y0, dx0 = sample(y, 0), sample(dx, 0)
+    for n in (8, 9, 16):
+        assert np.array_equal(sample(y, n), y0), n
+        assert np.array_equal(sample(dx, n), dx0), n
+    xv = x1.reshape(S, S, S, Cc)
+    xp = np.pad(xv, ((2, 2), (2, 2), (2, 2), (0, 0))).astype(np.float64)
+    for _ in range(8):
+        dd, hh, ww = rng.integers(0, S, 3)
+        co = int(rng.integers(0, Cc))
+        patch = xp[dd:dd + 5, hh:hh + 5, ww:ww + 5, :]                       # [kd,kh,kw,ci]
+        ref = float(np.einsum("abci,iabc->", patch, w[co].astype(np.float64))) + float(b[co])
+        assert abs(y0[dd, hh, ww, co] - ref) < 2e-4 * max(1.0, abs(ref)), (dd, hh, ww, co)
+    # weight gradient: chunks accumulate; N identical samples -> N x the one-sample gradient
+    dw1, dwN, db = vec(np.zeros(w.size)), vec(np.zeros(w.size)), vec(np.zeros(Cc))
+    d.call("msk_conv3d_wgrad", cd, xs.msk(), gs.msk(), vp(dw1), vp(db), 0)
+    d.call("msk_conv3d_wgrad", cd, x.msk(), dy.msk(), vp(dwN), vp(db), 0)
+    a, c = vec_back(dw1, w.size).astype(np.float64), vec_back(dwN, w.size).astype(np.float64)
+    assert np.abs(c - N * a).max() < 2e-4 * np.abs(N * a).max()
+    assert np.abs(vec_back(db, Cc) - N * g1.sum(axis=0, dtype=np.float64)).max() < 1e-3 * np.sqrt(N * vox)
+    for t in (x, y, dy, dx, xs, gs):
+        d.free(t.ptr)
