@@ -45,6 +45,7 @@ struct msk_ctx {
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
+  long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
   int wgrad_rounds = 8;  // LDS wgrad: target workgroups per CU (split-K granularity)
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
   // side stream: weight gradients run concurrently with the data-gradient chain (they only share
@@ -76,7 +77,7 @@ int msk_join_side_impl(msk_ctx* ctx);
 struct msk_side_scope {
   msk_ctx* ctx;
   bool active;
-  explicit msk_side_scope(msk_ctx* c) : ctx(c), active(c->wgrad_async && c->side != nullptr) {
+  explicit msk_side_scope(msk_ctx* c, bool want = true) : ctx(c), active(want && c->wgrad_async && c->side != nullptr) {
     if (!active) return;
     hipEventRecord(ctx->ev_fork, ctx->stream);
     hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);

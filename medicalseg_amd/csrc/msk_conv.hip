@@ -409,7 +409,7 @@ int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float*
 
 int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
-  msk_side_scope side(ctx);
+  msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);
   WGrad g{};
   g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
   g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
@@ -448,7 +448,7 @@ int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float
 
 int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, true) != 0) return -1;
-  msk_side_scope side(ctx);
+  msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(x) <= ctx->wgrad_async_max_m);
   // dWT[ci][co][tap] = sum_ipos x[ipos][ci] * dy[ipos*s + k][co]: conv wgrad with A = dy, B = x
   WGrad g{};
   g.A = (const float*)dy.p; g.ald = dy.ld; g.B = (const float*)x.p; g.bld = x.ld;
