@@ -45,6 +45,7 @@ struct msk_ctx {
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
+  char prof_prefix[48] = {0};  // empty = profile every launch
   long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
   int wgrad_rounds = 8;  // LDS wgrad: target workgroups per CU (split-K granularity)
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch
@@ -108,8 +109,14 @@ struct msk_side_scope {
 // Launch bracket: set device stream, optional per-kernel profiling, error check.
 struct msk_launch_scope {
   msk_ctx* ctx;
-  msk_launch_scope(msk_ctx* c, const char* tag) : ctx(c) { if (c->prof) msk_prof_begin(c, tag); }
-  ~msk_launch_scope() { if (ctx->prof) msk_prof_end(ctx); }
+  bool on;
+  // prof_prefix (option "prof_only_halo"): bracket only the launches whose tag starts with it -- two events
+  // around EVERY launch cost ~4 % of the training step (packet-processor barriers between back-to-back kernels)
+  msk_launch_scope(msk_ctx* c, const char* tag)
+      : ctx(c), on(c->prof && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0)) {
+    if (on) msk_prof_begin(c, tag);
+  }
+  ~msk_launch_scope() { if (on) msk_prof_end(ctx); }
 };
 
 #define MSK_LAUNCH_CHECK(ctx)                                                            \
