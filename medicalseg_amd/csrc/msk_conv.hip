@@ -29,8 +29,9 @@ pack_weights_k(const float* __restrict__ w, int A, int B, int taps, int swap, in
       tap = (int)(r / KC);
       k = kc * 8 + h * 4 + q;
     } else {
-      n = (int)(idx % N);
-      long r = idx / N;
+      const int NP = npad > 0 ? npad : N;  // direct layout with a padded row pitch (columns >= N are zero)
+      n = (int)(idx % NP);
+      long r = idx / NP;
       k = (int)(r % K);
       tap = (int)(r / K);
     }
@@ -256,6 +257,9 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
     int r = ctx->conv_impl == 8 ? 0 : msk_gconv_halo_tightk(ctx, g, w, A, B, swap);  // 8 = A/B: skip the tight-K kernel
     if (r < 0) return r;
     if (r == 1) return 0;
+    r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
+    if (r < 0) return r;
+    if (r == 1) return 0;
     r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
@@ -315,7 +319,7 @@ int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
 
 int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps, int kd,
                      int kh, int kw, int mfma, int K, int N, int KC, int npad, float* out) {
-  const long total = mfma ? (long)taps * KC * 2 * npad * 4 : (long)taps * K * N;
+  const long total = mfma ? (long)taps * KC * 2 * npad * 4 : (long)taps * K * (npad > 0 ? npad : N);
   msk_launch_scope ls(ctx, mfma ? "pack_weights_mfma" : "pack_weights_direct");
   hipLaunchKernelGGL(pack_weights_k, dim3(grid_for(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, A, B, taps,
                      swap, flip_taps, kd, kh, kw, mfma, K, N, KC, npad, out, total);

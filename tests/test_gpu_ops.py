@@ -28,6 +28,9 @@ CONV_CASES = [
     (128, 96, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 4, 8, 8)),     # TW=8, Cout not multiple of 64
     (1, 16, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 8, 8, 12)),      # in_tr: Cin=1
     (32, 3, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 6, 8, 33)),      # out_tr: Cout=3
+    (32, 4, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 5, 9, 17)),      # two-voxel VALU kernel: CN even, ragged tiles
+    (32, 1, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 4, 8, 16)),
+    (32, 2, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 9, 7, 40)),
     (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),      # out_tr.conv2
     (3, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
