@@ -89,11 +89,20 @@ class SyntheticCT:
         self.transforms = Compose(transforms or [], device=device_aug)
         self.dataset_json_path = dataset_json_path
         self.file_list = [["synthetic_{}".format(i), ""] for i in range(self.num_samples)]
+        self._cache = {}
 
     def __len__(self):
         return self.num_samples
 
     def make(self, idx):
+        """Deterministic in (seed, idx): generated once and kept (the numpy generation of a 128^3 volume costs ~70 ms,
+        about one training step on an MI355X, and would otherwise sit in reader_cost every epoch)."""
+        cached = self._cache.get(idx)
+        if cached is None:
+            cached = self._cache[idx] = self._generate(idx)
+        return cached[0].copy(), cached[1].copy()
+
+    def _generate(self, idx):
         rng = np.random.default_rng(self.seed + idx)
         D, H, W = self.shape
         hu = np.clip(rng.standard_normal(self.shape, dtype=np.float32) * 450.0 - 600.0, -2000, 2000)
