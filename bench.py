@@ -57,27 +57,43 @@ def halo_tile_for(d, h, w):
     return best
 
 
-def halo_variant_work(n, d, h, w):
-    """{kernel name: (algorithmic FLOPs, algorithmic HBM bytes, launches)} per training step for every
-    conv_halo_mfma_k<TD, TH, TW, 5> variant: 2*125*Cin*Cout FLOPs per output voxel and input + output +
-    weights once, forward + data gradient of each 5^3 LUConv layer (cubic volumes: level dims = w)."""
+WINO_MAC_RATIO = 0.6  # F(2,5) along W: 6 multiplications per 2 outputs instead of 10 -> 75 of 125 MACs
+
+
+def halo_variant_work(n, d, h, w, num_cu=256):
+    """{kernel name: [algorithmic FLOPs, algorithmic HBM bytes, launches, executed MFMA FLOPs]} per training step
+    for the kernels that run the 5^3 LUConv layers, forward + data gradient (cubic volumes: level dims = w).
+    Algorithmic = SURVEY 8 d3's direct-convolution count, 2*125*Cin*Cout FLOPs per output voxel, and input + output
+    + weights once.  Mirror of the dispatch in msk_conv.hip: whole 4x8x8 tiles and >= 2 workgroups per CU ->
+    conv_halo_wino_k (1-D Winograd F(2,5): executes 0.6 of the algorithmic MACs), else conv_halo_mfma_k<tile>."""
     work = {}
     for ci, co, vv, ww in vnet_lu_layers(d, h, w):
-        td, th, tw = HALO_TILES[halo_tile_for(ww, ww, ww)]
-        name = "conv_halo_mfma_k<%d, %d, %d, 5>" % (td, th, tw)
-        f, b, l = work.get(name, (0.0, 0.0, 0))
-        work[name] = (f + 2 * (2.0 * 125 * ci * co * vv * n), b + 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co)), l + 2)
+        ntn = -(-co // 32)
+        nblk = n * (ww // 4) * (ww // 8) * (ww // 8)
+        if ww % 8 == 0 and ci >= 8 and co >= 8 and nblk * ntn >= 2 * num_cu:
+            name, ratio = "conv_halo_wino_k", WINO_MAC_RATIO
+        else:
+            td, th, tw = HALO_TILES[halo_tile_for(ww, ww, ww)]
+            name, ratio = "conv_halo_mfma_k<%d, %d, %d, 5>" % (td, th, tw), 1.0
+        f = 2 * (2.0 * 125 * ci * co * vv * n)
+        e = work.setdefault(name, [0.0, 0.0, 0, 0.0])
+        e[0] += f
+        e[1] += 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co))
+        e[2] += 2
+        e[3] += f * ratio
     return work
 
 
-def _serialized(prof, dom, flops_step, steps=2):
+def _serialized(prof, dom, flops_step, exec_step, steps=2):
     """The dominant kernel without cross-stream sharing (weight gradients on the main stream)."""
     ms = sum(v[1] for k, v in prof.items() if k.startswith(dom))
     calls = sum(v[0] for k, v in prof.items() if k.startswith(dom))
     if ms <= 0:
         return None
     ach = flops_step * steps / (ms * 1e-3) / 1e12
-    return {"achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(ms / max(calls, 1), 4),
+    ex = exec_step * steps / (ms * 1e-3) / 1e12
+    return {"achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "executed_mfma_frac": round(ex / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(ms / max(calls, 1), 4),
             "note": "same launches, weight-gradient stream disabled (untimed extra pass of %d steps)" % steps}
 
 
@@ -239,14 +255,14 @@ def main():
     voxels_per_step = world * B * S ** 3
     value = voxels_per_step / (elapsed / args.steps)
 
-    # dominant kernel = the MFMA halo-conv variant with the largest HIP-event time (kernel names are spelled
+    # dominant kernel = the 5^3 halo-conv kernel (Winograd or direct MFMA variant) with the largest HIP-event time (kernel names are spelled
     # as in rocprofv3's kernel stats)
     work = halo_variant_work(B, S, S, S)
     by_variant = {name: (sum(v[0] for k, v in prof.items() if k.startswith(name)),
                          sum(v[1] for k, v in prof.items() if k.startswith(name))) for name in work}
     DOM = max(by_variant, key=lambda k: by_variant[k][1])
     calls, kms = by_variant[DOM]
-    flops_step, bytes_step, launches_step = work[DOM]
+    flops_step, bytes_step, launches_step, exec_step = work[DOM]
     achieved = flops_step * args.steps / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic = None
@@ -260,9 +276,13 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "launches": calls, "avg_launch_ms": round(kms / max(calls, 1), 4),
                 "algorithmic_flop_per_launch": round(flops_step / max(launches_step, 1), 1),
+                # Winograd F(2,5) executes 0.6 of the direct-convolution MACs the algorithmic figure counts: the
+                # fraction of the MFMA peak the pipe actually sustains is reported next to the algorithmic one
+                "executed_mfma_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
+                "executed_mfma_frac": round(exec_step * args.steps / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if kms > 0 else 0.0,
                 "algorithmic_bytes_per_launch": round(bytes_step / max(launches_step, 1), 1),
                 "kernel_share_of_step": round(kms / max(elapsed * 1e3, 1e-9), 4),  # of wall time (streams overlap)
-                "serialized": _serialized(prof_serial, DOM, flops_step),
+                "serialized": _serialized(prof_serial, DOM, flops_step, exec_step),
                 "step_frac_of_fp32_roofline": round(step_flops_per_sample() * B * (S / 128.0) ** 3 / (ms_per_step * 1e-3)
                                                     / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     out = {"metric": "3D-voxels/sec fwd+bwd, VNet 128^3 fp32", "value": round(value, 1), "unit": "voxels/s",

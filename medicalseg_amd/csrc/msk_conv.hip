@@ -260,6 +260,9 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
     r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
     if (r < 0) return r;
     if (r == 1) return 0;
+    r = ctx->conv_impl == 11 ? 0 : msk_gconv_halo_wino(ctx, g, w, A, B, swap);  // 11 = direct kernel only (A/B); 10 = force
+    if (r < 0) return r;
+    if (r == 1) return 0;
     r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;

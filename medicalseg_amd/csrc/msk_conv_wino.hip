@@ -1,0 +1,268 @@
+// 'Same' 5x5x5 convolution (forward and data gradient of every LUConv layer, vnet.py:36) with a 1-D Winograd
+// F(2,5) transform along W: two outputs of a W row cost 6 multiplications per (kd, kh, ci, co) instead of 10,
+// i.e. 75 instead of 125 MFMA-MACs per output voxel and channel pair (1.67x fewer than conv_halo_mfma_k).
+//
+//   y[2t+i] = sum_xi AT[i][xi] * sum_{kd,kh,ci} V_xi[d+kd, h+kh, t][ci] * U_xi[kd,kh][ci][co]
+//   V_xi = sum_j BT[xi][j] x[.., 2t+j]   (j = 0..5),     U_xi = sum_kw G[xi][kw] w[kd,kh,kw]
+//   interpolation points {0, 1, -1, 2, -2, inf}: fp32 error ~1e-6 of max|y| over K = 800 products
+//   (numerical study in DESIGN.md; the direct kernel is ~1e-7) -- inside the 2e-5 conv tolerance of the tests.
+//
+// Structure: the raw halo tile is staged in LDS exactly like conv_halo_mfma_k (8-channel chunks, [quad][voxel][4],
+// rows split by W parity so that the stride-2 accesses x[2t+j] of a wavefront are contiguous); the INPUT TRANSFORM
+// runs in registers right before the MFMAs (6 LDS quads -> 6 transformed quads per (kd, kh), ~20 float4 VALU ops
+// that issue alongside 24 MFMAs); a wavefront owns 32 (d, h, t) positions and keeps the 6 xi-accumulators, so the
+// OUTPUT TRANSFORM is register math in the epilogue.
+#include "msk_conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct WinoArgs {
+  const float* src;
+  int sld;
+  float* dst;
+  int dld;
+  int N, D, H, W;
+  int CK, CN;
+  const float4* um;  // [xi][kd*5+kh][KC][2][npad] float4 (k = kc*8 + h*4 + q)
+  int KC, npad;
+  const float* bias;
+  int accumulate;
+  int tiles_d, tiles_h, tiles_w, nblk;
+  int vec;
+};
+
+__device__ __forceinline__ int xcd_remap_w(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// U[xi][r][kc][h][n][q] = sum_kw G[xi][kw] * w(tap = r*5 + kw (flipped when flip), k = kc*8+h*4+q, n)
+__global__ void __launch_bounds__(256)
+pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
+                    float* __restrict__ out) {
+  const float G[6][5] = {{0.25f, 0.f, 0.f, 0.f, 0.f},
+                         {-1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6},
+                         {-1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6},
+                         {1.f / 24, 1.f / 12, 1.f / 6, 1.f / 3, 2.f / 3},
+                         {1.f / 24, -1.f / 12, 1.f / 6, -1.f / 3, 2.f / 3},
+                         {0.f, 0.f, 0.f, 0.f, 1.f}};
+  const long per_xi = (long)25 * KC * 2 * npad * 4;
+  const long total = 6 * per_xi;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx & 3);
+    long r_ = idx >> 2;
+    const int n = (int)(r_ % npad);
+    r_ /= npad;
+    const int h = (int)(r_ & 1);
+    r_ >>= 1;
+    const int kc = (int)(r_ % KC);
+    r_ /= KC;
+    const int row = (int)(r_ % 25);
+    const int xi = (int)(r_ / 25);
+    const int k = kc * 8 + h * 4 + q;
+    float v = 0.f;
+    if (k < CK && n < CN) {
+      const int ia = swap ? n : k, ib = swap ? k : n;
+      const float* wp = w + ((long)ia * B + ib) * 125;
+      double s = 0.0;  // transform in double: the weights are packed once per call, cheap
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int tap = row * 5 + kw;
+        s += (double)G[xi][kw] * (double)wp[flip ? 124 - tap : tap];
+      }
+      v = (float)s;
+    }
+    out[idx] = v;
+  }
+}
+
+__device__ __forceinline__ float4 f4_lin(float a, const float4& x, float b, const float4& y) {
+  return make_float4(fmaf(a, x.x, b * y.x), fmaf(a, x.y, b * y.y), fmaf(a, x.z, b * y.z), fmaf(a, x.w, b * y.w));
+}
+__device__ __forceinline__ float4 f4_add(const float4& x, const float4& y) {
+  return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+__device__ __forceinline__ float4 f4_sub(const float4& x, const float4& y) {
+  return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+}
+
+// tile: 4 (D) x 8 (H) x 8 (W) outputs = 128 (d, h, t) positions, t = W pair; wave = d plane
+__global__ void __launch_bounds__(256, 2)
+conv_halo_wino_k(WinoArgs a) {
+  constexpr int TD = 4, TH = 8, TW = 8, P = 2;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;  // 8 x 12 x 12
+  constexpr int HWH = HW / 2;                                         // 6 quads per parity half-row
+  constexpr int NV = HD * HH * HW, NVP = NV | 1;
+  __shared__ float4 lds[2 * NVP];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int tile = xcd_remap_w(blockIdx.x, a.nblk);
+  const int twi = tile % a.tiles_w;
+  tile /= a.tiles_w;
+  const int thi = tile % a.tiles_h;
+  tile /= a.tiles_h;
+  const int tdi = tile % a.tiles_d;
+  const int n = tile / a.tiles_d;
+  const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+  const int nt = blockIdx.y;
+
+  // A row of this lane: (dz = wave, hy = li / 4, t = li % 4); LDS index of x[.., 2t + j]:
+  //   lh*NVP + ((dz + kd)*HH + hy + kh)*HW + (j & 1)*HWH + t + (j >> 1)
+  const int abase = lh * NVP + (wave * HH + (li >> 2)) * HW + (li & 3);
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int x = 0; x < 6; ++x)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
+
+  const long xistride = (long)25 * a.KC * 2 * a.npad;  // float4 units between xi planes
+  const long rowstride = (long)a.KC * 2 * a.npad;      // between (kd, kh) rows
+  const float4* ulane = a.um + ((long)lh * a.npad + nt * 32 + li);
+
+  for (int kc = 0; kc < a.KC; ++kc) {
+    __syncthreads();
+    constexpr int SG = 7;
+    for (int base = 0; base < NV * 2; base += SG * 256) {
+      float4 tmp[SG];
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        const int hv = it >> 1, q = it & 1;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = kc * 8 + q * 4;
+        if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
+          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          if (a.vec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c0 + 1 < a.CK) v.y = p[1];
+            if (c0 + 2 < a.CK) v.z = p[2];
+            if (c0 + 3 < a.CK) v.w = p[3];
+          }
+        }
+        tmp[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        if (it < NV * 2) {
+          const int hv = it >> 1, q = it & 1;
+          const int hw = hv % HW, rowi = hv / HW;  // rowi = hd*HH + hh
+          lds[q * NVP + rowi * HW + (hw & 1) * HWH + (hw >> 1)] = tmp[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    const float4* uk = ulane + (long)kc * 2 * a.npad;
+#pragma unroll 1
+    for (int rr = 0; rr < 25; ++rr) {
+      const int kd = rr / 5, kh = rr % 5;
+      const float4* row = lds + abase + (kd * HH + kh) * HW;
+      const float4 x0 = row[0], x1 = row[HWH], x2 = row[1], x3 = row[HWH + 1], x4 = row[2], x5 = row[HWH + 2];
+      float4 b[6];
+#pragma unroll
+      for (int x = 0; x < 6; ++x) b[x] = uk[x * xistride + rr * rowstride];
+      // V = BT x  (points 0, 1, -1, 2, -2, inf)
+      float4 v[6];
+      v[0] = f4_add(f4_lin(4.f, x0, -5.f, x2), x4);
+      {
+        const float4 p = f4_lin(-4.f, x2, 1.f, x4), q4 = f4_lin(-4.f, x1, 1.f, x3);
+        v[1] = f4_add(p, q4);
+        v[2] = f4_sub(p, q4);
+      }
+      {
+        const float4 p = f4_sub(x4, x2), q4 = f4_lin(2.f, x3, -2.f, x1);
+        v[3] = f4_add(p, q4);
+        v[4] = f4_sub(p, q4);
+      }
+      v[5] = f4_add(f4_lin(4.f, x1, -5.f, x3), x5);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].x, b[x].x, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].y, b[x].y, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].z, b[x].z, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].w, b[x].w, acc[x], 0, 0, 0);
+      }
+    }
+  }
+
+  // output transform + store: y0 = m0+m1+m2+m3+m4, y1 = m1-m2+2(m3-m4)+m5
+  const int co = nt * 32 + li;
+  if (co < a.CN) {
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const int gd = d0 + wave;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;  // = hy*4 + t
+      const int gh = h0 + (row >> 2), gw = w0 + 2 * (row & 3);
+      if (gd < a.D && gh < a.H && gw < a.W) {
+        const float m1 = acc[1][j], m2 = acc[2][j], m3 = acc[3][j], m4 = acc[4][j];
+        const float y0 = ((acc[0][j] + m1) + (m2 + m3)) + m4;
+        const float y1 = ((m1 - m2) + 2.f * (m3 - m4)) + acc[5][j];
+        float* o = a.dst + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.dld + co;
+        float r0 = y0 + bv;
+        if (a.accumulate) r0 += o[0];
+        o[0] = r0;
+        if (gw + 1 < a.W) {
+          float r1 = y1 + bv;
+          if (a.accumulate) r1 += o[a.dld];
+          o[a.dld] = r1;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5)) return 0;
+  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
+  if (g.CK < 8 || g.CN < 8) return 0;                       // tiny-channel layers have their own kernels
+  if (g.DD % 4 || g.DH % 8 || g.DW % 8) return 0;           // whole 4x8x8 tiles only (no padded-volume waste)
+  const int KC = (g.CK + 7) / 8;
+  const int npad = ((g.CN + 31) / 32) * 32;
+  const long nblk = (long)g.N * (g.DD / 4) * (g.DH / 8) * (g.DW / 8);
+  // the direct kernel splits K when the tiling cannot fill the chip; leave those small layers to it
+  if (nblk > 0x7fffffff) return 0;
+  if (nblk * (npad / 32) < 2L * ctx->num_cu && ctx->conv_impl != 10) return 0;  // (10 forces the kernel: tests)
+  const size_t ubytes = (size_t)6 * 25 * KC * 2 * npad * 4 * sizeof(float);
+  float* um = (float*)msk_workspace2(ctx, ubytes);
+  if (!um) return -1;
+  {
+    msk_launch_scope ls(ctx, "pack_weights_wino");
+    long blocks = ((long)(ubytes / sizeof(float)) + 255) / 256;
+    if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
+    hipLaunchKernelGGL(pack_wino_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
+                       g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  WinoArgs a{};
+  a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
+  a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CK = g.CK; a.CN = g.CN;
+  a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
+  a.bias = g.bias; a.accumulate = g.accumulate;
+  a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / 8; a.nblk = (int)nblk;
+  a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
+  const char* tag = "conv_halo_wino_k";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "conv_halo_wino_k[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", g.CK, g.CN, g.N, g.DD, g.DH, g.DW,
+             g.accumulate);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
+  hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32), dim3(256), 0, ctx->stream, a);
+  MSK_LAUNCH_CHECK(ctx);
+  return 1;
+}

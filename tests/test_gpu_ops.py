@@ -378,3 +378,49 @@ def test_interp_trilinear_fwd_bwd(case):
         from medicalseg_amd._lib import MskError
         with pytest.raises(MskError):
             d.call("msk_interp_trilinear_bwd", gt.msk(), dxt.msk(), 0, vp(scratch), C.c_size_t(4))
+
+
+WINO_CASES = [
+    # (Cin, Cout, (N, D, H, W)): whole 4x8x8 tiles
+    (32, 32, (2, 8, 16, 16)),
+    (64, 48, (1, 4, 8, 24)),      # Cout not a multiple of 32
+    (8, 40, (1, 12, 8, 8)),
+    (128, 128, (1, 4, 16, 8)),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv5_winograd_f25_matches_oracle(case):
+    """conv_halo_wino_k (1-D Winograd F(2,5) along W, msk_conv_wino.hip) forward and data gradient vs the float64
+    oracle.  Tolerance: the conv tolerance of this file (2e-5 * sqrt(K/1000 + 1) of max|ref|); the transform costs
+    about one decimal digit relative to the direct fp32 kernel (measured ~1e-6 vs ~1e-7)."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(dy.astype(np.float64), w.astype(np.float64), x.shape, s_, p)
+    xt, yt, dyt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0), t_from_ncdhw(dy)
+    dxt = t_empty(N, cin, D, H, W, fill=3.0)
+    wp, bp = vec(w.ravel()), vec(b)
+    d.set_option("conv_impl", 10)
+    d.set_option("prof_shapes", 0)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+        e_f, e_d = rel_err(t_to_ncdhw(yt), y_ref), rel_err(t_to_ncdhw(dxt), dx_ref)
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+        e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
+        d.prof_enable(False)
+        assert d.prof_report().get("conv_halo_wino_k", (0, 0))[0] == 3      # the Winograd kernel really ran
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    print("winograd rel err fwd %.2e dgrad %.2e" % (e_f, e_d))
+    assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125)

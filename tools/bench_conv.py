@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--halo-tile", type=int, default=-1)
     ap.add_argument("--wgrad-chunk", type=int, default=-1)
+    ap.add_argument("--impl", type=int, default=0, help="conv_impl knob (10 = Winograd F(2,5) halo kernel)")
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     from medicalseg_amd._lib import MskConvDesc
@@ -26,6 +27,7 @@ def main():
     dev.set_option("halo_tile", a.halo_tile)
     dev.set_option("wgrad_chunk", a.wgrad_chunk)
     dev.set_option("wgrad_async", 0)
+    dev.set_option("conv_impl", a.impl)
     n, s, c, k = a.n, a.size, a.c, a.k
     vox = n * s ** 3
     mk = lambda: Tensor(dev, dev.malloc(vox * c * 4), n, s, s, s, c, c, None)
