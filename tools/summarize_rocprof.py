@@ -48,7 +48,7 @@ def main(tag):
                 n = fe[k][1]
                 f_kb, w_kb = fe[k][0] / n, wr[k][0] / max(wr[k][1], 1)
                 name = k.split("(")[1].split("::")[-1] if "::" in k else k
-                short = k.replace("void (anonymous namespace)::", "").split("(")[0]
+                short = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
                 res[short] = {"launches": n, "FETCH_SIZE_KiB": round(f_kb, 1), "WRITE_SIZE_KiB": round(w_kb, 1),
                               "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
         with open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w") as f:
