@@ -1,0 +1,284 @@
+// Weight gradient of the 'same' 5x5x5 convolutions with the 1-D Winograd F(2,5) transform along W -- the
+// adjoint of conv_halo_wino_k (msk_conv_wino.hip):
+//   dU_xi[kd,kh][ca][cb] = sum_{n,d,h,t} V_xi[n, d+kd-2, h+kh-2, t][ca] * Y_xi[n, d, h, t][cb]
+//   V_xi = sum_j BT[xi][j] x[.., 2t-2+j]  (j = 0..5),   Y_xi = AT[0][xi] dy[.., 2t] + AT[1][xi] dy[.., 2t+1]
+//   dW[kd,kh,kw] = sum_xi G[xi][kw] dU_xi[kd,kh]                      (wgrad_wino_reduce_k, with the split-K sum)
+// 6 multiplications per W pair instead of 10: 0.6 of the MFMA work of wgrad_lds_mfma_k.
+//
+// Workgroup = 6 wavefronts, one per xi, owning one kd plane and one 32x32 (ca, cb) tile: 5 accumulators (kh) per
+// wave.  Per chunk (one output depth, R rows x WS columns) the x halo rows and the dy rows are staged once in LDS
+// ([voxel][32 channels]: every operand is a conflict-free ds_read_b32); a wave walks the rows of one column pair
+// with a 5-row sliding window of transformed x values, so each step costs 6 + 2 LDS reads, ~13 VALU ops and
+// 5 MFMAs (K = the two W pairs of the column pair: lane half = pair parity).
+#include "msk_conv.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int R = 8, WS = 16, P = 2;
+constexpr int XR = R + 2 * P, XW = WS + 2 * P;  // 12 x 20 halo
+constexpr int RPX = XW * 32 + 16, RPY = WS * 32 + 16;  // row pitches (floats): +16 -> the 4 rows of an MFMA K group
+                                                       // land on 4 different 16-bank groups (conflict-free ds_read_b32)
+constexpr int NT = 256;
+
+// Workgroup = 4 wavefronts = the four 16x16 quadrants of one 32x32 (ca, cb) tile of one kd plane; a wavefront keeps
+// ALL 30 (xi, kh) accumulators of its quadrant (v_mfma_f32_16x16x4_f32: 4 registers each = 120 VGPRs).  The MFMA K
+// dimension (4) runs over 4 consecutive OUTPUT ROWS of one W pair: lane group g = lane >> 4 transforms the x rows
+// r0+g .. r0+g+4 (6 quads -> 6 xi values each, 13 VALU ops per row) and its dy row, then issues 30 MFMAs:
+// 32 LDS reads and ~70 VALU ops per 30 MFMAs (the first version with one xi per wavefront and 32x32x2 MFMAs had
+// 5 MFMAs per 8 reads / 13 VALU ops and reached only 46 % MFMA utilisation with unbalanced 6-wave workgroups).
+__global__ void __launch_bounds__(NT, 2)
+wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial) {
+  __shared__ float xs[XR * RPX];
+  __shared__ float dys[R * RPY];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int ca_tiles = (g.CA + 31) >> 5, cb_tiles = (g.CB + 31) >> 5;
+  int b = blockIdx.x;
+  const int cbt = b % cb_tiles;
+  b /= cb_tiles;
+  const int cat = b % ca_tiles;
+  const int kd = b / ca_tiles;
+  const int split = blockIdx.y;
+  const int D = g.BD, H = g.BH, W = g.BW;
+  const int hblocks = (H + R - 1) / R, wblocks = (W + WS - 1) / WS;
+  const int qa = (wave & 1) * 16, qb = (wave >> 1) * 16;  // channel offsets of this wave's quadrant inside the tile
+
+  f32x4 acc[6][5];
+#pragma unroll
+  for (int x = 0; x < 6; ++x)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[x][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int c_begin = split * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > chunks_total) c_end = chunks_total;
+  constexpr int XITEMS = XR * XW * 8, DITEMS = R * WS * 8;
+
+  // Software pipeline: the global loads of chunk i+1 are issued into registers before the MFMA loop of chunk i and
+  // written to LDS after it (12 float4 = 48 VGPRs; the kernel runs 2 waves per SIMD either way).
+  constexpr int XPT = (XITEMS + NT - 1) / NT, DPT = (DITEMS + NT - 1) / NT;  // 8 + 4 float4 per thread
+  float4 px[XPT], pd[DPT];
+  auto next_valid = [&](int ch) {
+    while (ch < c_end) {
+      const int d = (ch / (wblocks * hblocks)) % D;
+      if ((unsigned)(d + kd - P) < (unsigned)D) break;
+      ++ch;
+    }
+    return ch;
+  };
+  auto load = [&](int ch) {
+    int t = ch;
+    const int wb = t % wblocks;
+    t /= wblocks;
+    const int hb = t % hblocks;
+    t /= hblocks;
+    const int d = t % D;
+    const int n = t / D;
+    const int id = d + kd - P;
+    const int h0 = hb * R, w0 = wb * WS;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int it = tid + i * NT;
+      const int q = it & 7, v = it >> 3;
+      const int row = v / XW, col = v % XW;
+      const int ih = h0 - P + row, iw = w0 - P + col;
+      const int c0 = cat * 32 + q * 4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
+        val = *reinterpret_cast<const float4*>(g.A + ((((long)n * D + id) * H + ih) * W + iw) * g.ald + c0);
+      px[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int it = tid + i * NT;
+      const int q = it & 7, v = it >> 3;
+      const int row = v / WS, col = v % WS;
+      const int oh = h0 + row, ow = w0 + col;
+      const int c0 = cbt * 32 + q * 4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
+        val = *reinterpret_cast<const float4*>(g.B + ((((long)n * D + d) * H + oh) * W + ow) * g.bld + c0);
+      pd[i] = val;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int it = tid + i * NT;
+      if (it < XITEMS) {
+        const int q = it & 7, v = it >> 3;
+        *reinterpret_cast<float4*>(&xs[(v / XW) * RPX + (v % XW) * 32 + q * 4]) = px[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int it = tid + i * NT;
+      if (it < DITEMS) {
+        const int q = it & 7, v = it >> 3;
+        *reinterpret_cast<float4*>(&dys[(v / WS) * RPY + (v % WS) * 32 + q * 4]) = pd[i];
+      }
+    }
+  };
+
+  int ch = next_valid(c_begin);
+  if (ch < c_end) load(ch);
+  while (ch < c_end) {
+    __syncthreads();  // every wave finished reading the previous chunk
+    store();
+    __syncthreads();
+    const int nxt = next_valid(ch + 1);
+    if (nxt < c_end) load(nxt);  // in flight during the MFMA loop below
+
+    const float* xlane = &xs[lg * RPX + qa + li];
+    const float* dlane = &dys[lg * RPY + qb + li];
+    // The (row group, W pair, kh) iterations are software-pipelined by hand: the six LDS reads of the NEXT x row (and
+    // the two dy reads of the next W pair) are issued before the six MFMAs of the current row, so the LDS latency and
+    // the 13-op transform overlap the matrix pipe (without this every kh exposed ~170 cycles before 192 MFMA cycles:
+    // PMC showed the MFMA pipe 60 % busy with almost no wave waiting on memory).
+    constexpr int STEPS = (R / 4) * (WS / 2);
+    float nx[6], ny0, ny1;
+    {
+      const float* p = xlane;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) nx[j] = p[j * 32];
+      ny0 = dlane[0];
+      ny1 = dlane[32];
+    }
+#pragma unroll 1
+    for (int st = 0; st < STEPS; ++st) {
+      const int rg = st / (WS / 2), tp = st % (WS / 2);
+      const int st1 = st + 1 < STEPS ? st + 1 : st;  // the last prefetch re-reads a valid address and is discarded
+      const int rg1 = st1 / (WS / 2), tp1 = st1 % (WS / 2);
+      const float* xp = xlane + rg * 4 * RPX + tp * 64;
+      const float y0 = ny0, y1 = ny1;
+      const float ys[6] = {y0, y0 + y1, y0 - y1, fmaf(2.f, y1, y0), fmaf(-2.f, y1, y0), y1};
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        const float x0 = nx[0], x1 = nx[1], x2 = nx[2], x3 = nx[3], x4 = nx[4], x5 = nx[5];
+        {  // prefetch the next row: (st, kh+1) or (st+1, 0)
+          const float* p = kh < 4 ? xp + (kh + 1) * RPX : xlane + rg1 * 4 * RPX + tp1 * 64;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) nx[j] = p[j * 32];
+          if (kh == 4) {
+            const float* dp = dlane + rg1 * 4 * RPY + tp1 * 64;
+            ny0 = dp[0];
+            ny1 = dp[32];
+          }
+        }
+        // V = BT x (points 0, 1, -1, 2, -2, inf), 13 operations
+        const float pa = fmaf(-4.f, x2, x4), qa_ = fmaf(-4.f, x1, x3);
+        const float pb = x4 - x2, qb_ = 2.f * (x3 - x1);
+        const float v[6] = {fmaf(4.f, x0, fmaf(-5.f, x2, x4)), pa + qa_, pa - qa_, pb + qb_, pb - qb_,
+                            fmaf(4.f, x1, fmaf(-5.f, x3, x5))};
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[x], acc[x][kh], 0, 0, 0);
+      }
+    }
+    ch = nxt;
+  }
+
+  // D: col = lane & 15 (cb), row = (lane >> 4) * 4 + reg (ca);  partial[split][xi][kd*5 + kh][ca][cb]
+  const int cb = cbt * 32 + qb + li;
+  if (cb < g.CB) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int oca = cat * 32 + qa + lg * 4 + j;
+          if (oca < g.CA)
+            partial[((((long)split * 6 + x) * 25 + kd * 5 + kh) * g.CA + oca) * g.CB + cb] = acc[x][kh][j];
+        }
+  }
+}
+
+// dw[cb][ca][(kd,kh,kw)] (+)= sum_xi G[xi][kw] * sum_split P[split][xi][kd*5+kh][ca][cb]   (fixed order, double)
+__global__ void __launch_bounds__(256)
+wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, float* __restrict__ dw, int accumulate) {
+  const double G[6][5] = {{0.25, 0, 0, 0, 0},
+                          {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
+                          {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
+                          {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
+                          {0, 0, 0, 0, 1}};
+  const long plane = (long)CA * CB;         // one (xi, row) plane
+  const long per = 6L * 25 * plane;         // one split
+  const long total = 25 * plane;            // outputs before the kw expansion
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long e = idx % plane;             // ca*CB + cb
+    const int row = (int)(idx / plane);     // kd*5 + kh
+    double u[6];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+      const float* p = partial + ((long)xi * 25 + row) * plane + e;
+      double s0 = 0.0, s1 = 0.0;
+      int k = 0;
+      for (; k + 1 < splits; k += 2) {
+        s0 += p[(long)k * per];
+        s1 += p[(long)(k + 1) * per];
+      }
+      if (k < splits) s0 += p[(long)k * per];
+      u[xi] = s0 + s1;
+    }
+    const int cb = (int)(e % CB), ca = (int)(e / CB);
+    float* o = dw + ((long)cb * CA + ca) * 125 + row * 5;
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      double s = 0.0;
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) s += G[xi][kw] * u[xi];
+      o[kw] = accumulate ? o[kw] + (float)s : (float)s;
+    }
+  }
+}
+
+}  // namespace
+
+int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2))
+    return 0;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
+  if (g.BW % 2 || g.BW < 16) return 0;  // W pairs; narrow volumes keep the direct LDS kernel's narrow chunk shapes
+  if (!(g.ald % 4 == 0 && g.bld % 4 == 0 && g.CA % 4 == 0 && g.CB % 4 == 0 && ((uintptr_t)g.A) % 16 == 0 &&
+        ((uintptr_t)g.B) % 16 == 0))
+    return 0;
+  const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
+  const long chunks = (long)g.N * g.BD * ((g.BH + R - 1) / R) * ((g.BW + WS - 1) / WS);
+  const long tasks = 5L * ca_tiles * cb_tiles;
+  long splits = ((long)ctx->num_cu * 6 + tasks - 1) / tasks;  // ~3 rounds of 2 resident workgroups per CU
+  if (splits > chunks) splits = chunks;
+  if (splits < 1) splits = 1;
+  const size_t per = (size_t)6 * 25 * g.CA * g.CB * sizeof(float);
+  while (splits > 1 && splits * per > ((size_t)1 << 30)) --splits;
+  const int cps = (int)((chunks + splits - 1) / splits);
+  splits = (chunks + cps - 1) / cps;
+  if (chunks > 0x7fffffff) return 0;
+  float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
+  if (!partial) return -1;
+  {
+    const char* tag = "wgrad_wino";
+    if (ctx->prof && ctx->prof_shapes) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "wgrad_wino[ca=%d,cb=%d,M=%ld,splits=%ld]", g.CA, g.CB, (long)g.N * g.BD * g.BH * g.BW, splits);
+      tag = msk_intern_tag(ctx, buf);
+    }
+    msk_launch_scope ls(ctx, tag);
+    hipLaunchKernelGGL(wgrad_wino_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
+                       (int)chunks, cps, partial);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "wgrad_wino_reduce");
+    const long total = 25L * g.CA * g.CB;
+    long blocks = (total + 255) / 256;
+    if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
+    hipLaunchKernelGGL(wgrad_wino_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial, (int)splits,
+                       g.CA, g.CB, g.dw, g.accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 1;
+}

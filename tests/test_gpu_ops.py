@@ -424,3 +424,36 @@ def test_conv5_winograd_f25_matches_oracle(case):
         d.set_option("conv_impl", 0)
     print("winograd rel err fwd %.2e dgrad %.2e" % (e_f, e_d))
     assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125)
+
+
+@pytest.mark.parametrize("case", [(32, 32, (2, 8, 16, 16)), (64, 48, (1, 4, 8, 24)), (8, 40, (1, 5, 9, 18)),
+                                  (128, 128, (1, 4, 16, 16))])
+def test_wgrad_winograd_f25_matches_oracle(case):
+    """wgrad_wino_k (msk_wgrad_wino.hip): the adjoint of the Winograd forward kernel, dU accumulated in the transformed
+    domain and mapped back with G^T in the split-K reduction.  Same tolerance as the direct weight-gradient kernels."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(cin * 11 + cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    dw_ref, db_ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s_, p)
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    dwp, dbp = vec(np.full(cout * cin * 125, 0.5, np.float32)), vec(np.zeros(cout, np.float32))
+    d.set_option("conv_impl", 12)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        got = vec_back(dwp, dw_ref.size).reshape(dw_ref.shape)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
+        got2 = vec_back(dwp, dw_ref.size).reshape(dw_ref.shape)
+        d.prof_enable(False)
+        assert d.prof_report().get("wgrad_wino", (0, 0))[0] == 2
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    M = N * D * H * W
+    e1, e2 = rel_err(got, dw_ref), rel_err(got2, 2 * dw_ref)
+    print("winograd wgrad rel err %.2e" % e1)
+    assert e1 < _conv_tol(M) * 2 and e2 < _conv_tol(M) * 2

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--halo-tile", type=int, default=-1)
     ap.add_argument("--wgrad-chunk", type=int, default=-1)
-    ap.add_argument("--impl", type=int, default=0, help="conv_impl knob (10 = Winograd F(2,5) halo kernel)")
+    ap.add_argument("--impl", type=int, default=0, help="conv_impl knob (10 = force Winograd halo kernel, 11 = direct only, 12 = Winograd wgrad)")
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     from medicalseg_amd._lib import MskConvDesc
