@@ -294,7 +294,7 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
-  if (ctx->conv_impl == 12) {  // opt in: Winograd weight gradient
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 13) {  // 13 = direct LDS kernel only (A/B)
     int r = msk_wgrad_wino(ctx, g);
     if (r < 0) return r;
     if (r == 1) return 0;
