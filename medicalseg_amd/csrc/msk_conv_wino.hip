@@ -31,6 +31,10 @@ struct WinoArgs {
   int accumulate;
   int tiles_d, tiles_h, tiles_w, nblk;
   int vec;
+  // deterministic split-K over the 8-channel chunks for layers with few tiles (256ch @ 16^3 / 8^3): blockIdx.z owns
+  // chunks [z*kc_per, (z+1)*kc_per) and writes an fp32 slab partial[z][voxel][CN]; wino_splitk_reduce_k adds them in order
+  int ksplit, kc_per;
+  float* partial;
 };
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nb) {
@@ -124,7 +128,9 @@ conv_halo_wino_k(WinoArgs a) {
   const long rowstride = (long)a.KC * 2 * a.npad;      // between (kd, kh) rows
   const float4* ulane = a.um + ((long)lh * a.npad + nt * 32 + li);
 
-  for (int kc = 0; kc < a.KC; ++kc) {
+  const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
+  const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
     __syncthreads();
     constexpr int SG = 7;
     for (int base = 0; base < NV * 2; base += SG * 256) {
@@ -208,7 +214,14 @@ conv_halo_wino_k(WinoArgs a) {
         const float m1 = acc[1][j], m2 = acc[2][j], m3 = acc[3][j], m4 = acc[4][j];
         const float y0 = ((acc[0][j] + m1) + (m2 + m3)) + m4;
         const float y1 = ((m1 - m2) + 2.f * (m3 - m4)) + acc[5][j];
-        float* o = a.dst + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.dld + co;
+        const long vox = (((long)n * a.D + gd) * a.H + gh) * a.W + gw;
+        if (a.ksplit > 1) {
+          float* pp = a.partial + ((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox) * a.CN + co;
+          pp[0] = y0;
+          if (gw + 1 < a.W) pp[a.CN] = y1;
+          continue;
+        }
+        float* o = a.dst + vox * a.dld + co;
         float r0 = y0 + bv;
         if (a.accumulate) r0 += o[0];
         o[0] = r0;
@@ -219,6 +232,20 @@ conv_halo_wino_k(WinoArgs a) {
         }
       }
     }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int CN, const float* __restrict__ bias,
+                     float* __restrict__ dst, int dld, int accumulate) {
+  const long total = voxels * CN;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / CN;
+    const int c = (int)(i - v * CN);
+    float s = bias ? bias[c] : 0.f;
+    for (int z = 0; z < ksplit; ++z) s += partial[(long)z * total + i];  // fixed order
+    float* o = dst + v * dld + c;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -235,7 +262,6 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   const long nblk = (long)g.N * (g.DD / 4) * (g.DH / 8) * (g.DW / 8);
   // the direct kernel splits K when the tiling cannot fill the chip; leave those small layers to it
   if (nblk > 0x7fffffff) return 0;
-  if (nblk * (npad / 32) < 2L * ctx->num_cu && ctx->conv_impl != 10) return 0;  // (10 forces the kernel: tests)
   const size_t ubytes = (size_t)6 * 25 * KC * 2 * npad * 4 * sizeof(float);
   float* um = (float*)msk_workspace2(ctx, ubytes);
   if (!um) return -1;
@@ -254,6 +280,22 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.bias = g.bias; a.accumulate = g.accumulate;
   a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / 8; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
+  // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted), like conv_halo_mfma_k
+  a.ksplit = 1;
+  a.kc_per = KC;
+  a.partial = nullptr;
+  const long mn_blocks = nblk * (npad / 32);
+  const long voxels = (long)g.N * g.DD * g.DH * g.DW;
+  if (mn_blocks < 2L * ctx->num_cu && KC >= 2) {
+    long want = (4L * ctx->num_cu + mn_blocks - 1) / mn_blocks;
+    if (want > KC) want = KC;
+    a.kc_per = (int)((KC + want - 1) / want);
+    a.ksplit = (KC + a.kc_per - 1) / a.kc_per;
+    if (a.ksplit > 1) {
+      a.partial = (float*)msk_workspace(ctx, (size_t)a.ksplit * voxels * g.CN * sizeof(float));
+      if (!a.partial) return -1;
+    }
+  }
   const char* tag = "conv_halo_wino_k";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[200];
@@ -261,8 +303,18 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
              g.accumulate);
     tag = msk_intern_tag(ctx, buf);
   }
-  msk_launch_scope ls(ctx, tag);
-  hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32), dim3(256), 0, ctx->stream, a);
-  MSK_LAUNCH_CHECK(ctx);
+  {
+    msk_launch_scope ls(ctx, tag);
+    hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  if (a.ksplit > 1) {
+    msk_launch_scope ls(ctx, "conv_splitk_reduce");
+    long blocks = (voxels * g.CN + 255) / 256;
+    if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
+    hipLaunchKernelGGL(wino_splitk_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.partial,
+                       a.ksplit, voxels, g.CN, g.bias, g.dst, g.dld, g.accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
   return 1;
 }
