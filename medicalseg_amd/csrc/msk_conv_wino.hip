@@ -83,14 +83,28 @@ pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int fli
   }
 }
 
-__device__ __forceinline__ float4 f4_lin(float a, const float4& x, float b, const float4& y) {
-  return make_float4(fmaf(a, x.x, b * y.x), fmaf(a, x.y, b * y.y), fmaf(a, x.z, b * y.z), fmaf(a, x.w, b * y.w));
-}
-__device__ __forceinline__ float4 f4_add(const float4& x, const float4& y) {
-  return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-}
-__device__ __forceinline__ float4 f4_sub(const float4& x, const float4& y) {
-  return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// One half (two channels) of a quad as a packed pair: the compiler maps these onto v_pk_fma_f32 / v_pk_add_f32 /
+// v_pk_mul_f32, i.e. 13 VALU instructions per half for the whole 6-point input transform.  (PMC: MFMA 69 % + other
+// VALU 18 % of the cycles -- fp32 MFMA and the vector ALU share the SIMD's issue, so every transform instruction
+// is paid in MFMA time.)
+struct Q2 {
+  f2 lo, hi;
+};
+__device__ __forceinline__ Q2 q2(const float4& v) { return Q2{(f2){v.x, v.y}, (f2){v.z, v.w}}; }
+
+__device__ __forceinline__ void wino_bt(const f2 x0, const f2 x1, const f2 x2, const f2 x3, const f2 x4, const f2 x5,
+                                        f2 (&v)[6]) {
+  const f2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
+  v[0] = c4 * x0 + (x4 - c5 * x2);
+  const f2 pa = x4 - c4 * x2, qa = x3 - c4 * x1;
+  v[1] = pa + qa;
+  v[2] = pa - qa;
+  const f2 pb = x4 - x2, qb = c2 * (x3 - x1);
+  v[3] = pb + qb;
+  v[4] = pb - qb;
+  v[5] = c4 * x1 + (x5 - c5 * x3);
 }
 
 // tile: 4 (D) x 8 (H) x 8 (W) outputs = 128 (d, h, t) positions, t = W pair; wave = d plane
@@ -126,7 +140,7 @@ conv_halo_wino_k(WinoArgs a) {
 
   const long xistride = (long)25 * a.KC * 2 * a.npad;  // float4 units between xi planes
   const long rowstride = (long)a.KC * 2 * a.npad;      // between (kd, kh) rows
-  const float4* ulane = a.um + ((long)lh * a.npad + nt * 32 + li);
+  const unsigned ulane_off = (unsigned)(lh * a.npad + nt * 32 + li);
 
   const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
@@ -168,35 +182,27 @@ conv_halo_wino_k(WinoArgs a) {
     }
     __syncthreads();
 
-    const float4* uk = ulane + (long)kc * 2 * a.npad;
+    const float4* uk = a.um + (long)kc * 2 * a.npad;  // wave-uniform base; the lane offset stays a 32-bit index
 #pragma unroll 1
     for (int rr = 0; rr < 25; ++rr) {
       const int kd = rr / 5, kh = rr % 5;
       const float4* row = lds + abase + (kd * HH + kh) * HW;
-      const float4 x0 = row[0], x1 = row[HWH], x2 = row[1], x3 = row[HWH + 1], x4 = row[2], x5 = row[HWH + 2];
+      const Q2 x0 = q2(row[0]), x1 = q2(row[HWH]), x2 = q2(row[1]), x3 = q2(row[HWH + 1]), x4 = q2(row[2]),
+               x5 = q2(row[HWH + 2]);
       float4 b[6];
+      const float4* ur = uk + rr * rowstride;
 #pragma unroll
-      for (int x = 0; x < 6; ++x) b[x] = uk[x * xistride + rr * rowstride];
-      // V = BT x  (points 0, 1, -1, 2, -2, inf)
-      float4 v[6];
-      v[0] = f4_add(f4_lin(4.f, x0, -5.f, x2), x4);
-      {
-        const float4 p = f4_lin(-4.f, x2, 1.f, x4), q4 = f4_lin(-4.f, x1, 1.f, x3);
-        v[1] = f4_add(p, q4);
-        v[2] = f4_sub(p, q4);
-      }
-      {
-        const float4 p = f4_sub(x4, x2), q4 = f4_lin(2.f, x3, -2.f, x1);
-        v[3] = f4_add(p, q4);
-        v[4] = f4_sub(p, q4);
-      }
-      v[5] = f4_add(f4_lin(4.f, x1, -5.f, x3), x5);
+      for (int x = 0; x < 6; ++x) b[x] = (ur + x * xistride)[ulane_off];
+      // V = BT x  (points 0, 1, -1, 2, -2, inf), two channels per packed instruction
+      f2 vl[6], vh[6];
+      wino_bt(x0.lo, x1.lo, x2.lo, x3.lo, x4.lo, x5.lo, vl);
+      wino_bt(x0.hi, x1.hi, x2.hi, x3.hi, x4.hi, x5.hi, vh);
 #pragma unroll
       for (int x = 0; x < 6; ++x) {
-        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].x, b[x].x, acc[x], 0, 0, 0);
-        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].y, b[x].y, acc[x], 0, 0, 0);
-        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].z, b[x].z, acc[x], 0, 0, 0);
-        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[x].w, b[x].w, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[x].x, b[x].x, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[x].y, b[x].y, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[x].x, b[x].z, acc[x], 0, 0, 0);
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[x].y, b[x].w, acc[x], 0, 0, 0);
       }
     }
   }
