@@ -22,6 +22,21 @@ constexpr int RPX = XW * 32 + 16, RPY = WS * 32 + 16;  // row pitches (floats): 
                                                        // land on 4 different 16-bank groups (conflict-free ds_read_b32)
 constexpr int NT = 256;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+// 6-point input transform of two independent rows at once (packed fp32: v_pk_fma_f32 / v_pk_add_f32)
+__device__ __forceinline__ void wino_bt2(const f2 x0, const f2 x1, const f2 x2, const f2 x3, const f2 x4, const f2 x5,
+                                         f2 (&v)[6]) {
+  const f2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
+  v[0] = c4 * x0 + (x4 - c5 * x2);
+  const f2 pa = x4 - c4 * x2, qa = x3 - c4 * x1;
+  v[1] = pa + qa;
+  v[2] = pa - qa;
+  const f2 pb = x4 - x2, qb = c2 * (x3 - x1);
+  v[3] = pb + qb;
+  v[4] = pb - qb;
+  v[5] = c4 * x1 + (x5 - c5 * x3);
+}
+
 // Workgroup = 4 wavefronts = the four 16x16 quadrants of one 32x32 (ca, cb) tile of one kd plane; a wavefront keeps
 // ALL 30 (xi, kh) accumulators of its quadrant (v_mfma_f32_16x16x4_f32: 4 registers each = 120 VGPRs).  The MFMA K
 // dimension (4) runs over 4 consecutive OUTPUT ROWS of one W pair: lane group g = lane >> 4 transforms the x rows
@@ -155,27 +170,52 @@ wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float*
       const float* xp = xlane + rg * 4 * RPX + tp * 64;
       const float y0 = ny0, y1 = ny1;
       const float ys[6] = {y0, y0 + y1, y0 - y1, fmaf(2.f, y1, y0), fmaf(-2.f, y1, y0), y1};
+      // this step's five x rows (the first one was prefetched), then the prefetch of the next step's first row
+      float xr[5][6];
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh) {
-        const float x0 = nx[0], x1 = nx[1], x2 = nx[2], x3 = nx[3], x4 = nx[4], x5 = nx[5];
-        {  // prefetch the next row: (st, kh+1) or (st+1, 0)
-          const float* p = kh < 4 ? xp + (kh + 1) * RPX : xlane + rg1 * 4 * RPX + tp1 * 64;
+      for (int j = 0; j < 6; ++j) xr[0][j] = nx[j];
 #pragma unroll
-          for (int j = 0; j < 6; ++j) nx[j] = p[j * 32];
-          if (kh == 4) {
-            const float* dp = dlane + rg1 * 4 * RPY + tp1 * 64;
-            ny0 = dp[0];
-            ny1 = dp[32];
-          }
-        }
-        // V = BT x (points 0, 1, -1, 2, -2, inf), 13 operations
+      for (int kh = 1; kh < 5; ++kh) {
+        const float* p = xp + kh * RPX;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xr[kh][j] = p[j * 32];
+      }
+      {
+        const float* p = xlane + rg1 * 4 * RPX + tp1 * 64;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nx[j] = p[j * 32];
+        const float* dp = dlane + rg1 * 4 * RPY + tp1 * 64;
+        ny0 = dp[0];
+        ny1 = dp[32];
+      }
+      // V = BT x: rows (0,1) and (2,3) as packed pairs (v_pk_* instructions), row 4 scalar: 39 instead of 65 VALU ops
+      f2 va[6], vb[6];
+      float vc[6];
+      wino_bt2((f2){xr[0][0], xr[1][0]}, (f2){xr[0][1], xr[1][1]}, (f2){xr[0][2], xr[1][2]}, (f2){xr[0][3], xr[1][3]},
+               (f2){xr[0][4], xr[1][4]}, (f2){xr[0][5], xr[1][5]}, va);
+      wino_bt2((f2){xr[2][0], xr[3][0]}, (f2){xr[2][1], xr[3][1]}, (f2){xr[2][2], xr[3][2]}, (f2){xr[2][3], xr[3][3]},
+               (f2){xr[2][4], xr[3][4]}, (f2){xr[2][5], xr[3][5]}, vb);
+      {
+        const float x0 = xr[4][0], x1 = xr[4][1], x2 = xr[4][2], x3 = xr[4][3], x4 = xr[4][4], x5 = xr[4][5];
         const float pa = fmaf(-4.f, x2, x4), qa_ = fmaf(-4.f, x1, x3);
         const float pb = x4 - x2, qb_ = 2.f * (x3 - x1);
-        const float v[6] = {fmaf(4.f, x0, fmaf(-5.f, x2, x4)), pa + qa_, pa - qa_, pb + qb_, pb - qb_,
-                            fmaf(4.f, x1, fmaf(-5.f, x3, x5))};
-#pragma unroll
-        for (int x = 0; x < 6; ++x) acc[x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[x], acc[x][kh], 0, 0, 0);
+        vc[0] = fmaf(4.f, x0, fmaf(-5.f, x2, x4));
+        vc[1] = pa + qa_;
+        vc[2] = pa - qa_;
+        vc[3] = pb + qb_;
+        vc[4] = pb - qb_;
+        vc[5] = fmaf(4.f, x1, fmaf(-5.f, x3, x5));
       }
+#pragma unroll
+      for (int x = 0; x < 6; ++x) acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[x].x, ys[x], acc[x][0], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[x].y, ys[x], acc[x][1], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) acc[x][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[x].x, ys[x], acc[x][2], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) acc[x][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[x].y, ys[x], acc[x][3], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < 6; ++x) acc[x][4] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[x], ys[x], acc[x][4], 0, 0, 0);
     }
     ch = nxt;
   }
