@@ -25,7 +25,7 @@ struct WinoArgs {
   int dld;
   int N, D, H, W;
   int CK, CN;
-  const float4* um;  // [xi][kd*5+kh][KC][2][npad] float4 (k = kc*8 + h*4 + q)
+  const float4* um;  // [kd*5+kh][KC][2][xi][npad] float4 (k = kc*8 + h*4 + q)
   int KC, npad;
   const float* bias;
   int accumulate;
@@ -43,7 +43,7 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// U[xi][r][kc][h][n][q] = sum_kw G[xi][kw] * w(tap = r*5 + kw (flipped when flip), k = kc*8+h*4+q, n)
+// U[r][kc][h][xi][n][q] = sum_kw G[xi][kw] * w(tap = r*5 + kw (flipped when flip), k = kc*8+h*4+q, n)
 __global__ void __launch_bounds__(256)
 pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
                     float* __restrict__ out) {
@@ -53,19 +53,20 @@ pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int fli
                          {1.f / 24, 1.f / 12, 1.f / 6, 1.f / 3, 2.f / 3},
                          {1.f / 24, -1.f / 12, 1.f / 6, -1.f / 3, 2.f / 3},
                          {0.f, 0.f, 0.f, 0.f, 1.f}};
-  const long per_xi = (long)25 * KC * 2 * npad * 4;
-  const long total = 6 * per_xi;
+  const long total = 6L * 25 * KC * 2 * npad * 4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // idx = ((((row*KC + kc)*2 + h)*6 + xi)*npad + n)*4 + q : the six xi planes of one (row, kc, h) are adjacent,
+    // so a tap needs ONE address computation and six immediate offsets
     const int q = (int)(idx & 3);
     long r_ = idx >> 2;
     const int n = (int)(r_ % npad);
     r_ /= npad;
+    const int xi = (int)(r_ % 6);
+    r_ /= 6;
     const int h = (int)(r_ & 1);
     r_ >>= 1;
     const int kc = (int)(r_ % KC);
-    r_ /= KC;
-    const int row = (int)(r_ % 25);
-    const int xi = (int)(r_ / 25);
+    const int row = (int)(r_ / KC);
     const int k = kc * 8 + h * 4 + q;
     float v = 0.f;
     if (k < CK && n < CN) {
@@ -138,9 +139,8 @@ conv_halo_wino_k(WinoArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
 
-  const long xistride = (long)25 * a.KC * 2 * a.npad;  // float4 units between xi planes
-  const long rowstride = (long)a.KC * 2 * a.npad;      // between (kd, kh) rows
-  const unsigned ulane_off = (unsigned)(lh * a.npad + nt * 32 + li);
+  const long rowstride = (long)a.KC * 2 * 6 * a.npad;  // float4 units between (kd, kh) rows
+  const unsigned ulane_off = (unsigned)(lh * 6 * a.npad + nt * 32 + li);
 
   const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
@@ -182,7 +182,7 @@ conv_halo_wino_k(WinoArgs a) {
     }
     __syncthreads();
 
-    const float4* uk = a.um + (long)kc * 2 * a.npad;  // wave-uniform base; the lane offset stays a 32-bit index
+    const float4* uk = a.um + (long)kc * 2 * 6 * a.npad;  // wave-uniform base; the lane offset stays a 32-bit index
 #pragma unroll 1
     for (int rr = 0; rr < 25; ++rr) {
       const int kd = rr / 5, kh = rr % 5;
@@ -190,9 +190,9 @@ conv_halo_wino_k(WinoArgs a) {
       const Q2 x0 = q2(row[0]), x1 = q2(row[HWH]), x2 = q2(row[1]), x3 = q2(row[HWH + 1]), x4 = q2(row[2]),
                x5 = q2(row[HWH + 2]);
       float4 b[6];
-      const float4* ur = uk + rr * rowstride;
+      const float4* ur = uk + rr * rowstride + ulane_off;
 #pragma unroll
-      for (int x = 0; x < 6; ++x) b[x] = (ur + x * xistride)[ulane_off];
+      for (int x = 0; x < 6; ++x) b[x] = ur[x * a.npad];
       // V = BT x  (points 0, 1, -1, 2, -2, inf), two channels per packed instruction
       f2 vl[6], vh[6];
       wino_bt(x0.lo, x1.lo, x2.lo, x3.lo, x4.lo, x5.lo, vl);
