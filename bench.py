@@ -64,13 +64,16 @@ def halo_variant_work(n, d, h, w, num_cu=256):
     """{kernel name: [algorithmic FLOPs, algorithmic HBM bytes, launches, executed MFMA FLOPs]} per training step
     for the kernels that run the 5^3 LUConv layers, forward + data gradient (cubic volumes: level dims = w).
     Algorithmic = SURVEY 8 d3's direct-convolution count, 2*125*Cin*Cout FLOPs per output voxel, and input + output
-    + weights once.  Mirror of the dispatch in msk_conv.hip: whole 4x8x8 tiles ->
-    conv_halo_wino_k (1-D Winograd F(2,5): executes 0.6 of the algorithmic MACs), else conv_halo_mfma_k<tile>."""
+    + weights once.  Mirror of the dispatch in msk_conv.hip: W % 16 == 0 -> conv_halo_wino4_k (1-D Winograd F(4,5):
+    executes 0.4 of the algorithmic MACs), whole 4x8x8 tiles -> conv_halo_wino_k (F(2,5): 0.6), else
+    conv_halo_mfma_k<tile>."""
     work = {}
     for ci, co, vv, ww in vnet_lu_layers(d, h, w):
         ntn = -(-co // 32)
         nblk = n * (ww // 4) * (ww // 8) * (ww // 8)
-        if ww % 8 == 0 and ci >= 8 and co >= 8:
+        if ww % 16 == 0 and ci >= 8 and co >= 8:
+            name, ratio = "conv_halo_wino4_k", 0.4   # F(4,5): 8 multiplications per 4 outputs instead of 20
+        elif ww % 8 == 0 and ci >= 8 and co >= 8:
             name, ratio = "conv_halo_wino_k", WINO_MAC_RATIO
         else:
             td, th, tw = HALO_TILES[halo_tile_for(ww, ww, ww)]

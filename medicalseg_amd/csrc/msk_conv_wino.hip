@@ -241,6 +241,206 @@ conv_halo_wino_k(WinoArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// F(4,5): four outputs of a W row from 8 multiplications (points 0, +-1, +-2, +-1/2, inf) -> 50 of the 125 direct
+// MACs per output (F(2,5): 75).  fp32 error ~4.5e-6 of max|y| at K = 800 (tools/winograd_numerics.py; F(2,5) 1.3e-6,
+// direct 6e-7).  Same structure as conv_halo_wino_k: tile 4 x 8 x 16 outputs = 128 (d, h, W-quad) positions, a wave
+// owns one d plane and the 8 xi accumulators (128 VGPRs); halo rows stored by W residue mod 4 so that the stride-4
+// accesses x[4t + j] of a wavefront are contiguous and the four rows of a 16-lane group sit on disjoint banks.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_wino4_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
+                     float* __restrict__ out) {
+  const double G[8][5] = {{-1, 0, 0, 0, 0},
+                          {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                          {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                          {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                          {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                          {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                          {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                          {0, 0, 0, 0, 1}};
+  const long total = 8L * 25 * KC * 2 * npad * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // idx = ((((row*KC + kc)*2 + h)*8 + xi)*npad + n)*4 + q
+    const int q = (int)(idx & 3);
+    long r_ = idx >> 2;
+    const int n = (int)(r_ % npad);
+    r_ /= npad;
+    const int xi = (int)(r_ & 7);
+    r_ >>= 3;
+    const int h = (int)(r_ & 1);
+    r_ >>= 1;
+    const int kc = (int)(r_ % KC);
+    const int row = (int)(r_ / KC);
+    const int k = kc * 8 + h * 4 + q;
+    float v = 0.f;
+    if (k < CK && n < CN) {
+      const int ia = swap ? n : k, ib = swap ? k : n;
+      const float* wp = w + ((long)ia * B + ib) * 125;
+      double s = 0.0;
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int tap = row * 5 + kw;
+        s += G[xi][kw] * (double)wp[flip ? 124 - tap : tap];
+      }
+      v = (float)s;
+    }
+    out[idx] = v;
+  }
+}
+
+__device__ __forceinline__ void wino4_bt(const f2 d0, const f2 d1, const f2 d2, const f2 d3, const f2 d4, const f2 d5,
+                                         const f2 d6, const f2 d7, f2 (&v)[8]) {
+  const f2 c525 = {5.25f, 5.25f}, c425 = {4.25f, 4.25f}, c025 = {0.25f, 0.25f}, c125 = {1.25f, 1.25f};
+  const f2 c05 = {0.5f, 0.5f}, c25 = {2.5f, 2.5f}, c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
+  v[0] = (d6 - d0) + c525 * (d2 - d4);
+  v[7] = (d7 - d1) + c525 * (d3 - d5);
+  const f2 t1 = (d2 + d6) - c425 * d4, t2 = (d1 + d5) - c425 * d3;
+  v[1] = t1 + t2;
+  v[2] = t1 - t2;
+  const f2 t3 = (d6 + c025 * d2) - c125 * d4, t4 = (c05 * d1 - c25 * d3) + c2 * d5;
+  v[3] = t3 + t4;
+  v[4] = t3 - t4;
+  const f2 t5 = (d6 + c4 * d2) - c5 * d4, t6 = (c2 * d1 - c25 * d3) + c05 * d5;
+  v[5] = t5 + t6;
+  v[6] = t5 - t6;
+}
+
+__global__ void __launch_bounds__(256, 2)
+conv_halo_wino4_k(WinoArgs a) {
+  constexpr int TD = 4, TH = 8, TW = 16, P = 2;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;  // 8 x 12 x 20
+  constexpr int HWQ = HW / 4;                                         // 5 quads per W residue class
+  constexpr int NV = HD * HH * HW, NVP = NV | 1;
+  __shared__ float4 lds[2 * NVP];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int tile = xcd_remap_w(blockIdx.x, a.nblk);
+  const int twi = tile % a.tiles_w;
+  tile /= a.tiles_w;
+  const int thi = tile % a.tiles_h;
+  tile /= a.tiles_h;
+  const int tdi = tile % a.tiles_d;
+  const int n = tile / a.tiles_d;
+  const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+  const int nt = blockIdx.y;
+
+  // A row of this lane: (dz = wave, hy = li / 4, t = li % 4); LDS index of x[.., 4t + j]:
+  //   lh*NVP + ((dz + kd)*HH + hy + kh)*HW + (j & 3)*HWQ + t + (j >> 2)
+  const int abase = lh * NVP + (wave * HH + (li >> 2)) * HW + (li & 3);
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
+
+  const long rowstride = (long)a.KC * 2 * 8 * a.npad;  // float4 units between (kd, kh) rows
+  const unsigned ulane_off = (unsigned)(lh * 8 * a.npad + nt * 32 + li);
+
+  const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
+  const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    __syncthreads();
+    constexpr int SG = 5;
+    for (int base = 0; base < NV * 2; base += SG * 256) {
+      float4 tmp[SG];
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        const int hv = it >> 1, q = it & 1;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = kc * 8 + q * 4;
+        if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
+          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          if (a.vec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c0 + 1 < a.CK) v.y = p[1];
+            if (c0 + 2 < a.CK) v.z = p[2];
+            if (c0 + 3 < a.CK) v.w = p[3];
+          }
+        }
+        tmp[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        if (it < NV * 2) {
+          const int hv = it >> 1, q = it & 1;
+          const int hw = hv % HW, rowi = hv / HW;
+          lds[q * NVP + rowi * HW + (hw & 3) * HWQ + (hw >> 2)] = tmp[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    const float4* uk = a.um + (long)kc * 2 * 8 * a.npad;
+#pragma unroll 1
+    for (int rr = 0; rr < 25; ++rr) {
+      const int kd = rr / 5, kh = rr % 5;
+      const float4* row = lds + abase + (kd * HH + kh) * HW;
+      Q2 x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = q2(row[(j & 3) * HWQ + (j >> 2)]);
+      float4 b[8];
+      const float4* ur = uk + rr * rowstride + ulane_off;
+#pragma unroll
+      for (int xq = 0; xq < 8; ++xq) b[xq] = ur[xq * a.npad];
+      f2 vl[8], vh[8];
+      wino4_bt(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, x[6].lo, x[7].lo, vl);
+      wino4_bt(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, x[6].hi, x[7].hi, vh);
+#pragma unroll
+      for (int xq = 0; xq < 8; ++xq) {
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].x, b[xq].x, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].y, b[xq].y, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].x, b[xq].z, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].y, b[xq].w, acc[xq], 0, 0, 0);
+      }
+    }
+  }
+
+  // output transform (AT, 4 x 8) + store
+  const int co = nt * 32 + li;
+  if (co < a.CN) {
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const int gd = d0 + wave;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;  // = hy*4 + t
+      const int gh = h0 + (row >> 2), gw = w0 + 4 * (row & 3);
+      if (gd < a.D && gh < a.H && gw < a.W) {
+        const float s12 = acc[1][j] + acc[2][j], d12 = acc[1][j] - acc[2][j];
+        const float s34 = acc[3][j] + acc[4][j], d34 = acc[3][j] - acc[4][j];
+        const float s56 = acc[5][j] + acc[6][j], d56 = acc[5][j] - acc[6][j];
+        float y[4];
+        y[0] = ((acc[0][j] + s12) + s34) + s56;
+        y[1] = (d12 + 2.f * d34) + 0.5f * d56;
+        y[2] = (s12 + 4.f * s34) + 0.25f * s56;
+        y[3] = ((d12 + 8.f * d34) + 0.125f * d56) + acc[7][j];
+        const long vox = (((long)n * a.D + gd) * a.H + gh) * a.W + gw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (gw + i < a.W) {
+            if (a.ksplit > 1) {
+              a.partial[((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox + i) * a.CN + co] = y[i];
+            } else {
+              float* o = a.dst + (vox + i) * a.dld + co;
+              float r = y[i] + bv;
+              if (a.accumulate) r += *o;
+              *o = r;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int CN, const float* __restrict__ bias,
                      float* __restrict__ dst, int dld, int accumulate) {
@@ -263,20 +463,26 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
   if (g.CK < 8 || g.CN < 8) return 0;                       // tiny-channel layers have their own kernels
   if (g.DD % 4 || g.DH % 8 || g.DW % 8) return 0;           // whole 4x8x8 tiles only (no padded-volume waste)
+  const bool f45 = (g.DW % 16 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
-  const long nblk = (long)g.N * (g.DD / 4) * (g.DH / 8) * (g.DW / 8);
+  const int twid = f45 ? 16 : 8, nxi = f45 ? 8 : 6;
+  const long nblk = (long)g.N * (g.DD / 4) * (g.DH / 8) * (g.DW / twid);
   // the direct kernel splits K when the tiling cannot fill the chip; leave those small layers to it
   if (nblk > 0x7fffffff) return 0;
-  const size_t ubytes = (size_t)6 * 25 * KC * 2 * npad * 4 * sizeof(float);
+  const size_t ubytes = (size_t)nxi * 25 * KC * 2 * npad * 4 * sizeof(float);
   float* um = (float*)msk_workspace2(ctx, ubytes);
   if (!um) return -1;
   {
     msk_launch_scope ls(ctx, "pack_weights_wino");
     long blocks = ((long)(ubytes / sizeof(float)) + 255) / 256;
     if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
-    hipLaunchKernelGGL(pack_wino_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
-                       g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
+    if (f45)
+      hipLaunchKernelGGL(pack_wino4_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
+                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
+    else
+      hipLaunchKernelGGL(pack_wino_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
+                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
     MSK_LAUNCH_CHECK(ctx);
   }
   WinoArgs a{};
@@ -284,7 +490,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CK = g.CK; a.CN = g.CN;
   a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
   a.bias = g.bias; a.accumulate = g.accumulate;
-  a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / 8; a.nblk = (int)nblk;
+  a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / twid; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted), like conv_halo_mfma_k
   a.ksplit = 1;
@@ -302,16 +508,17 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
       if (!a.partial) return -1;
     }
   }
-  const char* tag = "conv_halo_wino_k";
+  const char* tag = f45 ? "conv_halo_wino4_k" : "conv_halo_wino_k";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[200];
-    snprintf(buf, sizeof(buf), "conv_halo_wino_k[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", g.CK, g.CN, g.N, g.DD, g.DH, g.DW,
+    snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", tag, g.CK, g.CN, g.N, g.DD, g.DH, g.DW,
              g.accumulate);
     tag = msk_intern_tag(ctx, buf);
   }
   {
     msk_launch_scope ls(ctx, tag);
-    hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
+    if (f45) hipLaunchKernelGGL(conv_halo_wino4_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
     MSK_LAUNCH_CHECK(ctx);
   }
   if (a.ksplit > 1) {

@@ -381,8 +381,10 @@ def test_interp_trilinear_fwd_bwd(case):
 
 
 WINO_CASES = [
-    # (Cin, Cout, (N, D, H, W)): whole 4x8x8 tiles
+    # (Cin, Cout, (N, D, H, W)): whole 4x8x8 tiles; W % 16 == 0 -> F(4,5), else F(2,5)
     (32, 32, (2, 8, 16, 16)),
+    (64, 40, (1, 4, 8, 32)),
+    (16, 32, (1, 8, 8, 48)),
     (64, 48, (1, 4, 8, 24)),      # Cout not a multiple of 32
     (8, 40, (1, 12, 8, 8)),
     (128, 128, (1, 4, 16, 8)),
@@ -391,9 +393,9 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv5_winograd_f25_matches_oracle(case):
-    """conv_halo_wino_k (1-D Winograd F(2,5) along W, msk_conv_wino.hip) forward and data gradient vs the float64
-    oracle.  Tolerance: the conv tolerance of this file (2e-5 * sqrt(K/1000 + 1) of max|ref|); the transform costs
-    about one decimal digit relative to the direct fp32 kernel (measured ~1e-6 vs ~1e-7)."""
+    """conv_halo_wino_k / conv_halo_wino4_k (1-D Winograd F(2,5) / F(4,5) along W, msk_conv_wino.hip) forward and data
+    gradient vs the float64 oracle.  Tolerance: the conv tolerance of this file (2e-5 * sqrt(K/1000 + 1) of max|ref|);
+    the transforms cost about one decimal digit relative to the direct fp32 kernel (measured ~1e-6 / ~4e-6 vs ~1e-7)."""
     cin, cout, (N, D, H, W) = case
     k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
     d = dev()
@@ -418,7 +420,9 @@ def test_conv5_winograd_f25_matches_oracle(case):
         d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
         e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
         d.prof_enable(False)
-        assert d.prof_report().get("conv_halo_wino_k", (0, 0))[0] == 3      # the Winograd kernel really ran
+        rep = d.prof_report()                                                # the Winograd kernel really ran:
+        tag = "conv_halo_wino4_k" if W % 16 == 0 else "conv_halo_wino_k"     # F(4,5) when W tiles by 16, else F(2,5)
+        assert rep.get(tag, (0, 0))[0] == 3, rep
     finally:
         d.prof_enable(False)
         d.set_option("conv_impl", 0)
