@@ -236,6 +236,204 @@ wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// F(4,5) variant (W % 4 == 0): 8 xi planes, 40 (xi, kh) accumulators per wavefront (160 VGPRs), MFMA K = 4 output
+// rows of one W QUAD: per step 5 x 8 x-reads + 4 dy reads, 5 x 26 + 12 transform ops and 40 MFMAs.  Executes 0.4 of
+// the direct MACs (the F(2,5) kernel above: 0.6).  The x rows are transformed one at a time to keep the register
+// count below 256.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT, 2)
+wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial) {
+  __shared__ float xs[XR * RPX];
+  __shared__ float dys[R * RPY];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int ca_tiles = (g.CA + 31) >> 5, cb_tiles = (g.CB + 31) >> 5;
+  int b = blockIdx.x;
+  const int cbt = b % cb_tiles;
+  b /= cb_tiles;
+  const int cat = b % ca_tiles;
+  const int kd = b / ca_tiles;
+  const int split = blockIdx.y;
+  const int D = g.BD, H = g.BH, W = g.BW;
+  const int hblocks = (H + R - 1) / R, wblocks = (W + WS - 1) / WS;
+  const int qa = (wave & 1) * 16, qb = (wave >> 1) * 16;
+
+  f32x4 acc[8][5];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[x][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int c_begin = split * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > chunks_total) c_end = chunks_total;
+  constexpr int XITEMS = XR * XW * 8, DITEMS = R * WS * 8;
+
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    int t = ch;
+    const int wb = t % wblocks;
+    t /= wblocks;
+    const int hb = t % hblocks;
+    t /= hblocks;
+    const int d = t % D;
+    const int n = t / D;
+    const int id = d + kd - P;
+    if ((unsigned)id >= (unsigned)D) continue;  // block-uniform
+    const int h0 = hb * R, w0 = wb * WS;
+    __syncthreads();
+    for (int base = 0; base < XITEMS; base += 4 * NT) {
+      float4 tmp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        const int q = it & 7, v = it >> 3;
+        const int row = v / XW, col = v % XW;
+        const int ih = h0 - P + row, iw = w0 - P + col;
+        const int c0 = cat * 32 + q * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
+          val = *reinterpret_cast<const float4*>(g.A + ((((long)n * D + id) * H + ih) * W + iw) * g.ald + c0);
+        tmp[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        if (it < XITEMS) {
+          const int q = it & 7, v = it >> 3;
+          *reinterpret_cast<float4*>(&xs[(v / XW) * RPX + (v % XW) * 32 + q * 4]) = tmp[i];
+        }
+      }
+    }
+    for (int base = 0; base < DITEMS; base += 4 * NT) {
+      float4 tmp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        const int q = it & 7, v = it >> 3;
+        const int row = v / WS, col = v % WS;
+        const int oh = h0 + row, ow = w0 + col;
+        const int c0 = cbt * 32 + q * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
+          val = *reinterpret_cast<const float4*>(g.B + ((((long)n * D + d) * H + oh) * W + ow) * g.bld + c0);
+        tmp[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int it = base + tid + i * NT;
+        if (it < DITEMS) {
+          const int q = it & 7, v = it >> 3;
+          *reinterpret_cast<float4*>(&dys[(v / WS) * RPY + (v % WS) * 32 + q * 4]) = tmp[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    const float* xlane = &xs[lg * RPX + qa + li];
+    const float* dlane = &dys[lg * RPY + qb + li];
+#pragma unroll 1
+    for (int rg = 0; rg < R / 4; ++rg) {
+#pragma unroll 1
+      for (int tq = 0; tq < WS / 4; ++tq) {
+        // output-side transform Y = A dy of this lane's row (columns 4tq .. 4tq+3)
+        const float* dp = dlane + rg * 4 * RPY + tq * 128;
+        const float y0 = dp[0], y1 = dp[32], y2 = dp[64], y3 = dp[96];
+        float ys[8];
+        {
+          const float e = y0 + y2, o = y1 + y3;
+          ys[0] = y0;
+          ys[1] = e + o;
+          ys[2] = e - o;
+          const float e2 = fmaf(4.f, y2, y0), o2 = fmaf(8.f, y3, 2.f * y1);
+          ys[3] = e2 + o2;
+          ys[4] = e2 - o2;
+          const float e3 = fmaf(0.25f, y2, y0), o3 = fmaf(0.125f, y3, 0.5f * y1);
+          ys[5] = e3 + o3;
+          ys[6] = e3 - o3;
+          ys[7] = y3;
+        }
+        const float* xp = xlane + rg * 4 * RPX + tq * 128;
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+          const float* p = xp + kh * RPX;
+          const float d0 = p[0], d1 = p[32], d2 = p[64], d3 = p[96], d4 = p[128], d5 = p[160], d6 = p[192], d7 = p[224];
+          float v[8];
+          v[0] = (d6 - d0) + 5.25f * (d2 - d4);
+          v[7] = (d7 - d1) + 5.25f * (d3 - d5);
+          const float t1 = fmaf(-4.25f, d4, d2 + d6), t2 = fmaf(-4.25f, d3, d1 + d5);
+          v[1] = t1 + t2;
+          v[2] = t1 - t2;
+          const float t3 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), t4 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
+          v[3] = t3 + t4;
+          v[4] = t3 - t4;
+          const float t5 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), t6 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
+          v[5] = t5 + t6;
+          v[6] = t5 - t6;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) acc[x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[x], acc[x][kh], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int cb = cbt * 32 + qb + li;
+  if (cb < g.CB) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int oca = cat * 32 + qa + lg * 4 + j;
+          if (oca < g.CA)
+            partial[((((long)split * 8 + x) * 25 + kd * 5 + kh) * g.CA + oca) * g.CB + cb] = acc[x][kh][j];
+        }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, float* __restrict__ dw, int accumulate) {
+  const double G[8][5] = {{-1, 0, 0, 0, 0},
+                          {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                          {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                          {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                          {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                          {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                          {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                          {0, 0, 0, 0, 1}};
+  const long plane = (long)CA * CB;
+  const long per = 8L * 25 * plane;
+  const long total = 25 * plane;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long e = idx % plane;
+    const int row = (int)(idx / plane);
+    double u[8];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) {
+      const float* p = partial + ((long)xi * 25 + row) * plane + e;
+      double s0 = 0.0, s1 = 0.0;
+      int k = 0;
+      for (; k + 1 < splits; k += 2) {
+        s0 += p[(long)k * per];
+        s1 += p[(long)(k + 1) * per];
+      }
+      if (k < splits) s0 += p[(long)k * per];
+      u[xi] = s0 + s1;
+    }
+    const int cb = (int)(e % CB), ca = (int)(e / CB);
+    float* o = dw + ((long)cb * CA + ca) * 125 + row * 5;
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      double s = 0.0;
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) s += G[xi][kw] * u[xi];
+      o[kw] = accumulate ? o[kw] + (float)s : (float)s;
+    }
+  }
+}
+
 // dw[cb][ca][(kd,kh,kw)] (+)= sum_xi G[xi][kw] * sum_split P[split][xi][kd*5+kh][ca][cb]   (fixed order, double)
 __global__ void __launch_bounds__(256)
 wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, float* __restrict__ dw, int accumulate) {
@@ -292,7 +490,9 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
   long splits = ((long)ctx->num_cu * 6 + tasks - 1) / tasks;  // ~3 rounds of 2 resident workgroups per CU
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;
-  const size_t per = (size_t)6 * 25 * g.CA * g.CB * sizeof(float);
+  const bool f45 = (g.BW % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
+  const int nxi = f45 ? 8 : 6;
+  const size_t per = (size_t)nxi * 25 * g.CA * g.CB * sizeof(float);
   while (splits > 1 && splits * per > ((size_t)1 << 30)) --splits;
   const int cps = (int)((chunks + splits - 1) / splits);
   splits = (chunks + cps - 1) / cps;
@@ -300,15 +500,19 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
   float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
   if (!partial) return -1;
   {
-    const char* tag = "wgrad_wino";
+    const char* tag = f45 ? "wgrad_wino4" : "wgrad_wino";
     if (ctx->prof && ctx->prof_shapes) {
       char buf[160];
-      snprintf(buf, sizeof(buf), "wgrad_wino[ca=%d,cb=%d,M=%ld,splits=%ld]", g.CA, g.CB, (long)g.N * g.BD * g.BH * g.BW, splits);
+      snprintf(buf, sizeof(buf), "%s[ca=%d,cb=%d,M=%ld,splits=%ld]", tag, g.CA, g.CB, (long)g.N * g.BD * g.BH * g.BW, splits);
       tag = msk_intern_tag(ctx, buf);
     }
     msk_launch_scope ls(ctx, tag);
-    hipLaunchKernelGGL(wgrad_wino_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
-                       (int)chunks, cps, partial);
+    if (f45)
+      hipLaunchKernelGGL(wgrad_wino4_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
+                         (int)chunks, cps, partial);
+    else
+      hipLaunchKernelGGL(wgrad_wino_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
+                         (int)chunks, cps, partial);
     MSK_LAUNCH_CHECK(ctx);
   }
   {
@@ -316,8 +520,12 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
     const long total = 25L * g.CA * g.CB;
     long blocks = (total + 255) / 256;
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
-    hipLaunchKernelGGL(wgrad_wino_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial, (int)splits,
-                       g.CA, g.CB, g.dw, g.accumulate);
+    if (f45)
+      hipLaunchKernelGGL(wgrad_wino4_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial,
+                         (int)splits, g.CA, g.CB, g.dw, g.accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_wino_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial,
+                         (int)splits, g.CA, g.CB, g.dw, g.accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 1;
