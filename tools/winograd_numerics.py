@@ -1,5 +1,5 @@
-"""Construction and fp32 error study of the 1-D Winograd F(2,5) transform used by msk_conv_wino.hip /
-msk_wgrad_wino.hip (Cook-Toom with exact fractions; interpolation points 0, 1, -1, 2, -2, inf).
+"""Construction and fp32 error study of the 1-D Winograd transforms used by msk_conv_wino.hip / msk_wgrad_wino.hip
+(Cook-Toom with exact fractions): F(2,5) with points 0, 1, -1, 2, -2, inf and F(4,5) with 0, +-1, +-2, +-1/2, inf.
 
     python tools/winograd_numerics.py
 
@@ -50,8 +50,8 @@ def cook_toom(m, r, pts):
     return at, g, bt
 
 
-def study(pts, K=800, T=2000, seed=0):
-    m, r = 2, 5
+def study(pts, K=800, T=2000, seed=0, m=2):
+    r = 5
     at, g, bt = (np.array(x, dtype=np.float64) for x in cook_toom(m, r, pts))
     rng = np.random.default_rng(seed)
     gs = (rng.standard_normal((K, r)) / np.sqrt(K * r)).astype(np.float32)
@@ -75,4 +75,8 @@ if __name__ == "__main__":
             print("  ", [str(v) for v in row])
     for pts in ([0, 1, -1, 2, -2], [0, 1, -1, F(1, 2), -F(1, 2)], [0, 1, -1, 2, F(-1, 2)]):
         d, w = study(pts)
-        print("points %-28s direct fp32 err %.2e   winograd fp32 err %.2e" % ([str(p) for p in pts], d, w))
+        print("F(2,5) points %-28s direct fp32 err %.2e   winograd fp32 err %.2e" % ([str(p) for p in pts], d, w))
+    # F(4,5), the transform of conv_halo_wino4_k / wgrad_wino4_k (8 multiplications per 4 outputs)
+    for pts in ([0, 1, -1, 2, -2, F(1, 2), -F(1, 2)], [0, 1, -1, 2, -2, 3, -3]):
+        d, w = study(pts, m=4)
+        print("F(4,5) points %-36s direct fp32 err %.2e   winograd fp32 err %.2e" % ([str(p) for p in pts], d, w))
