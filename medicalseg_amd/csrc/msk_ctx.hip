@@ -265,6 +265,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wgrad_async_max_m = value;
     return 0;
   }
+  if (strcmp(key, "wgrad_wino_rounds") == 0) {
+    ctx->wgrad_wino_rounds = value > 0 ? value : 6;
+    return 0;
+  }
   if (strcmp(key, "wgrad_rounds") == 0) {
     ctx->wgrad_rounds = value > 0 ? value : 8;
     return 0;

@@ -487,7 +487,7 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
   const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
   const long chunks = (long)g.N * g.BD * ((g.BH + R - 1) / R) * ((g.BW + WS - 1) / WS);
   const long tasks = 5L * ca_tiles * cb_tiles;
-  long splits = ((long)ctx->num_cu * 6 + tasks - 1) / tasks;  // ~3 rounds of 2 resident workgroups per CU
+  long splits = ((long)ctx->num_cu * ctx->wgrad_wino_rounds + tasks - 1) / tasks;  // default 6: ~3 rounds of 2 resident workgroups per CU
   if (splits > chunks) splits = chunks;
   if (splits < 1) splits = 1;
   const bool f45 = (g.BW % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
