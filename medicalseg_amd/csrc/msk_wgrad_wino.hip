@@ -258,13 +258,17 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
   const int split = blockIdx.y;
   const int D = g.BD, H = g.BH, W = g.BW;
   const int hblocks = (H + R - 1) / R, wblocks = (W + WS - 1) / WS;
-  const int qa = (wave & 1) * 16, qb = (wave >> 1) * 16;
+  // wave = (ca half, xi half): it keeps 16 ca rows x BOTH 16-column cb halves for 4 of the 8 xi planes, so each x row is
+  // transformed for 4 xi only (12-14 instead of 26 VALU ops) and no two waves repeat the same transform work on x
+  const int qa = (wave & 1) * 16, xh = wave >> 1;
 
-  f32x4 acc[8][5];
+  f32x4 acc[2][4][5];  // [cb half][xi slot][kh]
 #pragma unroll
-  for (int x = 0; x < 8; ++x)
+  for (int hb_ = 0; hb_ < 2; ++hb_)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) acc[x][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[hb_][x][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int c_begin = split * chunks_per_split;
   int c_end = c_begin + chunks_per_split;
@@ -332,64 +336,80 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
     __syncthreads();
 
     const float* xlane = &xs[lg * RPX + qa + li];
-    const float* dlane = &dys[lg * RPY + qb + li];
+    const float* dlane = &dys[lg * RPY + li];
 #pragma unroll 1
     for (int rg = 0; rg < R / 4; ++rg) {
 #pragma unroll 1
       for (int tq = 0; tq < WS / 4; ++tq) {
-        // output-side transform Y = A dy of this lane's row (columns 4tq .. 4tq+3)
-        const float* dp = dlane + rg * 4 * RPY + tq * 128;
-        const float y0 = dp[0], y1 = dp[32], y2 = dp[64], y3 = dp[96];
-        float ys[8];
-        {
-          const float e = y0 + y2, o = y1 + y3;
-          ys[0] = y0;
-          ys[1] = e + o;
-          ys[2] = e - o;
-          const float e2 = fmaf(4.f, y2, y0), o2 = fmaf(8.f, y3, 2.f * y1);
-          ys[3] = e2 + o2;
-          ys[4] = e2 - o2;
-          const float e3 = fmaf(0.25f, y2, y0), o3 = fmaf(0.125f, y3, 0.5f * y1);
-          ys[5] = e3 + o3;
-          ys[6] = e3 - o3;
-          ys[7] = y3;
+        // output-side transform Y = A dy for this wave's 4 xi, both cb halves (columns 4tq .. 4tq+3 of this lane's row)
+        float ys[2][4];
+#pragma unroll
+        for (int hb_ = 0; hb_ < 2; ++hb_) {
+          const float* dp = dlane + rg * 4 * RPY + tq * 128 + hb_ * 16;
+          const float y0 = dp[0], y1 = dp[32], y2 = dp[64], y3 = dp[96];
+          if (xh == 0) {  // xi 0, 7, 1, 2
+            const float e = y0 + y2, o = y1 + y3;
+            ys[hb_][0] = y0;
+            ys[hb_][1] = y3;
+            ys[hb_][2] = e + o;
+            ys[hb_][3] = e - o;
+          } else {        // xi 3, 4, 5, 6
+            const float e2 = fmaf(4.f, y2, y0), o2 = fmaf(8.f, y3, 2.f * y1);
+            const float e3 = fmaf(0.25f, y2, y0), o3 = fmaf(0.125f, y3, 0.5f * y1);
+            ys[hb_][0] = e2 + o2;
+            ys[hb_][1] = e2 - o2;
+            ys[hb_][2] = e3 + o3;
+            ys[hb_][3] = e3 - o3;
+          }
         }
         const float* xp = xlane + rg * 4 * RPX + tq * 128;
 #pragma unroll
         for (int kh = 0; kh < 5; ++kh) {
           const float* p = xp + kh * RPX;
           const float d0 = p[0], d1 = p[32], d2 = p[64], d3 = p[96], d4 = p[128], d5 = p[160], d6 = p[192], d7 = p[224];
-          float v[8];
-          v[0] = (d6 - d0) + 5.25f * (d2 - d4);
-          v[7] = (d7 - d1) + 5.25f * (d3 - d5);
-          const float t1 = fmaf(-4.25f, d4, d2 + d6), t2 = fmaf(-4.25f, d3, d1 + d5);
-          v[1] = t1 + t2;
-          v[2] = t1 - t2;
-          const float t3 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), t4 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
-          v[3] = t3 + t4;
-          v[4] = t3 - t4;
-          const float t5 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), t6 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
-          v[5] = t5 + t6;
-          v[6] = t5 - t6;
+          float v[4];
+          if (xh == 0) {
+            v[0] = (d6 - d0) + 5.25f * (d2 - d4);
+            v[1] = (d7 - d1) + 5.25f * (d3 - d5);
+            const float t1 = fmaf(-4.25f, d4, d2 + d6), t2 = fmaf(-4.25f, d3, d1 + d5);
+            v[2] = t1 + t2;
+            v[3] = t1 - t2;
+          } else {
+            const float t3 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), t4 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
+            const float t5 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), t6 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
+            v[0] = t3 + t4;
+            v[1] = t3 - t4;
+            v[2] = t5 + t6;
+            v[3] = t5 - t6;
+          }
 #pragma unroll
-          for (int x = 0; x < 8; ++x) acc[x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[x], acc[x][kh], 0, 0, 0);
+          for (int x = 0; x < 4; ++x) {
+            acc[0][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[0][x], acc[0][x][kh], 0, 0, 0);
+            acc[1][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[1][x], acc[1][x][kh], 0, 0, 0);
+          }
         }
       }
     }
   }
 
-  const int cb = cbt * 32 + qb + li;
-  if (cb < g.CB) {
+  // xi plane of slot x: half 0 -> {0, 7, 1, 2}, half 1 -> {3, 4, 5, 6}
 #pragma unroll
-    for (int x = 0; x < 8; ++x)
+  for (int hb_ = 0; hb_ < 2; ++hb_) {
+    const int cb = cbt * 32 + hb_ * 16 + li;
+    if (cb < g.CB) {
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh)
+      for (int x = 0; x < 4; ++x) {
+        const int xi = xh == 0 ? (x == 0 ? 0 : (x == 1 ? 7 : x - 1)) : 3 + x;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int oca = cat * 32 + qa + lg * 4 + j;
-          if (oca < g.CA)
-            partial[((((long)split * 8 + x) * 25 + kd * 5 + kh) * g.CA + oca) * g.CB + cb] = acc[x][kh][j];
-        }
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int oca = cat * 32 + qa + lg * 4 + j;
+            if (oca < g.CA)
+              partial[((((long)split * 8 + xi) * 25 + kd * 5 + kh) * g.CA + oca) * g.CB + cb] = acc[hb_][x][kh][j];
+          }
+      }
+    }
   }
 }
 
