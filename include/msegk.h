@@ -78,10 +78,15 @@ int msk_prof_enable(msk_ctx* ctx, int on);
 int msk_prof_reset(msk_ctx* ctx);
 /* writes "tag\tcalls\ttotal_ms\n" lines into buf (NUL terminated); returns needed size via *len */
 int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
-/* knobs: "conv_impl" 0=auto 1=VALU reference kernels 3=reference wgrad only 4=reference gather-conv only
- * 5=no LDS wgrad 6=no k==s scatter kernel 7=scatter kernel at any size; "wgrad_async" 0|1; "prof_shapes" 0|1;
- * "poison_scratch" byte|-1 (debug); tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index),
- * "wgrad_rounds" (workgroups per CU targeted by the LDS wgrad split-K) */
+/* knobs (debugging / A-B measurements; 0 = the product dispatch):
+ *   "conv_impl": 1=VALU reference kernels everywhere, 3=reference wgrad only, 4=reference gather-conv only,
+ *     5=no LDS wgrad, 6=no k==s scatter kernel, 7=scatter kernel at any size, 8=no tight-K kernel,
+ *     9=one-voxel VALU kernel for 32->ncls, 10=Winograd forward kernel even for tiny grids, 11=direct (non-Winograd)
+ *     forward/data-gradient kernels, 13=direct weight-gradient kernels, 14=Winograd F(2,5) instead of F(4,5);
+ *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
+ *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
+ *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
+ *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);
 
 /* ---- layout at the boundary ------------------------------------------------ */
