@@ -85,6 +85,7 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *     forward/data-gradient kernels, 13=direct weight-gradient kernels, 14=Winograd F(2,5) instead of F(4,5);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
  *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
+ *   "direct_conv" 0|1 (1 = no Winograd kernels; also env MSEGK_DIRECT_CONV=1);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
  *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);

@@ -43,6 +43,7 @@ struct msk_ctx {
   bool prof_shapes = false;        // append problem shapes to conv tags
   // options
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
+  bool no_winograd = false;  // env MSEGK_DIRECT_CONV=1 / option "direct_conv": direct kernels only (bit-exact fp32 fmaf chains)
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
   char prof_prefix[48] = {0};  // empty = profile every launch

@@ -260,7 +260,7 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
     r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
     if (r < 0) return r;
     if (r == 1) return 0;
-    r = ctx->conv_impl == 11 ? 0 : msk_gconv_halo_wino(ctx, g, w, A, B, swap);  // 11 = direct kernel only (A/B); 10 = force
+    r = (ctx->conv_impl == 11 || ctx->no_winograd) ? 0 : msk_gconv_halo_wino(ctx, g, w, A, B, swap);  // 11 = direct kernel only (A/B)
     if (r < 0) return r;
     if (r == 1) return 0;
     r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
@@ -294,7 +294,7 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
-  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 13) {  // 13 = direct LDS kernel only (A/B)
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 13 && !ctx->no_winograd) {  // 13 = direct LDS kernel only (A/B)
     int r = msk_wgrad_wino(ctx, g);
     if (r < 0) return r;
     if (r == 1) return 0;

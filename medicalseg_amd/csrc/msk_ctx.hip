@@ -1,4 +1,6 @@
 // Context, memory, timing and per-kernel profiling for libmsegk (gfx950).
+#include <cstdlib>
+
 #include "msk_common.h"
 
 thread_local std::string g_msk_global_err;
@@ -105,6 +107,10 @@ int msk_ctx_create(int device, msk_ctx** out) {
   msk_ctx* ctx = new msk_ctx();
   ctx->device = device;
   ctx->wgrad_async = true;
+  {
+    const char* e = getenv("MSEGK_DIRECT_CONV");
+    ctx->no_winograd = e && e[0] && e[0] != '0';
+  }
   MSK_CHECK_HIP(ctx, hipSetDevice(device));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -263,6 +269,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wgrad_async_max_m") == 0) {
     ctx->wgrad_async_max_m = value;
+    return 0;
+  }
+  if (strcmp(key, "direct_conv") == 0) {  // 1 = no Winograd kernels (same as env MSEGK_DIRECT_CONV=1)
+    ctx->no_winograd = value != 0;
     return 0;
   }
   if (strcmp(key, "wgrad_wino_rounds") == 0) {

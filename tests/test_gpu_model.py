@@ -342,3 +342,49 @@ def test_checkpoint_resume_continues_bitwise(tmp_path):
         if k != "LR_Scheduler":
             assert np.array_equal(ref_opt[k], opt_sd2[k]), k
     assert ref_opt["LR_Scheduler"] == opt_sd2["LR_Scheduler"]
+
+
+def test_winograd_and_direct_kernels_agree_on_a_training_step():
+    """The product dispatch uses the Winograd F(4,5) / F(2,5) kernels for the 5^3 layers; `direct_conv` (env
+    MSEGK_DIRECT_CONV=1) selects the direct kernels (exact fp32 fmaf chains).  One training step at 32^3 (every level
+    down to 8^3 tiles for a Winograd kernel) must agree between the two: logits 2e-5 of max|logit|, loss 1e-5,
+    updated weights 1e-5 of their scale."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 1, 32, 32, 32)).astype(np.float32)
+    y = rng.integers(0, 3, (2, 32, 32, 32)).astype(np.int32)
+    out = []
+    for direct in (0, 1):
+        dev().set_option("direct_conv", direct)
+        try:
+            nn.seed(5)
+            model = VNet(num_classes=3)
+            model.train()
+            model.set_dropout_masks({})
+            opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+            losses = {"types": [MixedLoss([CrossEntropyLoss(weight=[1.0, 1.0, 1.0]), DiceLoss()], [1, 1])], "coef": [1]}
+            dev().prof_reset()
+            dev().prof_enable(True)
+            logits = model(x)
+            lg = logits[0].numpy()
+            ll, _ = loss_computation(logits, to_labels(y), losses)
+            loss = float(sum(ll))
+            sum(ll).backward()
+            opt.step()
+            dev().prof_enable(False)
+            tags = dev().prof_report()
+            ran_wino = any(k.startswith(("conv_halo_wino", "wgrad_wino")) for k in tags)
+            assert ran_wino == (direct == 0), sorted(tags)
+            sd = model.state_dict()
+            out.append((lg, loss, sd["up_tr32.ops.0.conv1.weight"], sd["down_tr64.ops.1.conv1.weight"], sd["in_tr.conv1.weight"]))
+        finally:
+            dev().prof_enable(False)
+            dev().set_option("direct_conv", 0)
+    (lg_w, loss_w, *w_w), (lg_d, loss_d, *w_d) = out
+    assert rel_err(lg_w, lg_d) < 2e-5
+    assert abs(loss_w - loss_d) < 1e-5 * abs(loss_d)
+    for a, b in zip(w_w, w_d):
+        assert np.abs(a - b).max() < 1e-5 * np.abs(b).max()
