@@ -242,10 +242,18 @@ wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float*
 // the direct MACs (the F(2,5) kernel above: 0.6).  The x rows are transformed one at a time to keep the register
 // count below 256.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int VP = 36;  // floats per staged voxel (32 channels + 4): the four W quads of an MFMA K group are 4 voxels =
+                        // 144 floats apart -> 16 banks apart -> conflict-free ds_read_b32 for the 4 x 16 lanes
+
+// MFMA K (4) = the four W QUADS of one output row; a lane group g = lane >> 4 owns quad g.  Walking down the rows of
+// the chunk, a lane keeps a 5-row sliding window of transformed x values, so a step costs ONE new x-row transform
+// (8 LDS reads, 12-14 VALU ops for this wave's 4 xi), the dy transform of the row (2 x 4 reads) and 40 MFMAs.
+// (The previous mapping, K = 4 consecutive rows of one quad, transformed five x rows per step: ~150 VALU
+// instructions per 40 MFMAs, MFMA pipe 53 % busy; fp32 MFMA shares the SIMD issue with the VALU.)
 __global__ void __launch_bounds__(NT, 2)
 wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial) {
-  __shared__ float xs[XR * RPX];
-  __shared__ float dys[R * RPY];
+  __shared__ float xs[XR * XW * VP];
+  __shared__ float dys[R * WS * VP];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -258,8 +266,7 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
   const int split = blockIdx.y;
   const int D = g.BD, H = g.BH, W = g.BW;
   const int hblocks = (H + R - 1) / R, wblocks = (W + WS - 1) / WS;
-  // wave = (ca half, xi half): it keeps 16 ca rows x BOTH 16-column cb halves for 4 of the 8 xi planes, so each x row is
-  // transformed for 4 xi only (12-14 instead of 26 VALU ops) and no two waves repeat the same transform work on x
+  // wave = (ca half, xi half): 16 ca rows x both 16-column cb halves for 4 of the 8 xi planes
   const int qa = (wave & 1) * 16, xh = wave >> 1;
 
   f32x4 acc[2][4][5];  // [cb half][xi slot][kh]
@@ -304,10 +311,7 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int it = base + tid + i * NT;
-        if (it < XITEMS) {
-          const int q = it & 7, v = it >> 3;
-          *reinterpret_cast<float4*>(&xs[(v / XW) * RPX + (v % XW) * 32 + q * 4]) = tmp[i];
-        }
+        if (it < XITEMS) *reinterpret_cast<float4*>(&xs[(it >> 3) * VP + (it & 7) * 4]) = tmp[i];
       }
     }
     for (int base = 0; base < DITEMS; base += 4 * NT) {
@@ -327,68 +331,69 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int it = base + tid + i * NT;
-        if (it < DITEMS) {
-          const int q = it & 7, v = it >> 3;
-          *reinterpret_cast<float4*>(&dys[(v / WS) * RPY + (v % WS) * 32 + q * 4]) = tmp[i];
-        }
+        if (it < DITEMS) *reinterpret_cast<float4*>(&dys[(it >> 3) * VP + (it & 7) * 4]) = tmp[i];
       }
     }
     __syncthreads();
 
-    const float* xlane = &xs[lg * RPX + qa + li];
-    const float* dlane = &dys[lg * RPY + li];
+    const float* xlane = &xs[4 * lg * VP + qa + li];   // halo columns 4g .. 4g+7 of this lane's W quad
+    const float* dlane = &dys[4 * lg * VP + li];       // output columns 4g .. 4g+3
+    auto xform = [&](int row, float (&v)[4]) {
+      const float* p = xlane + row * XW * VP;
+      const float d0 = p[0], d1 = p[VP], d2 = p[2 * VP], d3 = p[3 * VP], d4 = p[4 * VP], d5 = p[5 * VP], d6 = p[6 * VP],
+                  d7 = p[7 * VP];
+      if (xh == 0) {  // xi 0, 7, 1, 2
+        v[0] = (d6 - d0) + 5.25f * (d2 - d4);
+        v[1] = (d7 - d1) + 5.25f * (d3 - d5);
+        const float t1 = fmaf(-4.25f, d4, d2 + d6), t2 = fmaf(-4.25f, d3, d1 + d5);
+        v[2] = t1 + t2;
+        v[3] = t1 - t2;
+      } else {        // xi 3, 4, 5, 6
+        const float t3 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), t4 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
+        const float t5 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), t6 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
+        v[0] = t3 + t4;
+        v[1] = t3 - t4;
+        v[2] = t5 + t6;
+        v[3] = t5 - t6;
+      }
+    };
+    float win[5][4];  // transformed x rows r .. r+4 (kh = 0 .. 4) for this wave's 4 xi
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xform(k, win[k]);
 #pragma unroll 1
-    for (int rg = 0; rg < R / 4; ++rg) {
-#pragma unroll 1
-      for (int tq = 0; tq < WS / 4; ++tq) {
-        // output-side transform Y = A dy for this wave's 4 xi, both cb halves (columns 4tq .. 4tq+3 of this lane's row)
-        float ys[2][4];
+    for (int r = 0; r < R; ++r) {
+      xform(r + 4, win[4]);
+      float ys[2][4];
 #pragma unroll
-        for (int hb_ = 0; hb_ < 2; ++hb_) {
-          const float* dp = dlane + rg * 4 * RPY + tq * 128 + hb_ * 16;
-          const float y0 = dp[0], y1 = dp[32], y2 = dp[64], y3 = dp[96];
-          if (xh == 0) {  // xi 0, 7, 1, 2
-            const float e = y0 + y2, o = y1 + y3;
-            ys[hb_][0] = y0;
-            ys[hb_][1] = y3;
-            ys[hb_][2] = e + o;
-            ys[hb_][3] = e - o;
-          } else {        // xi 3, 4, 5, 6
-            const float e2 = fmaf(4.f, y2, y0), o2 = fmaf(8.f, y3, 2.f * y1);
-            const float e3 = fmaf(0.25f, y2, y0), o3 = fmaf(0.125f, y3, 0.5f * y1);
-            ys[hb_][0] = e2 + o2;
-            ys[hb_][1] = e2 - o2;
-            ys[hb_][2] = e3 + o3;
-            ys[hb_][3] = e3 - o3;
-          }
-        }
-        const float* xp = xlane + rg * 4 * RPX + tq * 128;
-#pragma unroll
-        for (int kh = 0; kh < 5; ++kh) {
-          const float* p = xp + kh * RPX;
-          const float d0 = p[0], d1 = p[32], d2 = p[64], d3 = p[96], d4 = p[128], d5 = p[160], d6 = p[192], d7 = p[224];
-          float v[4];
-          if (xh == 0) {
-            v[0] = (d6 - d0) + 5.25f * (d2 - d4);
-            v[1] = (d7 - d1) + 5.25f * (d3 - d5);
-            const float t1 = fmaf(-4.25f, d4, d2 + d6), t2 = fmaf(-4.25f, d3, d1 + d5);
-            v[2] = t1 + t2;
-            v[3] = t1 - t2;
-          } else {
-            const float t3 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), t4 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
-            const float t5 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), t6 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
-            v[0] = t3 + t4;
-            v[1] = t3 - t4;
-            v[2] = t5 + t6;
-            v[3] = t5 - t6;
-          }
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            acc[0][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[0][x], acc[0][x][kh], 0, 0, 0);
-            acc[1][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[x], ys[1][x], acc[1][x][kh], 0, 0, 0);
-          }
+      for (int hb_ = 0; hb_ < 2; ++hb_) {
+        const float* dp = dlane + r * WS * VP + hb_ * 16;
+        const float y0 = dp[0], y1 = dp[VP], y2 = dp[2 * VP], y3 = dp[3 * VP];
+        if (xh == 0) {
+          const float e = y0 + y2, o = y1 + y3;
+          ys[hb_][0] = y0;
+          ys[hb_][1] = y3;
+          ys[hb_][2] = e + o;
+          ys[hb_][3] = e - o;
+        } else {
+          const float e2 = fmaf(4.f, y2, y0), o2 = fmaf(8.f, y3, 2.f * y1);
+          const float e3 = fmaf(0.25f, y2, y0), o3 = fmaf(0.125f, y3, 0.5f * y1);
+          ys[hb_][0] = e2 + o2;
+          ys[hb_][1] = e2 - o2;
+          ys[hb_][2] = e3 + o3;
+          ys[hb_][3] = e3 - o3;
         }
       }
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          acc[0][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[kh][x], ys[0][x], acc[0][x][kh], 0, 0, 0);
+          acc[1][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[kh][x], ys[1][x], acc[1][x][kh], 0, 0, 0);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) win[k][x] = win[k + 1][x];
     }
   }
 
