@@ -87,7 +87,8 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
  *   "direct_conv" 0|1 (1 = no Winograd kernels; also env MSEGK_DIRECT_CONV=1);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
- *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels) */
+ *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels; "wgrad_wino_rounds" 0 = pick the
+ *   split count that fills whole waves of resident workgroups, the default) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);
 
 /* ---- layout at the boundary ------------------------------------------------ */

@@ -276,7 +276,7 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     return 0;
   }
   if (strcmp(key, "wgrad_wino_rounds") == 0) {
-    ctx->wgrad_wino_rounds = value > 0 ? value : 6;
+    ctx->wgrad_wino_rounds = value > 0 ? value : 0;
     return 0;
   }
   if (strcmp(key, "wgrad_rounds") == 0) {

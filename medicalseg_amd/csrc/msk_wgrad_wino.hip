@@ -527,13 +527,39 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
   const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
   const long chunks = (long)g.N * g.BD * ((g.BH + R - 1) / R) * ((g.BW + WS - 1) / WS);
   const long tasks = 5L * ca_tiles * cb_tiles;
-  long splits = ((long)ctx->num_cu * ctx->wgrad_wino_rounds + tasks - 1) / tasks;  // default 6: ~3 rounds of 2 resident workgroups per CU
-  if (splits > chunks) splits = chunks;
-  if (splits < 1) splits = 1;
   const bool f45 = (g.BW % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
   const int nxi = f45 ? 8 : 6;
   const size_t per = (size_t)nxi * 25 * g.CA * g.CB * sizeof(float);
-  while (splits > 1 && splits * per > ((size_t)1 << 30)) --splits;
+  long splits;
+  if (ctx->wgrad_wino_rounds > 0) {  // manual: ~rounds/2 waves of the 2 resident workgroups per CU
+    splits = ((long)ctx->num_cu * ctx->wgrad_wino_rounds + tasks - 1) / tasks;
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && splits * per > ((size_t)1 << 30)) --splits;
+  } else {
+    // All workgroups do the same work, two are resident per CU (242 VGPRs), so the kernel advances in waves of
+    // slots = 2 * num_cu workgroups: time ~ ceil(tasks * splits / slots) * chunks_per_split * t_chunk, and every
+    // split adds one slab to write and to reduce.  Measured on MI355X: t_chunk ~13.5 us with both slots busy, the
+    // reduce ~1 ns per KB of slab.  (A fixed 3 waves -- the first policy -- cost 4-40 % per layer: 515 workgroups
+    // on 512 slots is two waves.)
+    const long slots = 2L * ctx->num_cu;
+    long smax = chunks;
+    if (smax > (long)(((size_t)1 << 30) / per)) smax = (long)(((size_t)1 << 30) / per);
+    if (smax > slots * 6 / tasks + 1) smax = slots * 6 / tasks + 1;
+    if (smax < 1) smax = 1;
+    double best = 1e30;
+    splits = 1;
+    for (long s_ = 1; s_ <= smax; ++s_) {
+      const long c_ = (chunks + s_ - 1) / s_;
+      if ((chunks + c_ - 1) / c_ != s_) continue;
+      const long waves = (tasks * s_ + slots - 1) / slots;
+      const double cost = (double)waves * c_ * 13.5e-6 + (double)s_ * per * 1e-12;
+      if (cost < best) {
+        best = cost;
+        splits = s_;
+      }
+    }
+  }
   const int cps = (int)((chunks + splits - 1) / splits);
   splits = (chunks + cps - 1) / cps;
   if (chunks > 0x7fffffff) return 0;

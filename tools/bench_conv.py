@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--wgrad-chunk", type=int, default=-1)
     ap.add_argument("--impl", type=int, default=0, help="conv_impl knob (10 = force Winograd halo kernel, 11 = direct only, 12 = Winograd wgrad)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--profile", action="store_true", help="also print the per-kernel HIP-event breakdown of each case")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="extra msk_set_option knobs")
     a = ap.parse_args()
     from medicalseg_amd._lib import MskConvDesc
     from medicalseg_amd.device import Tensor, get_device
@@ -28,6 +30,9 @@ def main():
     dev.set_option("wgrad_chunk", a.wgrad_chunk)
     dev.set_option("wgrad_async", 0)
     dev.set_option("conv_impl", a.impl)
+    for kv in a.opt:
+        key, val = kv.split("=")
+        dev.set_option(key, int(val))
     n, s, c, k = a.n, a.size, a.c, a.k
     vox = n * s ** 3
     mk = lambda: Tensor(dev, dev.malloc(vox * c * 4), n, s, s, s, c, c, None)
@@ -53,6 +58,16 @@ def main():
         for _ in range(a.iters):
             fn()
         ms = dev.timer_stop() / a.iters
+        if a.profile:
+            dev.set_option("prof_only_halo", 0)
+            dev.prof_reset()
+            dev.prof_enable(True)
+            for _ in range(a.iters):
+                fn()
+            dev.sync()
+            dev.prof_enable(False)
+            for tag, (cnt, tms) in sorted(dev.prof_report().items(), key=lambda kv: -kv[1][1]):
+                print(f"    {tag:32s} x{cnt // a.iters}  {tms / a.iters:7.3f} ms")
         print(f"c={c} {n}x{s}^3 k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
 
 
