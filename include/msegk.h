@@ -261,6 +261,13 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);   /* joins the
 /* SyncBatchNorm backward sums (2*C floats, produced on the main stream): same reduction WITHOUT the join,
  * so the 24 per-step statistics exchanges do not serialise the side stream */
 int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count);
+/* Gradient buckets, overlapped with the rest of backward (the Paddle reducer's role behind core/train.py:82-85):
+ * the sum is enqueued on the context's COMMUNICATION stream with its own communicator (ncclCommSplit of the first,
+ * so it never queues behind the SyncBatchNorm exchanges of the compute stream); it starts after everything enqueued so
+ * far on the compute and weight-gradient streams and does not block either.  msk_dp_wait makes the compute stream
+ * wait for all outstanding buckets (call it before the optimizer); msk_sync implies it. */
+int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count);
+int msk_dp_wait(msk_ctx* ctx);
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank);
 int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root);
 int msk_dp_barrier(msk_ctx* ctx);

@@ -100,6 +100,8 @@ SIGNATURES = {
     "msk_dp_init": (_i, [_vp, C.c_char_p, _i, _i]),
     "msk_dp_allreduce_sum": (_i, [_vp, _vp, _sz]),
     "msk_dp_allreduce_stats": (_i, [_vp, _vp, _sz]),
+    "msk_dp_allreduce_async": (_i, [_vp, _vp, _sz]),
+    "msk_dp_wait": (_i, [_vp]),
     "msk_dp_allgather": (_i, [_vp, _vp, _vp, _sz]),
     "msk_dp_broadcast": (_i, [_vp, _vp, _sz, _i]),
     "msk_dp_barrier": (_i, [_vp]),

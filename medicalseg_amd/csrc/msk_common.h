@@ -60,7 +60,12 @@ struct msk_ctx {
   bool wgrad_async = false;
   bool side_dirty = false;
   // data parallel
-  void* comm = nullptr;  // ncclComm_t
+  void* comm = nullptr;  // ncclComm_t (compute stream: SyncBatchNorm exchanges, broadcast, barrier)
+  // gradient buckets: second communicator on its own stream, overlapped with the rest of backward
+  void* comm_grad = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr;
+  bool comm_pending = false;
   int rank = 0, world = 1;
   int num_cu = 256;
 };
@@ -74,6 +79,7 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 int msk_join_side_impl(msk_ctx* ctx);
+int msk_dp_wait_impl(msk_ctx* ctx);
 
 // Redirect launches of the enclosed scope to the side stream (with its own scratch) after making
 // it wait for everything enqueued so far on the main stream.

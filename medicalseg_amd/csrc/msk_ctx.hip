@@ -75,6 +75,15 @@ void msk_prof_end(msk_ctx* ctx) {
   if (ctx->prof_pending.size() > 4096) drain_prof(ctx);
 }
 
+int msk_dp_wait_impl(msk_ctx* ctx) {
+  if (ctx->comm_pending) {
+    MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_done, ctx->comm_stream));
+    MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_done, 0));
+    ctx->comm_pending = false;
+  }
+  return 0;
+}
+
 int msk_join_side_impl(msk_ctx* ctx) {
   if (ctx->side_dirty) {
     MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
@@ -148,6 +157,7 @@ const char* msk_last_error(msk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_msk
 
 int msk_sync(msk_ctx* ctx) {
   if (msk_join_side_impl(ctx) != 0) return -1;
+  if (msk_dp_wait_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -170,6 +180,7 @@ int msk_malloc(msk_ctx* ctx, size_t bytes, void** out) {
 int msk_free(msk_ctx* ctx, void* p) {
   if (!p) return 0;
   if (msk_join_side_impl(ctx) != 0) return -1;
+  if (msk_dp_wait_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MSK_CHECK_HIP(ctx, hipFree(p));
   return 0;

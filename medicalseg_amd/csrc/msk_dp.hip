@@ -35,6 +35,15 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   ctx->comm = (void*)comm;
   ctx->rank = rank;
   ctx->world = world;
+  // second communicator + stream for the gradient buckets (collective: every rank is inside msk_dp_init)
+  ncclComm_t comm_grad;
+  MSK_CHECK_NCCL(ctx, ncclCommSplit(comm, 0, rank, &comm_grad, nullptr));
+  ctx->comm_grad = (void*)comm_grad;
+  MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_main, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_side, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+  ctx->comm_pending = false;
   return 0;
 }
 
@@ -45,6 +54,24 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
 }
+
+int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
+  MSK_REQUIRE(ctx, ctx->comm_grad != nullptr, "msk_dp_init not called");
+  if (count == 0) return 0;
+  // the bucket's gradients come from the compute stream (data-gradient chain, bias/BN/PReLU gradients) and from the
+  // weight-gradient side stream: wait for the current tail of both, block neither
+  MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_main, ctx->stream));
+  MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_main, 0));
+  if (ctx->side_dirty) {
+    MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_side, ctx->side));
+    MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_side, 0));
+  }
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm_grad, ctx->comm_stream));
+  ctx->comm_pending = true;
+  return 0;
+}
+
+int msk_dp_wait(msk_ctx* ctx) { return msk_dp_wait_impl(ctx); }
 
 int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
   // per-channel BatchNorm-backward sums: produced on the main stream, so the weight-gradient side stream
@@ -79,6 +106,17 @@ int msk_dp_barrier(msk_ctx* ctx) {
 }
 
 int msk_dp_destroy(msk_ctx* ctx) {
+  if (ctx && ctx->comm_grad) {
+    hipStreamSynchronize(ctx->comm_stream);
+    ncclCommDestroy((ncclComm_t)ctx->comm_grad);
+    ctx->comm_grad = nullptr;
+    hipStreamDestroy(ctx->comm_stream);
+    hipEventDestroy(ctx->ev_comm_main);
+    hipEventDestroy(ctx->ev_comm_side);
+    hipEventDestroy(ctx->ev_comm_done);
+    ctx->comm_stream = nullptr;
+    ctx->comm_pending = false;
+  }
   if (ctx && ctx->comm) {
     ncclCommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;

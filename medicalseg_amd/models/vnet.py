@@ -214,6 +214,7 @@ class VNet(nn.Layer):
 
         self.pretrained = pretrained
         self._post_backward_hooks = []
+        self._grad_ready_hooks = []      # called with (model, block) once a block's backward is enqueued (parallel.py)
         self._build()
         self.init_weight()
 
@@ -281,19 +282,26 @@ class VNet(nn.Layer):
 
     def backward(self, dlogits: Tensor):
         """Adjoint of forward; accumulates parameter gradients into the flat arena."""
-        self.out_tr.backward(dlogits)
-        self.up_tr32.backward(self._feat.grad)
-        self.up_tr64.backward(self.up_tr32._x.grad)
-        self.up_tr128.backward(self.up_tr64._x.grad)
-        self.up_tr256.backward(self.up_tr128._x.grad)
         out16, out32, out64, out128, out256 = self._acts
-        self.down_tr256.backward(out256.grad)
-        self.down_tr128.backward(out128.grad)
-        self.down_tr64.backward(out64.grad)
-        self.down_tr32.backward(out32.grad)
-        self.in_tr.backward(out16.grad)
+        for block, dout in ((self.out_tr, lambda: dlogits),
+                            (self.up_tr32, lambda: self._feat.grad),
+                            (self.up_tr64, lambda: self.up_tr32._x.grad),
+                            (self.up_tr128, lambda: self.up_tr64._x.grad),
+                            (self.up_tr256, lambda: self.up_tr128._x.grad),
+                            (self.down_tr256, lambda: out256.grad),
+                            (self.down_tr128, lambda: out128.grad),
+                            (self.down_tr64, lambda: out64.grad),
+                            (self.down_tr32, lambda: out32.grad),
+                            (self.in_tr, lambda: out16.grad)):
+            block.backward(dout())
+            self._grads_ready(block)
         for hook in self._post_backward_hooks:
             hook(self)
+
+    def _grads_ready(self, block):
+        """The block's parameter gradients are all enqueued: data parallelism may put them on the wire."""
+        for hook in self._grad_ready_hooks:
+            hook(self, block)
 
     def test(self):
         np.random.seed(1)

@@ -78,6 +78,7 @@ class VNetDeepSup(VNet):
 
         self.pretrained = pretrained
         self._post_backward_hooks = []
+        self._grad_ready_hooks = []
         self._build()
         self.init_weight()
 
@@ -119,6 +120,7 @@ class VNetDeepSup(VNet):
             return
         interpolate_trilinear_backward(dresized, head)
         conv.run_backward(feat, head.grad, need_dx=True)
+        self._grads_ready(conv)
 
     def backward(self, dlogits):
         """dlogits: the four logit gradients in forward order (None = output unused)."""
@@ -127,21 +129,25 @@ class VNetDeepSup(VNet):
         dout, dd1, dd2, dd3 = dlogits
         u256, u128, u64 = self._ups
         h1, h2, h3 = self._heads
+        def run(block, dy):
+            block.backward(dy)
+            self._grads_ready(block)
+
         if dout is not None:
-            self.out_tr32.backward(dout)
-            self.up_tr32.backward(self._feat.grad)           # -> u64.grad (first writer)
+            run(self.out_tr32, dout)
+            run(self.up_tr32, self._feat.grad)               # -> u64.grad (first writer)
         self._head_backward(self.out_tr64, u64, h3, dd3)     # accumulates into u64.grad
-        self.up_tr64.backward(u64.grad)
+        run(self.up_tr64, u64.grad)
         self._head_backward(self.out_tr128, u128, h2, dd2)
-        self.up_tr128.backward(u128.grad)
+        run(self.up_tr128, u128.grad)
         self._head_backward(self.out_tr256, u256, h1, dd1)
-        self.up_tr256.backward(u256.grad)
+        run(self.up_tr256, u256.grad)
         out16, out32, out64, out128, out256 = self._acts
-        self.down_tr256.backward(out256.grad)
-        self.down_tr128.backward(out128.grad)
-        self.down_tr64.backward(out64.grad)
-        self.down_tr32.backward(out32.grad)
-        self.in_tr.backward(out16.grad)
+        run(self.down_tr256, out256.grad)
+        run(self.down_tr128, out128.grad)
+        run(self.down_tr64, out64.grad)
+        run(self.down_tr32, out32.grad)
+        run(self.in_tr, out16.grad)
         for hook in self._post_backward_hooks:
             hook(self)
 

@@ -152,15 +152,22 @@ class DataParallel:
     """paddle.DataParallel / fleet.distributed_model replacement.
 
     * parameters and BN buffers are broadcast from rank 0 at wrap time (App. B.9);
-    * after the model's backward the flat gradient arena (182.4 MB for VNet) is summed
-      with ONE RCCL all-reduce on the compute stream and the optimizer applies 1/nranks;
-    * BatchNorm statistics are exchanged inside the layers (SyncBatchNorm semantics)."""
+    * the flat gradient arena (182.4 MB for VNet) is summed in BUCKETS while backward is still running: the model
+      reports every block whose backward has been enqueued (`_grad_ready_hooks`); as soon as the finished blocks form
+      a contiguous tail of the arena of at least `bucket_bytes`, that slice goes to `msk_dp_allreduce_async` (second
+      communicator, communication stream).  Whatever is left is sent after the last block, then the compute stream
+      waits for all buckets (`msk_dp_wait`) before the optimizer, which applies 1/nranks;
+    * BatchNorm statistics are exchanged inside the layers (SyncBatchNorm semantics).
 
-    def __init__(self, model):
+    `overlap=False` keeps the single all-reduce after backward on the compute stream."""
+
+    def __init__(self, model, overlap=True, bucket_bytes=16 << 20, force=False):
         self._layers = model
         dev = model.dev
         self.dev = dev
-        if dev.world > 1:
+        self.bucket_elems = max(1, int(bucket_bytes) // 4)
+        self.buckets_last_step = []      # [(offset, count)] of the previous backward, for tests / logs
+        if dev.world > 1 or force:       # force: exercise the hooks on a 1-rank communicator (tests)
             dev.call("msk_dp_broadcast", C.c_void_p(model.arena.value_ptr), C.c_size_t(model.arena.count), 0)
             if model.buffer_arena.count:
                 dev.call("msk_dp_broadcast", C.c_void_p(model.buffer_arena.value_ptr),
@@ -169,11 +176,56 @@ class DataParallel:
             if fa is not None and fa.count:
                 dev.call("msk_dp_broadcast", C.c_void_p(fa.value_ptr), C.c_size_t(fa.count), 0)
             model.arena.grad_scale = 1.0 / dev.world
-            model._post_backward_hooks.append(self._allreduce)
+            if os.environ.get("MSEGK_DP_OVERLAP", "1") == "0":   # escape hatch: single all-reduce after backward
+                overlap = False
+            if overlap and hasattr(model, "_grad_ready_hooks"):
+                params = model.arena.params
+                self._index = {id(p): i for i, p in enumerate(params)}
+                self._start = [p.offset for p in params] + [model.arena.count]
+                self._done = [False] * len(params)
+                self._tail = len(params)     # params[_tail:] are already on the wire
+                self._members = {}
+                self._sent = []
+                model._grad_ready_hooks.append(self._block_ready)
+                model._post_backward_hooks.append(self._finish)
+            else:
+                model._post_backward_hooks.append(self._allreduce)
 
+    # -- single all-reduce (overlap=False) ------------------------------------------------
     def _allreduce(self, model):
         a = model.arena
         self.dev.call("msk_dp_allreduce_sum", C.c_void_p(a.grad_ptr), C.c_size_t(a.count))
+        self.buckets_last_step = [(0, a.count)]
+
+    # -- bucketed, overlapped --------------------------------------------------------------
+    def _send(self, lo_idx, hi_idx):
+        a = self._layers.arena
+        lo, hi = self._start[lo_idx], self._start[hi_idx]
+        if hi > lo:
+            self.dev.call("msk_dp_allreduce_async", C.c_void_p(a.grad_ptr + 4 * lo), C.c_size_t(hi - lo))
+            self._sent.append((lo, hi - lo))
+        self._tail = lo_idx
+
+    def _block_ready(self, model, block):
+        idx = self._members.get(id(block))
+        if idx is None:
+            idx = [self._index[id(p)] for p in block.parameters() if id(p) in self._index]
+            self._members[id(block)] = idx
+        for i in idx:
+            self._done[i] = True
+        lo = self._tail
+        while lo > 0 and self._done[lo - 1]:
+            lo -= 1
+        if lo < self._tail and (self._start[self._tail] - self._start[lo] >= self.bucket_elems or lo == 0):
+            self._send(lo, self._tail)
+
+    def _finish(self, model):
+        if self._tail > 0:               # everything is enqueued by now, finished-or-not bookkeeping aside
+            self._send(0, self._tail)
+        self.dev.call("msk_dp_wait")
+        self.buckets_last_step, self._sent = self._sent, []
+        self._done = [False] * len(self._done)
+        self._tail = len(self._done)
 
     def __call__(self, *args, **kw):
         return self._layers(*args, **kw)

@@ -51,4 +51,4 @@ typedef struct { void* p; int32_t n, d, h, w, c, ld; } fake_tensor;
 int msk_interp_scratch_bytes(void* c, fake_tensor s, fake_tensor d, size_t* b) {
   (void)c; *b = ((size_t)d.n * d.d * d.h * s.w + (size_t)d.n * d.d * s.h * s.w) * s.c * 4; return 0;
 }
-NOOP(msk_dp_init) NOOP(msk_dp_allreduce_sum) NOOP(msk_dp_allreduce_stats) NOOP(msk_dp_allgather) NOOP(msk_dp_broadcast) NOOP(msk_dp_barrier) NOOP(msk_dp_destroy)
+NOOP(msk_dp_init) NOOP(msk_dp_allreduce_sum) NOOP(msk_dp_allreduce_stats) NOOP(msk_dp_allreduce_async) NOOP(msk_dp_wait) NOOP(msk_dp_allgather) NOOP(msk_dp_broadcast) NOOP(msk_dp_barrier) NOOP(msk_dp_destroy)

@@ -114,6 +114,41 @@ def test_deepsup_control_flow_and_config(fake_pkg, tmp_path):
     assert "out_tr64.weight_velocity_0" in od and not any(k.startswith("out_tr_all") for k in od)
 
 
+def test_gradient_buckets_partition_the_arena(fake_pkg):
+    """parallel.DataParallel(overlap=True): the slices handed to msk_dp_allreduce_async while backward runs are
+    disjoint, each a tail of what was left, big enough, and together exactly the gradient arena."""
+    from medicalseg_amd import parallel
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet, VNetDeepSup
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 1, 16, 16, 16)).astype(np.float32)
+    y = rng.integers(0, 3, (1, 16, 16, 16)).astype(np.int32)
+    for cls, nout, min_buckets in ((VNet, 1, 4), (VNetDeepSup, 4, 3)):
+        model = cls(num_classes=3)
+        ddp = parallel.DataParallel(model, force=True, bucket_bytes=16 << 20)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])] * nout, "coef": [1.0 / nout] * nout}
+        for _ in range(2):                                  # the bookkeeping resets between steps
+            ll, _ = loss_computation(ddp(x), to_tensor(y), losses)
+            sum(ll).backward()
+            sent = ddp.buckets_last_step
+            assert len(sent) >= min_buckets, sent
+            end = model.arena.count
+            for off, cnt in sent:                           # sent from the back of the arena to the front
+                assert cnt > 0 and off + cnt == end, (off, cnt, end)
+                end = off
+            assert end == 0
+            assert all(cnt * 4 >= 16 << 20 for _, cnt in sent[:-1])
+            model.clear_gradients()
+    # overlap off: one all-reduce of the whole arena after backward
+    model = VNet(num_classes=3)
+    ddp = parallel.DataParallel(model, force=True, overlap=False)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    ll, _ = loss_computation(ddp(x), to_tensor(y), losses)
+    sum(ll).backward()
+    assert ddp.buckets_last_step == [(0, model.arena.count)]
+
+
 def test_stale_activation_is_detected(fake_pkg):
     from medicalseg_amd._lib import MskError
     from medicalseg_amd.models import VNet
