@@ -101,6 +101,16 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst);
  *   y[N,OD,OH,OW,Cout] = conv(x[N,ID,IH,IW,Cin], w[Cout,Cin,k]) + bias        */
 int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
                    const float* bias /*nullable*/, msk_tensor y);
+/* Inference path (core/infer.py:62-94, core/val.py:89-110 run the net in eval mode): the chain
+ * Conv3D -> BatchNorm3D(running statistics) -> PReLU of vnet.py:36-41 as ONE convolution.
+ *   msk_conv_fold_bn:    w'[co][...] = w[co][...] * scale[co];  b'[co] = b[co] * scale[co] + shift[co]
+ *                        (scale/shift from msk_bn_eval_coeffs; w canonical [Cout][inner = Cin * taps]; bias nullable)
+ *   msk_conv3d_fwd_act:  y = PReLU_slope(conv(x, w) + bias); the Winograd kernels apply the slope in their epilogue,
+ *                        every other kernel is followed by one in-place pass (same result).  slope nullable.        */
+int msk_conv_fold_bn(msk_ctx* ctx, const float* w, const float* bias, const float* scale, const float* shift,
+                     int cout, long inner, float* w_folded, float* b_folded);
+int msk_conv3d_fwd_act(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias,
+                       const float* prelu_slope, msk_tensor y);
 /* autograd of the above (core/train.py:139 loss.backward()):
  *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,

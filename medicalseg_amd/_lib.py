@@ -63,6 +63,8 @@ SIGNATURES = {
     "msk_ncdhw_to_ndhwc": (_i, [_vp, _vp, _T]),
     "msk_ndhwc_to_ncdhw": (_i, [_vp, _T, _vp]),
     "msk_conv3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),
+    "msk_conv_fold_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp, _vp]),
+    "msk_conv3d_fwd_act": (_i, [_vp, _CD, _T, _vp, _vp, _vp, _T]),
     "msk_conv3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
     "msk_conv3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_convT3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),

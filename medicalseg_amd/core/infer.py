@@ -2,14 +2,19 @@
 import collections.abc
 import ctypes as C
 
+from .. import nn
 from ..device import IntTensor
 
 
 def inference(model, im, ori_shape=None, transforms=None):
     """Returns (pred int32 [N,1,D,H,W] on device, logits Tensor).  Reverse-resize of the
     reference (infer.py:43-59,88-90) is only reachable with Resize3D in the val transforms,
-    which no shipped config uses (and which fails upstream): it raises here."""
-    logits = model(im)
+    which no shipped config uses (and which fails upstream): it raises here.
+
+    An eval-mode model runs its conv -> BN -> PReLU units as single folded convolutions here
+    (nn.fused_inference); a model left in training mode runs the ordinary kernels."""
+    with nn.fused_inference():
+        logits = model(im)
     if not isinstance(logits, collections.abc.Sequence):
         raise TypeError("The type of logits must be one of collections.abc.Sequence, e.g. list, tuple. "
                         "But received {}".format(type(logits)))

@@ -6,6 +6,7 @@ import time
 
 import numpy as np
 
+from .. import nn
 from ..datasets import DataLoader
 from ..device import to_tensor
 from ..utils import TimeAverager, logger, loss_computation, save_array
@@ -31,24 +32,25 @@ def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_
     mdice = 0.0
     channel_dice_array = np.array([])
     loss_all = 0.0
-    for it, (im, label, idx) in enumerate(loader):
-        reader_cost_averager.record(time.time() - batch_start)
-        label_t = to_tensor(label.astype('int32'))
-        pred, logits = infer.inference(model, to_tensor(im), ori_shape=label.shape[-3:],
-                                       transforms=eval_dataset.transforms.transforms)
-        loss, per_channel_dice = loss_computation(logits, label_t, new_loss)
-        loss = sum(loss)
-        loss_all += loss.numpy()
-        pcd = np.asarray(per_channel_dice)
-        mdice += np.mean(pcd)
-        channel_dice_array = pcd.copy() if channel_dice_array.size == 0 else channel_dice_array + pcd
-        if it < 5 and save_dir is not None:
-            save_array(save_path=os.path.join(save_dir, str(it)),
-                       save_content={'pred': pred.numpy(), 'label': label, 'img': im}, form=('npy', ))
-        batch_cost_averager.record(time.time() - batch_start, num_samples=len(label))
-        reader_cost_averager.reset()
-        batch_cost_averager.reset()
-        batch_start = time.time()
+    with nn.fused_inference():       # one scope for the whole set: BN is folded into the conv weights once
+        for it, (im, label, idx) in enumerate(loader):
+            reader_cost_averager.record(time.time() - batch_start)
+            label_t = to_tensor(label.astype('int32'))
+            pred, logits = infer.inference(model, to_tensor(im), ori_shape=label.shape[-3:],
+                                           transforms=eval_dataset.transforms.transforms)
+            loss, per_channel_dice = loss_computation(logits, label_t, new_loss)
+            loss = sum(loss)
+            loss_all += loss.numpy()
+            pcd = np.asarray(per_channel_dice)
+            mdice += np.mean(pcd)
+            channel_dice_array = pcd.copy() if channel_dice_array.size == 0 else channel_dice_array + pcd
+            if it < 5 and save_dir is not None:
+                save_array(save_path=os.path.join(save_dir, str(it)),
+                           save_content={'pred': pred.numpy(), 'label': label, 'img': im}, form=('npy', ))
+            batch_cost_averager.record(time.time() - batch_start, num_samples=len(label))
+            reader_cost_averager.reset()
+            batch_cost_averager.reset()
+            batch_start = time.time()
     total_iters = max(total_iters, 1)
     mdice /= total_iters
     channel_dice_array = channel_dice_array / total_iters

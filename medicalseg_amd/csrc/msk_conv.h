@@ -19,6 +19,8 @@ struct GConv {
   const float* bias;  // [CN] or null
   int accumulate;
   int flip;           // MFMA halo path: taps are enumerated flipped (conv dgrad as a 'same' conv)
+  const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
+                      // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
 };
 
 // Weight gradient: dW[cb][ca][tap] (+)= sum_opos A[opos*s - p + k][ca] * B[opos][cb]

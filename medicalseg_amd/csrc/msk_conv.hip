@@ -240,7 +240,7 @@ int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& i
 }
 
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
-int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
+int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag, bool* act_fused) {
   const int taps = g.kd * g.kh * g.kw;
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 &&
       g.ph == 0 && g.pw == 0 && g.CK <= 8 && g.CN <= 8) {
@@ -262,7 +262,10 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
     if (r == 1) return 0;
     r = (ctx->conv_impl == 11 || ctx->no_winograd) ? 0 : msk_gconv_halo_wino(ctx, g, w, A, B, swap);  // 11 = direct kernel only (A/B)
     if (r < 0) return r;
-    if (r == 1) return 0;
+    if (r == 1) {
+      *act_fused = true;  // the Winograd epilogues apply g.prelu
+      return 0;
+    }
     r = msk_gconv_halo_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;
@@ -291,6 +294,44 @@ int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap,
   hipLaunchKernelGGL(gconv_direct_k, dim3(grid_for(total, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+// y = prelu(y) in place: the activation of msk_conv3d_fwd_act behind the kernels without a fused epilogue
+__global__ void __launch_bounds__(256)
+prelu_inplace_k(float* __restrict__ y, int ld, int C, long voxels, const float* __restrict__ slope) {
+  const long total = voxels * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / C;
+    const int c = (int)(i - v * C);
+    float* o = y + v * ld + c;
+    const float t = *o;
+    if (t < 0.f) *o = t * slope[c];
+  }
+}
+
+int run_gconv_one(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag) {
+  bool fused = false;
+  if (int rc = run_gconv_dispatch(ctx, g, w, A, B, swap, tag, &fused)) return rc;
+  if (g.prelu && !fused) {
+    const long voxels = (long)g.N * g.DD * g.DH * g.DW;
+    msk_launch_scope ls(ctx, "prelu_inplace");
+    hipLaunchKernelGGL(prelu_inplace_k, dim3(grid_for(voxels * g.CN, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g.dst,
+                       g.dld, g.CN, voxels, g.prelu);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+// w'[co][...] = w[co][...] * scale[co],  b'[co] = b[co] * scale[co] + shift[co]   (eval-mode BatchNorm folded into
+// the convolution in front of it; canonical Conv3D weight layout [Cout][Cin * taps])
+__global__ void __launch_bounds__(256)
+fold_bn_k(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
+          const float* __restrict__ shift, int cout, long inner, float* __restrict__ wf, float* __restrict__ bf) {
+  const long total = (long)cout * inner;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    wf[i] = w[i] * scale[i / inner];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < cout) bf[t] = (b ? b[t] : 0.f) * scale[t] + shift[t];
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
@@ -447,6 +488,30 @@ int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* d
 }
 
 extern "C" {
+
+int msk_conv_fold_bn(msk_ctx* ctx, const float* w, const float* bias, const float* scale, const float* shift, int cout,
+                     long inner, float* w_folded, float* b_folded) {
+  MSK_REQUIRE(ctx, w && scale && shift && w_folded && b_folded && cout > 0 && inner > 0, "bad arguments");
+  msk_launch_scope ls(ctx, "fold_bn");
+  hipLaunchKernelGGL(fold_bn_k, dim3(grid_for((long)cout * inner, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, bias, scale,
+                     shift, cout, inner, w_folded, b_folded);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_conv3d_fwd_act(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias,
+                       const float* prelu_slope, msk_tensor y) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.prelu = prelu_slope;
+  return run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct");
+}
 
 int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;

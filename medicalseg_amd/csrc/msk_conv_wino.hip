@@ -28,6 +28,7 @@ struct WinoArgs {
   const float4* um;  // [kd*5+kh][KC][2][xi][npad] float4 (k = kc*8 + h*4 + q)
   int KC, npad;
   const float* bias;
+  const float* prelu;  // per-channel slope applied after bias (inference epilogue), or null
   int accumulate;
   int tiles_d, tiles_h, tiles_w, nblk;
   int vec;
@@ -211,6 +212,7 @@ conv_halo_wino_k(WinoArgs a) {
   const int co = nt * 32 + li;
   if (co < a.CN) {
     const float bv = a.bias ? a.bias[co] : 0.f;
+    const float slope = a.prelu ? a.prelu[co] : 1.f;
     const int gd = d0 + wave;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -230,11 +232,11 @@ conv_halo_wino_k(WinoArgs a) {
         float* o = a.dst + vox * a.dld + co;
         float r0 = y0 + bv;
         if (a.accumulate) r0 += o[0];
-        o[0] = r0;
+        o[0] = r0 > 0.f ? r0 : slope * r0;
         if (gw + 1 < a.W) {
           float r1 = y1 + bv;
           if (a.accumulate) r1 += o[a.dld];
-          o[a.dld] = r1;
+          o[a.dld] = r1 > 0.f ? r1 : slope * r1;
         }
       }
     }
@@ -413,6 +415,7 @@ conv_halo_wino4_k(WinoArgs a) {
   const int co = nt * 32 + li;
   if (co < a.CN) {
     const float bv = a.bias ? a.bias[co] : 0.f;
+    const float slope = a.prelu ? a.prelu[co] : 1.f;
     const int gd = d0 + wave;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -437,7 +440,7 @@ conv_halo_wino4_k(WinoArgs a) {
               float* o = a.dst + (vox + i) * a.dld + co;
               float r = y[i] + bv;
               if (a.accumulate) r += *o;
-              *o = r;
+              *o = r > 0.f ? r : slope * r;
             }
           }
         }
@@ -448,7 +451,7 @@ conv_halo_wino4_k(WinoArgs a) {
 
 __global__ void __launch_bounds__(256)
 wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int CN, const float* __restrict__ bias,
-                     float* __restrict__ dst, int dld, int accumulate) {
+                     const float* __restrict__ prelu, float* __restrict__ dst, int dld, int accumulate) {
   const long total = voxels * CN;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long v = i / CN;
@@ -456,7 +459,9 @@ wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels,
     float s = bias ? bias[c] : 0.f;
     for (int z = 0; z < ksplit; ++z) s += partial[(long)z * total + i];  // fixed order
     float* o = dst + v * dld + c;
-    *o = accumulate ? *o + s : s;
+    if (accumulate) s += *o;
+    if (prelu && s < 0.f) s *= prelu[c];
+    *o = s;
   }
 }
 
@@ -494,7 +499,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
   a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CK = g.CK; a.CN = g.CN;
   a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
-  a.bias = g.bias; a.accumulate = g.accumulate;
+  a.bias = g.bias; a.prelu = g.prelu; a.accumulate = g.accumulate;
   a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / twid; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted), like conv_halo_mfma_k
@@ -531,7 +536,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
     long blocks = (voxels * g.CN + 255) / 256;
     if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
     hipLaunchKernelGGL(wino_splitk_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.partial,
-                       a.ksplit, voxels, g.CN, g.bias, g.dst, g.dld, g.accumulate);
+                       a.ksplit, voxels, g.CN, g.bias, g.prelu, g.dst, g.dld, g.accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 1;

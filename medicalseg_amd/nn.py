@@ -401,6 +401,27 @@ class Dropout3D(Layer):
 # ----------------------------------------------------------------------------------------
 # fused execution units
 # ----------------------------------------------------------------------------------------
+_FUSED_INFERENCE = {"on": False, "epoch": 0}
+
+
+class fused_inference:
+    """Context manager: inside it, eval-mode conv -> BN -> PReLU units run as one folded convolution
+    (`ConvBNAct._forward_folded`).  `core.val.evaluate` and `core.infer.inference` use it; nothing that calls
+    backward may.  The folded weights are rebuilt on first use in every scope, so parameter or running-statistics
+    changes between scopes are always picked up."""
+
+    def __enter__(self):
+        self._prev = _FUSED_INFERENCE["on"]
+        _FUSED_INFERENCE["on"] = True
+        if not self._prev:               # a nested scope keeps the outer scope's folded weights
+            _FUSED_INFERENCE["epoch"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _FUSED_INFERENCE["on"] = self._prev
+        return False
+
+
 def _fp(ptr):
     return C.c_void_p(ptr) if ptr else None
 
@@ -414,8 +435,36 @@ class ConvBNAct:
     def __init__(self, conv, bn: BatchNorm3D, act: PReLU | None):
         self.conv, self.bn, self.act = conv, bn, act
 
+    def _forward_folded(self, x: Tensor, out: Tensor | None) -> Tensor:
+        """Inference: eval-mode BatchNorm folded into the convolution, PReLU in the conv epilogue --
+        one kernel, no pre-activation tensor.  The folded weights are rebuilt once per `fused_inference()` scope."""
+        dev, conv, bn = x.dev, self.conv, self.bn
+        if x.c != conv.cin:
+            raise ValueError(f"Conv3D expects {conv.cin} input channels, got {x.c}")
+        if getattr(self, "_fold_epoch", None) != _FUSED_INFERENCE["epoch"]:
+            if not hasattr(self, "_fold_w"):
+                self._fold_w = dev.malloc(conv.weight.size * 4)
+                self._fold_b = dev.malloc(conv.cout * 4)
+            sc, Cn = bn.scratch(dev), bn.num_features
+            dev.call("msk_bn_eval_coeffs", Cn, _fp(bn.weight.ptr), _fp(bn.bias.ptr), _fp(bn._mean.ptr),
+                     _fp(bn._variance.ptr), C.c_float(bn.epsilon), _fp(sc["mean"]), _fp(sc["invstd"]),
+                     _fp(sc["scale"]), _fp(sc["shift"]))
+            dev.call("msk_conv_fold_bn", _fp(conv.weight.ptr), _fp(conv.bias.ptr), _fp(sc["scale"]), _fp(sc["shift"]),
+                     conv.cout, C.c_long(conv.weight.size // conv.cout), _fp(self._fold_w), _fp(self._fold_b))
+            self._fold_epoch = _FUSED_INFERENCE["epoch"]
+        if out is None:
+            od, oh, ow = conv.out_dims(x)
+            out = Tensor.empty(dev, x.n, od, oh, ow, conv.cout)
+        alpha = self.act._weight.ptr if self.act is not None else None
+        dev.call("msk_conv3d_fwd_act", conv.desc(), x.msk(), _fp(self._fold_w), _fp(self._fold_b), _fp(alpha), out.msk())
+        self.x, self.res, self.y, self.out, self.bn_mode = x, None, None, out, 3   # 3: no backward through this
+        return out
+
     def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None) -> Tensor:
         dev = x.dev
+        if (_FUSED_INFERENCE["on"] and not self.bn.training and res is None and type(self.conv) is Conv3D
+                and (self.act is None or isinstance(self.act, PReLU))):
+            return self._forward_folded(x, out)
         self.x, self.res = x, res
         y = self.conv.run_forward(x)
         self.y = y
@@ -446,6 +495,9 @@ class ConvBNAct:
 
     def backward(self, dout: Tensor, need_dx=True, res_needs_grad=True):
         """dout: gradient w.r.t. the unit's output (may be a channel slice)."""
+        if self.bn_mode == 3:
+            raise RuntimeError("backward through a forward pass run under nn.fused_inference() (BN folded into the "
+                               "convolution: no pre-activation tensor was kept)")
         dev = dout.dev
         bn, sc = self.bn, self.bn.scratch(dev)
         Cn = bn.num_features

@@ -388,3 +388,50 @@ def test_winograd_and_direct_kernels_agree_on_a_training_step():
     assert abs(loss_w - loss_d) < 1e-5 * abs(loss_d)
     for a, b in zip(w_w, w_d):
         assert np.abs(a - b).max() < 1e-5 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("model_name", ["VNet", "VNetDeepSup"])
+def test_fused_inference_matches_eval_forward(model_name):
+    """inside nn.fused_inference() the eval-mode net runs conv+BN+PReLU units as single folded
+    convolutions.  Logits agree with the unfused eval forward (2e-5 of max|logit|), the argmax map agrees except
+    at numerical ties, evaluate() -- which uses the fused path -- returns the unfused mDice, a later change of
+    the parameters is picked up by the next scope, and backward through a fused forward is refused."""
+    from medicalseg_amd import models, nn
+    from medicalseg_amd.core import infer
+    from medicalseg_amd.device import to_tensor
+    rng = np.random.default_rng(5)
+    model = getattr(models, model_name)(num_classes=3)
+    state = model.state_dict()
+    for k_, v in state.items():                      # non-trivial running statistics and slopes
+        if k_.endswith("._mean"):
+            state[k_] = rng.standard_normal(v.shape).astype(np.float32) * 0.1
+        elif k_.endswith("._variance"):
+            state[k_] = rng.uniform(0.5, 1.5, v.shape).astype(np.float32)
+        elif "relu" in k_ and k_.endswith("_weight"):
+            state[k_] = rng.uniform(0.1, 0.4, v.shape).astype(np.float32)
+    model.set_state_dict(state)
+    model.eval()
+    x = rng.standard_normal((1, 1, 32, 32, 32)).astype(np.float32)
+    plain = model(to_tensor(x))[0].numpy()
+    with nn.fused_inference():
+        outs = model(to_tensor(x))
+        fused = outs[0].numpy()
+        with pytest.raises(RuntimeError, match="fused_inference"):
+            model.backward(outs[0] if model_name == "VNet" else list(outs))
+    scale = np.abs(plain).max()
+    assert np.abs(fused - plain).max() <= 2e-5 * scale, np.abs(fused - plain).max() / scale
+    pred, logit = infer.inference(model, to_tensor(x))
+    assert np.array_equal(logit.numpy(), fused)                       # inference() takes the fused path itself
+    top2 = np.sort(plain, axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 1e-4 * scale
+    assert np.array_equal(pred.numpy()[:, 0][clear], plain.argmax(1)[clear])
+    # a parameter change between scopes is seen (weights are refolded per scope)
+    state["in_tr.bn1._mean"] = state["in_tr.bn1._mean"] + 0.5
+    name = [k_ for k_ in state if k_.endswith("ops.0.bn1._mean")][0]
+    state[name] = state[name] + 0.5
+    model.set_state_dict(state)
+    plain2 = model(to_tensor(x))[0].numpy()
+    with nn.fused_inference():
+        fused2 = model(to_tensor(x))[0].numpy()
+    assert np.abs(plain2 - plain).max() > 1e-3 * scale
+    assert np.abs(fused2 - plain2).max() <= 2e-5 * np.abs(plain2).max()

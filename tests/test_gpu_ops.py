@@ -461,3 +461,62 @@ def test_wgrad_winograd_f25_matches_oracle(case):
     e1, e2 = rel_err(got, dw_ref), rel_err(got2, 2 * dw_ref)
     print("winograd wgrad rel err %.2e" % e1)
     assert e1 < _conv_tol(M) * 2 and e2 < _conv_tol(M) * 2
+
+
+FOLD_CASES = [
+    # (Cin, Cout, k, pad, (N, D, H, W), kernel that must run)
+    (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue
+    (64, 48, 5, 2, (1, 4, 8, 24), "conv_halo_wino_k"),        # F(2,5) epilogue, Cout not a multiple of 32
+    (128, 128, 5, 2, (1, 4, 8, 16), "conv_splitk_reduce"),    # few tiles -> split K: slope applied in the reduce
+    (16, 8, 3, 1, (1, 6, 7, 9), "prelu_inplace"),             # no Winograd kernel: in-place pass after the conv
+]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_conv_fold_bn_and_fused_prelu_epilogue(case):
+    """Inference path: msk_conv_fold_bn + msk_conv3d_fwd_act == PReLU(BN_eval(conv(x))) of the float64
+    oracle, through every epilogue that applies the slope (both Winograd kernels, the split-K reduce) and through the
+    in-place pass behind the other kernels."""
+    cin, cout, k_, p_, (N, D, H, W), tag = case
+    k, s_, p = (k_,) * 3, (1, 1, 1), (p_,) * 3
+    d = dev()
+    rng = np.random.default_rng(cin + 3 * cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * k_ ** 3)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    mean, var = rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    slope = rng.uniform(0.05, 0.5, cout).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    sh = (1, cout, 1, 1, 1)
+    z = (y - f8(mean).reshape(sh)) / np.sqrt(f8(var).reshape(sh) + 1e-5) * f8(gamma).reshape(sh) + f8(beta).reshape(sh)
+    ref = np.where(z > 0, z, z * f8(slope).reshape(sh))
+    xt, yt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0)
+    wp, bp, wf, bf = vec(w.ravel()), vec(b), vec(np.zeros(w.size)), vec(np.zeros(cout))
+    sc = [vec(np.zeros(cout)) for _ in range(4)]   # mean, invstd, scale, shift
+    d.call("msk_bn_eval_coeffs", cout, vp(vec(gamma)), vp(vec(beta)), vp(vec(mean)), vp(vec(var)), C.c_float(1e-5),
+           vp(sc[0]), vp(sc[1]), vp(sc[2]), vp(sc[3]))
+    d.call("msk_conv_fold_bn", vp(wp), vp(bp), vp(sc[2]), vp(sc[3]), cout, C.c_long(w.size // cout), vp(wf), vp(bf))
+    scale = f8(gamma) / np.sqrt(f8(var) + 1e-5)
+    assert rel_err(vec_back(wf, w.size).reshape(w.shape), f8(w) * scale.reshape(cout, 1, 1, 1, 1)) < 1e-6
+    assert rel_err(vec_back(bf, cout), f8(b) * scale + f8(beta) - f8(mean) * scale) < 1e-6
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd_act", _desc(k, s_, p), xt.msk(), vp(wf), vp(bf), vp(vec(slope)), yt.msk())
+        got = t_to_ncdhw(yt)
+        d.prof_enable(False)
+        rep = d.prof_report()
+        assert rep.get(tag, (0, 0))[0] == 1, rep
+        assert ("prelu_inplace" in rep) == (tag == "prelu_inplace"), rep
+    finally:
+        d.prof_enable(False)
+    e = rel_err(got, ref)
+    print("folded conv rel err %.2e" % e)
+    assert e < _conv_tol(cin * k_ ** 3)
+    # slope NULL: plain convolution with the folded weights
+    d.call("msk_conv3d_fwd_act", _desc(k, s_, p), xt.msk(), vp(wf), vp(bf), None, yt.msk())
+    assert rel_err(t_to_ncdhw(yt), z) < _conv_tol(cin * k_ ** 3)
