@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c", type=int, default=32)
+    ap.add_argument("--cn", type=int, default=0, help="output channels (default: --c)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--n", type=int, default=2)
     ap.add_argument("--k", type=int, default=5)
@@ -34,18 +35,19 @@ def main():
         key, val = kv.split("=")
         dev.set_option(key, int(val))
     n, s, c, k = a.n, a.size, a.c, a.k
+    cn = a.cn or c
     vox = n * s ** 3
-    mk = lambda: Tensor(dev, dev.malloc(vox * c * 4), n, s, s, s, c, c, None)
-    x, y, dy, dx = mk(), mk(), mk(), mk()
+    mk = lambda ch: Tensor(dev, dev.malloc(vox * ch * 4), n, s, s, s, ch, ch, None)
+    x, y, dy, dx = mk(c), mk(cn), mk(cn), mk(c)
     rng = np.random.default_rng(0)
     for t in (x, dy):
-        dev.h2d(t.ptr, rng.standard_normal(vox * c, dtype=np.float32))
-    w = dev.malloc(c * c * k ** 3 * 4)
-    dev.h2d(w, (rng.standard_normal(c * c * k ** 3) * 0.01).astype(np.float32))
-    dw, b, db = dev.malloc(c * c * k ** 3 * 4), dev.small(c), dev.small(c)
+        dev.h2d(t.ptr, rng.standard_normal(vox * t.c, dtype=np.float32))
+    w = dev.malloc(c * cn * k ** 3 * 4)
+    dev.h2d(w, (rng.standard_normal(c * cn * k ** 3) * 0.01).astype(np.float32))
+    dw, b, db = dev.malloc(c * cn * k ** 3 * 4), dev.small(cn), dev.small(cn)
     cd = MskConvDesc(k, k, k, 1, 1, 1, k // 2, k // 2, k // 2)
     vp = C.c_void_p
-    gf = 2.0 * k ** 3 * c * c * vox / 1e9
+    gf = 2.0 * k ** 3 * c * cn * vox / 1e9
     cases = {
         "fwd": lambda: dev.call("msk_conv3d_fwd", cd, x.msk(), vp(w), vp(b), y.msk()),
         "dgrad": lambda: dev.call("msk_conv3d_dgrad", cd, dy.msk(), vp(w), dx.msk(), 0),
@@ -68,7 +70,7 @@ def main():
             dev.prof_enable(False)
             for tag, (cnt, tms) in sorted(dev.prof_report().items(), key=lambda kv: -kv[1][1]):
                 print(f"    {tag:32s} x{cnt // a.iters}  {tms / a.iters:7.3f} ms")
-        print(f"c={c} {n}x{s}^3 k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
+        print(f"c={c}->{cn} {n}x{s}^3 k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
