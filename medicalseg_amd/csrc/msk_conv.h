@@ -34,6 +34,10 @@ struct WGrad {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
+  // Winograd kernels only (filled by msk_wgrad_wino): BD/BH/BW are then LOGICAL dims, a permutation of the tensor's
+  // axes, and a voxel's index is n*vsn + d*vsd + h*vsh + w*vsw
+  long vsn;
+  int vsd, vsh, vsw;
 };
 
 // Packed-weight layouts

@@ -23,7 +23,9 @@ struct WinoArgs {
   int sld;
   float* dst;
   int dld;
-  int N, D, H, W;
+  int N, D, H, W;         // LOGICAL dims: the kernel tiles 4 x 8 x {8,16} over (D, H, W) and transforms along W ...
+  long svn;               // ... which may be any permutation of the tensor's axes: voxel index =
+  int svd, svh, svw;      //     n*svn + d*svd + h*svh + w*svw  (identity: H*W, W, 1)
   int CK, CN;
   const float4* um;  // [kd*5+kh][KC][2][xi][npad] float4 (k = kc*8 + h*4 + q)
   int KC, npad;
@@ -47,7 +49,7 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nb) {
 // U[r][kc][h][xi][n][q] = sum_kw G[xi][kw] * w(tap = r*5 + kw (flipped when flip), k = kc*8+h*4+q, n)
 __global__ void __launch_bounds__(256)
 pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
-                    float* __restrict__ out) {
+                    int tsd, int tsh, int tsw, float* __restrict__ out) {
   const float G[6][5] = {{0.25f, 0.f, 0.f, 0.f, 0.f},
                          {-1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6},
                          {-1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6},
@@ -76,7 +78,7 @@ pack_wino_weights_k(const float* __restrict__ w, int A, int B, int swap, int fli
       double s = 0.0;  // transform in double: the weights are packed once per call, cheap
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw) {
-        const int tap = row * 5 + kw;
+        const int tap = (row / 5) * tsd + (row % 5) * tsh + kw * tsw;  // logical (kd, kh, kw) -> canonical tap
         s += (double)G[xi][kw] * (double)wp[flip ? 124 - tap : tap];
       }
       v = (float)s;
@@ -159,7 +161,7 @@ conv_halo_wino_k(WinoArgs a) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c0 = kc * 8 + q * 4;
         if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
-          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          const float* p = a.src + ((long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw) * a.sld + c0;
           if (a.vec) {
             v = *reinterpret_cast<const float4*>(p);
           } else {
@@ -222,11 +224,11 @@ conv_halo_wino_k(WinoArgs a) {
         const float m1 = acc[1][j], m2 = acc[2][j], m3 = acc[3][j], m4 = acc[4][j];
         const float y0 = ((acc[0][j] + m1) + (m2 + m3)) + m4;
         const float y1 = ((m1 - m2) + 2.f * (m3 - m4)) + acc[5][j];
-        const long vox = (((long)n * a.D + gd) * a.H + gh) * a.W + gw;
+        const long vox = (long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw;
         if (a.ksplit > 1) {
           float* pp = a.partial + ((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox) * a.CN + co;
           pp[0] = y0;
-          if (gw + 1 < a.W) pp[a.CN] = y1;
+          if (gw + 1 < a.W) pp[(long)a.svw * a.CN] = y1;
           continue;
         }
         float* o = a.dst + vox * a.dld + co;
@@ -235,8 +237,9 @@ conv_halo_wino_k(WinoArgs a) {
         o[0] = r0 > 0.f ? r0 : slope * r0;
         if (gw + 1 < a.W) {
           float r1 = y1 + bv;
-          if (a.accumulate) r1 += o[a.dld];
-          o[a.dld] = r1 > 0.f ? r1 : slope * r1;
+          float* o1 = o + (long)a.svw * a.dld;
+          if (a.accumulate) r1 += *o1;
+          *o1 = r1 > 0.f ? r1 : slope * r1;
         }
       }
     }
@@ -252,7 +255,7 @@ conv_halo_wino_k(WinoArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 pack_wino4_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
-                     float* __restrict__ out) {
+                     int tsd, int tsh, int tsw, float* __restrict__ out) {
   const double G[8][5] = {{-1, 0, 0, 0, 0},
                           {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                           {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -280,7 +283,7 @@ pack_wino4_weights_k(const float* __restrict__ w, int A, int B, int swap, int fl
       const float* wp = w + ((long)ia * B + ib) * 125;
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw) {
-        const int tap = row * 5 + kw;
+        const int tap = (row / 5) * tsd + (row % 5) * tsh + kw * tsw;  // logical (kd, kh, kw) -> canonical tap
         t[kw] = (double)wp[flip ? 124 - tap : tap];
       }
     }
@@ -362,7 +365,7 @@ conv_halo_wino4_k(WinoArgs a) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c0 = kc * 8 + q * 4;
         if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
-          const float* p = a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0;
+          const float* p = a.src + ((long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw) * a.sld + c0;
           if (a.vec) {
             v = *reinterpret_cast<const float4*>(p);
           } else {
@@ -430,14 +433,14 @@ conv_halo_wino4_k(WinoArgs a) {
         y[1] = (d12 + 2.f * d34) + 0.5f * d56;
         y[2] = (s12 + 4.f * s34) + 0.25f * s56;
         y[3] = ((d12 + 8.f * d34) + 0.125f * d56) + acc[7][j];
-        const long vox = (((long)n * a.D + gd) * a.H + gh) * a.W + gw;
+        const long vox = (long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (gw + i < a.W) {
             if (a.ksplit > 1) {
-              a.partial[((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox + i) * a.CN + co] = y[i];
+              a.partial[((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox + (long)i * a.svw) * a.CN + co] = y[i];
             } else {
-              float* o = a.dst + (vox + i) * a.dld + co;
+              float* o = a.dst + (vox + (long)i * a.svw) * a.dld + co;
               float r = y[i] + bv;
               if (a.accumulate) r += *o;
               *o = r > 0.f ? r : slope * r;
@@ -472,12 +475,36 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   if (!(g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
   if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
   if (g.CK < 8 || g.CN < 8) return 0;                       // tiny-channel layers have their own kernels
-  if (g.DD % 4 || g.DH % 8 || g.DW % 8) return 0;           // whole 4x8x8 tiles only (no padded-volume waste)
-  const bool f45 = (g.DW % 16 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
+  // The kernels tile 4 x 8 x {8,16} over LOGICAL axes (d, h, w) and transform along w; any permutation of the tensor's
+  // axes can play those roles (addresses are strided per voxel, the weights are packed with the taps permuted the same
+  // way).  The anisotropic MRI slabs (512 x 512 x 12, W = 12 / 8 / 4) get their transform along H this way.
+  // Preference: F(4,5) (w % 16 == 0) over F(2,5); among equals the least padding of a ragged d, then the identity.
+  const int dims[3] = {g.DD, g.DH, g.DW};
+  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};  // logical (d,h,w) <- axis
+  int best = -1, best_f45 = 0;
+  long best_cost = 0;
+  for (int i = 0; i < 6; ++i) {
+    const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
+    if (lh_ % 8 || lw_ % 8) continue;                          // whole tiles in h and w; d may be ragged (bounds-checked)
+    const int f = (lw_ % 16 == 0) && ctx->conv_impl != 14;     // 14 = F(2,5) only (A/B)
+    const long cost = (long)((ld_ + 3) / 4) * 4 * lh_ * lw_;   // padded volume
+    if (cost * 2 > (long)ld_ * lh_ * lw_ * 3) continue;        // more than 1.5x padding: the direct kernel wins
+    if (best < 0 || f > best_f45 || (f == best_f45 && cost < best_cost)) {
+      best = i;
+      best_f45 = f;
+      best_cost = cost;
+    }
+  }
+  if (best < 0) return 0;
+  const int* pm = kPerms[best];
+  const int LD = dims[pm[0]], LH = dims[pm[1]], LW = dims[pm[2]];
+  const int vstr[3] = {g.DH * g.DW, g.DW, 1};   // voxel strides of the tensor's (D, H, W)
+  const int tstr[3] = {25, 5, 1};               // tap strides of the canonical weight's (kd, kh, kw)
+  const bool f45 = best_f45 != 0;
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
   const int twid = f45 ? 16 : 8, nxi = f45 ? 8 : 6;
-  const long nblk = (long)g.N * (g.DD / 4) * (g.DH / 8) * (g.DW / twid);
+  const long nblk = (long)g.N * ((LD + 3) / 4) * (LH / 8) * (LW / twid);
   // the direct kernel splits K when the tiling cannot fill the chip; leave those small layers to it
   if (nblk > 0x7fffffff) return 0;
   const size_t ubytes = (size_t)nxi * 25 * KC * 2 * npad * 4 * sizeof(float);
@@ -489,18 +516,19 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
     if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
     if (f45)
       hipLaunchKernelGGL(pack_wino4_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
-                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
+                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], um);
     else
       hipLaunchKernelGGL(pack_wino_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
-                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, um);
+                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], um);
     MSK_LAUNCH_CHECK(ctx);
   }
   WinoArgs a{};
   a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
-  a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CK = g.CK; a.CN = g.CN;
+  a.N = g.N; a.D = LD; a.H = LH; a.W = LW; a.CK = g.CK; a.CN = g.CN;
+  a.svn = (long)g.DD * g.DH * g.DW; a.svd = vstr[pm[0]]; a.svh = vstr[pm[1]]; a.svw = vstr[pm[2]];
   a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
   a.bias = g.bias; a.prelu = g.prelu; a.accumulate = g.accumulate;
-  a.tiles_d = g.DD / 4; a.tiles_h = g.DH / 8; a.tiles_w = g.DW / twid; a.nblk = (int)nblk;
+  a.tiles_d = (LD + 3) / 4; a.tiles_h = LH / 8; a.tiles_w = LW / twid; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   // split K when the (M, N) tiling alone cannot fill the chip (~4 workgroups per CU wanted), like conv_halo_mfma_k
   a.ksplit = 1;

@@ -103,7 +103,7 @@ wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float*
       const int c0 = cat * 32 + q * 4;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
-        val = *reinterpret_cast<const float4*>(g.A + ((((long)n * D + id) * H + ih) * W + iw) * g.ald + c0);
+        val = *reinterpret_cast<const float4*>(g.A + ((long)n * g.vsn + (long)id * g.vsd + (long)ih * g.vsh + (long)iw * g.vsw) * g.ald + c0);
       px[i] = val;
     }
 #pragma unroll
@@ -115,7 +115,7 @@ wgrad_wino_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float*
       const int c0 = cbt * 32 + q * 4;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
-        val = *reinterpret_cast<const float4*>(g.B + ((((long)n * D + d) * H + oh) * W + ow) * g.bld + c0);
+        val = *reinterpret_cast<const float4*>(g.B + ((long)n * g.vsn + (long)d * g.vsd + (long)oh * g.vsh + (long)ow * g.vsw) * g.bld + c0);
       pd[i] = val;
     }
   };
@@ -305,7 +305,7 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
         const int c0 = cat * 32 + q * 4;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
-          val = *reinterpret_cast<const float4*>(g.A + ((((long)n * D + id) * H + ih) * W + iw) * g.ald + c0);
+          val = *reinterpret_cast<const float4*>(g.A + ((long)n * g.vsn + (long)id * g.vsd + (long)ih * g.vsh + (long)iw * g.vsw) * g.ald + c0);
         tmp[i] = val;
       }
 #pragma unroll
@@ -325,7 +325,7 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
         const int c0 = cbt * 32 + q * 4;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
-          val = *reinterpret_cast<const float4*>(g.B + ((((long)n * D + d) * H + oh) * W + ow) * g.bld + c0);
+          val = *reinterpret_cast<const float4*>(g.B + ((long)n * g.vsn + (long)d * g.vsd + (long)oh * g.vsh + (long)ow * g.vsw) * g.bld + c0);
         tmp[i] = val;
       }
 #pragma unroll
@@ -423,7 +423,8 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
 // (The first version gave each output element to one thread that walked all splits x 8 planes alone: 25.6 K threads
 // for a 32 -> 32 layer, 0.18 ms per call, latency bound.)
 __global__ void __launch_bounds__(256)
-wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, float* __restrict__ dw, int accumulate) {
+wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, int tsd, int tsh, int tsw,
+                     float* __restrict__ dw, int accumulate) {
   const double G[8][5] = {{-1, 0, 0, 0, 0},
                           {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                           {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -461,13 +462,13 @@ wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int 
 #pragma unroll
       for (int xi = 0; xi < 8; ++xi) u[xi] = (u[xi] + sh[0][lane][xi]) + (sh[1][lane][xi] + sh[2][lane][xi]);
       const int cb = (int)(e % CB), ca = (int)(e / CB);
-      float* o = dw + ((long)cb * CA + ca) * 125 + row * 5;
+      float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;  // logical (kd, kh) -> canonical tap
 #pragma unroll
       for (int kw = 0; kw < 5; ++kw) {
         double s_ = 0.0;
 #pragma unroll
         for (int xi = 0; xi < 8; ++xi) s_ += G[xi][kw] * u[xi];
-        o[kw] = accumulate ? o[kw] + (float)s_ : (float)s_;
+        o[kw * tsw] = accumulate ? o[kw * tsw] + (float)s_ : (float)s_;
       }
     }
     __syncthreads();
@@ -476,7 +477,8 @@ wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int 
 
 // dw[cb][ca][(kd,kh,kw)] (+)= sum_xi G[xi][kw] * sum_split P[split][xi][kd*5+kh][ca][cb]   (fixed order, double)
 __global__ void __launch_bounds__(256)
-wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, float* __restrict__ dw, int accumulate) {
+wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, int tsd, int tsh, int tsw,
+                    float* __restrict__ dw, int accumulate) {
   const double G[6][5] = {{0.25, 0, 0, 0, 0},
                           {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
                           {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -503,31 +505,56 @@ wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int C
       u[xi] = s0 + s1;
     }
     const int cb = (int)(e % CB), ca = (int)(e / CB);
-    float* o = dw + ((long)cb * CA + ca) * 125 + row * 5;
+    float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
 #pragma unroll
     for (int kw = 0; kw < 5; ++kw) {
       double s = 0.0;
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) s += G[xi][kw] * u[xi];
-      o[kw] = accumulate ? o[kw] + (float)s : (float)s;
+      o[kw * tsw] = accumulate ? o[kw * tsw] + (float)s : (float)s;
     }
   }
 }
 
 }  // namespace
 
-int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2))
+int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
+  if (!(g_in.kd == 5 && g_in.kh == 5 && g_in.kw == 5 && g_in.sd == 1 && g_in.sh == 1 && g_in.sw == 1 && g_in.pd == 2 &&
+        g_in.ph == 2 && g_in.pw == 2))
     return 0;
-  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
-  if (g.BW % 2 || g.BW < 16) return 0;  // W pairs; narrow volumes keep the direct LDS kernel's narrow chunk shapes
-  if (!(g.ald % 4 == 0 && g.bld % 4 == 0 && g.CA % 4 == 0 && g.CB % 4 == 0 && ((uintptr_t)g.A) % 16 == 0 &&
-        ((uintptr_t)g.B) % 16 == 0))
+  if (!(g_in.AD == g_in.BD && g_in.AH == g_in.BH && g_in.AW == g_in.BW)) return 0;
+  if (!(g_in.ald % 4 == 0 && g_in.bld % 4 == 0 && g_in.CA % 4 == 0 && g_in.CB % 4 == 0 && ((uintptr_t)g_in.A) % 16 == 0 &&
+        ((uintptr_t)g_in.B) % 16 == 0))
     return 0;
+  // Logical axes (d: planes / kd tasks, h: 8-row chunks, w: 16-column chunks + transform) = the permutation of the
+  // tensor's axes with the least chunk padding among those whose w is even and >= 16 (narrower volumes keep the direct
+  // LDS kernel); F(4,5) (w % 4 == 0) first, the identity on ties.  MRI slabs (W = 12 / 9 / 8 / 4 / 2) transform along H.
+  const int dims[3] = {g_in.BD, g_in.BH, g_in.BW};
+  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
+  int best = -1, best_f45 = 0;
+  long best_cost = 0;
+  for (int i = 0; i < 6; ++i) {
+    const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
+    if (lw_ % 2 || lw_ < 16) continue;
+    const int f = (lw_ % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
+    const long cost = (long)ld_ * (((lh_ + R - 1) / R) * R) * (((lw_ + WS - 1) / WS) * WS);
+    if (best < 0 || f > best_f45 || (f == best_f45 && cost < best_cost)) {
+      best = i;
+      best_f45 = f;
+      best_cost = cost;
+    }
+  }
+  if (best < 0) return 0;
+  const int* pm = kPerms[best];
+  const int vstr[3] = {g_in.BH * g_in.BW, g_in.BW, 1}, tstr[3] = {25, 5, 1};
+  WGrad g = g_in;
+  g.BD = g.AD = dims[pm[0]]; g.BH = g.AH = dims[pm[1]]; g.BW = g.AW = dims[pm[2]];
+  g.vsn = (long)g_in.BD * g_in.BH * g_in.BW; g.vsd = vstr[pm[0]]; g.vsh = vstr[pm[1]]; g.vsw = vstr[pm[2]];
+  const int tsd = tstr[pm[0]], tsh = tstr[pm[1]], tsw = tstr[pm[2]];
   const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;
   const long chunks = (long)g.N * g.BD * ((g.BH + R - 1) / R) * ((g.BW + WS - 1) / WS);
   const long tasks = 5L * ca_tiles * cb_tiles;
-  const bool f45 = (g.BW % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
+  const bool f45 = best_f45 != 0;
   const int nxi = f45 ? 8 : 6;
   const size_t per = (size_t)nxi * 25 * g.CA * g.CB * sizeof(float);
   long splits;
@@ -588,10 +615,10 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g) {
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
     if (f45)
       hipLaunchKernelGGL(wgrad_wino4_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial,
-                         (int)splits, g.CA, g.CB, g.dw, g.accumulate);
+                         (int)splits, g.CA, g.CB, tsd, tsh, tsw, g.dw, g.accumulate);
     else
       hipLaunchKernelGGL(wgrad_wino_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial,
-                         (int)splits, g.CA, g.CB, g.dw, g.accumulate);
+                         (int)splits, g.CA, g.CB, tsd, tsh, tsw, g.dw, g.accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 1;

@@ -387,8 +387,23 @@ WINO_CASES = [
     (16, 32, (1, 8, 8, 48)),
     (64, 48, (1, 4, 8, 24)),      # Cout not a multiple of 32
     (8, 40, (1, 12, 8, 8)),
-    (128, 128, (1, 4, 16, 8)),
+    (128, 128, (1, 4, 16, 8)),    # W = 8: the transform runs along H (16) instead -> F(4,5) on permuted axes
+    (16, 32, (1, 16, 32, 12)),    # MRI-like slab: W = 12 tiles along neither 8 nor 16 -> logical (d, h, w) = (W, D, H)
+    (32, 20, (1, 8, 16, 4)),      # deeper MRI level (W = 4)
+    (16, 16, (1, 8, 4, 16)),      # H = 4: logical (d, h, w) = (H, D, W)
+    (32, 32, (1, 16, 16, 9)),     # MRI level 2 (W = 9): ragged planes along W (3 tiles of 4), transform along H
+    (16, 24, (2, 6, 8, 16)),      # ragged D in the identity orientation
 ]
+
+
+def _wino_variant(D, H, W):
+    """Mirror of the axis choice in msk_gconv_halo_wino: any permutation of (D, H, W) with d % 4 == h % 8 == w % 8 == 0
+    may carry the tiles; F(4,5) needs w % 16 == 0 and is preferred."""
+    import itertools
+    ok = [(d, h, w) for d, h, w in itertools.permutations((D, H, W))
+          if h % 8 == 0 and w % 8 == 0 and (d + 3) // 4 * 4 * 2 <= d * 3]      # d may be ragged up to 1.5x padding
+    assert ok
+    return "conv_halo_wino4_k" if any(w % 16 == 0 for _, _, w in ok) else "conv_halo_wino_k"
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
@@ -421,7 +436,7 @@ def test_conv5_winograd_f25_matches_oracle(case):
         e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
         d.prof_enable(False)
         rep = d.prof_report()                                                # the Winograd kernel really ran:
-        tag = "conv_halo_wino4_k" if W % 16 == 0 else "conv_halo_wino_k"     # F(4,5) when W tiles by 16, else F(2,5)
+        tag = _wino_variant(D, H, W)                                         # F(4,5) when some axis tiles by 16
         assert rep.get(tag, (0, 0))[0] == 3, rep
     finally:
         d.prof_enable(False)
@@ -430,8 +445,20 @@ def test_conv5_winograd_f25_matches_oracle(case):
     assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125)
 
 
+def _wgrad_wino_variant(D, H, W):
+    """Mirror of msk_wgrad_wino's axis choice: the transform axis is any axis that is even and >= 16; F(4,5) when one
+    of them is a multiple of 4."""
+    ws = [w for w in (D, H, W) if w % 2 == 0 and w >= 16]
+    assert ws
+    return "wgrad_wino4" if any(w % 4 == 0 for w in ws) else "wgrad_wino"
+
+
 @pytest.mark.parametrize("case", [(32, 32, (2, 8, 16, 16)), (64, 48, (1, 4, 8, 24)), (8, 40, (1, 5, 9, 18)),
-                                  (128, 128, (1, 4, 16, 16))])
+                                  (128, 128, (1, 4, 16, 16)),
+                                  (16, 32, (1, 16, 32, 12)),    # MRI-like slab: transform along H, planes along W
+                                  (32, 16, (1, 20, 24, 9)),     # odd W (MRI level 2)
+                                  (16, 16, (1, 32, 18, 2)),     # W = 2 (deepest MRI level); 18: F(2,5) unless D (32) wins
+                                  (8, 8, (1, 6, 18, 3))])       # only H is usable and 18 % 4 != 0 -> F(2,5) along H
 def test_wgrad_winograd_f25_matches_oracle(case):
     """wgrad_wino_k (msk_wgrad_wino.hip): the adjoint of the Winograd forward kernel, dU accumulated in the transformed
     domain and mapped back with G^T in the split-K reduction.  Same tolerance as the direct weight-gradient kernels."""
@@ -453,7 +480,7 @@ def test_wgrad_winograd_f25_matches_oracle(case):
         d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
         got2 = vec_back(dwp, dw_ref.size).reshape(dw_ref.shape)
         d.prof_enable(False)
-        assert d.prof_report().get("wgrad_wino4" if W % 4 == 0 else "wgrad_wino", (0, 0))[0] == 2   # F(4,5) / F(2,5)
+        assert d.prof_report().get(_wgrad_wino_variant(D, H, W), (0, 0))[0] == 2                   # F(4,5) / F(2,5)
     finally:
         d.prof_enable(False)
         d.set_option("conv_impl", 0)
@@ -467,6 +494,7 @@ FOLD_CASES = [
     # (Cin, Cout, k, pad, (N, D, H, W), kernel that must run)
     (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue
     (64, 48, 5, 2, (1, 4, 8, 24), "conv_halo_wino_k"),        # F(2,5) epilogue, Cout not a multiple of 32
+    (32, 24, 5, 2, (1, 16, 32, 12), "conv_halo_wino4_k"),     # permuted axes (transform along H)
     (128, 128, 5, 2, (1, 4, 8, 16), "conv_splitk_reduce"),    # few tiles -> split K: slope applied in the reduce
     (16, 8, 3, 1, (1, 6, 7, 9), "prelu_inplace"),             # no Winograd kernel: in-place pass after the conv
 ]
