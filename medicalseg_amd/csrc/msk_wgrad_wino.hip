@@ -609,7 +609,13 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
     MSK_LAUNCH_CHECK(ctx);
   }
   {
-    msk_launch_scope ls(ctx, "wgrad_wino_reduce");
+    const char* rtag = "wgrad_wino_reduce";
+    if (ctx->prof && ctx->prof_shapes) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "wgrad_wino_reduce[ca=%d,cb=%d,splits=%ld,f45=%d]", g.CA, g.CB, splits, (int)f45);
+      rtag = msk_intern_tag(ctx, buf);
+    }
+    msk_launch_scope ls(ctx, rtag);
     const long total = 25L * g.CA * g.CB;
     long blocks = f45 ? (total + 63) / 64 : (total + 255) / 256;
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;

@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--c", type=int, default=32)
     ap.add_argument("--cn", type=int, default=0, help="output channels (default: --c)")
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--dhw", default=None, help="D,H,W of a non-cubic volume (overrides --size)")
+    ap.add_argument("--acc", type=int, default=0, help="accumulate flag of dgrad / wgrad")
     ap.add_argument("--n", type=int, default=2)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--halo-tile", type=int, default=-1)
@@ -36,8 +38,9 @@ def main():
         dev.set_option(key, int(val))
     n, s, c, k = a.n, a.size, a.c, a.k
     cn = a.cn or c
-    vox = n * s ** 3
-    mk = lambda ch: Tensor(dev, dev.malloc(vox * ch * 4), n, s, s, s, ch, ch, None)
+    D, H, W = (int(v) for v in a.dhw.split(",")) if a.dhw else (s, s, s)
+    vox = n * D * H * W
+    mk = lambda ch: Tensor(dev, dev.malloc(vox * ch * 4), n, D, H, W, ch, ch, None)
     x, y, dy, dx = mk(c), mk(cn), mk(cn), mk(c)
     rng = np.random.default_rng(0)
     for t in (x, dy):
@@ -50,8 +53,8 @@ def main():
     gf = 2.0 * k ** 3 * c * cn * vox / 1e9
     cases = {
         "fwd": lambda: dev.call("msk_conv3d_fwd", cd, x.msk(), vp(w), vp(b), y.msk()),
-        "dgrad": lambda: dev.call("msk_conv3d_dgrad", cd, dy.msk(), vp(w), dx.msk(), 0),
-        "wgrad": lambda: dev.call("msk_conv3d_wgrad", cd, x.msk(), dy.msk(), vp(dw), vp(db), 0),
+        "dgrad": lambda: dev.call("msk_conv3d_dgrad", cd, dy.msk(), vp(w), dx.msk(), a.acc),
+        "wgrad": lambda: dev.call("msk_conv3d_wgrad", cd, x.msk(), dy.msk(), vp(dw), vp(db), a.acc),
     }
     for name, fn in cases.items():
         fn()
@@ -70,7 +73,7 @@ def main():
             dev.prof_enable(False)
             for tag, (cnt, tms) in sorted(dev.prof_report().items(), key=lambda kv: -kv[1][1]):
                 print(f"    {tag:32s} x{cnt // a.iters}  {tms / a.iters:7.3f} ms")
-        print(f"c={c}->{cn} {n}x{s}^3 k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
+        print(f"c={c}->{cn} {n}x{D}x{H}x{W} k={k} tile={a.halo_tile} chunk={a.wgrad_chunk} {name:6s} {ms:8.3f} ms  {gf / ms:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
