@@ -535,7 +535,7 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
   long best_cost = 0;
   for (int i = 0; i < 6; ++i) {
     const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
-    if (lw_ % 2 || lw_ < 16) continue;
+    if (lw_ % 2 || lw_ < 8) continue;   // w = 8: half of a 16-column chunk is padding, still ahead of the direct kernel
     const int f = (lw_ % 4 == 0) && ctx->conv_impl != 14;  // 14 = F(2,5) only (A/B)
     const long cost = (long)ld_ * (((lh_ + R - 1) / R) * R) * (((lw_ + WS - 1) / WS) * WS);
     if (best < 0 || f > best_f45 || (f == best_f45 && cost < best_cost)) {

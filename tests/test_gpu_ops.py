@@ -448,7 +448,7 @@ def test_conv5_winograd_f25_matches_oracle(case):
 def _wgrad_wino_variant(D, H, W):
     """Mirror of msk_wgrad_wino's axis choice: the transform axis is any axis that is even and >= 16; F(4,5) when one
     of them is a multiple of 4."""
-    ws = [w for w in (D, H, W) if w % 2 == 0 and w >= 16]
+    ws = [w for w in (D, H, W) if w % 2 == 0 and w >= 8]
     assert ws
     return "wgrad_wino4" if any(w % 4 == 0 for w in ws) else "wgrad_wino"
 
@@ -458,6 +458,7 @@ def _wgrad_wino_variant(D, H, W):
                                   (16, 32, (1, 16, 32, 12)),    # MRI-like slab: transform along H, planes along W
                                   (32, 16, (1, 20, 24, 9)),     # odd W (MRI level 2)
                                   (16, 16, (1, 32, 18, 2)),     # W = 2 (deepest MRI level); 18: F(2,5) unless D (32) wins
+                                  (32, 32, (2, 8, 8, 8)),       # 8^3 (deepest lung level): half-empty 16-column chunks
                                   (8, 8, (1, 6, 18, 3))])       # only H is usable and 18 % 4 != 0 -> F(2,5) along H
 def test_wgrad_winograd_f25_matches_oracle(case):
     """wgrad_wino_k (msk_wgrad_wino.hip): the adjoint of the Winograd forward kernel, dU accumulated in the transformed
