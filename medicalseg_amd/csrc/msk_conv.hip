@@ -145,12 +145,13 @@ wgrad_direct_k(WGrad g, int splits, float* __restrict__ partial /*[split][tap][C
 }
 
 __global__ void __launch_bounds__(kThreads)
-wgrad_reduce_k(const float* __restrict__ partial, int splits, int taps, int CA, int CB, float* __restrict__ dw,
-               int accumulate) {
+wgrad_reduce_k(const float* __restrict__ partial, int splits, int stride, int taps, int CA, int CB,
+               float* __restrict__ dw, int accumulate) {
   // block = 64 consecutive outputs x 4 split slices: coalesced 256-byte reads of every slab,
   // 4-way split parallelism + 4 independent accumulators per thread (fixed order: deterministic)
   __shared__ double sh[4][64];
   const long per = (long)taps * CA * CB;
+  const long pitch = per * stride;  // slab k of the (pre-reduced) set sits at k*stride
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   for (long base = (long)blockIdx.x * 64; base < per; base += (long)gridDim.x * 64) {
     const long idx = base + lane;
@@ -158,12 +159,12 @@ wgrad_reduce_k(const float* __restrict__ partial, int splits, int taps, int CA, 
     if (idx < per) {
       int k = slice;
       for (; k + 12 < splits; k += 16) {
-        s0 += partial[(long)k * per + idx];
-        s1 += partial[(long)(k + 4) * per + idx];
-        s2 += partial[(long)(k + 8) * per + idx];
-        s3 += partial[(long)(k + 12) * per + idx];
+        s0 += partial[(long)k * pitch + idx];
+        s1 += partial[(long)(k + 4) * pitch + idx];
+        s2 += partial[(long)(k + 8) * pitch + idx];
+        s3 += partial[(long)(k + 12) * pitch + idx];
       }
-      for (; k < splits; k += 4) s0 += partial[(long)k * per + idx];
+      for (; k < splits; k += 4) s0 += partial[(long)k * pitch + idx];
     }
     sh[slice][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -379,15 +380,16 @@ int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int s
 // float4 variant (CB % 4 == 0): a lane owns 4 consecutive cb of one (tap, ca) row -> 1 KiB per wavefront load,
 // two slabs in flight per slice (the scalar version moved 256 B per load and reached ~1.6 TB/s)
 __global__ void __launch_bounds__(kThreads)
-wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int taps, int CA, int CB, float* __restrict__ dw,
-                  int accumulate) {
+wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int stride, int taps, int CA, int CB,
+                  float* __restrict__ dw, int accumulate) {
   __shared__ double sh[4][64][4];
-  const long per = (long)taps * CA * CB, per4 = per >> 2;
+  const long per = (long)taps * CA * CB, per4 = (per >> 2) * stride;  // slab pitch in float4 (slab k at k*stride)
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  for (long base = (long)blockIdx.x * 64; base < per4; base += (long)gridDim.x * 64) {
+  const long n4 = per >> 2;
+  for (long base = (long)blockIdx.x * 64; base < n4; base += (long)gridDim.x * 64) {
     const long i4 = base + lane;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    if (i4 < per4) {
+    if (i4 < n4) {
       const float4* p = reinterpret_cast<const float4*>(partial) + i4;
       int k = slice;
       for (; k + 12 < splits; k += 16) {  // four slabs in flight
@@ -406,7 +408,7 @@ wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int taps, int C
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh[slice][lane][j] = a[j] + b[j];
     __syncthreads();
-    if (slice == 0 && i4 < per4) {
+    if (slice == 0 && i4 < n4) {
       const long idx = i4 << 2;  // = (tap*CA + ca)*CB + cb
       const int cb = (int)(idx % CB);
       const long r = idx / CB;
@@ -423,21 +425,66 @@ wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int taps, int C
   }
 }
 
+// First stage for "few outputs, thousands of slabs" (in_tr / out_tr / the 2x2x2 convs: 2 K - 12 K outputs, up to
+// 12 288 split slabs): block row y adds the slabs [y*chunk, (y+1)*chunk) in a fixed order and leaves the sum in the
+// FIRST slab of its range (only slice 0 ever reads that slab, and it writes after its own reads).  The final kernels
+// then walk splits/chunk slabs with a slab stride of `chunk`.  (Alone, the final kernel had 8 blocks walking 12 288
+// slabs for in_tr: 0.36 ms.)
+__global__ void __launch_bounds__(kThreads)
+wgrad_prereduce_k(float* __restrict__ partial, int splits, int chunk, long per) {
+  __shared__ double sh[3][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int k0 = blockIdx.y * chunk;
+  const int k1 = min(splits, k0 + chunk);
+  for (long base = (long)blockIdx.x * 64; base < per; base += (long)gridDim.x * 64) {
+    const long i = base + lane;
+    double a = 0.0, b = 0.0;
+    if (i < per) {
+      const float* p = partial + i;
+      int k = k0 + slice;
+      for (; k + 4 < k1; k += 8) {
+        a += (double)p[(long)k * per];
+        b += (double)p[(long)(k + 4) * per];
+      }
+      if (k < k1) a += (double)p[(long)k * per];
+    }
+    if (slice > 0) sh[slice - 1][lane] = a + b;
+    __syncthreads();
+    if (slice == 0 && i < per) partial[(long)k0 * per + i] = (float)(((a + b) + sh[0][lane]) + (sh[1][lane] + sh[2][lane]));
+    __syncthreads();
+  }
+}
+
 int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
                      int accumulate) {
   const long per = (long)taps * CA * CB;
   msk_launch_scope ls(ctx, "wgrad_reduce");
+  int stride = 1;
+  {
+    const long eb = (per + 63) / 64;                   // element blocks of the final kernels
+    if (splits >= 256 && eb <= 2L * ctx->num_cu) {      // too few element blocks to keep the chip busy on their own
+      long rows = 8L * ctx->num_cu / eb;                // block rows wanted
+      if (rows > splits / 16) rows = splits / 16;       // at least 16 slabs per row
+      const int chunk = (int)((splits + rows - 1) / rows);
+      const int nrows = (splits + chunk - 1) / chunk;
+      hipLaunchKernelGGL(wgrad_prereduce_k, dim3((unsigned)eb, (unsigned)nrows), dim3(kThreads), 0, ctx->stream,
+                         const_cast<float*>(partial), splits, chunk, per);
+      MSK_LAUNCH_CHECK(ctx);
+      stride = chunk;
+      splits = nrows;
+    }
+  }
   if (CB % 4 == 0 && (((uintptr_t)partial) & 15) == 0) {
     long rb = (per / 4 + 63) / 64;
     if (rb > (long)ctx->num_cu * 32) rb = (long)ctx->num_cu * 32;
-    hipLaunchKernelGGL(wgrad_reduce_v4_k, dim3((unsigned)rb), dim3(kThreads), 0, ctx->stream, partial, splits, taps, CA, CB,
-                       dw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_v4_k, dim3((unsigned)rb), dim3(kThreads), 0, ctx->stream, partial, splits, stride, taps,
+                       CA, CB, dw, accumulate);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
   long rblocks = (per + 63) / 64;
   if (rblocks > (long)ctx->num_cu * 32) rblocks = (long)ctx->num_cu * 32;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)rblocks), dim3(kThreads), 0, ctx->stream, partial, splits,
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)rblocks), dim3(kThreads), 0, ctx->stream, partial, splits, stride,
                      taps, CA, CB, dw, accumulate);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
