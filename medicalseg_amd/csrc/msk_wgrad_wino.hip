@@ -475,6 +475,57 @@ wgrad_wino4_reduce_k(const float* __restrict__ partial, int splits, int CA, int 
   }
 }
 
+// Few slabs, large planes (the 128- and 256-channel layers: 1-3 splits of 13-52 MB): no slices to combine, so a thread
+// takes FOUR consecutive cb (one 16-byte load per plane) and walks the slabs itself -- same summation order as the
+// sliced kernel for splits <= 3.  (Sliced kernel at splits = 1: 3 of 4 wavefronts idle, 4-byte loads, 0.13 ms per
+// 256 x 256 layer for 84 MB of traffic.)
+__global__ void __launch_bounds__(256)
+wgrad_wino4_reduce_few_k(const float* __restrict__ partial, int splits, int CA, int CB, int tsd, int tsh, int tsw,
+                         float* __restrict__ dw, int accumulate) {
+  const double G[8][5] = {{-1, 0, 0, 0, 0},
+                          {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                          {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                          {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                          {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                          {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                          {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                          {0, 0, 0, 0, 1}};
+  const long plane4 = (long)CA * CB / 4;
+  const long per4 = 8L * 25 * plane4;
+  const long total4 = 25 * plane4;
+  const float4* p4 = reinterpret_cast<const float4*>(partial);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+    const long e4 = idx % plane4;
+    const int row = (int)(idx / plane4);
+    double u[8][4];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) {
+      const float4 v = p4[((long)xi * 25 + row) * plane4 + e4];
+      u[xi][0] = v.x; u[xi][1] = v.y; u[xi][2] = v.z; u[xi][3] = v.w;
+    }
+    for (int k = 1; k < splits; ++k) {
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) {
+        const float4 v = p4[(long)k * per4 + ((long)xi * 25 + row) * plane4 + e4];
+        u[xi][0] += v.x; u[xi][1] += v.y; u[xi][2] += v.z; u[xi][3] += v.w;
+      }
+    }
+    const long e = e4 * 4;
+    const int cb = (int)(e % CB), ca = (int)(e / CB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* o = dw + ((long)(cb + j) * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) s_ += G[xi][kw] * u[xi][j];
+        o[kw * tsw] = accumulate ? o[kw * tsw] + (float)s_ : (float)s_;
+      }
+    }
+  }
+}
+
 // dw[cb][ca][(kd,kh,kw)] (+)= sum_xi G[xi][kw] * sum_split P[split][xi][kd*5+kh][ca][cb]   (fixed order, double)
 __global__ void __launch_bounds__(256)
 wgrad_wino_reduce_k(const float* __restrict__ partial, int splits, int CA, int CB, int tsd, int tsh, int tsw,
@@ -619,7 +670,12 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
     const long total = 25L * g.CA * g.CB;
     long blocks = f45 ? (total + 63) / 64 : (total + 255) / 256;
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
-    if (f45)
+    if (f45 && splits <= 3 && ((uintptr_t)partial) % 16 == 0) {
+      long fb = (total / 4 + 255) / 256;
+      if (fb > 32L * ctx->num_cu) fb = 32L * ctx->num_cu;
+      hipLaunchKernelGGL(wgrad_wino4_reduce_few_k, dim3((unsigned)fb), dim3(256), 0, ctx->stream, (const float*)partial,
+                         (int)splits, g.CA, g.CB, tsd, tsh, tsw, g.dw, g.accumulate);
+    } else if (f45)
       hipLaunchKernelGGL(wgrad_wino4_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)partial,
                          (int)splits, g.CA, g.CB, tsd, tsh, tsw, g.dw, g.accumulate);
     else
