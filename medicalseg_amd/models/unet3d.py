@@ -1,0 +1,256 @@
+"""UNet3D -- BUILDER-DEFINED: the reference has no UNet3D (its READMEs say "Unet ... To be
+continue", configs/lung_coronavirus/README.md:15-21); BASELINE.json's configs[3] names one, so this is the plain
+3-D U-Net that config describes -- 3x3x3 convolutions, InstanceNorm + PReLU, kernel = stride 2 down / transposed-up
+convolutions, skip concatenation -- assembled from the SAME C-ABI kernels as VNet (`msk_conv3d_*` on the MFMA halo
+kernel with KS = 3, `msk_convT3d_*`, the BatchNorm statistics / affine+PReLU passes run per sample for the instance
+statistics).  fp32 only: there is no fp16 path and, with no reference model, no parity claim beyond the torch-CPU
+restatement in oracle/unet3d_torch.py (tests/test_gpu_unet3d.py).
+
+Registered as `UNet3D` so a YAML `model: {type: UNet3D, ...}` builds it through the unchanged Config path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import nn
+from ..cvlibs import manager
+from ..device import Tensor, get_device, to_tensor
+from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _fp, copy_scale
+from .vnet import VNet
+
+
+class InstanceNorm3D(nn.Layer):
+    """paddle.nn.InstanceNorm3D(num_features, epsilon=1e-5): statistics per (sample, channel) over D*H*W in training
+    AND eval mode, learnable `scale` / `bias`, no running statistics."""
+
+    def __init__(self, num_features, epsilon=1e-5):
+        super().__init__()
+        self.num_features = int(num_features)
+        self.epsilon = float(epsilon)
+        self.scale = Parameter(np.ones(num_features))
+        self.bias = Parameter(np.zeros(num_features))
+        self._scratch = None
+
+    @property
+    def weight(self):
+        return self.scale
+
+    def scratch(self, dev, n):
+        """stats[2C] sums[3C] dummy running mean/var [2C], then per sample: scale shift mean invstd [4C]."""
+        Cn = self.num_features
+        if self._scratch is None or self._scratch["n"] < n:
+            base = dev.small(7 * Cn + n * 4 * Cn)
+            s = {"n": n, "stats": base, "sums": base + 4 * 2 * Cn, "rmean": base + 4 * 5 * Cn, "rvar": base + 4 * 6 * Cn,
+                 "per": base + 4 * 7 * Cn}
+            self._scratch = s
+        return self._scratch
+
+    def sample_coeffs(self, sc, i):
+        Cn, p = self.num_features, sc["per"] + 4 * i * 4 * self.num_features
+        return {"scale": p, "shift": p + 4 * Cn, "mean": p + 8 * Cn, "invstd": p + 12 * Cn}
+
+
+def _sample(t: Tensor, i: int) -> Tensor:
+    """View of sample i of an NDHWC tensor (channel-slice views keep their voxel stride)."""
+    v = Tensor(t.dev, t.ptr + 4 * i * t.d * t.h * t.w * t.ld, 1, t.d, t.h, t.w, t.c, t.ld, t.gen)
+    return v
+
+
+class ConvINAct(ConvBNAct):
+    """conv (or convT) -> InstanceNorm -> PReLU: the BatchNorm unit of nn.ConvBNAct with the statistics, the
+    normalise+PReLU pass and their adjoints run once per sample (one sample = one instance)."""
+
+    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+        if res is not None:
+            raise ValueError("ConvINAct has no residual input")
+        dev, norm = x.dev, self.bn
+        self.x, self.res = x, None
+        y = self.conv.run_forward(x)
+        self.y = y
+        if out is None:
+            out = y.empty_like()
+        sc, Cn = norm.scratch(dev, y.n), norm.num_features
+        alpha = self.act._weight.ptr if self.act is not None else None
+        vox = float(y.d * y.h * y.w)
+        for i in range(y.n):
+            yv, co = _sample(y, i), norm.sample_coeffs(sc, i)
+            dev.call("msk_bn_stats", yv.msk(), _fp(sc["stats"]))
+            dev.call("msk_bn_finalize", _fp(sc["stats"]), 1, C.c_double(vox), Cn, _fp(norm.scale.ptr), _fp(norm.bias.ptr),
+                     C.c_float(norm.epsilon), C.c_float(1.0), _fp(sc["rmean"]), _fp(sc["rvar"]), _fp(co["mean"]),
+                     _fp(co["invstd"]), _fp(co["scale"]), _fp(co["shift"]))
+            dev.call("msk_affine_act_fwd", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                     _sample(out, i).msk())
+        self.out, self.bn_mode = out, 1
+        return out
+
+    def backward(self, dout: Tensor, need_dx=True, res_needs_grad=True):
+        dev, norm, y = dout.dev, self.bn, self.y
+        sc, Cn = norm.scratch(dev, y.n), norm.num_features
+        alpha = self.act._weight.ptr if self.act is not None else None
+        vox = float(y.d * y.h * y.w)
+        dy = y.empty_like()
+        for i in range(y.n):
+            yv, dv, co = _sample(y, i), _sample(dout, i), norm.sample_coeffs(sc, i)
+            dev.call("msk_affine_act_bwd_reduce", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                     _fp(co["mean"]), _fp(co["invstd"]), dv.msk(), _fp(sc["sums"]))
+            dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(norm.scale.grad_ptr), _fp(norm.bias.grad_ptr),
+                     _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
+            dev.call("msk_affine_act_bwd_apply", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                     _fp(co["mean"]), _fp(co["invstd"]), _fp(norm.scale.ptr), dv.msk(), _fp(sc["sums"]),
+                     C.c_double(vox), 1, _sample(dy, i).msk(), NULL_TENSOR, 0)
+        self.dy = dy
+        # the conv bias gradient is identically zero behind per-sample statistics (the backward removes the mean)
+        self.conv.run_backward(self.x, dy, need_dx=need_dx, bias_grad=False)
+
+
+class DoubleConv(nn.Layer):
+    """[conv3^3 (pad 1) -> InstanceNorm -> PReLU] x 2"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3D(cin, cout, kernel_size=3, padding=1)
+        self.norm1 = InstanceNorm3D(cout)
+        self.relu1 = nn.PReLU(cout)
+        self.conv2 = nn.Conv3D(cout, cout, kernel_size=3, padding=1)
+        self.norm2 = InstanceNorm3D(cout)
+        self.relu2 = nn.PReLU(cout)
+        self._u1 = ConvINAct(self.conv1, self.norm1, self.relu1)
+        self._u2 = ConvINAct(self.conv2, self.norm2, self.relu2)
+
+    def forward(self, x, out=None):
+        return self._u2.forward(self._u1.forward(x), out=out)
+
+    def backward(self, dout, need_dx=True):
+        self._u2.backward(dout)
+        self._u1.backward(self._u1.out.grad, need_dx=need_dx)
+
+
+class Down(nn.Layer):
+    """conv(k = s = 2) -> InstanceNorm -> PReLU (no pooling kernel exists on the path; a strided conv halves the grid)"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv3D(c, c, kernel_size=2, stride=2)
+        self.norm = InstanceNorm3D(c)
+        self.relu = nn.PReLU(c)
+        self._u = ConvINAct(self.conv, self.norm, self.relu)
+
+    def forward(self, x):
+        return self._u.forward(x)
+
+    def backward(self, dout):
+        self._u.backward(dout)
+
+
+class Up(nn.Layer):
+    """convT(k = s = 2, c_hi -> c_lo) -> InstanceNorm -> PReLU, concat with the skip, DoubleConv(2 c_lo -> c_lo)"""
+
+    def __init__(self, c_hi, c_lo):
+        super().__init__()
+        self.up_conv = nn.Conv3DTranspose(c_hi, c_lo, kernel_size=2, stride=2)
+        self.norm = InstanceNorm3D(c_lo)
+        self.relu = nn.PReLU(c_lo)
+        self.ops = DoubleConv(2 * c_lo, c_lo)
+        self.c_lo = c_lo
+        self._up = ConvINAct(self.up_conv, self.norm, self.relu)
+
+    def forward(self, x, skip):
+        od, oh, ow = self.up_conv.out_dims(x)
+        if (od, oh, ow) != (skip.d, skip.h, skip.w) or skip.c != self.c_lo:
+            raise ValueError(f"skip connection shape {skip.shape} does not match the up-sampled "
+                             f"({x.n}, {self.c_lo}, {od}, {oh}, {ow}): every input side must be a multiple of 2^(depth-1)")
+        self._x, self._skip = x, skip
+        xcat = Tensor.empty(x.dev, x.n, od, oh, ow, 2 * self.c_lo)
+        self._up.forward(x, out=xcat.channel_slice(0, self.c_lo))
+        copy_scale(skip, None, xcat.channel_slice(self.c_lo, 2 * self.c_lo))
+        self._xcat = xcat
+        return self.ops.forward(xcat)
+
+    def backward(self, dout):
+        self.ops.backward(dout)
+        gcat, skip = self._xcat.grad, self._skip
+        sg = skip.ensure_grad()
+        copy_scale(gcat.channel_slice(self.c_lo, 2 * self.c_lo), None, sg, accumulate=skip.grad_written)
+        skip.grad_written = True
+        self._up.backward(gcat.channel_slice(0, self.c_lo))
+
+
+@manager.MODELS.add_component
+class UNet3D(VNet):
+    """UNet3D(in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None): `depth` resolution levels
+    with base_channels * 2^level channels; returns `[logits]` like every medicalseg model (core/train.py:132)."""
+
+    num_outputs = 1
+
+    def __init__(self, in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None):
+        nn.Layer.__init__(self)
+        if depth < 2:
+            raise ValueError("UNet3D needs depth >= 2")
+        self.best_loss = 1000000
+        self.in_channels, self.num_classes, self.depth = int(in_channels), int(num_classes), int(depth)
+        ch = [int(base_channels) * (1 << i) for i in range(depth)]
+        self.encoders, self.downs, self.ups = [], [], []
+        for i in range(depth):
+            enc = DoubleConv(in_channels if i == 0 else ch[i - 1], ch[i])
+            setattr(self, f"enc{i}", enc)
+            self.encoders.append(enc)
+            if i < depth - 1:
+                down = Down(ch[i])
+                setattr(self, f"down{i}", down)
+                self.downs.append(down)
+        for i in range(depth - 2, -1, -1):
+            up = Up(ch[i + 1], ch[i])
+            setattr(self, f"up{i}", up)
+            self.ups.append(up)                      # deepest first
+        self.head = nn.Conv3D(ch[0], num_classes, kernel_size=1)
+        self.pretrained = pretrained
+        self._post_backward_hooks = []
+        self._grad_ready_hooks = []
+        self._build()
+        self.init_weight()
+
+    def dropout_layers(self):
+        return {}
+
+    def forward(self, x):
+        if not isinstance(x, Tensor):
+            x = to_tensor(x, self.dev)
+        if x.c != self.in_channels:
+            raise ValueError(f"UNet3D expects {self.in_channels} input channel(s), got {x.c}")
+        self.dev.arena.reset()
+        skips, t = [], x
+        for i, enc in enumerate(self.encoders):
+            # the first encoder's input is the image: it needs no data gradient
+            t = enc.forward(t)
+            if i < self.depth - 1:
+                skips.append(t)
+                t = self.downs[i].forward(t)
+        self._skips, self._bott = skips, t
+        for up, skip in zip(self.ups, reversed(skips)):
+            t = up.forward(t, skip)
+        self._feat = t
+        logits = self.head.run_forward(t)
+        logits.producer = self
+        return [logits, ]
+
+    def backward(self, dlogits: Tensor):
+        self.head.run_backward(self._feat, dlogits, need_dx=True)
+        self._grads_ready(self.head)
+        g = self._feat.grad
+        for j, up in enumerate(reversed(self.ups)):          # shallowest first
+            up.backward(g)
+            self._grads_ready(up)
+            g = up._x.grad
+        # g = gradient of the bottleneck output
+        for i in range(self.depth - 1, -1, -1):
+            if i < self.depth - 1:
+                self.downs[i].backward(g)
+                self._grads_ready(self.downs[i])
+                g = self._skips[i].grad
+            self.encoders[i].backward(g, need_dx=i > 0)
+            self._grads_ready(self.encoders[i])
+            if i > 0:
+                g = self.downs[i - 1]._u.out.grad
+        for hook in self._post_backward_hooks:
+            hook(self)

@@ -149,6 +149,34 @@ def test_gradient_buckets_partition_the_arena(fake_pkg):
     assert ddp.buckets_last_step == [(0, model.arena.count)]
 
 
+def test_unet3d_control_flow_and_config(fake_pkg):
+    """Builder-defined UNet3D: YAML -> Config -> model, shapes, one step of the data-parallel bucket hooks."""
+    from medicalseg_amd import parallel
+    from medicalseg_amd.cvlibs import Config
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.utils import loss_computation
+    cfg = Config(os.path.join(HERE, "..", "configs", "synthetic", "unet3d_synthetic_liver_192_192_64.yml"))
+    assert cfg.dic["model"]["type"] == "UNet3D" and cfg.batch_size == 2
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, UNet3D
+    model = UNet3D(num_classes=3, base_channels=8, depth=3)
+    names = [n for n, _ in model.named_parameters()]
+    assert "enc0.norm1.scale" in names and "up0.up_conv.weight" in names and "head.bias" in names
+    ddp = parallel.DataParallel(model, force=True, bucket_bytes=1 << 10)
+    x = np.zeros((2, 1, 16, 16, 8), np.float32)
+    out = ddp(x)[0]
+    assert out.shape == (2, 3, 16, 16, 8)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    ll, _ = loss_computation([out], to_tensor(np.zeros((2, 16, 16, 8), np.int32)), losses)
+    sum(ll).backward()
+    end = model.arena.count
+    for off, cnt in ddp.buckets_last_step:
+        assert off + cnt == end
+        end = off
+    assert end == 0 and len(ddp.buckets_last_step) >= 2
+    with pytest.raises(ValueError):
+        model(np.zeros((1, 1, 10, 16, 8), np.float32))      # 10 is not a multiple of 2^(depth-1)
+
+
 def test_stale_activation_is_detected(fake_pkg):
     from medicalseg_amd._lib import MskError
     from medicalseg_amd.models import VNet
