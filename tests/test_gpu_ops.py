@@ -549,3 +549,51 @@ def test_conv_fold_bn_and_fused_prelu_epilogue(case):
     # slope NULL: plain convolution with the folded weights
     d.call("msk_conv3d_fwd_act", _desc(k, s_, p), xt.msk(), vp(wf), vp(bf), None, yt.msk())
     assert rel_err(t_to_ncdhw(yt), z) < _conv_tol(cin * k_ ** 3)
+
+
+def _fuzz_cases():
+    rng = np.random.default_rng(20260928)
+    sizes = [2, 3, 4, 5, 8, 9, 12, 16, 18, 24, 32]
+    chans = [4, 8, 12, 16, 20, 32, 40]
+    cases = []
+    while len(cases) < 24:
+        n = int(rng.integers(1, 3))
+        d, h, w = (int(rng.choice(sizes)) for _ in range(3))
+        if n * d * h * w > 9000:
+            continue
+        cases.append((int(rng.choice(chans)), int(rng.choice(chans)), (n, d, h, w)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases())
+def test_conv5_dispatch_fuzz_matches_oracle(case):
+    """Seeded shape fuzz of the 5^3 'same' convolution through the DEFAULT dispatch (Winograd on whichever axis
+    permutation tiles, ragged planes, split-K, direct MFMA / VALU fallbacks): forward, data gradient (fresh and
+    accumulating) and weight gradient against the float64 oracle, whatever kernel the shape lands on."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(cin * 131 + cout * 17 + D * 7 + H * 3 + W)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    dw_ref, db_ref = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, yt, dyt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0), t_from_ncdhw(dy)
+    dxt = t_empty(N, cin, D, H, W, fill=3.0)
+    wp, bp = vec(w.ravel()), vec(b)
+    dwp, dbp = vec(np.full(w.size, 0.25, np.float32)), vec(np.zeros(cout, np.float32))
+    d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+    d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+    e_f, e_d = rel_err(t_to_ncdhw(yt), y_ref), rel_err(t_to_ncdhw(dxt), dx_ref)
+    d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+    e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
+    d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+    e_w = rel_err(vec_back(dwp, w.size).reshape(w.shape), dw_ref)
+    e_b = rel_err(vec_back(dbp, cout), db_ref)
+    M = N * D * H * W
+    assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125), (e_f, e_d, e_acc)
+    assert e_w < _conv_tol(M) * 2 and e_b < 1e-5, (e_w, e_b)
