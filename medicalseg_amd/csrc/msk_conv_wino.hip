@@ -28,6 +28,7 @@ struct WinoArgs {
   int svd, svh, svw;      //     n*svn + d*svd + h*svh + w*svw  (identity: H*W, W, 1)
   int CK, CN;
   const float4* um;  // [kd*5+kh][KC][2][xi][npad] float4 (k = kc*8 + h*4 + q)
+  unsigned um_bytes;
   int KC, npad;
   const float* bias;
   const float* prelu;  // per-channel slope applied after bias (inference epilogue), or null
@@ -39,6 +40,14 @@ struct WinoArgs {
   int ksplit, kc_per;
   float* partial;
 };
+
+// Transformed weights through a raw buffer resource: the (kc, row, xi) part of the address is wave-uniform and goes
+// into the scalar offset, the lane part is one constant byte offset -- no 64-bit vector address arithmetic per load
+// (the flat-pointer form cost 9 v_lshl_add_u64 per 32 MFMAs).
+typedef unsigned int v4u_t __attribute__((vector_size(16)));
+__device__ __forceinline__ float4 ubuf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
+}
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nb) {
   const int q = nb >> 3, r = nb & 7;
@@ -147,7 +156,8 @@ conv_halo_wino_k(WinoArgs a) {
     for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
 
   const long rowstride = (long)a.KC * 2 * 6 * a.npad;  // float4 units between (kd, kh) rows
-  const unsigned ulane_off = (unsigned)(lh * 6 * a.npad + nt * 32 + li);
+  const unsigned ulane_off = (unsigned)(lh * 6 * a.npad + nt * 32 + li) * 16u;  // bytes
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.um, 0, a.um_bytes, 0x00020000);
 
   const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
@@ -189,7 +199,6 @@ conv_halo_wino_k(WinoArgs a) {
     }
     __syncthreads();
 
-    const float4* uk = a.um + (long)kc * 2 * 6 * a.npad;  // wave-uniform base; the lane offset stays a 32-bit index
 #pragma unroll 1
     for (int rr = 0; rr < 25; ++rr) {
       const int kd = rr / 5, kh = rr % 5;
@@ -197,9 +206,9 @@ conv_halo_wino_k(WinoArgs a) {
       const Q2 x0 = q2(row[0]), x1 = q2(row[HWH]), x2 = q2(row[1]), x3 = q2(row[HWH + 1]), x4 = q2(row[2]),
                x5 = q2(row[HWH + 2]);
       float4 b[6];
-      const float4* ur = uk + rr * rowstride + ulane_off;
+      const unsigned ubase = (unsigned)(((long)kc * 2 * 6 * a.npad + rr * rowstride) * 16);
 #pragma unroll
-      for (int x = 0; x < 6; ++x) b[x] = ur[x * a.npad];
+      for (int x = 0; x < 6; ++x) b[x] = ubuf_load(ures, ulane_off, ubase + (unsigned)(x * a.npad) * 16u);
       // V = BT x  (points 0, 1, -1, 2, -2, inf), two channels per packed instruction
       f2 vl[6], vh[6];
       wino_bt(x0.lo, x1.lo, x2.lo, x3.lo, x4.lo, x5.lo, vl);
@@ -351,7 +360,8 @@ conv_halo_wino4_k(WinoArgs a) {
     for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
 
   const long rowstride = (long)a.KC * 2 * 8 * a.npad;  // float4 units between (kd, kh) rows
-  const unsigned ulane_off = (unsigned)(lh * 8 * a.npad + nt * 32 + li);
+  const unsigned ulane_off = (unsigned)(lh * 8 * a.npad + nt * 32 + li) * 16u;  // bytes
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.um, 0, a.um_bytes, 0x00020000);
 
   const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
@@ -393,7 +403,6 @@ conv_halo_wino4_k(WinoArgs a) {
     }
     __syncthreads();
 
-    const float4* uk = a.um + (long)kc * 2 * 8 * a.npad;
 #pragma unroll 1
     for (int rr = 0; rr < 25; ++rr) {
       const int kd = rr / 5, kh = rr % 5;
@@ -402,9 +411,9 @@ conv_halo_wino4_k(WinoArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = q2(row[(j & 3) * HWQ + (j >> 2)]);
       float4 b[8];
-      const float4* ur = uk + rr * rowstride + ulane_off;
+      const unsigned ubase = (unsigned)(((long)kc * 2 * 8 * a.npad + rr * rowstride) * 16);
 #pragma unroll
-      for (int xq = 0; xq < 8; ++xq) b[xq] = ur[xq * a.npad];
+      for (int xq = 0; xq < 8; ++xq) b[xq] = ubuf_load(ures, ulane_off, ubase + (unsigned)(xq * a.npad) * 16u);
       f2 vl[8], vh[8];
       wino4_bt(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, x[6].lo, x[7].lo, vl);
       wino4_bt(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, x[6].hi, x[7].hi, vh);
@@ -531,6 +540,8 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.N = g.N; a.D = LD; a.H = LH; a.W = LW; a.CK = g.CK; a.CN = g.CN;
   a.svn = (long)g.DD * g.DH * g.DW; a.svd = vstr[pm[0]]; a.svh = vstr[pm[1]]; a.svw = vstr[pm[2]];
   a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
+  if (ubytes >= 0xFFFFFFF0ull) return 0;  // 32-bit buffer offsets (52 MB for 256 -> 256 channels)
+  a.um_bytes = (unsigned)ubytes;
   a.bias = g.bias; a.prelu = g.prelu; a.accumulate = g.accumulate;
   a.tiles_d = (LD + 3) / 4; a.tiles_h = LH / 8; a.tiles_w = LW / twid; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
