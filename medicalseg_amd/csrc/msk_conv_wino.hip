@@ -329,6 +329,58 @@ __device__ __forceinline__ void wino4_bt(const f2 d0, const f2 d1, const f2 d2, 
   v[6] = t5 - t6;
 }
 
+// The same transform with every operation forced onto the packed fp32 pipe (v_pk_add_f32 / v_pk_fma_f32 /
+// v_pk_mul_f32, constants as SGPR pairs): left to itself the compiler emits about half of the transform as scalar
+// v_add_f32 / v_fma_f32 pairs (41 scalar + 30 packed instructions per 32 MFMAs; fp32 MFMA shares the SIMD's issue with
+// them), this is 25 packed instructions per two channels.  2.5*d3 is shared between t4 and t6.
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 c) {  // c: wave-uniform constant pair
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+  return r;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 c, f2 b) {  // a*c + b
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_fnma(f2 a, f2 c, f2 b) {  // b - a*c
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_fms(f2 a, f2 c, f2 b) {  // a*c - b
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void wino4_bt_pk(const f2 d0, const f2 d1, const f2 d2, const f2 d3, const f2 d4, const f2 d5,
+                                            const f2 d6, const f2 d7, f2 (&v)[8]) {
+  const f2 c525 = {5.25f, 5.25f}, c425 = {4.25f, 4.25f}, c025 = {0.25f, 0.25f}, c125 = {1.25f, 1.25f};
+  const f2 c05 = {0.5f, 0.5f}, c25 = {2.5f, 2.5f}, c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
+  v[0] = pk_fma(pk_sub(d2, d4), c525, pk_sub(d6, d0));
+  v[7] = pk_fma(pk_sub(d3, d5), c525, pk_sub(d7, d1));
+  const f2 t1 = pk_fnma(d4, c425, pk_add(d2, d6)), t2 = pk_fnma(d3, c425, pk_add(d1, d5));
+  v[1] = pk_add(t1, t2);
+  v[2] = pk_sub(t1, t2);
+  const f2 m3 = pk_mul(d3, c25);
+  const f2 t3 = pk_fnma(d4, c125, pk_fma(d2, c025, d6)), t4 = pk_fma(d5, c2, pk_fms(d1, c05, m3));
+  v[3] = pk_add(t3, t4);
+  v[4] = pk_sub(t3, t4);
+  const f2 t5 = pk_fnma(d4, c5, pk_fma(d2, c4, d6)), t6 = pk_fma(d5, c05, pk_fms(d1, c2, m3));
+  v[5] = pk_add(t5, t6);
+  v[6] = pk_sub(t5, t6);
+}
+
 __global__ void __launch_bounds__(256, 2)
 conv_halo_wino4_k(WinoArgs a) {
   constexpr int TD = 4, TH = 8, TW = 16, P = 2;
@@ -415,8 +467,8 @@ conv_halo_wino4_k(WinoArgs a) {
 #pragma unroll
       for (int xq = 0; xq < 8; ++xq) b[xq] = ubuf_load(ures, ulane_off, ubase + (unsigned)(xq * a.npad) * 16u);
       f2 vl[8], vh[8];
-      wino4_bt(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, x[6].lo, x[7].lo, vl);
-      wino4_bt(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, x[6].hi, x[7].hi, vh);
+      wino4_bt_pk(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, x[6].lo, x[7].lo, vl);
+      wino4_bt_pk(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, x[6].hi, x[7].hi, vh);
 #pragma unroll
       for (int xq = 0; xq < 8; ++xq) {
         acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].x, b[xq].x, acc[xq], 0, 0, 0);
