@@ -29,6 +29,7 @@ struct WinoArgs {
   int CK, CN;
   const float4* um;  // [kd*5+kh][KC][2][xi][npad] float4 (k = kc*8 + h*4 + q)
   unsigned um_bytes;
+  unsigned src_bytes;  // extent of src for the staging buffer loads (< 4 GiB: run_gconv chunks the batch)
   int KC, npad;
   const float* bias;
   const float* prelu;  // per-channel slope applied after bias (inference epilogue), or null
@@ -417,8 +418,53 @@ conv_halo_wino4_k(WinoArgs a) {
 
   const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
   const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
+  // Staging, vector path: a thread owns up to two (h, w, channel-quad) columns of the halo tile for the whole kernel and
+  // walks the 8 d planes.  Its LDS slot and its byte offset inside the tensor are fixed per tile (computed once, not
+  // per element and per channel chunk: the generic loop below spends ~13 VALU instructions per element on index
+  // arithmetic, 15 elements per thread and chunk), the plane / channel-chunk part of the address is wave-uniform and
+  // rides in the buffer load's scalar offset, and out-of-volume columns read zeros through an out-of-range offset.
+  constexpr unsigned kOOBw = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  int st_lds[2];
+  unsigned st_off[2];
+  bool st_live[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    const int item = tid + s_ * 256;  // (hh, hw, q), q fastest: neighbouring lanes read neighbouring 16 B
+    const int q = item & 1, col = item >> 1;
+    const int hh = col / HW, hw = col % HW;
+    const int gh = h0 - P + hh, gw = w0 - P + hw;
+    st_live[s_] = item < HH * HW * 2;
+    const bool ok = st_live[s_] && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    st_lds[s_] = q * NVP + hh * HW + (hw & 3) * HWQ + (hw >> 2);
+    st_off[s_] = ok ? (unsigned)((((long)n * a.svn + (long)gh * a.svh + (long)gw * a.svw) * a.sld + q * 4) * 4) : kOOBw;
+  }
+
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     __syncthreads();
+    if (a.vec) {
+      unsigned voff[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) voff[s_] = (kc * 8 + (((tid + s_ * 256) & 1) << 2) < a.CK) ? st_off[s_] : kOOBw;
+#pragma unroll
+      for (int hd0 = 0; hd0 < HD; hd0 += 4) {
+        float4 tmp[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int gd = d0 - P + hd0 + i;
+          const bool dok = gd >= 0 && gd < a.D;  // wave-uniform
+          const unsigned soff = dok ? (unsigned)(((long)gd * a.svd * a.sld + kc * 8) * 4) : 0u;
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+            tmp[i][s_] = dok ? ubuf_load(sres, voff[s_], soff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+            if (st_live[s_]) lds[st_lds[s_] + (hd0 + i) * HH * HW] = tmp[i][s_];
+      }
+    } else {
     constexpr int SG = 5;
     for (int base = 0; base < NV * 2; base += SG * 256) {
       float4 tmp[SG];
@@ -452,6 +498,7 @@ conv_halo_wino4_k(WinoArgs a) {
           lds[q * NVP + rowi * HW + (hw & 3) * HWQ + (hw >> 2)] = tmp[i];
         }
       }
+    }
     }
     __syncthreads();
 
@@ -594,6 +641,11 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   a.um = reinterpret_cast<const float4*>(um); a.KC = KC; a.npad = npad;
   if (ubytes >= 0xFFFFFFF0ull) return 0;  // 32-bit buffer offsets (52 MB for 256 -> 256 channels)
   a.um_bytes = (unsigned)ubytes;
+  {
+    const size_t sb = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
+    if (sb >= 0xFFFFFFF0ull) return 0;
+    a.src_bytes = (unsigned)sb;
+  }
   a.bias = g.bias; a.prelu = g.prelu; a.accumulate = g.accumulate;
   a.tiles_d = (LD + 3) / 4; a.tiles_h = LH / 8; a.tiles_w = LW / twid; a.nblk = (int)nblk;
   a.vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
