@@ -36,8 +36,12 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   ctx->rank = rank;
   ctx->world = world;
   // second communicator + stream for the gradient buckets (collective: every rank is inside msk_dp_init)
-  ncclComm_t comm_grad;
-  MSK_CHECK_NCCL(ctx, ncclCommSplit(comm, 0, rank, &comm_grad, nullptr));
+  ncclComm_t comm_grad = nullptr;
+  if (ncclCommSplit(comm, 0, rank, &comm_grad, nullptr) != ncclSuccess || comm_grad == nullptr) {
+    // no second communicator: the buckets then go through the first one ON THE COMPUTE STREAM (correct, not
+    // overlapped) -- see msk_dp_allreduce_async
+    comm_grad = nullptr;
+  }
   ctx->comm_grad = (void*)comm_grad;
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_main, hipEventDisableTiming));
@@ -56,8 +60,9 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
 }
 
 int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
-  MSK_REQUIRE(ctx, ctx->comm_grad != nullptr, "msk_dp_init not called");
+  MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (count == 0) return 0;
+  if (ctx->comm_grad == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);  // ncclCommSplit was not available
   // the bucket's gradients come from the compute stream (data-gradient chain, bias/BN/PReLU gradients) and from the
   // weight-gradient side stream: wait for the current tail of both, block neither
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_main, ctx->stream));
@@ -106,9 +111,9 @@ int msk_dp_barrier(msk_ctx* ctx) {
 }
 
 int msk_dp_destroy(msk_ctx* ctx) {
-  if (ctx && ctx->comm_grad) {
+  if (ctx && ctx->comm_stream) {
     hipStreamSynchronize(ctx->comm_stream);
-    ncclCommDestroy((ncclComm_t)ctx->comm_grad);
+    if (ctx->comm_grad) ncclCommDestroy((ncclComm_t)ctx->comm_grad);
     ctx->comm_grad = nullptr;
     hipStreamDestroy(ctx->comm_stream);
     hipEventDestroy(ctx->ev_comm_main);
