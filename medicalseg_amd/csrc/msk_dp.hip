@@ -3,6 +3,9 @@
 // (core/train.py:81-85, cvlibs/config.py:322).  All collectives are enqueued on the
 // context's compute stream so they order with the kernels that produce/consume them.
 #include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <cstdio>
 
 #include "msk_common.h"
 
@@ -12,9 +15,31 @@
     if (_r != ncclSuccess) return msk_fail(ctx, __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); \
   } while (0)
 
+namespace {
+// RCCL 2.27 prints a version banner ("RCCL version : ...", 5 lines) to STDOUT when a communicator is created; through
+// a pipe it sits in the C stdio buffer until exit, i.e. it would land after bench.py's single JSON line.  While RCCL
+// initialises, fd 1 points at stderr, and the buffer is flushed before fd 1 is restored.
+struct StdoutToStderr {
+  int saved;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved >= 0) {
+      dup2(saved, 1);
+      close(saved);
+    }
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int msk_dp_unique_id(char* id128) {
+  StdoutToStderr quiet;
   static_assert(sizeof(ncclUniqueId) <= MSK_UNIQUE_ID_BYTES, "unique id size");
   ncclUniqueId id;
   ncclResult_t r = ncclGetUniqueId(&id);
@@ -30,6 +55,7 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   MSK_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  StdoutToStderr quiet;
   ncclComm_t comm;
   MSK_CHECK_NCCL(ctx, ncclCommInitRank(&comm, world, id, rank));
   ctx->comm = (void*)comm;
