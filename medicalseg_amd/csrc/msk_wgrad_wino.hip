@@ -357,12 +357,13 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
         v[3] = t5 - t6;
       }
     };
-    float win[5][4];  // transformed x rows r .. r+4 (kh = 0 .. 4) for this wave's 4 xi
+    // RPT output rows per trip: the window of transformed x rows (r .. r+3+RPT, this wave's 4 xi) is shifted once per
+    // RPT * 40 MFMAs (16 v_mov) instead of once per 40.  RPT = 4 spills (256 VGPRs + 176 B of scratch, 1.5x slower).
+    constexpr int RPT = 2;
+    float win[4 + RPT][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) xform(k, win[k]);
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-      xform(r + 4, win[4]);
+    auto row_step = [&](int r, int w0_) {
       float ys[2][4];
 #pragma unroll
       for (int hb_ = 0; hb_ < 2; ++hb_) {
@@ -387,13 +388,22 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
       for (int kh = 0; kh < 5; ++kh)
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          acc[0][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[kh][x], ys[0][x], acc[0][x][kh], 0, 0, 0);
-          acc[1][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[kh][x], ys[1][x], acc[1][x][kh], 0, 0, 0);
+          acc[0][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[w0_ + kh][x], ys[0][x], acc[0][x][kh], 0, 0, 0);
+          acc[1][x][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[w0_ + kh][x], ys[1][x], acc[1][x][kh], 0, 0, 0);
         }
+    };
+    static_assert(R % RPT == 0, "whole trips");
+#pragma unroll 1
+    for (int r = 0; r < R; r += RPT) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        xform(r + 4 + j, win[4 + j]);
+        row_step(r + j, j);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) win[k][x] = win[k + 1][x];
+        for (int x = 0; x < 4; ++x) win[k][x] = win[k + RPT][x];
     }
   }
 
