@@ -251,7 +251,8 @@ constexpr int VP = 36;  // floats per staged voxel (32 channels + 4): the four W
 // (The previous mapping, K = 4 consecutive rows of one quad, transformed five x rows per step: ~150 VALU
 // instructions per 40 MFMAs, MFMA pipe 53 % busy; fp32 MFMA shares the SIMD issue with the VALU.)
 __global__ void __launch_bounds__(NT, 2)
-wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial) {
+wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float* __restrict__ partial, unsigned a_bytes,
+              unsigned b_bytes) {
   __shared__ float xs[XR * XW * VP];
   __shared__ float dys[R * WS * VP];
   const int tid = threadIdx.x;
@@ -281,6 +282,9 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
   int c_end = c_begin + chunks_per_split;
   if (c_end > chunks_total) c_end = chunks_total;
   constexpr int XITEMS = XR * XW * 8, DITEMS = R * WS * 8;
+  typedef unsigned int v4u_t __attribute__((vector_size(16)));
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
 
   for (int ch = c_begin; ch < c_end; ++ch) {
     int t = ch;
@@ -293,6 +297,8 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
     const int id = d + kd - P;
     if ((unsigned)id >= (unsigned)D) continue;  // block-uniform
     const int h0 = hb * R, w0 = wb * WS;
+    const unsigned a_plane = (unsigned)((((long)n * g.vsn + (long)id * g.vsd) * g.ald) * 4);
+    const unsigned b_plane = (unsigned)((((long)n * g.vsn + (long)d * g.vsd) * g.bld) * 4);
     __syncthreads();
     for (int base = 0; base < XITEMS; base += 4 * NT) {
       float4 tmp[4];
@@ -303,10 +309,12 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
         const int row = v / XW, col = v % XW;
         const int ih = h0 - P + row, iw = w0 - P + col;
         const int c0 = cat * 32 + q * 4;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA)
-          val = *reinterpret_cast<const float4*>(g.A + ((long)n * g.vsn + (long)id * g.vsd + (long)ih * g.vsh + (long)iw * g.vsw) * g.ald + c0);
-        tmp[i] = val;
+        // wave-uniform (n, plane) part of the address in the scalar offset, the lane part in 32 bits; columns outside
+        // the volume read zeros through an out-of-range offset (64-bit pointer arithmetic per element: ~65 slow
+        // VALU instructions per chunk)
+        const bool ok = it < XITEMS && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c0 < g.CA;
+        const unsigned voff = ok ? (unsigned)((ih * g.vsh + iw * g.vsw) * g.ald + c0) * 4u : 0xFFFFFFF0u;
+        tmp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)voff, (int)a_plane, 0));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -323,10 +331,9 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
         const int row = v / WS, col = v % WS;
         const int oh = h0 + row, ow = w0 + col;
         const int c0 = cbt * 32 + q * 4;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < DITEMS && oh < H && ow < W && c0 < g.CB)
-          val = *reinterpret_cast<const float4*>(g.B + ((long)n * g.vsn + (long)d * g.vsd + (long)oh * g.vsh + (long)ow * g.vsw) * g.bld + c0);
-        tmp[i] = val;
+        const bool ok = it < DITEMS && oh < H && ow < W && c0 < g.CB;
+        const unsigned voff = ok ? (unsigned)((oh * g.vsh + ow * g.vsw) * g.bld + c0) * 4u : 0xFFFFFFF0u;
+        tmp[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)voff, (int)b_plane, 0));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -651,6 +658,9 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
   const int cps = (int)((chunks + splits - 1) / splits);
   splits = (chunks + cps - 1) / cps;
   if (chunks > 0x7fffffff) return 0;
+  const size_t abytes = (size_t)g.N * g.BD * g.BH * g.BW * g.ald * sizeof(float);
+  const size_t bbytes = (size_t)g.N * g.BD * g.BH * g.BW * g.bld * sizeof(float);
+  if (abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull) return 0;  // 32-bit buffer offsets (run_wgrad chunks the batch)
   float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
   if (!partial) return -1;
   {
@@ -663,7 +673,7 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g_in) {
     msk_launch_scope ls(ctx, tag);
     if (f45)
       hipLaunchKernelGGL(wgrad_wino4_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
-                         (int)chunks, cps, partial);
+                         (int)chunks, cps, partial, (unsigned)abytes, (unsigned)bbytes);
     else
       hipLaunchKernelGGL(wgrad_wino_k, dim3((unsigned)tasks, (unsigned)splits), dim3(NT), 0, ctx->stream, g, (int)splits,
                          (int)chunks, cps, partial);
