@@ -27,6 +27,7 @@ struct V2Args {
   const float* bias;
   int accumulate;
   int tiles_d, tiles_h, tiles_w, nblk;
+  unsigned src_bytes;  // extent of src for the staging buffer loads (< 4 GiB: run_gconv chunks the batch)
 };
 
 __device__ __forceinline__ int xcd_remap_v2(int bid, int nb) {
@@ -66,29 +67,37 @@ conv_halo_valu2_k(V2Args a) {
 #pragma unroll
     for (int p = 0; p < (NP > 0 ? NP : 1); ++p) accp[v][p] = (f2){0.f, 0.f};
 
+  // Staging: a thread owns ONE (h, w) column of the halo tile (12 x 20 = 240 columns) for the whole kernel: its LDS
+  // slot and its byte offset in the tensor are computed once per tile, the plane and the channel quad of a pass ride in
+  // the buffer load's scalar offset, columns outside the volume read zeros through an out-of-range offset.  (The
+  // generic loop re-derived (d, h, w) with divisions and a 64-bit address for each of its 60 elements per thread --
+  // in a kernel that is VALU-issue bound.)
+  typedef unsigned int v4u_t __attribute__((vector_size(16)));
+  const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  const bool st_live = tid < HH * HW;
+  const int st_hh = tid / HW, st_hw = tid % HW;
+  const int st_gh = h0 - P + st_hh, st_gw = w0 - P + st_hw;
+  const int st_lds = st_hh * RP + (st_hw & 1) * HWH + (st_hw >> 1);
+  const unsigned st_off = (st_live && st_gh >= 0 && st_gh < a.H && st_gw >= 0 && st_gw < a.W)
+                              ? (unsigned)((((long)n * a.D * a.H + st_gh) * a.W + st_gw) * a.sld * 4)
+                              : 0xFFFFFFF0u;
 #pragma unroll 1
   for (int qc = 0; qc < QC; ++qc) {
     const int c0 = qc * 4;
     __syncthreads();
-    for (int sb = 0; sb < NV; sb += 4 * 256) {
-      float4 tmp[4];
+    {
+      float4 tmp[HD];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int hv = sb + tid + i * 256;
-        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hv < NV && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
-          v = *reinterpret_cast<const float4*>(a.src + ((((long)n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld + c0);
-        tmp[i] = v;
+      for (int hd = 0; hd < HD; ++hd) {
+        const int gd = d0 - P + hd;
+        const bool dok = gd >= 0 && gd < a.D;  // wave-uniform
+        const unsigned soff = dok ? (unsigned)(((long)gd * a.H * a.W * a.sld + c0) * 4) : 0u;
+        tmp[hd] = dok ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sres, (int)st_off, (int)soff, 0))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      if (st_live) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int hv = sb + tid + i * 256;
-        if (hv < NV) {
-          const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-          lds[(hd * HH + hh) * RP + (hw & 1) * HWH + (hw >> 1)] = tmp[i];
-        }
+        for (int hd = 0; hd < HD; ++hd) lds[hd * HH * RP + st_lds] = tmp[hd];
       }
     }
     __syncthreads();
@@ -162,6 +171,11 @@ int msk_gconv_halo_valu2(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   a.tiles_d = msk_cdiv(a.D, 4); a.tiles_h = msk_cdiv(a.H, 8); a.tiles_w = msk_cdiv(a.W, 16);
   const long nblk = (long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
   if (nblk > 0x7fffffff) return 0;
+  {
+    const size_t sb = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
+    if (sb >= 0xFFFFFFF0ull) return 0;
+    a.src_bytes = (unsigned)sb;
+  }
   a.nblk = (int)nblk;
   const char* tag = "conv_halo_valu2";
   if (ctx->prof && ctx->prof_shapes) {
