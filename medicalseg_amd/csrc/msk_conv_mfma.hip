@@ -537,8 +537,9 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
   if (((long)blockIdx.x * 4 + wave) * 32 >= Mq || QD <= 0 || QH <= 0 || QW <= 0) return;
   const bool mok = m < Mq;
   const long mm = mok ? m : 0;
-  const int qw = (int)(mm % QW), qh = (int)((mm / QW) % QH), qd = (int)((mm / ((long)QW * QH)) % QD);
-  const int n = (int)(mm / ((long)QW * QH * QD));
+  const unsigned mmu = (unsigned)mm, mt1 = mmu / (unsigned)QW, mt2 = mt1 / (unsigned)QH;  // Mq < 2^31
+  const int qw = (int)(mmu - mt1 * (unsigned)QW), qh = (int)(mt1 - mt2 * (unsigned)QH);
+  const int n = (int)(mt2 / (unsigned)QD), qd = (int)(mt2 - (unsigned)n * (unsigned)QD);
   const int od = qd * cs_d + rd, oh = qh * cs_h + rh, ow = qw * cs_w + rw;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, src_bytes, 0x00020000);
   const int nt0 = blockIdx.z * NR;
@@ -622,7 +623,37 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
   }
 
   // epilogue: rows = the tile's 32 dst voxels (decoded per row), cols = output channels
+  // The lane's first row is decoded with three 32-bit divisions (Mq < 2^31: tensors are chunked below 4 GiB), the
+  // other 15 follow by carries (rows advance by 1, 1, 1, 5).  The 64-bit divisions by run-time values that stood
+  // here for every row and N tile cost more instructions than the whole MFMA loop of these k = s layers.
   const long mbase = ((long)blockIdx.x * 4 + wave) * 32;
+  long rowoff[16];
+  bool rowok[16];
+  {
+    const long m0 = mbase + 4 * lh;
+    const unsigned mu = (unsigned)(m0 < Mq ? m0 : 0);
+    const unsigned t1 = mu / (unsigned)QW, t2 = t1 / (unsigned)QH;
+    unsigned w_ = mu - t1 * (unsigned)QW, h_ = t1 - t2 * (unsigned)QH;
+    unsigned n_ = t2 / (unsigned)QD, d_ = t2 - n_ * (unsigned)QD;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j > 0) {
+        w_ += (j & 3) ? 1u : 5u;
+        while (w_ >= (unsigned)QW) {
+          w_ -= (unsigned)QW;
+          if (++h_ >= (unsigned)QH) {
+            h_ = 0;
+            if (++d_ >= (unsigned)QD) {
+              d_ = 0;
+              ++n_;
+            }
+          }
+        }
+      }
+      rowok[j] = mbase + (j & 3) + 8 * (j >> 2) + 4 * lh < Mq;
+      rowoff[j] = ((((long)n_ * g.DD + d_ * cs_d + rd) * g.DH + h_ * cs_h + rh) * g.DW + w_ * cs_w + rw) * g.dld;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int co = (nt0 + r) * 32 + li;
@@ -630,12 +661,8 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
     const float bvs = g.bias ? g.bias[co] : 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;
-      const long mr = mbase + row;
-      if (mr < Mq) {
-        const int w_ = (int)(mr % QW), h_ = (int)((mr / QW) % QH), d_ = (int)((mr / ((long)QW * QH)) % QD);
-        const int n_ = (int)(mr / ((long)QW * QH * QD));
-        float* o = g.dst + ((((long)n_ * g.DD + d_ * cs_d + rd) * g.DH + h_ * cs_h + rh) * g.DW + w_ * cs_w + rw) * g.dld + co;
+      if (rowok[j]) {
+        float* o = g.dst + rowoff[j] + co;
         float v = acc[r][j] + bvs;
         if (g.accumulate) v += *o;
         *o = v;

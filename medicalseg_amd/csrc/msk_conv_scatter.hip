@@ -97,12 +97,35 @@ convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad, i
   unsigned rowbase[16];
   bool rowok[16];
   const long mw = (long)blockIdx.x * 128 + wave * 32;
+  // The lane's first row is decoded with divisions, the other 15 follow by carries (rows advance by 1, 1, 1, 5):
+  // 64 run-time divisions per lane cost more than the MFMA loop of these k = s layers.
+  unsigned w_, h_, d_, n_;
+  {
+    const long m0 = mw + 4 * lh;
+    const unsigned r = (unsigned)(m0 < M ? m0 : 0);
+    const unsigned t1 = r / (unsigned)g.SW, t2 = t1 / (unsigned)g.SH;
+    w_ = r - t1 * (unsigned)g.SW;
+    h_ = t1 - t2 * (unsigned)g.SH;
+    n_ = t2 / (unsigned)g.SD;
+    d_ = t2 - n_ * (unsigned)g.SD;
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
+    if (j > 0) {
+      w_ += (j & 3) ? 1u : 5u;
+      while (w_ >= (unsigned)g.SW) {
+        w_ -= (unsigned)g.SW;
+        if (++h_ >= (unsigned)g.SH) {
+          h_ = 0;
+          if (++d_ >= (unsigned)g.SD) {
+            d_ = 0;
+            ++n_;
+          }
+        }
+      }
+    }
     const long mr = mw + (j & 3) + 8 * (j >> 2) + 4 * lh;
     rowok[j] = mr < M;
-    const unsigned r = (unsigned)(rowok[j] ? mr : 0);
-    const unsigned w_ = r % g.SW, h_ = (r / g.SW) % g.SH, d_ = (r / (g.SW * g.SH)) % g.SD, n_ = r / (g.SW * g.SH * g.SD);
     rowbase[j] = (((n_ * g.DD + d_ * g.sd) * g.DH + h_ * g.sh) * g.DW + w_ * g.sw) * g.dld;
   }
   const int taps = g.kd * g.kh * g.kw;
