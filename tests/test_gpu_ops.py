@@ -44,6 +44,9 @@ CONV_CASES = [
     (128, 20, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 5, 9, 12)),    # VNetDeepSup out_tr128 (MRI, ncls 20)
     (256, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 6, 6)),      # VNetDeepSup out_tr256
     (5, 7, (3, 2, 1), (2, 1, 1), (1, 0, 0), (1, 7, 6, 5)),        # odd everything -> reference kernels
+    (8, 16, (2, 2, 4), (2, 2, 4), (0, 0, 0), (1, 5, 6, 13)),      # k == s with 16 taps: two tap groups in wgrad_ks, floor dims
+    (4, 8, (3, 3, 3), (3, 3, 3), (0, 0, 0), (2, 7, 9, 10)),       # k == s with 27 taps (4 tap groups, last one partial)
+    (48, 40, (2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 9, 6, 34)),     # k == s, two channel tiles each side, odd D
 ]
 
 
@@ -102,6 +105,7 @@ CONVT_CASES = [
     (12, 5, (2, 2, 2), (2, 2, 2), (2, 3, 3, 5)),      # CK % 8 != 0, taps*CN % 32 != 0
     (16, 8, (2, 2, 1), (2, 2, 1), (1, 4, 4, 6)),      # anisotropic k == s
     (40, 24, (1, 2, 2), (1, 2, 2), (2, 5, 4, 3)),
+    (16, 8, (2, 2, 4), (2, 2, 4), (1, 3, 3, 3)),      # 16 taps
 ]
 
 
