@@ -143,8 +143,8 @@ def cpu_baseline(size=128, ncls=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)   # warm-up 5, time >= 20 steps
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="samples per GPU")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--num-classes", type=int, default=3)
