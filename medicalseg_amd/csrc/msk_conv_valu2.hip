@@ -72,7 +72,6 @@ conv_halo_valu2_k(V2Args a) {
   // the buffer load's scalar offset, columns outside the volume read zeros through an out-of-range offset.  (The
   // generic loop re-derived (d, h, w) with divisions and a 64-bit address for each of its 60 elements per thread --
   // in a kernel that is VALU-issue bound.)
-  typedef unsigned int v4u_t __attribute__((vector_size(16)));
   const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
   const bool st_live = tid < HH * HW;
   const int st_hh = tid / HW, st_hw = tid % HW;

@@ -282,7 +282,6 @@ wgrad_wino4_k(WGrad g, int splits, int chunks_total, int chunks_per_split, float
   int c_end = c_begin + chunks_per_split;
   if (c_end > chunks_total) c_end = chunks_total;
   constexpr int XITEMS = XR * XW * 8, DITEMS = R * WS * 8;
-  typedef unsigned int v4u_t __attribute__((vector_size(16)));
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
 

@@ -15,7 +15,7 @@ import numpy as np
 
 from .. import nn
 from ..cvlibs import manager
-from ..device import Tensor, get_device, to_tensor
+from ..device import Tensor, to_tensor
 from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _fp, copy_scale
 from .vnet import VNet
 
