@@ -22,6 +22,7 @@ struct TKArgs {
   int N, D, H, W;
   int CN, npad;
   const float* wt;  // [HT][CK][2][npad]
+  unsigned wt_bytes, src_bytes;
   const float* bias;
   int accumulate;
   int tiles_d, tiles_h, tiles_w, nblk;
@@ -83,13 +84,17 @@ conv_halo_tightk_k(TKArgs a) {
     const int tap = (i / HT) * HT + (i % HT);
     toff[i] = tap < TAPS ? ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS : 0;
   }
+  const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
   for (int hv = tid; hv < NV; hv += 256) {
     const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
     const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
     const bool in = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-    const float* p = a.src + ((((long)n * a.D + (in ? gd : 0)) * a.H + (in ? gh : 0)) * a.W + (in ? gw : 0)) * a.sld;
+    // 32-bit offsets into a buffer resource (tensors are chunked below 4 GiB); halo voxels outside the volume read
+    // zeros through an out-of-range offset
+    const unsigned voff = in ? (unsigned)((((n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld) * 4u : 0xFFFFFFF0u;
 #pragma unroll
-    for (int c = 0; c < CK; ++c) lds[c * NVP + hv] = in ? p[c] : 0.f;
+    for (int c = 0; c < CK; ++c)
+      lds[c * NVP + hv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sres, (int)voff, 4 * c, 0));
   }
   __syncthreads();
 
@@ -105,14 +110,18 @@ conv_halo_tightk_k(TKArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
 
-  const float* wl = a.wt + (long)lh * a.npad + nt * 32 + li;
+  // weights through a raw buffer resource: the (tap pair, channel) part of the address is wave-uniform and rides in
+  // the scalar offset, the lane part is one constant (a flat pointer cost ~3 VALU instructions per load)
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const unsigned wlane = (unsigned)(lh * a.npad + nt * 32 + li) * 4u;
   const int* tl = toff + lh * HT;
 #pragma unroll 3
   for (int ti = 0; ti < HT; ++ti) {
     const int off = tl[ti];
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
-      const float b = wl[(long)(ti * CK + c) * 2 * a.npad];
+      const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          wres, (int)wlane, (int)((unsigned)((ti * CK + c) * 2 * a.npad) * 4u), 0));
 #pragma unroll
       for (int r = 0; r < MR; ++r)
         acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[c * NVP + abase[r] + off], b, acc[r], 0, 0, 0);
@@ -184,6 +193,12 @@ int msk_gconv_halo_tightk(msk_ctx* ctx, const GConv& g, const float* w_canon, in
   a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
   a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW;
   a.CN = g.CN; a.npad = npad; a.wt = wt; a.bias = g.bias; a.accumulate = g.accumulate;
+  a.wt_bytes = (unsigned)((size_t)HT * g.CK * 2 * npad * sizeof(float));
+  {
+    const size_t sb = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
+    if (sb >= 0xFFFFFFF0ull) return 0;
+    a.src_bytes = (unsigned)sb;
+  }
   const char* tag = "conv_halo_tightk";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[160];
