@@ -551,7 +551,10 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
     for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
 
   const long tapstride = (long)KC * 2 * npad;
-  const float4* wlane = wm + ((long)lh * npad + nt0 * 32 + li);
+  // packed weights through a raw buffer resource: (tap, chunk, N tile) in the scalar offset, one constant lane offset
+  const unsigned wbytes = (unsigned)((long)g.kd * g.kh * g.kw * KC * 2 * npad * 16);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)wm, 0, wbytes, 0x00020000);
+  const unsigned wlane_b = (unsigned)(lh * npad + nt0 * 32 + li) * 16u;
   for (int a = 0; a < g.kd; ++a) {
     int id;
     if (!g.transposed) {
@@ -582,7 +585,7 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
         const bool ok = mok && (unsigned)id < (unsigned)g.SD && (unsigned)ih < (unsigned)g.SH && (unsigned)iw < (unsigned)g.SW;
         const unsigned vbase = (unsigned)(((n * g.SD + id) * g.SH + ih) * g.SW + iw) * (unsigned)g.sld;
         const int tap = (a * g.kh + b) * g.kw + c;
-        const float4* wt = wlane + (long)tap * tapstride;
+        const unsigned wtap_b = (unsigned)(tap * tapstride * 16);
         // K chunks in batches of KB: every load of the batch is issued before its MFMAs (these
         // layers have only a handful of MFMAs per wave; a load->MFMA chain per chunk was pure latency)
         constexpr int KB = NR >= 4 ? 2 : 4;
@@ -605,7 +608,9 @@ gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, un
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r)
-              bv[u][r] = kin ? wt[(long)kc * 2 * npad + r * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
+              bv[u][r] = kin ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                   wres, (int)wlane_b, (int)(wtap_b + (unsigned)(kc * 2 * npad + r * 32) * 16u), 0))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int u = 0; u < KB; ++u) {
