@@ -516,6 +516,7 @@ conv_halo_wino4_k(WinoArgs a) {
       f2 vl[8], vh[8];
       wino4_bt_pk(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, x[6].lo, x[7].lo, vl);
       wino4_bt_pk(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, x[6].hi, x[7].hi, vh);
+      __builtin_amdgcn_s_setprio(2);  // the wavefront in its MFMA burst wins the issue arbitration over its SIMD mate
 #pragma unroll
       for (int xq = 0; xq < 8; ++xq) {
         acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].x, b[xq].x, acc[xq], 0, 0, 0);
@@ -523,6 +524,7 @@ conv_halo_wino4_k(WinoArgs a) {
         acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].x, b[xq].z, acc[xq], 0, 0, 0);
         acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].y, b[xq].w, acc[xq], 0, 0, 0);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 
