@@ -122,7 +122,15 @@ int msk_ctx_create(int device, msk_ctx** out) {
   }
   MSK_CHECK_HIP(ctx, hipSetDevice(device));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  {
+    // the weight-gradient stream only has to finish before the optimizer: lowest priority, so that the workgroups of
+    // the data-gradient chain (the critical path) are dispatched first
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    const char* e = getenv("MSEGK_SIDE_PRIORITY");   // A/B: "0" = normal priority
+    const int prio = (e && e[0] == '0') ? 0 : least;
+    MSK_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio));
+  }
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t0));
