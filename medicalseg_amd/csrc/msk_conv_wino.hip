@@ -566,6 +566,241 @@ conv_halo_wino4_k(WinoArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// F(4,3): the 3 x 3 x 3 'same' convolutions (UNet3D's DoubleConvs, the deep-supervision heads): four outputs of a row
+// from 6 multiplications (points 0, +-1, +-2, inf -- the same six points as F(2,5), hence the same input transform)
+// -> 18 of the 27 direct MACs per output... per axis 6/12 = 0.5.  Same structure as conv_halo_wino4_k: tile 4 x 8 x 16
+// outputs, halo 6 x 10 x 18 stored by W residue mod 4 (row pitch 20 quads), 9 (kd, kh) rows, 6 xi accumulators.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_bt_pk(const f2 d0, const f2 d1, const f2 d2, const f2 d3, const f2 d4, const f2 d5,
+                                           f2 (&v)[6]) {
+  const f2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
+  v[0] = pk_fma(d0, c4, pk_fnma(d2, c5, d4));
+  const f2 pa = pk_fnma(d2, c4, d4), qa = pk_fnma(d1, c4, d3);
+  v[1] = pk_add(pa, qa);
+  v[2] = pk_sub(pa, qa);
+  const f2 pb = pk_sub(d4, d2), sd = pk_sub(d3, d1);
+  v[3] = pk_fma(sd, c2, pb);
+  v[4] = pk_fnma(sd, c2, pb);
+  v[5] = pk_fma(d1, c4, pk_fnma(d3, c5, d5));
+}
+
+// U[r][kc][h][xi][n][q] = sum_kw G[xi][kw] * w(tap, k = kc*8+h*4+q, n), r = kd*3 + kh, canonical tap from the permuted axes
+__global__ void __launch_bounds__(256)
+pack_wino43_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int npad,
+                      int tsd, int tsh, int tsw, float* __restrict__ out) {
+  const double G[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+  const long total = 9L * KC * 2 * npad * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx & 3);
+    long r_ = idx >> 2;
+    const int n = (int)(r_ % npad);
+    r_ /= npad;
+    const int h = (int)(r_ & 1);
+    r_ >>= 1;
+    const int kc = (int)(r_ % KC);
+    const int row = (int)(r_ / KC);
+    const int k = kc * 8 + h * 4 + q;
+    double t[3] = {0, 0, 0};
+    if (k < CK && n < CN) {
+      const int ia = swap ? n : k, ib = swap ? k : n;
+      const float* wp = w + ((long)ia * B + ib) * 27;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tap = (row / 3) * tsd + (row % 3) * tsh + kw * tsw;
+        t[kw] = (double)wp[flip ? 26 - tap : tap];
+      }
+    }
+    float* o = out + ((((long)(row * KC + kc) * 2 + h) * 6) * npad + n) * 4 + q;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) o[(long)xi * npad * 4] = (float)(G[xi][0] * t[0] + G[xi][1] * t[1] + G[xi][2] * t[2]);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+conv_halo_wino43_k(WinoArgs a) {
+  constexpr int TD = 4, TH = 8, TW = 16, P = 1;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;  // 6 x 10 x 18
+  constexpr int HWQ = (HW + 3) / 4, RPW = 4 * HWQ;                    // 5 slots per W residue class, row pitch 20
+  constexpr int NV = HD * HH * HW, NVP = (HD * HH * RPW) | 1;
+  __shared__ float4 lds[2 * NVP];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int tile = xcd_remap_w(blockIdx.x, a.nblk);
+  const int twi = tile % a.tiles_w;
+  tile /= a.tiles_w;
+  const int thi = tile % a.tiles_h;
+  tile /= a.tiles_h;
+  const int tdi = tile % a.tiles_d;
+  const int n = tile / a.tiles_d;
+  const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+  const int nt = blockIdx.y;
+
+  // A row of this lane: (dz = wave, hy = li / 4, t = li % 4); LDS index of x[.., 4t + j]:
+  //   lh*NVP + ((dz + kd)*HH + hy + kh)*HW + (j & 3)*HWQ + t + (j >> 2)
+  const int abase = lh * NVP + (wave * HH + (li >> 2)) * RPW + (li & 3);
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int x = 0; x < 6; ++x)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[x][j] = 0.f;
+
+  const long rowstride = (long)a.KC * 2 * 6 * a.npad;  // float4 units between (kd, kh) rows
+  const unsigned ulane_off = (unsigned)(lh * 6 * a.npad + nt * 32 + li) * 16u;  // bytes
+  const __amdgpu_buffer_rsrc_t ures = __builtin_amdgcn_make_buffer_rsrc((void*)a.um, 0, a.um_bytes, 0x00020000);
+
+  const int kc_begin = a.ksplit > 1 ? (int)blockIdx.z * a.kc_per : 0;
+  const int kc_end = a.ksplit > 1 ? min(a.KC, kc_begin + a.kc_per) : a.KC;
+  // Staging, vector path: a thread owns up to two (h, w, channel-quad) columns of the halo tile for the whole kernel and
+  // walks the 8 d planes.  Its LDS slot and its byte offset inside the tensor are fixed per tile (computed once, not
+  // per element and per channel chunk: the generic loop below spends ~13 VALU instructions per element on index
+  // arithmetic, 15 elements per thread and chunk), the plane / channel-chunk part of the address is wave-uniform and
+  // rides in the buffer load's scalar offset, and out-of-volume columns read zeros through an out-of-range offset.
+  constexpr unsigned kOOBw = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+  int st_lds[2];
+  unsigned st_off[2];
+  bool st_live[2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    const int item = tid + s_ * 256;  // (hh, hw, q), q fastest: neighbouring lanes read neighbouring 16 B
+    const int q = item & 1, col = item >> 1;
+    const int hh = col / HW, hw = col % HW;
+    const int gh = h0 - P + hh, gw = w0 - P + hw;
+    st_live[s_] = item < HH * HW * 2;
+    const bool ok = st_live[s_] && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    st_lds[s_] = q * NVP + hh * RPW + (hw & 3) * HWQ + (hw >> 2);
+    st_off[s_] = ok ? (unsigned)((((long)n * a.svn + (long)gh * a.svh + (long)gw * a.svw) * a.sld + q * 4) * 4) : kOOBw;
+  }
+
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    __syncthreads();
+    if (a.vec) {
+      unsigned voff[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) voff[s_] = (kc * 8 + (((tid + s_ * 256) & 1) << 2) < a.CK) ? st_off[s_] : kOOBw;
+#pragma unroll
+      for (int hd0 = 0; hd0 < HD; hd0 += 3) {
+        float4 tmp[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int gd = d0 - P + hd0 + i;
+          const bool dok = gd >= 0 && gd < a.D;  // wave-uniform
+          const unsigned soff = dok ? (unsigned)(((long)gd * a.svd * a.sld + kc * 8) * 4) : 0u;
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+            tmp[i][s_] = dok ? ubuf_load(sres, voff[s_], soff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+            if (st_live[s_]) lds[st_lds[s_] + (hd0 + i) * HH * RPW] = tmp[i][s_];
+      }
+    } else {
+    constexpr int SG = 5;
+    for (int base = 0; base < NV * 2; base += SG * 256) {
+      float4 tmp[SG];
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        const int hv = it >> 1, q = it & 1;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = kc * 8 + q * 4;
+        if (it < NV * 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && c0 < a.CK) {
+          const float* p = a.src + ((long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw) * a.sld + c0;
+          if (a.vec) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c0 + 1 < a.CK) v.y = p[1];
+            if (c0 + 2 < a.CK) v.z = p[2];
+            if (c0 + 3 < a.CK) v.w = p[3];
+          }
+        }
+        tmp[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int it = base + tid + i * 256;
+        if (it < NV * 2) {
+          const int hv = it >> 1, q = it & 1;
+          const int hw = hv % HW, rowi = hv / HW;
+          lds[q * NVP + rowi * RPW + (hw & 3) * HWQ + (hw >> 2)] = tmp[i];
+        }
+      }
+    }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int rr = 0; rr < 9; ++rr) {
+      const int kd = rr / 3, kh = rr % 3;
+      const float4* row = lds + abase + (kd * HH + kh) * RPW;
+      Q2 x[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) x[j] = q2(row[(j & 3) * HWQ + (j >> 2)]);
+      float4 b[6];
+      const unsigned ubase = (unsigned)(((long)kc * 2 * 6 * a.npad + rr * rowstride) * 16);
+#pragma unroll
+      for (int xq = 0; xq < 6; ++xq) b[xq] = ubuf_load(ures, ulane_off, ubase + (unsigned)(xq * a.npad) * 16u);
+      f2 vl[6], vh[6];
+      wino_bt_pk(x[0].lo, x[1].lo, x[2].lo, x[3].lo, x[4].lo, x[5].lo, vl);
+      wino_bt_pk(x[0].hi, x[1].hi, x[2].hi, x[3].hi, x[4].hi, x[5].hi, vh);
+      __builtin_amdgcn_s_setprio(2);  // the wavefront in its MFMA burst wins the issue arbitration over its SIMD mate
+#pragma unroll
+      for (int xq = 0; xq < 6; ++xq) {
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].x, b[xq].x, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[xq].y, b[xq].y, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].x, b[xq].z, acc[xq], 0, 0, 0);
+        acc[xq] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[xq].y, b[xq].w, acc[xq], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // output transform (AT, 4 x 6) + store
+  const int co = nt * 32 + li;
+  if (co < a.CN) {
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float slope = a.prelu ? a.prelu[co] : 1.f;
+    const int gd = d0 + wave;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lh;  // = hy*4 + t
+      const int gh = h0 + (row >> 2), gw = w0 + 4 * (row & 3);
+      if (gd < a.D && gh < a.H && gw < a.W) {
+        const float s12 = acc[1][j] + acc[2][j], d12 = acc[1][j] - acc[2][j];
+        const float s34 = acc[3][j] + acc[4][j], d34 = acc[3][j] - acc[4][j];
+        float y[4];
+        y[0] = (acc[0][j] + s12) + s34;
+        y[1] = d12 + 2.f * d34;
+        y[2] = s12 + 4.f * s34;
+        y[3] = (d12 + 8.f * d34) + acc[5][j];
+        const long vox = (long)n * a.svn + (long)gd * a.svd + (long)gh * a.svh + (long)gw * a.svw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (gw + i < a.W) {
+            if (a.ksplit > 1) {
+              a.partial[((long)blockIdx.z * ((long)a.N * a.D * a.H * a.W) + vox + (long)i * a.svw) * a.CN + co] = y[i];
+            } else {
+              float* o = a.dst + (vox + (long)i * a.svw) * a.dld + co;
+              float r = y[i] + bv;
+              if (a.accumulate) r += *o;
+              *o = r > 0.f ? r : slope * r;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels, int CN, const float* __restrict__ bias,
                      const float* __restrict__ prelu, float* __restrict__ dst, int dld, int accumulate) {
@@ -585,10 +820,13 @@ wino_splitk_reduce_k(const float* __restrict__ partial, int ksplit, long voxels,
 }  // namespace
 
 int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5)) return 0;
-  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;  // F(4,3) only
+  if (!(k5 || k3)) return 0;
+  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
   if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
   if (g.CK < 8 || g.CN < 8) return 0;                       // tiny-channel layers have their own kernels
+  if (k3 && ctx->conv_impl == 14) return 0;
   // The kernels tile 4 x 8 x {8,16} over LOGICAL axes (d, h, w) and transform along w; any permutation of the tensor's
   // axes can play those roles (addresses are strided per voxel, the weights are packed with the taps permuted the same
   // way).  The anisotropic MRI slabs (512 x 512 x 12, W = 12 / 8 / 4) get their transform along H this way.
@@ -601,6 +839,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
     const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
     if (lh_ % 8 || lw_ % 8) continue;                          // whole tiles in h and w; d may be ragged (bounds-checked)
     const int f = (lw_ % 16 == 0) && ctx->conv_impl != 14;     // 14 = F(2,5) only (A/B)
+    if (k3 && !f) continue;                                    // 3^3: only the 16-wide F(4,3) kernel exists
     const long cost = (long)((ld_ + 3) / 4) * 4 * lh_ * lw_;   // padded volume
     if (cost * 2 > (long)ld_ * lh_ * lw_ * 3) continue;        // more than 1.5x padding: the direct kernel wins
     if (best < 0 || f > best_f45 || (f == best_f45 && cost < best_cost)) {
@@ -613,22 +852,25 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   const int* pm = kPerms[best];
   const int LD = dims[pm[0]], LH = dims[pm[1]], LW = dims[pm[2]];
   const int vstr[3] = {g.DH * g.DW, g.DW, 1};   // voxel strides of the tensor's (D, H, W)
-  const int tstr[3] = {25, 5, 1};               // tap strides of the canonical weight's (kd, kh, kw)
+  const int tstr[3] = {k3 ? 9 : 25, k3 ? 3 : 5, 1};   // tap strides of the canonical weight's (kd, kh, kw)
   const bool f45 = best_f45 != 0;
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
-  const int twid = f45 ? 16 : 8, nxi = f45 ? 8 : 6;
+  const int twid = f45 ? 16 : 8, nxi = k3 ? 6 : (f45 ? 8 : 6), nrows = k3 ? 9 : 25;
   const long nblk = (long)g.N * ((LD + 3) / 4) * (LH / 8) * (LW / twid);
   // the direct kernel splits K when the tiling cannot fill the chip; leave those small layers to it
   if (nblk > 0x7fffffff) return 0;
-  const size_t ubytes = (size_t)nxi * 25 * KC * 2 * npad * 4 * sizeof(float);
+  const size_t ubytes = (size_t)nxi * nrows * KC * 2 * npad * 4 * sizeof(float);
   float* um = (float*)msk_workspace2(ctx, ubytes);
   if (!um) return -1;
   {
     msk_launch_scope ls(ctx, "pack_weights_wino");
     long blocks = ((long)(ubytes / sizeof(float)) + 255) / 256;
     if (blocks > 8L * ctx->num_cu) blocks = 8L * ctx->num_cu;
-    if (f45)
+    if (k3)
+      hipLaunchKernelGGL(pack_wino43_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
+                         g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], um);
+    else if (f45)
       hipLaunchKernelGGL(pack_wino4_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
                          g.transposed ? 1 : 0, g.CK, g.CN, KC, npad, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], um);
     else
@@ -667,7 +909,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
       if (!a.partial) return -1;
     }
   }
-  const char* tag = f45 ? "conv_halo_wino4_k" : "conv_halo_wino_k";
+  const char* tag = k3 ? "conv_halo_wino43_k" : (f45 ? "conv_halo_wino4_k" : "conv_halo_wino_k");
   if (ctx->prof && ctx->prof_shapes) {
     char buf[200];
     snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", tag, g.CK, g.CN, g.N, g.DD, g.DH, g.DW,
@@ -676,7 +918,8 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   }
   {
     msk_launch_scope ls(ctx, tag);
-    if (f45) hipLaunchKernelGGL(conv_halo_wino4_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
+    if (k3) hipLaunchKernelGGL(conv_halo_wino43_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
+    else if (f45) hipLaunchKernelGGL(conv_halo_wino4_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(conv_halo_wino_k, dim3((unsigned)nblk, npad / 32, a.ksplit), dim3(256), 0, ctx->stream, a);
     MSK_LAUNCH_CHECK(ctx);
   }

@@ -601,3 +601,52 @@ def test_conv5_dispatch_fuzz_matches_oracle(case):
     M = N * D * H * W
     assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125), (e_f, e_d, e_acc)
     assert e_w < _conv_tol(M) * 2 and e_b < 1e-5, (e_w, e_b)
+
+
+WINO3_CASES = [
+    # (Cin, Cout, (N, D, H, W)): 3 x 3 x 3 'same' convs that tile 4 x 8 x 16 over some axis permutation -> F(4,3)
+    (32, 32, (2, 8, 16, 16)),
+    (64, 40, (1, 4, 8, 32)),       # Cout not a multiple of 32
+    (16, 24, (1, 6, 8, 16)),       # ragged planes (6 = 4 + 2)
+    (16, 32, (1, 16, 32, 12)),     # permuted axes (transform along H)
+    (128, 128, (1, 4, 8, 16)),     # one tile -> split K
+    (12, 20, (2, 6, 8, 48)),       # Cin not a multiple of 8, ragged D
+]
+
+
+@pytest.mark.parametrize("case", WINO3_CASES)
+def test_conv3_winograd_f43_matches_oracle(case):
+    """conv_halo_wino43_k (1-D Winograd F(4,3) for the 3 x 3 x 3 convolutions: UNet3D's DoubleConvs, the deep-supervision
+    heads) forward, data gradient (fresh and accumulating) against the float64 oracle at the conv tolerance of this file."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    d = dev()
+    rng = np.random.default_rng(cin * 5 + cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    xt, yt, dyt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0), t_from_ncdhw(dy)
+    dxt = t_empty(N, cin, D, H, W, fill=3.0)
+    wp, bp = vec(w.ravel()), vec(b)
+    d.set_option("conv_impl", 10)
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+        e_f, e_d = rel_err(t_to_ncdhw(yt), y_ref), rel_err(t_to_ncdhw(dxt), dx_ref)
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+        e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
+        d.prof_enable(False)
+        assert d.prof_report().get("conv_halo_wino43_k", (0, 0))[0] == 3, d.prof_report()
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    print("F(4,3) rel err fwd %.2e dgrad %.2e" % (e_f, e_d))
+    assert e_f < _conv_tol(cin * 27) and e_d < _conv_tol(cout * 27) and e_acc < _conv_tol(cout * 27), (e_f, e_d, e_acc)
