@@ -432,6 +432,7 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
                            const float* __restrict__ invstd, const float* __restrict__ dout, int ldd, long voxels,
                            int C, int QCB, int VL, float* __restrict__ da, int ldda, float* __restrict__ db,
                            int lddb, int db_acc, float* __restrict__ partial /*[nb][NQ][4*QCB]*/) {
+  __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
   constexpr int NQ = JOIN ? 1 : 3;
   __shared__ float sh[NQ * 4][kThreads];
   const int t = threadIdx.x;
@@ -622,6 +623,7 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
                           const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
                           const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx, int lddx,
                           float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C, int cshift) {
+  __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
   const long g = (long)blockIdx.x * kThreads + threadIdx.x;
   const int c = (int)(g & ((C >> 2) - 1)) * 4;
   const long vstride = ((long)gridDim.x * kThreads) >> cshift;
