@@ -618,7 +618,7 @@ pack_wino43_weights_k(const float* __restrict__ w, int A, int B, int swap, int f
   }
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)  // 96 accumulator registers leave room for three wavefronts per SIMD
 conv_halo_wino43_k(WinoArgs a) {
   constexpr int TD = 4, TH = 8, TW = 16, P = 1;
   constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;  // 6 x 10 x 18
