@@ -336,6 +336,11 @@ fold_bn_k(const float* __restrict__ w, const float* __restrict__ b, const float*
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 18) {  // 18 = folded kernel for in_tr (A/B)
+    int r = msk_wgrad_c1(ctx, g);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 16) {  // 16 = generic tap-row kernel (A/B)
     int r = msk_wgrad_ks(ctx, g);
     if (r < 0) return r;

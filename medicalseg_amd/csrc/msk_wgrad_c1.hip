@@ -1,0 +1,133 @@
+// Weight gradient of a 'same' 5^3 convolution with ONE input channel (in_tr.conv1, 1 -> 16, vnet.py:67):
+//     dW[cb][0][tap] = sum_v x[v + tap] * dy[v][cb]
+// i.e. 125 x 16 dot products over all voxels.  It is the LAST weight gradient of a backward pass, so nothing hides it:
+// the optimizer waits for it.  The generic folded kernel (wgrad_fold_mfma_k<true>) gathers x straight from global
+// memory, one dword per lane and tap (0.63 ms + 0.03 ms reduce for 2 x 128^3; the tensors are 17 MB and 268 MB).
+// Here the 1-channel x halo of a 4 x 8 x 32 voxel tile sits in LDS (13.8 KB), the MFMA rows are TAPS
+// (v_mfma_f32_16x16x4_f32: 16 taps x 16 output channels x 4 voxels; 8 row tiles cover 125 taps), the A operand is
+// one ds_read_b32 at (voxel + tap offset from an LDS table), the B operand one coalesced dword of dy (16 channels of 4
+// consecutive voxels = 256 B per load).  A workgroup walks tiles round-robin and writes ONE partial slab.
+#include "msk_conv.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB1 = 0xFFFFFFF0u;
+
+__device__ __forceinline__ float c1_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256)
+wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, float* __restrict__ partial, unsigned a_bytes,
+                unsigned b_bytes) {
+  constexpr int TD = 4, TH = 8, TW = 32, P = KS / 2;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
+  constexpr int NV = HD * HH * HW;
+  constexpr int TAPS = KS * KS * KS, RT = (TAPS + 15) / 16;  // 8 row tiles of 16 taps
+  __shared__ float xs[NV + 1];                                // xs[NV] = 0: the address of the padding taps
+  __shared__ int toff[RT * 16];
+  __shared__ float red[4][RT * 16 * 16];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+  const int D = g.BD, H = g.BH, W = g.BW;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
+
+  for (int i = tid; i < RT * 16; i += 256)
+    toff[i] = i < TAPS ? ((i / (KS * KS)) * HH + (i / KS) % KS) * HW + i % KS : NV;
+  if (tid == 0) xs[NV] = 0.f;
+
+  __syncthreads();
+  int to[RT];  // this lane's tap offsets (halo index space), one per row tile
+#pragma unroll
+  for (int t = 0; t < RT; ++t) to[t] = toff[t * 16 + r];
+
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t_ = tile;
+    const int twi = t_ % tiles_w;
+    t_ /= tiles_w;
+    const int thi = t_ % tiles_h;
+    t_ /= tiles_h;
+    const int tdi = t_ % tiles_d;
+    const int n = t_ / tiles_d;
+    const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+    __syncthreads();  // the previous tile's readers are done (and toff / xs[NV] are visible on the first trip)
+    for (int hv = tid; hv < NV; hv += 256) {
+      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+      const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      xs[hv] = c1_load(ra, in ? (unsigned)((((n * D + gd) * H + gh) * W + gw) * g.ald) * 4u : kOOB1);
+    }
+    __syncthreads();
+    const int gd = d0 + wave;  // this wavefront's plane
+    if (gd < D) {
+#pragma unroll 2
+      for (int s = 0; s < TH * (TW / 4); ++s) {
+        const int h = s / (TW / 4), w = (s % (TW / 4)) * 4 + kq;
+        const int gh = h0 + h, gw = w0 + w;
+        const bool vok = gh < H && gw < W;
+        // x of a voxel outside the volume only ever meets dy = 0 (vok false -> b = 0), so its halo index needs no guard
+        const int base = (wave * HH + h) * HW + w;
+        const float b = c1_load(rb, (vok && r < g.CB) ? (unsigned)(((((n * D + gd) * H + gh) * W + gw) * g.bld) + r) * 4u : kOOB1);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[base + to[t]], b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // D[row = 4*(lane >> 4) + j][col = lane & 15]: row = tap within the row tile, col = cb.  Sum the four planes' waves.
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][(t * 16 + 4 * kq + j) * 16 + r] = acc[t][j];
+  __syncthreads();
+  for (int i = tid; i < RT * 16 * 16; i += 256) {
+    const int tap = i >> 4, cb = i & 15;
+    if (tap < TAPS && cb < g.CB)
+      partial[((long)blockIdx.x * TAPS + tap) * g.CB + cb] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+}  // namespace
+
+// returns 1 when handled, 0 when not eligible, < 0 on error
+int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
+  if (!(g.CA == 1 && g.CB >= 1 && g.CB <= 16)) return 0;
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2))
+    return 0;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
+  const long M = (long)g.N * g.BD * g.BH * g.BW;
+  const size_t abytes = (size_t)M * g.ald * sizeof(float), bbytes = (size_t)M * g.bld * sizeof(float);
+  if (M >= (1L << 30) || abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull) return 0;
+  const int tiles_d = (g.BD + 3) / 4, tiles_h = (g.BH + 7) / 8, tiles_w = (g.BW + 31) / 32;
+  const long ntiles = (long)g.N * tiles_d * tiles_h * tiles_w;
+  if (ntiles > 0x7fffffff) return 0;
+  long splits = 2L * ctx->num_cu;  // persistent workgroups (LDS: 13.8 KB halo + 32 KB reduction buffer -> 3 per CU)
+  if (splits > ntiles) splits = ntiles;
+  const int taps = 125;
+  const size_t per = (size_t)taps * g.CB * sizeof(float);
+  float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
+  if (!partial) return -1;
+  {
+    const char* tag = "wgrad_c1_mfma";
+    if (ctx->prof && ctx->prof_shapes) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "wgrad_c1_mfma[cb=%d,M=%ld,splits=%ld]", g.CB, M, splits);
+      tag = msk_intern_tag(ctx, buf);
+    }
+    msk_launch_scope ls(ctx, tag);
+    hipLaunchKernelGGL((wgrad_c1_mfma_k<5>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
+                       tiles_w, partial, (unsigned)abytes, (unsigned)bbytes);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  const int rc = msk_wgrad_reduce(ctx, partial, (int)splits, taps, 1, g.CB, g.dw, g.accumulate);
+  return rc == 0 ? 1 : rc;
+}
