@@ -68,17 +68,28 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
     __syncthreads();
     const int gd = d0 + wave;  // this wavefront's plane
     if (gd < D) {
-#pragma unroll 2
-      for (int s = 0; s < TH * (TW / 4); ++s) {
-        const int h = s / (TW / 4), w = (s % (TW / 4)) * 4 + kq;
-        const int gh = h0 + h, gw = w0 + w;
-        const bool vok = gh < H && gw < W;
-        // x of a voxel outside the volume only ever meets dy = 0 (vok false -> b = 0), so its halo index needs no guard
-        const int base = (wave * HH + h) * HW + w;
-        const float b = c1_load(rb, (vok && r < g.CB) ? (unsigned)(((((n * D + gd) * H + gh) * W + gw) * g.bld) + r) * 4u : kOOB1);
+      // batches of UB K-steps: all dy loads of a batch are in flight before its MFMAs (one load -> 8 MFMAs per step
+      // left the loop waiting on global latency)
+      constexpr int UB = 8;
+#pragma unroll 1
+      for (int s0 = 0; s0 < TH * (TW / 4); s0 += UB) {
+        float bv[UB];
+        int bs[UB];
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[base + to[t]], b, acc[t], 0, 0, 0);
+        for (int u = 0; u < UB; ++u) {
+          const int s = s0 + u;
+          const int h = s / (TW / 4), w = (s % (TW / 4)) * 4 + kq;
+          const int gh = h0 + h, gw = w0 + w;
+          const bool vok = gh < H && gw < W;
+          // x of a voxel outside the volume only ever meets dy = 0 (vok false -> b = 0): its halo index needs no guard
+          bs[u] = (wave * HH + h) * HW + w;
+          bv[u] = c1_load(rb, (vok && r < g.CB) ? (unsigned)(((((n * D + gd) * H + gh) * W + gw) * g.bld) + r) * 4u : kOOB1);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[bs[u] + to[t]], bv[u], acc[t], 0, 0, 0);
       }
     }
   }
