@@ -41,7 +41,7 @@ pack_scatter_weights_k(const float* __restrict__ w, int A, int B, int taps, int 
 constexpr int NTG = 4;   // N tiles (of 32 columns) per workgroup pass: 64 accumulator registers
 constexpr int KCB = 8;   // 8-channel chunks held in registers at a time (64 channels)
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)  // 172 registers without the bound: 4 over the three-wavefront limit
 convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad, int vec) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
