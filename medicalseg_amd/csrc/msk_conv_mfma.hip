@@ -518,7 +518,7 @@ wgrad_mfma_k(WGrad g, int splits, float* __restrict__ partial, unsigned a_bytes,
 // M = 32 dst voxels per wave, N = NR x 32 output channels in registers, K = taps x channels
 // in chunks of 8 with the same packed weights as the halo kernel.
 template <int NR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NR <= 2 ? 4 : (NR <= 4 ? 3 : 2))  // latency bound: as many wavefronts as the accumulators allow
 gconv_gather_mfma_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned src_bytes, int vec,
                     int tiles_max) {
   const int tid = threadIdx.x;
