@@ -60,6 +60,7 @@ int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
 // kernel == stride transposed gather (up-convs, down-conv data gradients): taps folded into N (msk_conv_scatter.hip)
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
+int msk_wgrad_cbs(msk_ctx* ctx, const WGrad& g); // <= 4 output channels, 5^3 same (msk_wgrad_cbs.hip)
 int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g);  // one input channel, 5^3 same (msk_wgrad_c1.hip)
 int msk_wgrad_ks(msk_ctx* ctx, const WGrad& g);  // kernel == stride, no padding (msk_wgrad_ks.hip)
 // weight gradient of 'same' 5^3 convs with the Winograd F(2,5) transform along W (msk_wgrad_wino.hip)

@@ -336,8 +336,11 @@ fold_bn_k(const float* __restrict__ w, const float* __restrict__ b, const float*
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
-  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 18) {  // 18 = folded kernel for in_tr (A/B)
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 18) {  // 18 = folded gather kernels for in_tr / out_tr (A/B)
     int r = msk_wgrad_c1(ctx, g);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+    r = msk_wgrad_cbs(ctx, g);
     if (r < 0) return r;
     if (r == 1) return 0;
   }
