@@ -25,7 +25,7 @@ wgrad_cbs_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, flo
                  unsigned b_bytes) {
   constexpr int TD = 4, TH = 8, TW = 32, P = KS / 2;
   constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
-  constexpr int NV = HD * HH * HW, NVP = NV + 1;  // slot NV of plane 0 is the zero the padding pairs read
+  constexpr int NV = HD * HH * HW, NVP = NV + 1;  // odd plane pitch
   constexpr int TAPS = KS * KS * KS;
   extern __shared__ float ys[];                    // [CB][NVP]
 
@@ -47,7 +47,7 @@ wgrad_cbs_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, flo
       const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
       po[t] = cb * NVP - (((kd - P) * HH + (kh - P)) * HW + (kw - P));
     } else {
-      po[t] = 0x40000000;                          // marker: padding pair
+      po[t] = 0;                                   // padding pair: reads something valid, its rows are never stored
     }
   }
 
@@ -74,9 +74,8 @@ wgrad_cbs_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, flo
       const unsigned off = in ? (unsigned)((((n * D + gd) * H + gh) * W + gw) * g.bld) * 4u : kOOBc;
       for (int cb = 0; cb < CB; ++cb) ys[cb * NVP + hv] = cbs_load(rb, off == kOOBc ? kOOBc : off + 4u * cb);
     }
-    if (tid == 0) ys[NV] = 0.f;
     __syncthreads();
-    constexpr int UB = 4;
+    constexpr int UB = 8;
 #pragma unroll 1
     for (int s0 = 0; s0 < TD * TH * (TW / 4); s0 += UB) {
       float xv[UB][CT];
@@ -97,7 +96,7 @@ wgrad_cbs_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, flo
       for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int t = 0; t < RTW; ++t) {
-          const float a = ys[po[t] == 0x40000000 ? NV : ctr[u] + po[t]];
+          const float a = ys[ctr[u] + po[t]];
 #pragma unroll
           for (int c = 0; c < CT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[u][c], acc[t][c], 0, 0, 0);
         }
