@@ -183,10 +183,12 @@ class UNet3D(VNet):
 
     num_outputs = 1
 
-    def __init__(self, in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None):
+    def __init__(self, in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None, elu=False):
         nn.Layer.__init__(self)
         if depth < 2:
             raise ValueError("UNet3D needs depth >= 2")
+        if elu:  # the VNet configs this one usually inherits from carry `elu: False`
+            raise ValueError("UNet3D has PReLU activations only")
         self.best_loss = 1000000
         self.in_channels, self.num_classes, self.depth = int(in_channels), int(num_classes), int(depth)
         ch = [int(base_channels) * (1 << i) for i in range(depth)]

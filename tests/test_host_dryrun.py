@@ -157,6 +157,8 @@ def test_unet3d_control_flow_and_config(fake_pkg):
     from medicalseg_amd.utils import loss_computation
     cfg = Config(os.path.join(HERE, "..", "configs", "synthetic", "unet3d_synthetic_liver_192_192_64.yml"))
     assert cfg.dic["model"]["type"] == "UNet3D" and cfg.batch_size == 2
+    built = cfg.model                       # through ComponentFactory with the keys inherited from the VNet base config
+    assert type(built).__name__ == "UNet3D" and built.depth == 4
     from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, UNet3D
     model = UNet3D(num_classes=3, base_channels=8, depth=3)
     names = [n for n, _ in model.named_parameters()]
