@@ -82,10 +82,13 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
             # values of this iteration (tiny device buffers) are fetched at the log boundary
             vals = _snapshot(dev, loss, loss_list, per_channel_dice)
             pending.append(vals)
+            if it % log_iters == 0:
+                # the iterations of this window were only enqueued so far: their device time has to land inside the
+                # window's batch_cost / ips (recording before the sync under-reported the step by ~14 %)
+                dev.sync()
             batch_cost_averager.record(time.time() - batch_start, num_samples=batch_size)
 
             if it % log_iters == 0:
-                dev.sync()
                 avg_loss, avg_loss_list, mdice = _reduce_pending(dev, pending)
                 pending = []
                 if local_rank == 0:
