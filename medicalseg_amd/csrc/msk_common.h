@@ -59,6 +59,12 @@ struct msk_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool wgrad_async = false;
   bool side_dirty = false;
+  // msk_h2d staging: two pinned buffers so that a batch upload neither synchronises the stream nor waits for the
+  // previous step (the host may run one upload ahead)
+  void* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes[2] = {0, 0};
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  int stage_next = 0;
   // data parallel
   void* comm = nullptr;  // ncclComm_t (compute stream: SyncBatchNorm exchanges, broadcast, barrier)
   // gradient buckets: second communicator on its own stream, overlapped with the rest of backward
