@@ -59,7 +59,10 @@ int msk_device_name(msk_ctx* ctx, char* buf, int buflen);
 int msk_malloc(msk_ctx* ctx, size_t bytes, void** out);
 int msk_free(msk_ctx* ctx, void* p);
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes);
-int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* blocking for pageable src */
+/* host (pageable) -> device, ordered on the compute stream; src may be reused as soon as the call returns.
+ * 64 KB .. 64 MB (the per-iteration batch upload of core/train.py:122-124) go through two internal pinned staging
+ * buffers and do NOT synchronise the stream; other sizes copy and synchronise. */
+int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes);
 int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes);  /* synchronises the stream */
 /* asynchronous host->device copy from PINNED memory (msk_pinned_alloc): returns immediately, the
  * source must stay untouched until the stream passes the copy (tools/prepare.py:200-259 loader path) */
