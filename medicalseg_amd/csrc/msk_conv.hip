@@ -261,6 +261,14 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
     if (r < 0) return r;
     if (r == 1) return 0;
+    // 20 = fp32-MFMA Winograd kernels instead of the bf16x3 pipeline (A/B); option "wino_bf3" 0 does the same
+    r = (ctx->conv_impl == 10 || ctx->conv_impl == 11 || ctx->conv_impl == 14 || ctx->conv_impl == 20 || ctx->no_winograd || !ctx->wbf)
+            ? 0 : msk_gconv_wino_bf3(ctx, g, w, A, B, swap);
+    if (r < 0) return r;
+    if (r == 1) {
+      *act_fused = true;  // wbf_tout_k applies g.prelu
+      return 0;
+    }
     r = (ctx->conv_impl == 11 || ctx->no_winograd) ? 0 : msk_gconv_halo_wino(ctx, g, w, A, B, swap);  // 11 = direct kernel only (A/B)
     if (r < 0) return r;
     if (r == 1) {

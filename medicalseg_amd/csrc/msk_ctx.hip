@@ -119,6 +119,8 @@ int msk_ctx_create(int device, msk_ctx** out) {
   {
     const char* e = getenv("MSEGK_DIRECT_CONV");
     ctx->no_winograd = e && e[0] && e[0] != '0';
+    const char* f = getenv("MSEGK_WBF");
+    if (f && f[0] == '0') ctx->wbf = false;
   }
   MSK_CHECK_HIP(ctx, hipSetDevice(device));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -312,6 +314,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wgrad_async_max_m") == 0) {
     ctx->wgrad_async_max_m = value;
+    return 0;
+  }
+  if (strcmp(key, "wino_bf3") == 0) {  // 0 = fp32-MFMA Winograd kernels instead of the bf16x3 three-stage pipeline
+    ctx->wbf = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "wbf_variant") == 0) {
+    ctx->wbf_variant = value;
     return 0;
   }
   if (strcmp(key, "direct_conv") == 0) {  // 1 = no Winograd kernels (same as env MSEGK_DIRECT_CONV=1)
