@@ -449,9 +449,12 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
 
   // tile variants {id, MR, WM, WN, TD, TH} by output channels (first = preferred when the padding is equal)
   struct Var { int id, MR, WM, WN, TD, TH; };
-  static const Var kVars[6] = {{0, 4, 4, 1, 16, 32}, {4, 2, 4, 1, 16, 16},    // CN == 32
-                               {1, 4, 2, 2, 16, 16}, {5, 2, 2, 2, 8, 16},     // CN == 64
-                               {2, 4, 1, 4, 8, 16},  {3, 2, 1, 4, 8, 8}};     // CN % 128 == 0
+  // Measured (tools/bench_conv.py, 2 x 128^3 .. 2 x 16^3): the MR = 2 variants win everywhere (32ch@128^3 3.06 vs 3.13 ms,
+  // 128ch@32^3 0.60 vs 0.85 ms, 256ch@16^3 0.32 vs 0.45 ms): smaller LDS tiles -> 3-4 workgroups per CU hide the
+  // staging barriers; the MR = 4 variants halve the B-fragment traffic and stay selectable ("wbf_variant").
+  static const Var kVars[6] = {{4, 2, 4, 1, 16, 16}, {0, 4, 4, 1, 16, 32},    // CN == 32
+                               {5, 2, 2, 2, 8, 16},  {1, 4, 2, 2, 16, 16},    // CN == 64
+                               {3, 2, 1, 4, 8, 8},   {2, 4, 1, 4, 8, 16}};    // CN % 128 == 0
   int v0;
   if (g.CN == 32) v0 = 0;
   else if (g.CN == 64) v0 = 2;

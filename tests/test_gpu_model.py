@@ -376,7 +376,7 @@ def test_winograd_and_direct_kernels_agree_on_a_training_step():
             opt.step()
             dev().prof_enable(False)
             tags = dev().prof_report()
-            ran_wino = any(k.startswith(("conv_halo_wino", "wgrad_wino")) for k in tags)
+            ran_wino = any(k.startswith(("conv_halo_wino", "wgrad_wino", "wbf_")) for k in tags)
             assert ran_wino == (direct == 0), sorted(tags)
             sd = model.state_dict()
             out.append((lg, loss, sd["up_tr32.ops.0.conv1.weight"], sd["down_tr64.ops.1.conv1.weight"], sd["in_tr.conv1.weight"]))

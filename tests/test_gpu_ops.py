@@ -497,7 +497,8 @@ def test_wgrad_winograd_f25_matches_oracle(case):
 
 FOLD_CASES = [
     # (Cin, Cout, k, pad, (N, D, H, W), kernel that must run)
-    (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue
+    (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue (fp32-MFMA kernels: wino_bf3 = 0 below)
+    (32, 32, 5, 2, (2, 16, 16, 16), "wbf_tout_k"),            # bf16x3 pipeline: slope applied by the output transform
     (64, 48, 5, 2, (1, 4, 8, 24), "conv_halo_wino_k"),        # F(2,5) epilogue, Cout not a multiple of 32
     (32, 24, 5, 2, (1, 16, 32, 12), "conv_halo_wino4_k"),     # permuted axes (transform along H)
     (128, 128, 5, 2, (1, 4, 8, 16), "conv_splitk_reduce"),    # few tiles -> split K: slope applied in the reduce
@@ -536,6 +537,7 @@ def test_conv_fold_bn_and_fused_prelu_epilogue(case):
     assert rel_err(vec_back(bf, cout), f8(b) * scale + f8(beta) - f8(mean) * scale) < 1e-6
     d.set_option("prof_shapes", 0)
     d.set_option("prof_only_halo", 0)
+    d.set_option("wino_bf3", 1 if tag.startswith("wbf") else 0)
     try:
         d.prof_reset()
         d.prof_enable(True)
@@ -547,6 +549,7 @@ def test_conv_fold_bn_and_fused_prelu_epilogue(case):
         assert ("prelu_inplace" in rep) == (tag == "prelu_inplace"), rep
     finally:
         d.prof_enable(False)
+        d.set_option("wino_bf3", 1)
     e = rel_err(got, ref)
     print("folded conv rel err %.2e" % e)
     assert e < _conv_tol(cin * k_ ** 3)
