@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Imedicalseg_amd/csr
 OBJS=""
 for f in medicalseg_amd/csrc/*.hip; do
   o=build/$(basename ${f%.hip}).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ include/msegk.h -nt $o ] || [ medicalseg_amd/csrc/msk_common.h -nt $o ] || [ medicalseg_amd/csrc/msk_conv.h -nt $o ]; then
+  if [ ! -f $o ] || [ $f -nt $o ] || [ include/msegk.h -nt $o ] || [ medicalseg_amd/csrc/msk_common.h -nt $o ] || [ medicalseg_amd/csrc/msk_conv.h -nt $o ] || [ medicalseg_amd/csrc/msk_wbf.h -nt $o ]; then
     hipcc $FLAGS $EXTRA -c $f -o $o &
   fi
   OBJS="$OBJS $o"

@@ -59,6 +59,8 @@ int msk_gconv_halo_valu2(msk_ctx* ctx, const GConv& g, const float* w_canon, int
 int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv as a three-stage Winograd F(4,5) pipeline with bf16x3 operands on the bf16 matrix pipe (msk_conv_wbf.hip)
 int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// weight gradient of the same layers on the bf16 matrix pipe (msk_wgrad_wbf.hip)
+int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g);
 // kernel == stride transposed gather (up-convs, down-conv data gradients): taps folded into N (msk_conv_scatter.hip)
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);

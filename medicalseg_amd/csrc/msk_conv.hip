@@ -357,6 +357,13 @@ int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
     if (r < 0) return r;
     if (r == 1) return 0;
   }
+  // 20 / 21 = fp32-MFMA Winograd weight gradient instead of the bf16x3 kernel (A/B; 21 keeps the bf16x3 forward)
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 12 && ctx->conv_impl != 13 && ctx->conv_impl != 14 &&
+      ctx->conv_impl != 20 && ctx->conv_impl != 21 && !ctx->no_winograd && ctx->wbf) {
+    int r = msk_wgrad_wbf(ctx, g);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 13 && !ctx->no_winograd) {  // 13 = direct LDS kernel only (A/B)
     int r = msk_wgrad_wino(ctx, g);
     if (r < 0) return r;

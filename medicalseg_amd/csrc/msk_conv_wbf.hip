@@ -25,24 +25,9 @@
 //                                            address arithmetic, no bounds checks; channel = kc*16 + khalf*8 + j
 //   U [xi][tap][kc][piece][khalf][CN]        B fragment of lane (khalf, co) is one contiguous slot
 //   M [ks][xi][n][t][d][h][CN] fp32
-#include "msk_conv.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include "msk_wbf.h"
 
 namespace {
-
-// x = hi + mid + lo exactly (x fp32, pieces bf16, round-to-nearest-even at each step), two values at a time
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-  f32x2 x = {x0, x1};
-  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-  f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
-  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-  f32x2 r2 = {r.x - __uint_as_float(mid << 16), r.y - __uint_as_float(mid & 0xffff0000u)};
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-}
 
 __device__ __forceinline__ void split3_one(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
   hi = __builtin_bit_cast(unsigned short, (__bf16)x);
@@ -109,16 +94,6 @@ wbf_pack_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip
 // ---------------------------------------------------------------------------------------------------------
 // stage 1: input transform + split
 // ---------------------------------------------------------------------------------------------------------
-struct TinArgs {
-  const float* src;
-  int sld;
-  long svn;
-  int svd, svh, svw;  // voxel strides of the logical axes
-  int N, LD, LH, LW, T, CK, KC;
-  int DP, HP;
-  char* V;
-  long v_xi;  // bytes between xi planes
-};
 
 __device__ __forceinline__ void bt8(const float d0, const float d1, const float d2, const float d3, const float d4,
                                     const float d5, const float d6, const float d7, float (&v)[8]) {
@@ -136,11 +111,27 @@ __device__ __forceinline__ void bt8(const float d0, const float d1, const float 
   v[6] = t5 - t6;
 }
 
-// thread = (n, padded position (dp, hp), 8-channel group); walks t = 0 .. T-1 with a sliding 8-wide W window (x is read
-// once).  Lanes: 4 channel groups fastest (one 128-byte line of x per 4 lanes), then 64 consecutive positions (each
-// (xi, piece) store of a wavefront covers 4 runs of 16 consecutive slots).
+// adjoint of the output transform: Y_xi = sum_j AT[j][xi] dy_j  (AT as in wbf_tout_k)
+__device__ __forceinline__ void at8(const float e0, const float e1, const float e2, const float e3, float (&v)[8]) {
+  v[0] = e0;
+  v[7] = e3;
+  const float s02 = e0 + e2, s13 = e1 + e3;
+  v[1] = s02 + s13;
+  v[2] = s02 - s13;
+  const float p = e0 + 4.f * e2, q = 2.f * e1 + 8.f * e3;
+  v[3] = p + q;
+  v[4] = p - q;
+  const float p2 = e0 + 0.25f * e2, q2 = 0.5f * e1 + 0.125f * e3;
+  v[5] = p2 + q2;
+  v[6] = p2 - q2;
+}
+
+// thread = (n, padded position (dp, hp), 8-channel group); walks t = 0 .. T-1 (MODE 0: with a sliding 8-wide W window, x
+// is read once).  Lanes: 4 channel groups fastest (one 128-byte line of x per 4 lanes), then 64 consecutive positions
+// (each (xi, piece) store of a wavefront covers 4 runs of 16 consecutive slots).
+template <int MODE>
 __global__ void __launch_bounds__(256)
-wbf_tin_k(TinArgs a) {
+wbf_tin_k(WbfTinArgs a) {
   const int cgl = threadIdx.x & 3, pl = threadIdx.x >> 2;
   const int ncgb = a.CK >> 5;
   const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
@@ -156,59 +147,88 @@ wbf_tin_k(TinArgs a) {
   const long tstep = (long)a.KC * 6 * plane;
   const float* xb = a.src + ((long)n * a.svn + (long)d * a.svd + (long)h * a.svh) * a.sld + cg * 8;
   const long wstep = (long)a.svw * a.sld;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 win[8][2];
+  if (MODE == 0) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int w = j - 2;
-    if (live && w >= 0 && w < a.LW) {
-      const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
-      win[j][0] = p[0];
-      win[j][1] = p[1];
-    } else {
-      win[j][0] = win[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 8; ++j) {
+      const int w = j - 2;
+      if (live && w >= 0 && w < a.LW) {
+        const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
+        win[j][0] = p[0];
+        win[j][1] = p[1];
+      } else {
+        win[j][0] = win[j][1] = z4;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (live && j < a.LW) {
+        const float4* p = reinterpret_cast<const float4*>(xb + j * wstep);
+        win[j][0] = p[0];
+        win[j][1] = p[1];
+      } else {
+        win[j][0] = win[j][1] = z4;
+      }
     }
   }
   for (int t = 0; t < a.T; ++t) {
     float4 nxt[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int w = 4 * t + 6 + j;  // window of t+1: w = 4(t+1) - 2 + (4 + j)
+      const int w = MODE == 0 ? 4 * t + 6 + j : 4 * t + 4 + j;  // the part of tile t + 1 not yet in registers
       if (live && t + 1 < a.T && w < a.LW) {
         const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
         nxt[j][0] = p[0];
         nxt[j][1] = p[1];
       } else {
-        nxt[j][0] = nxt[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        nxt[j][0] = nxt[j][1] = z4;
       }
     }
     float v[8][8];  // [channel][xi]
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      bt8(win[0][q].x, win[1][q].x, win[2][q].x, win[3][q].x, win[4][q].x, win[5][q].x, win[6][q].x, win[7][q].x, v[q * 4 + 0]);
-      bt8(win[0][q].y, win[1][q].y, win[2][q].y, win[3][q].y, win[4][q].y, win[5][q].y, win[6][q].y, win[7][q].y, v[q * 4 + 1]);
-      bt8(win[0][q].z, win[1][q].z, win[2][q].z, win[3][q].z, win[4][q].z, win[5][q].z, win[6][q].z, win[7][q].z, v[q * 4 + 2]);
-      bt8(win[0][q].w, win[1][q].w, win[2][q].w, win[3][q].w, win[4][q].w, win[5][q].w, win[6][q].w, win[7][q].w, v[q * 4 + 3]);
+      if (MODE == 0) {
+        bt8(win[0][q].x, win[1][q].x, win[2][q].x, win[3][q].x, win[4][q].x, win[5][q].x, win[6][q].x, win[7][q].x, v[q * 4 + 0]);
+        bt8(win[0][q].y, win[1][q].y, win[2][q].y, win[3][q].y, win[4][q].y, win[5][q].y, win[6][q].y, win[7][q].y, v[q * 4 + 1]);
+        bt8(win[0][q].z, win[1][q].z, win[2][q].z, win[3][q].z, win[4][q].z, win[5][q].z, win[6][q].z, win[7][q].z, v[q * 4 + 2]);
+        bt8(win[0][q].w, win[1][q].w, win[2][q].w, win[3][q].w, win[4][q].w, win[5][q].w, win[6][q].w, win[7][q].w, v[q * 4 + 3]);
+      } else {
+        at8(win[0][q].x, win[1][q].x, win[2][q].x, win[3][q].x, v[q * 4 + 0]);
+        at8(win[0][q].y, win[1][q].y, win[2][q].y, win[3][q].y, v[q * 4 + 1]);
+        at8(win[0][q].z, win[1][q].z, win[2][q].z, win[3][q].z, v[q * 4 + 2]);
+        at8(win[0][q].w, win[1][q].w, win[2][q].w, win[3][q].w, v[q * 4 + 3]);
+      }
     }
     char* vt = vb + t * tstep;
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi) {
       uint4 hi, mid, lo;
-      split3_pair(v[0][xi], v[1][xi], hi.x, mid.x, lo.x);
-      split3_pair(v[2][xi], v[3][xi], hi.y, mid.y, lo.y);
-      split3_pair(v[4][xi], v[5][xi], hi.z, mid.z, lo.z);
-      split3_pair(v[6][xi], v[7][xi], hi.w, mid.w, lo.w);
+      wbf_split3_pair(v[0][xi], v[1][xi], hi.x, mid.x, lo.x);
+      wbf_split3_pair(v[2][xi], v[3][xi], hi.y, mid.y, lo.y);
+      wbf_split3_pair(v[4][xi], v[5][xi], hi.z, mid.z, lo.z);
+      wbf_split3_pair(v[6][xi], v[7][xi], hi.w, mid.w, lo.w);
       char* o = vt + (long)xi * a.v_xi;
       *reinterpret_cast<uint4*>(o) = hi;
       *reinterpret_cast<uint4*>(o + 2 * plane) = mid;
       *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
     }
+    if (MODE == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      win[j][0] = win[j + 4][0];
-      win[j][1] = win[j + 4][1];
-      win[j + 4][0] = nxt[j][0];
-      win[j + 4][1] = nxt[j][1];
+      for (int j = 0; j < 4; ++j) {
+        win[j][0] = win[j + 4][0];
+        win[j][1] = win[j + 4][1];
+        win[j + 4][0] = nxt[j][0];
+        win[j + 4][1] = nxt[j][1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        win[j][0] = nxt[j][0];
+        win[j][1] = nxt[j][1];
+      }
     }
   }
 }
@@ -437,6 +457,17 @@ void launch_gemm(msk_ctx* ctx, const GemmArgs& a, long nblk) {
 
 }  // namespace
 
+int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& ta) {
+  const int pblocks = (ta.DP * ta.HP + 63) / 64;
+  msk_launch_scope ls(ctx, mode == 0 ? "wbf_tin_k" : "wbf_ty_k");
+  if (mode == 0)
+    hipLaunchKernelGGL(wbf_tin_k<0>, dim3((unsigned)(pblocks * (ta.CK / 32)), ta.N), dim3(256), 0, ctx->stream, ta);
+  else
+    hipLaunchKernelGGL(wbf_tin_k<1>, dim3((unsigned)(pblocks * (ta.CK / 32)), ta.N), dim3(256), 0, ctx->stream, ta);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 // Returns 1 if handled, 0 if the problem is not eligible, < 0 on error.
 int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
   if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
@@ -529,15 +560,12 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
     MSK_LAUNCH_CHECK(ctx);
   }
   {
-    TinArgs ta{};
+    WbfTinArgs ta{};
     ta.src = g.src; ta.sld = g.sld;
     ta.svn = (long)g.DD * g.DH * g.DW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
     ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CK; ta.KC = KC;
     ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
-    const int pblocks = (DP * HP + 63) / 64;
-    msk_launch_scope ls(ctx, "wbf_tin_k");
-    hipLaunchKernelGGL(wbf_tin_k, dim3((unsigned)(pblocks * (g.CK / 32)), g.N), dim3(256), 0, ctx->stream, ta);
-    MSK_LAUNCH_CHECK(ctx);
+    if (msk_wbf_transform(ctx, 0, ta) != 0) return -1;
   }
   {
     GemmArgs ga{};

@@ -1,0 +1,310 @@
+// Weight gradient of the 'same' 5x5x5 convolutions (every LUConv layer, vnet.py:36; autograd of core/train.py:139) on
+// the bf16 matrix pipe with fp32-exact operands -- the adjoint of the three-stage pipeline of msk_conv_wbf.hip:
+//
+//   dU_xi[kd,kh][ci][co] = sum_{n,d,h,t} V_xi[n, d+kd-2, h+kh-2, t][ci] * Y_xi[n, d, h, t][co]
+//   V = B^T x (wbf_tin_k<0>),  Y = A dy (wbf_tin_k<1>),  both split exactly into three bf16 pieces in HBM;
+//   dw[co][ci][kd,kh,kw] (+)= sum_xi G[xi][kw] dU_xi[kd,kh][ci][co]          (wbf_wgrad_reduce_k, split-K slabs in order)
+//
+// The reduction runs over POSITIONS, so both MFMA operands need 8 consecutive positions of one channel per lane while
+// the transformed tensors are position-major ([slot][8 channels]: the layout the forward pipeline stages with plain
+// LDS-DMA).  gfx950's transposing LDS read does the conversion for free: ds_read_b64_tr_b16 lets each 16-lane group
+// fetch a [4 positions][16 channels] block (lane i supplies the address of position i/4, channels 4(i%4)..+3) and
+// hands lane i channel i of the 4 positions (verified on hardware: tools/probes/tr16_probe.hip).  Two reads give the
+// 8-position fragment of v_mfma_f32_16x16x32_bf16 (M = 16 input channels, N = 16 output channels, K = 32 positions).
+//
+// Workgroup = 5 wavefronts = the 5 kd rows of the 25 taps; one 16-channel chunk of ci x 32 output channels; the V halo
+// tile (8+4) x (TH+4) and the Y tile 8 x TH of one (n, t) plane are staged once and serve all 25 taps.  A wavefront
+// keeps 5 (kh) x 2 (co halves) accumulators and walks the tile in K-steps of 32 positions; per K-step 42 transposing
+// reads feed 60 MFMAs.  The workgroup loops over its share of the position tiles (split-K over tiles, slabs reduced in
+// a fixed order) and writes its partial dU once.  Six bf16 products per fp32 product, as in the forward pipeline.
+#include "msk_wbf.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+struct WgArgs {
+  const char* V;  // x side, chunk count KCA
+  const char* Y;  // dy side, chunk count KCB
+  float* P;       // partial dU: [xi][ks][kci][cob][tap][16][32]
+  int N, T, KCA, KCB, DP, HP;
+  int tiles_d, tiles_h, ntiles, ksplit, tiles_per;
+  int ncob;
+  long v_xi, y_xi, plane;  // bytes
+};
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_base, unsigned byte_off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_base + byte_off));
+}
+
+#define WGW_MFMA(acc, av, bv) \
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0)
+
+template <int TH>
+__global__ void __launch_bounds__(320)
+wbf_wgrad_k(WgArgs a) {
+  constexpr int TD = 8, HPt = TH + 4, NSV = (TD + 4) * HPt, NSY = TD * TH;
+  constexpr int RV1 = (NSV + 63) / 64, RY1 = (NSY + 63) / 64;           // LDS-DMA rounds per plane
+  constexpr int PSV = RV1 * 1024 + (TH == 16 ? 64 : 128);               // plane strides: the pad keeps the two khalf planes
+  constexpr int PSY = RY1 * 1024 + 64;                                  //   of a transposing read on disjoint banks
+  constexpr int YBASE = 6 * PSV;
+  constexpr int NRV = 6 * RV1, NRY = 12 * RY1, NR = NRV + NRY, RPW = (NR + 4) / 5;  // rounds per wavefront
+  constexpr int KSTEPS = TD * TH / 32, ROWS_PER_STEP = 32 / TH;
+  __shared__ __attribute__((aligned(16))) char lds[6 * PSV + 12 * PSY];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int g = lane >> 4, i = lane & 15;
+
+  int b = blockIdx.x;
+  const int xi = b & 7;
+  b >>= 3;
+  const int cob = b % a.ncob;
+  b /= a.ncob;
+  const int kci = b % a.KCA;
+  const int ks = b / a.KCA;
+
+  const __amdgpu_buffer_rsrc_t vres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.V + (long)xi * a.v_xi), 0, 0xFFFFFFF0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (long)xi * a.y_xi), 0, 0xFFFFFFF0u, 0x00020000);
+
+  // LDS-DMA rounds of this wavefront: R = wave + 5 j.  V rounds first (plane pk, 64 slots each), then Y rounds
+  // (chunk c, plane pk).  voff = byte offset inside the (n, t) block of the tensor, relative to the tile origin.
+  unsigned voff[RPW];
+  int ldst[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int R = wave + 5 * j;
+    if (R < NRV) {
+      const int pk = R / RV1, sub = R - pk * RV1;
+      int slot = sub * 64 + lane;
+      if (slot >= NSV) slot = 0;  // overshoot of the last round lands in the plane's pad
+      const int row = slot / HPt, col = slot - row * HPt;
+      voff[j] = (unsigned)(((long)kci * 6 + pk) * a.plane + ((long)row * a.HP + col) * 16);
+      ldst[j] = pk * PSV + sub * 1024;
+    } else {
+      const int Ry = R - NRV;
+      const int cp = Ry / RY1, sub = Ry - cp * RY1;  // cp = c*6 + pk
+      int slot = sub * 64 + lane;
+      if (slot >= NSY) slot = 0;
+      const int row = slot / TH, col = slot - row * TH;
+      voff[j] = (unsigned)(((long)cob * 12 + cp) * a.plane + ((long)(row + 2) * a.HP + col + 2) * 16);
+      ldst[j] = YBASE + cp * PSY + sub * 1024;
+    }
+  }
+
+  // per-lane LDS byte offsets of the transposing reads (position q = 8 g + 4 r + i/4 of the K-step, channel quad i%4)
+  const int q0 = 8 * g + (i >> 2);
+  const int khalf = (i & 3) >> 1, sub8 = (i & 1) * 8;
+  const unsigned va = (unsigned)(khalf * PSV + (((q0 / TH) + wave) * HPt + (q0 % TH)) * 16 + sub8);  // + kd = wave rows
+  const unsigned ya = (unsigned)(YBASE + khalf * PSY + ((q0 / TH) * TH + (q0 % TH)) * 16 + sub8);
+
+  f32x4 acc[5][2];
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[kh][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int t0 = ks * a.tiles_per;
+  const int t1 = min(a.ntiles, t0 + a.tiles_per);
+  const int tiles_nt = a.tiles_d * a.tiles_h;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int nt = tile / tiles_nt, rem = tile - nt * tiles_nt;  // nt = n*T + t
+    const int tdi = rem / a.tiles_h, thi = rem - tdi * a.tiles_h;
+    const unsigned origin = (unsigned)(((long)(tdi * TD) * a.HP + thi * TH) * 16);
+    const unsigned vso = (unsigned)((long)nt * a.KCA * 6 * a.plane) + origin;
+    const unsigned yso = (unsigned)((long)nt * a.KCB * 6 * a.plane) + origin;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int R = wave + 5 * j;
+      if (R < NRV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + ldst[j]), 16,
+                                                 (int)voff[j], (int)vso, 0, 0);
+      else if (R < NR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yres, (__attribute__((address_space(3))) void*)(lds + ldst[j]), 16,
+                                                 (int)voff[j], (int)yso, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int kst = 0; kst < KSTEPS; ++kst) {
+      s16x8 bq[2][3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned o = ya + (unsigned)((c * 6 + p * 2) * PSY + kst * ROWS_PER_STEP * TH * 16);
+          const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
+          bq[c][p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        s16x8 aq[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned o = va + (unsigned)(p * 2 * PSV + (kst * ROWS_PER_STEP * HPt + kh) * 16);
+          const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
+          aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          WGW_MFMA(acc[kh][c], aq[2], bq[c][0]);  // small terms first
+          WGW_MFMA(acc[kh][c], aq[0], bq[c][2]);
+          WGW_MFMA(acc[kh][c], aq[1], bq[c][1]);
+          WGW_MFMA(acc[kh][c], aq[1], bq[c][0]);
+          WGW_MFMA(acc[kh][c], aq[0], bq[c][1]);
+          WGW_MFMA(acc[kh][c], aq[0], bq[c][0]);
+        }
+      }
+    }
+  }
+
+  // partial dU[xi][ks][kci][cob][tap = wave*5 + kh][ci = 4 g + reg][co = c*16 + i]
+  float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * 25 + wave * 5) * 512;
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb[kh * 512 + (4 * g + r) * 32 + c * 16 + i] = acc[kh][c][r];
+}
+
+// dw[cb][ca][canonical tap(kd, kh, kw)] (+)= sum_xi G[xi][kw] * sum_ks P[xi][ks][ca/16][cb/32][kd*5+kh][ca%16][cb%32]
+__global__ void __launch_bounds__(256)
+wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int KCA, int ncob, int CA, int CB, int tsd, int tsh, int tsw,
+                   float* __restrict__ dw, int accumulate) {
+  const double G[8][5] = {{-1, 0, 0, 0, 0},
+                          {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                          {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                          {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                          {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                          {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                          {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                          {0, 0, 0, 0, 1}};
+  const long total = 25L * CA * CB;
+  const long slab = (long)KCA * ncob * 25 * 512;  // floats per (xi, ks)
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cb = (int)(idx % CB);
+    long r_ = idx / CB;
+    const int ca = (int)(r_ % CA);
+    const int row = (int)(r_ / CA);  // kd*5 + kh
+    const long off = ((((long)(ca >> 4) * ncob + (cb >> 5)) * 25 + row) * 16 + (ca & 15)) * 32 + (cb & 31);
+    double s[8];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) {
+      const float* p = P + (long)xi * ksplit * slab + off;
+      double acc = 0.0;
+      for (int z = 0; z < ksplit; ++z) acc += (double)p[(long)z * slab];  // fixed order
+      s[xi] = acc;
+    }
+    float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      double v = 0.0;
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) v += G[xi][kw] * s[xi];
+      float* q = o + kw * tsw;
+      *q = accumulate ? *q + (float)v : (float)v;
+    }
+  }
+}
+
+}  // namespace
+
+// Returns 1 if handled, 0 if not eligible, < 0 on error.
+int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
+  if (g.CA < 32 || g.CA % 32 || g.CB < 32 || g.CB % 32) return 0;
+  if (g.ald % 4 || g.bld % 4 || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15)) return 0;
+
+  // logical axes as in msk_gconv_wino_bf3: transform along w (multiple of 4), position tiles 8 x TH over (d, h)
+  const int dims[3] = {g.BD, g.BH, g.BW};
+  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
+  int best = -1, bTH = 16;
+  double best_waste = 0;
+  for (int i = 0; i < 6; ++i) {
+    const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
+    if (lw_ % 4) continue;
+    for (int th = 16; th >= 8; th -= 8) {
+      const long padded = (long)((ld_ + 7) / 8) * 8 * ((lh_ + th - 1) / th) * th;
+      const double waste = (double)padded / ((double)ld_ * lh_);
+      if (waste > 1.35) continue;
+      if (best < 0 || waste < best_waste - 1e-9) {
+        best = i; best_waste = waste; bTH = th;
+      }
+    }
+  }
+  if (best < 0) return 0;
+  const int* pm = kPerms[best];
+  const int TH = bTH;
+  const int LD = dims[pm[0]], LH = dims[pm[1]], LW = dims[pm[2]];
+  const int vstr[3] = {g.BH * g.BW, g.BW, 1};
+  const int tstr[3] = {25, 5, 1};
+  const int T = LW / 4, KCA = g.CA / 16, KCB = g.CB / 16, ncob = g.CB / 32;
+  const int tiles_d = (LD + 7) / 8, tiles_h = (LH + TH - 1) / TH;
+  const int DP = tiles_d * 8 + 4, HP = tiles_h * TH + 4;
+  const long ntiles = (long)g.N * T * tiles_d * tiles_h;
+  if (ntiles > 0x7fffffffL) return 0;
+
+  // split K (position tiles): about 3 workgroups per CU in total
+  const long base_blocks = 8L * KCA * ncob;
+  long ksplit = (3L * ctx->num_cu + base_blocks / 2) / base_blocks;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > ntiles) ksplit = ntiles;
+  const int tiles_per = (int)((ntiles + ksplit - 1) / ksplit);
+  ksplit = (ntiles + tiles_per - 1) / tiles_per;
+
+  const size_t plane = (size_t)DP * HP * 16;
+  const size_t v_xi = (size_t)g.N * T * KCA * 6 * plane, y_xi = (size_t)g.N * T * KCB * 6 * plane;
+  if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return 0;
+  const size_t p_floats = (size_t)8 * ksplit * KCA * ncob * 25 * 512;
+  const size_t vb = (8 * v_xi + 255) & ~(size_t)255, yb = (8 * y_xi + 255) & ~(size_t)255;
+  char* wsp = (char*)msk_workspace(ctx, vb + yb + p_floats * sizeof(float) + 256);
+  if (!wsp) return -1;
+  char* V = wsp;
+  char* Y = wsp + vb;
+  float* P = (float*)(wsp + vb + yb);
+
+  WbfTinArgs ta{};
+  ta.src = g.A; ta.sld = g.ald;
+  ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
+  ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
+  ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
+  if (msk_wbf_transform(ctx, 0, ta) != 0) return -1;
+  ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
+  if (msk_wbf_transform(ctx, 1, ta) != 0) return -1;
+
+  WgArgs wa{};
+  wa.V = V; wa.Y = Y; wa.P = P;
+  wa.N = g.N; wa.T = T; wa.KCA = KCA; wa.KCB = KCB; wa.DP = DP; wa.HP = HP;
+  wa.tiles_d = tiles_d; wa.tiles_h = tiles_h; wa.ntiles = (int)ntiles; wa.ksplit = (int)ksplit; wa.tiles_per = tiles_per;
+  wa.ncob = ncob; wa.v_xi = (long)v_xi; wa.y_xi = (long)y_xi; wa.plane = (long)plane;
+  const long nblk = base_blocks * ksplit;
+  {
+    const char* tag = "wbf_wgrad_k";
+    if (ctx->prof && ctx->prof_shapes) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "wbf_wgrad_k[ca=%d,cb=%d,n=%d,dhw=%dx%dx%d,ks=%ld]", g.CA, g.CB, g.N, g.BD, g.BH, g.BW, ksplit);
+      tag = msk_intern_tag(ctx, buf);
+    }
+    msk_launch_scope ls(ctx, tag);
+    if (TH == 16) hipLaunchKernelGGL(wbf_wgrad_k<16>, dim3((unsigned)nblk), dim3(320), 0, ctx->stream, wa);
+    else hipLaunchKernelGGL(wbf_wgrad_k<8>, dim3((unsigned)nblk), dim3(320), 0, ctx->stream, wa);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "wbf_wgrad_reduce");
+    long blocks = (25L * g.CA * g.CB + 255) / 256;
+    if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
+    hipLaunchKernelGGL(wbf_wgrad_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, KCA,
+                       ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 1;
+}

@@ -111,3 +111,55 @@ def test_wbf_channel_slices_and_fused_activation():
     assert rel_err(got, act_ref) < _conv_tol(cin * 125)
     full = d.d2h(yt.ptr, (N, D, H, W, 40), np.float32)
     assert np.all(full[..., cout:] == 9.0)          # the slice's neighbours are untouched
+
+
+WGRAD_CASES = [
+    # (Cin, Cout, (N, D, H, W))
+    (32, 32, (2, 16, 32, 16)),      # 8 x 16 tiles, many tiles per workgroup (split K over tiles)
+    (32, 64, (1, 14, 30, 8)),       # ragged tiles, two output-channel blocks
+    (64, 32, (2, 8, 8, 8)),         # 8 x 8 tiles (TH = 8), 4 input chunks
+    (128, 128, (1, 8, 16, 4)),      # T = 1
+    (32, 32, (1, 16, 8, 7)),        # W % 4 != 0: transform along another axis
+    (64, 64, (1, 12, 16, 15)),      # transform along D
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wbf_wgrad_matches_oracle(case):
+    """wbf_wgrad_k (transposing LDS reads, v_mfma_f32_16x16x32_bf16, six products per fp32 product) + its split-K / G^T
+    reduce against the float64 oracle, fresh and accumulating, and next to the exact-fp32 kernels on the same inputs."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(cin * 13 + cout + H)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    dw_ref, db_ref = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    nw = cout * cin * 125
+    dwp, dbp = vec(np.full(nw, 0.5, np.float32)), vec(np.zeros(cout, np.float32))
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    d.set_option("wgrad_async", 0)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        got = d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
+        got2 = d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape)
+        d.prof_enable(False)
+        rep = d.prof_report()
+        assert rep.get("wbf_wgrad_k", (0, 0))[0] == 2, rep
+        d.set_option("wino_bf3", 0)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        old = d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape)
+    finally:
+        d.set_option("wino_bf3", 1)
+        d.set_option("wgrad_async", 1)
+    e, e2, eo = rel_err(got, dw_ref), rel_err(got2, 2 * dw_ref), rel_err(old, dw_ref)
+    M = N * D * H * W
+    print(f"\nwbf wgrad {case}: {e:.2e} (accumulating {e2:.2e}; fp32 kernels {eo:.2e})")
+    assert e < _conv_tol(M) and e2 < _conv_tol(M)
+    assert e < 4e-6
