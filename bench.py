@@ -8,8 +8,9 @@ already resident in HBM (BASELINE.json configs[1]; configs[2] at --gpus 8).
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is
 not imported).  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (the conv_halo_mfma_k<..., 5> variant with the largest time: the 5x5x5
-                  convs and their data gradients), HIP-event time over the timed region, algorithmic FLOPs;
+  roofline     -- the dominant kernel (wbf_gemm_k: the matrix stage of the 5x5x5 convs and their data gradients),
+                  HIP-event time over the timed region; achieved/frac = EXECUTED bf16 FLOPs against the 2.5 PFLOP/s
+                  dense bf16 MFMA peak, the algorithmic (direct-convolution) rate under its own keys;
   cpu_baseline -- the CPU oracle timed on the host cores on a bounded sample (rank 0, N=1).
 """
 import argparse
@@ -40,64 +41,43 @@ def vnet_lu_layers(d, h, w):
     return layers
 
 
-HALO_TILES = ((2, 4, 32), (2, 8, 16), (4, 8, 8), (4, 16, 4), (8, 16, 2))
-HALO_ORDER = (2, 1, 0, 3, 4)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
+WINO_F45_MAC_RATIO = 0.4        # 1-D Winograd F(4,5): 8 multiplications per 4 outputs instead of 20
+BF16X3_PRODUCTS = 6             # bf16 products per fp32 product (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
 
 
-def halo_tile_for(d, h, w):
-    """Mirror of the tile choice in msk_gconv_halo_mfma (msk_conv_mfma.hip): fewest padded voxels,
-    ties to the first in HALO_ORDER."""
-    best, best_util = 0, -1.0
-    for i in HALO_ORDER:
-        td, th, tw = HALO_TILES[i]
-        padded = -(-d // td) * td * (-(-h // th)) * th * (-(-w // tw)) * tw
-        util = d * h * w / padded
-        if util > best_util * 1.02:
-            best, best_util = i, util
-    return best
-
-
-WINO_MAC_RATIO = 0.6  # F(2,5) along W: 6 multiplications per 2 outputs instead of 10 -> 75 of 125 MACs
-
-
-def halo_variant_work(n, d, h, w, num_cu=256):
-    """{kernel name: [algorithmic FLOPs, algorithmic HBM bytes, launches, executed MFMA FLOPs]} per training step
-    for the kernels that run the 5^3 LUConv layers, forward + data gradient (cubic volumes: level dims = w).
-    Algorithmic = SURVEY 8 d3's direct-convolution count, 2*125*Cin*Cout FLOPs per output voxel, and input + output
-    + weights once.  Mirror of the dispatch in msk_conv.hip: W % 16 == 0 -> conv_halo_wino4_k (1-D Winograd F(4,5):
-    executes 0.4 of the algorithmic MACs), whole 4x8x8 tiles -> conv_halo_wino_k (F(2,5): 0.6), else
-    conv_halo_mfma_k<tile>."""
-    work = {}
+def lu_conv_work(n, d, h, w):
+    """Per training step, for the 5^3 LUConv layers: algorithmic FLOPs (SURVEY 8 d3's
+    direct-convolution count, 2*125*Cin*Cout per output voxel), the FLOPs the bf16 matrix pipe EXECUTES for them in the
+    three-stage Winograd F(4,5) x bf16x3 pipeline (0.4 x 6 = 2.4 bf16 MACs per algorithmic MAC), algorithmic HBM bytes
+    (input + output + weights once) and launch counts, for
+      'wbf_gemm_k'  : forward + data gradient (msk_conv_wbf.hip), 2 launches per layer,
+      'wbf_wgrad_k' : weight gradient (msk_wgrad_wbf.hip), 1 launch per layer."""
+    work = {"wbf_gemm_k": [0.0, 0.0, 0, 0.0], "wbf_wgrad_k": [0.0, 0.0, 0, 0.0]}
     for ci, co, vv, ww in vnet_lu_layers(d, h, w):
-        ntn = -(-co // 32)
-        nblk = n * (ww // 4) * (ww // 8) * (ww // 8)
-        if ww % 16 == 0 and ci >= 8 and co >= 8:
-            name, ratio = "conv_halo_wino4_k", 0.4   # F(4,5): 8 multiplications per 4 outputs instead of 20
-        elif ww % 8 == 0 and ci >= 8 and co >= 8:
-            name, ratio = "conv_halo_wino_k", WINO_MAC_RATIO
-        else:
-            td, th, tw = HALO_TILES[halo_tile_for(ww, ww, ww)]
-            name, ratio = "conv_halo_mfma_k<%d, %d, %d, 5>" % (td, th, tw), 1.0
-        f = 2 * (2.0 * 125 * ci * co * vv * n)
-        e = work.setdefault(name, [0.0, 0.0, 0, 0.0])
-        e[0] += f
-        e[1] += 2 * (4.0 * (vv * n * (ci + co) + 125 * ci * co))
-        e[2] += 2
-        e[3] += f * ratio
+        f = 2.0 * 125 * ci * co * vv * n
+        by = 4.0 * (vv * n * (ci + co) + 125 * ci * co)
+        for name, passes in (("wbf_gemm_k", 2), ("wbf_wgrad_k", 1)):
+            e = work[name]
+            e[0] += passes * f
+            e[1] += passes * by
+            e[2] += passes
+            e[3] += passes * f * WINO_F45_MAC_RATIO * BF16X3_PRODUCTS
     return work
 
 
-def _serialized(prof, dom, flops_step, exec_step, steps=2):
-    """The dominant kernel without cross-stream sharing (weight gradients on the main stream)."""
-    ms = sum(v[1] for k, v in prof.items() if k.startswith(dom))
-    calls = sum(v[0] for k, v in prof.items() if k.startswith(dom))
+def _kernel_line(prof, name, flops_step, exec_step, steps, note=None):
+    ms = sum(v[1] for k, v in prof.items() if k.startswith(name))
+    calls = sum(v[0] for k, v in prof.items() if k.startswith(name))
     if ms <= 0:
         return None
-    ach = flops_step * steps / (ms * 1e-3) / 1e12
     ex = exec_step * steps / (ms * 1e-3) / 1e12
-    return {"achieved": round(ach, 2), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "executed_mfma_frac": round(ex / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(ms / max(calls, 1), 4),
-            "note": "same launches, weight-gradient stream disabled (untimed extra pass of %d steps)" % steps}
+    out = {"achieved": round(ex, 1), "frac": round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+           "algorithmic_tflops": round(flops_step * steps / (ms * 1e-3) / 1e12, 1),
+           "launches": calls, "avg_launch_ms": round(ms / max(calls, 1), 4)}
+    if note:
+        out["note"] = note
+    return out
 
 
 def step_flops_per_sample():
@@ -261,39 +241,57 @@ def main():
     voxels_per_step = world * B * S ** 3
     value = voxels_per_step / (elapsed / args.steps)
 
-    # dominant kernel = the 5^3 halo-conv kernel (Winograd or direct MFMA variant) with the largest HIP-event time (kernel names are spelled
-    # as in rocprofv3's kernel stats)
-    work = halo_variant_work(B, S, S, S)
-    by_variant = {name: (sum(v[0] for k, v in prof.items() if k.startswith(name)),
-                         sum(v[1] for k, v in prof.items() if k.startswith(name))) for name in work}
-    DOM = max(by_variant, key=lambda k: by_variant[k][1])
-    calls, kms = by_variant[DOM]
+    # Dominant kernel: wbf_gemm_k (msk_conv_wbf.hip), the matrix stage of every LUConv forward and data gradient
+    # (30 launches per step).  HIP events bracket its launches only (option "prof_only_halo").
+    #   achieved = bf16 FLOPs the matrix pipe EXECUTES for it per second  (<= peak: a true fraction of the roof)
+    #   algorithmic_tflops = SURVEY 8 d3's direct-convolution FLOPs per second (what the work is worth; the pipeline executes
+    #   0.4 x 6 = 2.4 bf16 MACs per algorithmic MAC, so this can exceed the fp32 peak but never 2500 / 2.4)
+    work = lu_conv_work(B, S, S, S)
+    DOM = "wbf_gemm_k"
     flops_step, bytes_step, launches_step, exec_step = work[DOM]
-    achieved = flops_step * args.steps / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    line = _kernel_line(prof, DOM, flops_step, exec_step, args.steps) or {"achieved": 0.0, "frac": 0.0,
+                                                                          "algorithmic_tflops": 0.0, "launches": 0,
+                                                                          "avg_launch_ms": 0.0}
+    kms = line["avg_launch_ms"] * line["launches"]
     total_kernel_ms = sum(v[1] for v in prof.values())
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     if os.path.exists(tpath) and S == 128 and B == 2:   # PMC pass of this exact workload (tools/summarize_rocprof.py)
         try:
-            traffic = json.load(open(tpath)).get(DOM, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(DOM, {}).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                          "captured %s, NOT measured in this run" % tj.get("_captured", "in round 2")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": DOM, "achieved": round(achieved, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "launches": calls, "avg_launch_ms": round(kms / max(calls, 1), 4),
+    lu_flops = sum(v[0] for v in work.values())            # algorithmic FLOPs of the LUConv layers, fwd + dgrad + wgrad
+    lu_exec = sum(v[3] for v in work.values())
+    total_flops = step_flops_per_sample() * B * (S / 128.0) ** 3
+    # time the executed work needs at the peaks: LUConv layers on the bf16 pipe, everything else at the fp32 peak
+    t_floor = lu_exec / (PEAK_BF16_MFMA_TFLOPS * 1e12) + max(total_flops - lu_flops, 0.0) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    roofline = {"bound": "mfma", "kernel": DOM, "achieved": line["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": line["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "launches": line["launches"], "avg_launch_ms": line["avg_launch_ms"],
+                "executed_bf16_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
                 "algorithmic_flop_per_launch": round(flops_step / max(launches_step, 1), 1),
-                # Winograd F(2,5) executes 0.6 of the direct-convolution MACs the algorithmic figure counts: the
-                # fraction of the MFMA peak the pipe actually sustains is reported next to the algorithmic one
-                "executed_mfma_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
-                "executed_mfma_frac": round(exec_step * args.steps / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if kms > 0 else 0.0,
+                "algorithmic_tflops": line["algorithmic_tflops"],
+                "algorithmic_speedup_vs_fp32_mfma_peak": round(line["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                 "algorithmic_bytes_per_launch": round(bytes_step / max(launches_step, 1), 1),
                 "kernel_share_of_step": round(kms / max(elapsed * 1e3, 1e-9), 4),  # of wall time (streams overlap)
-                "serialized": _serialized(prof_serial, DOM, flops_step, exec_step),
-                "step_frac_of_fp32_roofline": round(step_flops_per_sample() * B * (S / 128.0) ** 3 / (ms_per_step * 1e-3)
-                                                    / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                "serialized": _kernel_line(prof_serial, DOM, flops_step, exec_step, 2,
+                                           "same launches, weight-gradient stream disabled (untimed extra pass of 2 steps)"),
+                "wgrad_kernel": _kernel_line(prof_serial, "wbf_wgrad_k", work["wbf_wgrad_k"][0], work["wbf_wgrad_k"][3], 2,
+                                             "wbf_wgrad_k in the same untimed pass (it runs on the side stream in the timed region)"),
+                # fraction of the step the EXECUTED work would take at the hardware peaks (bf16 pipe for the LUConv
+                # layers, fp32 MFMA peak for the remaining convolutions); <= 1
+                "step_executed_frac": round(t_floor / (ms_per_step * 1e-3), 4),
+                "step_algorithmic_speedup_vs_fp32_roofline": round(total_flops / (ms_per_step * 1e-3) / 1e12
+                                                                   / PEAK_FP32_MFMA_TFLOPS, 4)}
     out = {"metric": "3D-voxels/sec fwd+bwd, VNet 128^3 fp32", "value": round(value, 1), "unit": "voxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "dtype_note": "fp32 tensors end to end; the LUConv matrix products run as six bf16 MFMA products of exactly split "
+                         "fp32 operands with fp32 accumulation (fp32-class error, tests/test_gpu_wbf.py)",
            "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes (BASELINE configs[%d])"
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,

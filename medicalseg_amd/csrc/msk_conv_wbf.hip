@@ -334,28 +334,49 @@ wbf_gemm_k(GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // 25 taps, fully unrolled; the B fragments of tap + 1 are requested before the MFMAs of tap start (an L2 round trip
-    // is ~600 cycles, one tap is MR * 6 * 32 = 384 .. 768 cycles of matrix pipe)
+    // 25 taps, fully unrolled, software pipelined by hand: the A fragments (LDS) and B fragments (L2) of tap + 1 are
+    // requested before the MFMAs of tap, and the scheduler may not move them (sched_barrier) -- left alone it sinks every
+    // load to its first use to save registers, and each tap then waits out an LDS and an L2 round trip
+    // (PMC: matrix pipe 66 % busy).  Consecutive MFMAs alternate between the accumulators.
+    uint4 aq[2][MR][3];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      const uint4* ap = lds + arow[mr];
+      aq[0][mr][0] = ap[0];
+      aq[0][mr][1] = ap[2 * NSLOT];
+      aq[0][mr][2] = ap[4 * NSLOT];
+    }
 #pragma unroll
     for (int tap = 0; tap < 25; ++tap) {
+      const int cur = tap & 1, nx = cur ^ 1;
       if (tap + 1 < 25) {
         const unsigned ub = (unsigned)(tap + 1) * utap + ukc;
-        bq[(tap + 1) & 1][0] = buf_load16(ures, ulane, ub);
-        bq[(tap + 1) & 1][1] = buf_load16(ures, ulane, ub + ustep);
-        bq[(tap + 1) & 1][2] = buf_load16(ures, ulane, ub + 2 * ustep);
-      }
-      const uint4 b0 = bq[tap & 1][0], b1 = bq[tap & 1][1], b2 = bq[tap & 1][2];
+        bq[nx][0] = buf_load16(ures, ulane, ub);
+        bq[nx][1] = buf_load16(ures, ulane, ub + ustep);
+        bq[nx][2] = buf_load16(ures, ulane, ub + 2 * ustep);
 #pragma unroll
-      for (int mr = 0; mr < MR; ++mr) {
-        const uint4* ap = lds + arow[mr] + (tap / 5) * HPt + (tap % 5);
-        const uint4 a0 = ap[0], a1 = ap[2 * NSLOT], a2 = ap[4 * NSLOT];
-        WBF_MFMA(acc[mr], a2, b0);  // small terms first
-        WBF_MFMA(acc[mr], a0, b2);
-        WBF_MFMA(acc[mr], a1, b1);
-        WBF_MFMA(acc[mr], a1, b0);
-        WBF_MFMA(acc[mr], a0, b1);
-        WBF_MFMA(acc[mr], a0, b0);
+        for (int mr = 0; mr < MR; ++mr) {
+          const uint4* ap = lds + arow[mr] + ((tap + 1) / 5) * HPt + ((tap + 1) % 5);
+          aq[nx][mr][0] = ap[0];
+          aq[nx][mr][1] = ap[2 * NSLOT];
+          aq[nx][mr][2] = ap[4 * NSLOT];
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][2], bq[cur][0]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][2]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][1], bq[cur][1]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][1], bq[cur][0]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][1]);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -309,7 +309,7 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     return 0;
   }
   if (strcmp(key, "prof_only_halo") == 0) {  // per-kernel profile restricted to the MFMA halo convs (bench.py roofline)
-    snprintf(ctx->prof_prefix, sizeof(ctx->prof_prefix), "%s", value ? "conv_halo_" : "");  // all 5^3 halo-conv kernels
+    snprintf(ctx->prof_prefix, sizeof(ctx->prof_prefix), "%s", value ? (ctx->wbf ? "wbf_gemm_k" : "conv_halo_") : "");
     return 0;
   }
   if (strcmp(key, "wgrad_async_max_m") == 0) {

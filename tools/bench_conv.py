@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--wgrad-chunk", type=int, default=-1)
     ap.add_argument("--impl", type=int, default=0, help="conv_impl knob (10 = force Winograd halo kernel, 11 = direct only, 12 = Winograd wgrad)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--zero", action="store_true", help="all-zero tensors and weights: DVFS check (a power-limited kernel "
+                    "runs faster on zeros, MI355X_MICROARCH.md 'DVFS give-back')")
     ap.add_argument("--profile", action="store_true", help="also print the per-kernel HIP-event breakdown of each case")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="extra msk_set_option knobs")
     a = ap.parse_args()
@@ -44,9 +46,9 @@ def main():
     x, y, dy, dx = mk(c), mk(cn), mk(cn), mk(c)
     rng = np.random.default_rng(0)
     for t in (x, dy):
-        dev.h2d(t.ptr, rng.standard_normal(vox * t.c, dtype=np.float32))
+        dev.h2d(t.ptr, np.zeros(vox * t.c, np.float32) if a.zero else rng.standard_normal(vox * t.c, dtype=np.float32))
     w = dev.malloc(c * cn * k ** 3 * 4)
-    dev.h2d(w, (rng.standard_normal(c * cn * k ** 3) * 0.01).astype(np.float32))
+    dev.h2d(w, (rng.standard_normal(c * cn * k ** 3) * (0.0 if a.zero else 0.01)).astype(np.float32))
     dw, b, db = dev.malloc(c * cn * k ** 3 * 4), dev.small(cn), dev.small(cn)
     cd = MskConvDesc(k, k, k, 1, 1, 1, k // 2, k // 2, k // 2)
     vp = C.c_void_p
