@@ -115,6 +115,22 @@ int msk_conv_fold_bn(msk_ctx* ctx, const float* w, const float* bias, const floa
                      int cout, long inner, float* w_folded, float* b_folded);
 int msk_conv3d_fwd_act(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias,
                        const float* prelu_slope, msk_tensor y);
+/* Training-path forms of Conv3D forward / weight gradient for the conv -> BatchNorm units of vnet.py:36-41:
+ *   msk_conv3d_fwd_ex:   as msk_conv3d_fwd; additionally
+ *       stats_local (nullable): BatchNorm statistics of y (the msk_bn_stats record, mean[Cout] then M2[Cout]) -- taken in
+ *                    the convolution's output stage when the kernel supports it (no second read of y), else by msk_bn_stats;
+ *       xform (nullable): caller-owned device buffer of msk_conv3d_xform_bytes() bytes that receives the transformed input
+ *                    (Winograd B^T x, split into bf16 pieces) the convolution computes anyway; it stays valid while x is
+ *                    unchanged.  Pass it only when msk_conv3d_xform_bytes() > 0.
+ *   msk_conv3d_wgrad_ex: as msk_conv3d_wgrad; xform (nullable) = the buffer msk_conv3d_fwd_ex filled for the SAME x,
+ *                    which saves recomputing the transform of x (the layer input kept for backward, vnet.py:41).
+ *   msk_conv3d_xform_bytes: size of that buffer for input x and cout output channels; 0 = the convolution does not
+ *                    produce one (pass NULL).                                                              */
+size_t msk_conv3d_xform_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout);
+int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias /*nullable*/,
+                      msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/);
+int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
+                        int accumulate, const void* xform /*nullable*/);
 /* autograd of the above (core/train.py:139 loss.backward()):
  *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,

@@ -65,6 +65,9 @@ SIGNATURES = {
     "msk_conv3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),
     "msk_conv_fold_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp, _vp]),
     "msk_conv3d_fwd_act": (_i, [_vp, _CD, _T, _vp, _vp, _vp, _T]),
+    "msk_conv3d_xform_bytes": (_sz, [_vp, _CD, _T, _i]),
+    "msk_conv3d_fwd_ex": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp]),
+    "msk_conv3d_wgrad_ex": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp]),
     "msk_conv3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
     "msk_conv3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_convT3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),

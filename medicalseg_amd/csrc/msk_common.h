@@ -45,6 +45,8 @@ struct msk_ctx {
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   bool no_winograd = false;  // env MSEGK_DIRECT_CONV=1 / option "direct_conv": direct kernels only (bit-exact fp32 fmaf chains)
   bool wbf = true;  // env MSEGK_WBF=0 / option "wino_bf3" 0: keep the fp32-MFMA Winograd kernels (exact-fp32 products)
+  bool stats_fused = false;  // set by a conv kernel that wrote GConv::stats itself
+  bool xform_written = false;  // set when GConv::xform was filled
   int wbf_variant = -1;  // tuning: force a tile variant of wbf_gemm_k (-1 = least padding)
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table

@@ -19,6 +19,9 @@ struct GConv {
   const float* bias;  // [CN] or null
   int accumulate;
   int flip;           // MFMA halo path: taps are enumerated flipped (conv dgrad as a 'same' conv)
+  float* stats;       // msk_conv3d_fwd_ex: BatchNorm statistics (mean[CN], M2[CN]) of dst wanted; a kernel that produced them in
+                      // its epilogue sets ctx->stats_fused, otherwise the caller runs msk_bn_stats
+  void* xform;        // msk_conv3d_fwd_ex: caller-owned buffer that receives the transformed input (msk_conv3d_xform_bytes)
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
 };
@@ -32,6 +35,7 @@ struct WGrad {
   int N, AD, AH, AW, BD, BH, BW;
   int CA, CB;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  const void* xform;  // msk_conv3d_wgrad_ex: transformed A written by msk_conv3d_fwd_ex for the same tensor, or null
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
   // Winograd kernels only (filled by msk_wgrad_wino): BD/BH/BW are then LOGICAL dims, a permutation of the tensor's

@@ -4,6 +4,7 @@
 // The six public ops (Conv3D fwd/dgrad/wgrad, Conv3DTranspose fwd/dgrad/wgrad) reduce to
 // two device problems (msk_conv.h): a "gather convolution" and a weight gradient.
 #include "msk_conv.h"
+#include "msk_wbf.h"
 
 namespace {
 
@@ -553,6 +554,7 @@ int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* d
   const int total = g.N;
   for (int n0 = 0; n0 < total; n0 += (int)nmax) {
     WGrad c = g;
+    c.xform = nullptr;
     c.N = total - n0 < nmax ? total - n0 : (int)nmax;
     c.A = g.A + (size_t)n0 * (aper / sizeof(float));
     c.B = g.B + (size_t)n0 * (bper / sizeof(float));
@@ -599,6 +601,60 @@ int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
   g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
   // w[Cout][Cin][tap]: k = Cin = b, n = Cout = a -> swap
   return run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct");
+}
+
+size_t msk_conv3d_xform_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout) {
+  if (!ctx->wbf || ctx->no_winograd || ctx->conv_impl != 0) return 0;
+  if (!(cd.kd == 5 && cd.kh == 5 && cd.kw == 5 && cd.sd == 1 && cd.sh == 1 && cd.sw == 1 && cd.pd == 2 && cd.ph == 2 &&
+        cd.pw == 2))
+    return 0;
+  if (cout < 32 || cout % 32) return 0;
+  const size_t per = (size_t)x.d * x.h * x.w * (x.ld > cout ? x.ld : cout) * sizeof(float);
+  if (per > 0 && (size_t)x.n > kChunkBytes / per) return 0;  // chunked batches do not keep the transform
+  if (x.ld % 4 || (((uintptr_t)x.p) & 15)) return 0;
+  return msk_wbf_fwd_xform_bytes(ctx, x.n, x.d, x.h, x.w, x.c, cout);
+}
+
+int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                      float* stats_local, void* xform) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  const size_t sper = (size_t)g.SD * g.SH * g.SW * g.sld * sizeof(float), dper = (size_t)g.DD * g.DH * g.DW * g.dld * sizeof(float);
+  const size_t per = sper > dper ? sper : dper;
+  const bool chunked = per > 0 && (size_t)g.N > kChunkBytes / per;
+  ctx->stats_fused = false;
+  ctx->xform_written = false;
+  if (!chunked) {
+    g.stats = stats_local;
+    g.xform = xform;
+  }
+  if (int rc = run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct")) return rc;
+  if (xform && !ctx->xform_written)
+    return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_fwd_ex",
+                    "xform buffer given but the transform pipeline did not run (size it with msk_conv3d_xform_bytes: 0 = pass NULL)");
+  if (stats_local && !ctx->stats_fused) return msk_bn_stats(ctx, y, stats_local);
+  return 0;
+}
+
+int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
+                        const void* xform) {
+  if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
+  msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);
+  WGrad g{};
+  g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
+  g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
+  g.CA = x.c; g.CB = dy.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.dw = dw; g.accumulate = accumulate;
+  g.xform = xform;
+  return run_wgrad(ctx, g, dy, db, accumulate);
 }
 
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate) {

@@ -409,11 +409,33 @@ struct ToutArgs {
   const float* bias;
   const float* prelu;
   int accumulate;
+  float* stat_partial;  // STATS: per-block BatchNorm records [gridDim.x][CN][3] = (n, mean, M2) of the stored values
 };
 
+struct WfRec {
+  float n, mean, m2;
+};
+__device__ __forceinline__ WfRec wfrec_merge(WfRec a, WfRec b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  WfRec r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean, f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+// STATS: the BatchNorm statistics of the convolution output (vnet.py:38,41 -- conv followed by BatchNorm) are taken
+// here, from the values on their way to HBM: shifted sums per thread (a thread keeps its channel quad over the grid-stride
+// loop because gridDim.x * 256 is a multiple of CN / 4), Chan merge inside the block, one record per block and channel;
+// msk_bn_stats_merge finishes in double.  Saves the separate read of y by bn_stats_partial.
+template <bool STATS>
 __global__ void __launch_bounds__(256)
 wbf_tout_k(ToutArgs a) {
   const int c4n = a.CN >> 2;
+  float sk[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float cnt = 0.f;
   const long total = (long)a.N * a.T * a.LD * a.LH * c4n;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
@@ -466,6 +488,52 @@ wbf_tout_k(ToutArgs a) {
         r.z = r.z > 0.f ? r.z : sl.z * r.z;
         r.w = r.w > 0.f ? r.w : sl.w * r.w;
         *op = r;
+        if (STATS) {
+          const float rv[4] = {r.x, r.y, r.z, r.w};
+          if (cnt == 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sk[j] = rv[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dlt = rv[j] - sk[j];
+            s1[j] += dlt;
+            s2[j] = fmaf(dlt, dlt, s2[j]);
+          }
+          cnt += 1.f;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    __shared__ WfRec sh[4][256];
+    const int t = threadIdx.x, vl = t / c4n, VL = 256 / c4n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      WfRec w = {0.f, 0.f, 0.f};
+      if (cnt > 0.f) {
+        w.n = cnt;
+        w.mean = sk[j] + s1[j] / cnt;
+        w.m2 = fmaxf(s2[j] - s1[j] * s1[j] / cnt, 0.f);
+      }
+      sh[j][t] = w;
+    }
+    __syncthreads();
+    for (int s_ = VL >> 1; s_ > 0; s_ >>= 1) {
+      if (vl < s_) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[j][t] = wfrec_merge(sh[j][t], sh[j][t + s_ * c4n]);
+      }
+      __syncthreads();
+    }
+    if (vl == 0) {
+      const int c = (t % c4n) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* p_ = a.stat_partial + ((long)blockIdx.x * a.CN + c + j) * 3;
+        p_[0] = sh[j][t].n;
+        p_[1] = sh[j][t].mean;
+        p_[2] = sh[j][t].m2;
       }
     }
   }
@@ -489,6 +557,50 @@ int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& ta) {
   return 0;
 }
 
+namespace {
+// tile variants {id, MR, WM, WN, TD, TH} by output channels (first = preferred)
+struct Var { int id, MR, WM, WN, TD, TH; };
+// Measured (tools/bench_conv.py, 2 x 128^3 .. 2 x 16^3): the MR = 2 variants win everywhere (32ch@128^3 3.06 vs 3.13 ms,
+// 128ch@32^3 0.60 vs 0.85 ms, 256ch@16^3 0.32 vs 0.45 ms): smaller LDS tiles -> 3-4 workgroups per CU hide the
+// staging barriers; the MR = 4 variants halve the B-fragment traffic and stay selectable ("wbf_variant").
+const Var kVars[6] = {{4, 2, 4, 1, 16, 16}, {0, 4, 4, 1, 16, 32},    // CN == 32
+                      {5, 2, 2, 2, 8, 16},  {1, 4, 2, 2, 16, 16},    // CN == 64
+                      {3, 2, 1, 4, 8, 8},   {2, 4, 1, 4, 8, 16}};    // CN % 128 == 0
+const Var* pick_variant(const msk_ctx* ctx, const WbfGeom& geo, int CN) {
+  int v0;
+  if (CN == 32) v0 = 0;
+  else if (CN == 64) v0 = 2;
+  else if (CN >= 128 && CN % 128 == 0) v0 = 4;
+  else return nullptr;
+  for (int c = v0; c < v0 + 2; ++c) {
+    const Var& v = kVars[c];
+    if (ctx->wbf_variant >= 0 && ctx->wbf_variant != v.id) continue;  // tuning knob "wbf_variant"
+    if (wbf_tile_ok(geo, v.TD, v.TH)) return &v;
+  }
+  return nullptr;
+}
+}  // namespace
+
+// Bytes of the transformed input V = split(B^T x) of a 'same' 5^3 convolution over a [n, d, h, w, c] tensor in the shared
+// geometry, or 0 when the tensor is not eligible.
+size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout) {
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(cout, &mtd, &mth);
+  if (c < 32 || c % 32 || !wbf_pick_geom(d, h, w, mtd, mth, &geo)) return 0;
+  const size_t v_xi = (size_t)n * geo.T * (c / 16) * 6 * geo.DP * geo.HP * 16;
+  if (v_xi >= 0xFFFFFFF0ull) return 0;
+  return 8 * v_xi;
+}
+// the same, 0 unless msk_gconv_wino_bf3 will run the forward convolution c -> cout of that tensor
+size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout) {
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(cout, &mtd, &mth);
+  if (!wbf_pick_geom(d, h, w, mtd, mth, &geo) || !pick_variant(ctx, geo, cout)) return 0;
+  return msk_wbf_xform_bytes(n, d, h, w, c, cout);
+}
+
 // Returns 1 if handled, 0 if the problem is not eligible, < 0 on error.
 int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
   if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
@@ -499,49 +611,21 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
   if (g.bias && (((uintptr_t)g.bias) & 15)) return 0;
   if (g.prelu && (((uintptr_t)g.prelu) & 15)) return 0;
 
-  // tile variants {id, MR, WM, WN, TD, TH} by output channels (first = preferred when the padding is equal)
-  struct Var { int id, MR, WM, WN, TD, TH; };
-  // Measured (tools/bench_conv.py, 2 x 128^3 .. 2 x 16^3): the MR = 2 variants win everywhere (32ch@128^3 3.06 vs 3.13 ms,
-  // 128ch@32^3 0.60 vs 0.85 ms, 256ch@16^3 0.32 vs 0.45 ms): smaller LDS tiles -> 3-4 workgroups per CU hide the
-  // staging barriers; the MR = 4 variants halve the B-fragment traffic and stay selectable ("wbf_variant").
-  static const Var kVars[6] = {{4, 2, 4, 1, 16, 16}, {0, 4, 4, 1, 16, 32},    // CN == 32
-                               {5, 2, 2, 2, 8, 16},  {1, 4, 2, 2, 16, 16},    // CN == 64
-                               {3, 2, 1, 4, 8, 8},   {2, 4, 1, 4, 8, 16}};    // CN % 128 == 0
-  int v0;
-  if (g.CN == 32) v0 = 0;
-  else if (g.CN == 64) v0 = 2;
-  else if (g.CN % 128 == 0) v0 = 4;
-  else return 0;
-
-  // logical axes: the transform runs along w (any tensor axis that is a multiple of 4), tiles over (d, h)
-  const int dims[3] = {g.DD, g.DH, g.DW};
-  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
-  int best = -1;
-  double best_waste = 0;
-  const Var* bv = nullptr;
-  for (int i = 0; i < 6; ++i) {
-    const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
-    if (lw_ % 4) continue;
-    for (int c = v0; c < v0 + 2; ++c) {
-      const Var& v = kVars[c];
-      if (ctx->wbf_variant >= 0 && ctx->wbf_variant != v.id) continue;  // tuning knob "wbf_variant"
-      const long padded = (long)((ld_ + v.TD - 1) / v.TD) * v.TD * ((lh_ + v.TH - 1) / v.TH) * v.TH;
-      const double waste = (double)padded / ((double)ld_ * lh_);
-      if (waste > 1.35) continue;
-      if (best < 0 || waste < best_waste - 1e-9) {
-        best = i; best_waste = waste; bv = &v;
-      }
-    }
-  }
-  if (best < 0) return 0;
+  // logical axes and plane dims (shared with the weight gradient), then the first tile variant of the class that fits
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(g.CN, &mtd, &mth);
+  if (!wbf_pick_geom(g.DD, g.DH, g.DW, mtd, mth, &geo)) return 0;
+  const Var* bv = pick_variant(ctx, geo, g.CN);
+  if (!bv) return 0;
   const int TD = bv->TD, TH = bv->TH, variant = bv->id;
-  const int* pm = kPerms[best];
-  const int LD = dims[pm[0]], LH = dims[pm[1]], LW = dims[pm[2]];
+  const int* pm = geo.perm;
+  const int LD = geo.LD, LH = geo.LH, LW = geo.LW;
   const int vstr[3] = {g.DH * g.DW, g.DW, 1};
   const int tstr[3] = {25, 5, 1};
-  const int T = LW / 4, KC = g.CK / 16;
+  const int T = geo.T, KC = g.CK / 16;
   const int tiles_d = (LD + TD - 1) / TD, tiles_h = (LH + TH - 1) / TH;
-  const int DP = tiles_d * TD + 4, HP = tiles_h * TH + 4;
+  const int DP = geo.DP, HP = geo.HP;
   const int WN = bv->WN;
   const int ngrp = g.CN / (WN * 32);
 
@@ -563,11 +647,17 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
   if (v_xi >= 0xFFFFFFF0ull) return 0;                     // 32-bit offsets inside one xi plane
   const size_t u_xi = (size_t)25 * KC * 3 * 2 * g.CN * 16;
   if (u_xi >= 0xFFFFFFF0ull) return 0;
-  const size_t v_bytes = 8 * v_xi, m_bytes = (size_t)ksplit * 8 * m_xi * sizeof(float);
-  char* wsp = (char*)msk_workspace(ctx, v_bytes + m_bytes + 256);
+  const size_t v_bytes = (8 * v_xi + 255) & ~(size_t)255, m_bytes = ((size_t)ksplit * 8 * m_xi * sizeof(float) + 255) & ~(size_t)255;
+  long tout_blocks = ((long)m_xi / 4 + 255) / 256;
+  if (tout_blocks > 16L * ctx->num_cu) tout_blocks = 16L * ctx->num_cu;
+  const int c4n = g.CN / 4;
+  const bool fuse_stats = g.stats != nullptr && !g.accumulate && !g.prelu && c4n <= 256 && (c4n & (c4n - 1)) == 0;
+  const size_t s_bytes = fuse_stats ? (size_t)tout_blocks * g.CN * 3 * sizeof(float) : 0;
+  char* wsp = (char*)msk_workspace(ctx, (g.xform ? 0 : v_bytes) + m_bytes + s_bytes + 256);
   if (!wsp) return -1;
-  char* V = wsp;
-  float* M = (float*)(wsp + ((v_bytes + 255) & ~(size_t)255));
+  char* V = g.xform ? (char*)g.xform : wsp;
+  float* M = (float*)(g.xform ? wsp : wsp + v_bytes);
+  float* SP = (float*)((char*)M + m_bytes);
   char* U = (char*)msk_workspace2(ctx, 8 * u_xi);
   if (!U) return -1;
 
@@ -618,11 +708,18 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
     oa.dst = g.dst; oa.dld = g.dld;
     oa.dvn = (long)g.DD * g.DH * g.DW; oa.dvd = vstr[pm[0]]; oa.dvh = vstr[pm[1]]; oa.dvw = vstr[pm[2]];
     oa.bias = g.bias; oa.prelu = g.prelu; oa.accumulate = g.accumulate;
-    long blocks = ((long)m_xi / 4 + 255) / 256;
-    if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
-    msk_launch_scope ls(ctx, "wbf_tout_k");
-    hipLaunchKernelGGL(wbf_tout_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, oa);
-    MSK_LAUNCH_CHECK(ctx);
+    oa.stat_partial = SP;
+    {
+      msk_launch_scope ls(ctx, "wbf_tout_k");
+      if (fuse_stats) hipLaunchKernelGGL(wbf_tout_k<true>, dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);
+      else hipLaunchKernelGGL(wbf_tout_k<false>, dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    if (fuse_stats) {
+      if (msk_bn_stats_merge(ctx, SP, (int)tout_blocks, g.CN, g.stats) != 0) return -1;
+      ctx->stats_fused = true;
+    }
   }
+  if (g.xform) ctx->xform_written = true;
   return 1;
 }

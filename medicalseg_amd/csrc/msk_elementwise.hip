@@ -6,6 +6,7 @@
 // buffer are first-class).  Threads map (channel fastest) so that a wavefront
 // reads 256 contiguous bytes (or 1 KiB with the float4 variants).
 #include "msk_common.h"
+#include "msk_wbf.h"
 
 namespace {
 
@@ -866,6 +867,17 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }
+
+}  // extern "C"
+
+int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats) {
+  msk_launch_scope ls(ctx, "bn_stats_merge");
+  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(64), 0, ctx->stream, partial, nb, C, C, stats);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" {
 
 int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
   const long voxels = msk_voxels(x);

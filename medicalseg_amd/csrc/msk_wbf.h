@@ -34,3 +34,55 @@ struct WbfTinArgs {
   long v_xi;  // bytes between xi planes
 };
 int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& a);
+
+// Geometry shared by the forward / data-gradient pipeline and the weight gradient (so that V = B^T x written by the forward
+// pass can be handed to the weight gradient, msk_conv3d_fwd_ex / msk_conv3d_wgrad_ex): which tensor axes play the
+// logical (d, h, w) roles -- the transform runs along w, a multiple of 4; (d, h) carry the position tiles -- and the padded
+// plane dims of the transformed tensor.  Depends on the spatial dims only.
+struct WbfGeom {
+  int perm[3];        // logical (d, h, w) <- tensor axis
+  int LD, LH, LW, T;
+  int DP, HP;         // plane dims: tile-rounded + 4 halo slots
+};
+// (minTD, minTH): the coarsest position tile a consumer of this geometry needs -- a function of the layer's OUTPUT channel
+// count (wbf_min_tile), so that the forward pass and the weight gradient of one layer agree.
+inline void wbf_min_tile(int cout, int* td, int* th) {
+  *td = cout == 32 ? 16 : 8;
+  *th = cout <= 64 ? 16 : 8;
+}
+inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* out) {
+  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
+  const int dims[3] = {D, H, W};
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < 6; ++i) {
+    const int ld = dims[kPerms[i][0]], lh = dims[kPerms[i][1]], lw = dims[kPerms[i][2]];
+    if (lw % 4) continue;
+    if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > 1.35 * (double)ld * lh) continue;
+    const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) / ((double)ld * lh);  // padding at the finest tile
+    if (best < 0 || cost < best_cost - 1e-9) {
+      best = i;
+      best_cost = cost;
+    }
+  }
+  if (best < 0) return false;
+  for (int j = 0; j < 3; ++j) out->perm[j] = kPerms[best][j];
+  out->LD = dims[out->perm[0]];
+  out->LH = dims[out->perm[1]];
+  out->LW = dims[out->perm[2]];
+  out->T = out->LW / 4;
+  const int rd = out->LD >= 16 ? 16 : 8, rh = out->LH >= 32 ? 32 : (out->LH >= 16 ? 16 : 8);
+  out->DP = (out->LD + rd - 1) / rd * rd + 4;
+  out->HP = (out->LH + rh - 1) / rh * rh + 4;
+  return true;
+}
+// a (TD x TH) position tiling fits the planes and wastes at most 35 % of the matrix work on padding
+inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
+  const int td = (g.LD + TD - 1) / TD * TD, th = (g.LH + TH - 1) / TH * TH;
+  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= 1.35 * (double)g.LD * g.LH;
+}
+size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout);
+size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout);
+// merge of per-block BatchNorm partial records [nb][C][3] = (n, mean, M2) into stats[2C] (msk_elementwise.hip)
+int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats);
+

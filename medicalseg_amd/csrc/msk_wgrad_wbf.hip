@@ -223,32 +223,23 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   if (g.CA < 32 || g.CA % 32 || g.CB < 32 || g.CB % 32) return 0;
   if (g.ald % 4 || g.bld % 4 || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15)) return 0;
 
-  // logical axes as in msk_gconv_wino_bf3: transform along w (multiple of 4), position tiles 8 x TH over (d, h)
-  const int dims[3] = {g.BD, g.BH, g.BW};
-  static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
-  int best = -1, bTH = 16;
-  double best_waste = 0;
-  for (int i = 0; i < 6; ++i) {
-    const int ld_ = dims[kPerms[i][0]], lh_ = dims[kPerms[i][1]], lw_ = dims[kPerms[i][2]];
-    if (lw_ % 4) continue;
-    for (int th = 16; th >= 8; th -= 8) {
-      const long padded = (long)((ld_ + 7) / 8) * 8 * ((lh_ + th - 1) / th) * th;
-      const double waste = (double)padded / ((double)ld_ * lh_);
-      if (waste > 1.35) continue;
-      if (best < 0 || waste < best_waste - 1e-9) {
-        best = i; best_waste = waste; bTH = th;
-      }
-    }
-  }
-  if (best < 0) return 0;
-  const int* pm = kPerms[best];
-  const int TH = bTH;
-  const int LD = dims[pm[0]], LH = dims[pm[1]], LW = dims[pm[2]];
+  // logical axes and plane dims shared with msk_gconv_wino_bf3; position tiles 8 x TH over (d, h)
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(g.CB, &mtd, &mth);
+  bool shared_geom = wbf_pick_geom(g.BD, g.BH, g.BW, mtd, mth, &geo);   // the geometry the layer's forward pass used
+  if (!shared_geom && !wbf_pick_geom(g.BD, g.BH, g.BW, 8, 8, &geo)) return 0;  // (its forward ran on other kernels)
+  int TH = 0;
+  if (wbf_tile_ok(geo, 8, 16)) TH = 16;
+  else if (wbf_tile_ok(geo, 8, 8)) TH = 8;
+  if (!TH) return 0;
+  const int* pm = geo.perm;
+  const int LD = geo.LD, LH = geo.LH, LW = geo.LW;
   const int vstr[3] = {g.BH * g.BW, g.BW, 1};
   const int tstr[3] = {25, 5, 1};
-  const int T = LW / 4, KCA = g.CA / 16, KCB = g.CB / 16, ncob = g.CB / 32;
+  const int T = geo.T, KCA = g.CA / 16, KCB = g.CB / 16, ncob = g.CB / 32;
   const int tiles_d = (LD + 7) / 8, tiles_h = (LH + TH - 1) / TH;
-  const int DP = tiles_d * 8 + 4, HP = tiles_h * TH + 4;
+  const int DP = geo.DP, HP = geo.HP;
   const long ntiles = (long)g.N * T * tiles_d * tiles_h;
   if (ntiles > 0x7fffffffL) return 0;
 
@@ -265,18 +256,19 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return 0;
   const size_t p_floats = (size_t)8 * ksplit * KCA * ncob * 25 * 512;
   const size_t vb = (8 * v_xi + 255) & ~(size_t)255, yb = (8 * y_xi + 255) & ~(size_t)255;
-  char* wsp = (char*)msk_workspace(ctx, vb + yb + p_floats * sizeof(float) + 256);
+  const bool have_v = g.xform != nullptr && shared_geom && msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB) == 8 * v_xi;
+  char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + yb + p_floats * sizeof(float) + 256);
   if (!wsp) return -1;
-  char* V = wsp;
-  char* Y = wsp + vb;
-  float* P = (float*)(wsp + vb + yb);
+  char* V = have_v ? (char*)const_cast<void*>(g.xform) : wsp;
+  char* Y = have_v ? wsp : wsp + vb;
+  float* P = (float*)(Y + yb);
 
   WbfTinArgs ta{};
   ta.src = g.A; ta.sld = g.ald;
   ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
   ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
   ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
-  if (msk_wbf_transform(ctx, 0, ta) != 0) return -1;
+  if (!have_v && msk_wbf_transform(ctx, 0, ta) != 0) return -1;  // else: V written by msk_conv3d_fwd_ex for this tensor
   ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
   if (msk_wbf_transform(ctx, 1, ta) != 0) return -1;
 

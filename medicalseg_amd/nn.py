@@ -233,20 +233,41 @@ class Conv3D(Layer):
     def out_dims(self, x: Tensor):
         return tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip((x.d, x.h, x.w), self.p, self.k, self.s))
 
-    def run_forward(self, x: Tensor, y: Tensor | None = None) -> Tensor:
+    def run_forward(self, x: Tensor, y: Tensor | None = None, stats_ptr=None, keep_xform=False) -> Tensor:
+        """stats_ptr: device buffer [2*Cout] that receives the BatchNorm statistics record of y (taken in the
+        convolution's output stage when the kernel can, msk_conv3d_fwd_ex).  keep_xform: keep the transformed input the
+        convolution computes anyway in the activation arena for this layer's weight gradient."""
         if x.c != self.cin:
             raise ValueError(f"Conv3D expects {self.cin} input channels, got {x.c}")
         od, oh, ow = self.out_dims(x)
         if y is None:
             y = Tensor.empty(x.dev, x.n, od, oh, ow, self.cout)
-        x.dev.call("msk_conv3d_fwd", self.desc(), x.msk(), C.c_void_p(self.weight.ptr),
-                   C.c_void_p(self.bias.ptr), y.msk())
+        dev = x.dev
+        self._xform = None
+        if stats_ptr is None and not keep_xform:
+            dev.call("msk_conv3d_fwd", self.desc(), x.msk(), C.c_void_p(self.weight.ptr),
+                     C.c_void_p(self.bias.ptr), y.msk())
+            return y
+        xf = None
+        if keep_xform:
+            nbytes = int(dev.lib.msk_conv3d_xform_bytes(dev.ctx, self.desc(), x.msk(), self.cout))
+            if nbytes > 0:
+                xf = dev.arena.alloc(nbytes)
+        dev.call("msk_conv3d_fwd_ex", self.desc(), x.msk(), C.c_void_p(self.weight.ptr), C.c_void_p(self.bias.ptr),
+                 y.msk(), C.c_void_p(stats_ptr) if stats_ptr else None, C.c_void_p(xf) if xf else None)
+        self._xform = (xf, x.ptr, dev.arena.gen) if xf else None
         return y
 
     def run_backward(self, x: Tensor, dy: Tensor, need_dx=True, bias_grad=True):
         dev = x.dev
-        dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
-                 C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
+        xf = getattr(self, "_xform", None)
+        if xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen:   # same tensor, same arena generation
+            dev.call("msk_conv3d_wgrad_ex", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1, C.c_void_p(xf[0]))
+        else:
+            dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
+        self._xform = None
         if need_dx:
             dx = x.ensure_grad()
             dev.call("msk_conv3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
@@ -466,12 +487,17 @@ class ConvBNAct:
                 and (self.act is None or isinstance(self.act, PReLU))):
             return self._forward_folded(x, out)
         self.x, self.res = x, res
-        y = self.conv.run_forward(x)
-        self.y = y
         bn, sc = self.bn, self.bn.scratch(dev)
         Cn = bn.num_features
+        if bn.training and type(self.conv) is Conv3D:
+            # statistics from the convolution's output stage, transformed input kept for the weight gradient
+            y = self.conv.run_forward(x, stats_ptr=sc["stats"], keep_xform=True)
+        else:
+            y = self.conv.run_forward(x)
+            if bn.training:
+                dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
+        self.y = y
         if bn.training:
-            dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
             gathered, nstat = sc["stats"], 1
             if dev.world > 1 and BatchNorm3D.sync:
                 dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))

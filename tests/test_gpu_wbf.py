@@ -163,3 +163,47 @@ def test_wbf_wgrad_matches_oracle(case):
     print(f"\nwbf wgrad {case}: {e:.2e} (accumulating {e2:.2e}; fp32 kernels {eo:.2e})")
     assert e < _conv_tol(M) and e2 < _conv_tol(M)
     assert e < 4e-6
+
+
+@pytest.mark.parametrize("case", [(32, 32, (2, 16, 32, 16)), (64, 128, (1, 8, 16, 8)), (32, 64, (1, 14, 30, 8)),
+                                  (16, 16, (1, 8, 8, 8))])
+def test_conv3d_fwd_ex_stats_and_kept_transform(case):
+    """msk_conv3d_fwd_ex: (a) the BatchNorm statistics record taken in the output transform equals msk_bn_stats of the
+    stored y (float64 oracle: mean / M2 of y_ref); (b) the transformed input it leaves in the caller's buffer gives the
+    SAME weight gradient bits through msk_conv3d_wgrad_ex as the transform msk_conv3d_wgrad recomputes; the last case is
+    not eligible for the pipeline (16 channels): xform_bytes = 0 and the statistics come from msk_bn_stats."""
+    import ctypes as C
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(cin + cout + D)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    xt, yt, dyt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0), t_from_ncdhw(dy)
+    wp, bp = vec(w.ravel()), vec(b)
+    stats = vec(np.zeros(2 * cout, np.float32))
+    nbytes = int(d.lib.msk_conv3d_xform_bytes(d.ctx, _desc(k, s_, p), xt.msk(), cout))
+    assert (nbytes > 0) == (cin >= 32)
+    xf = d.malloc(nbytes) if nbytes else None
+    d.set_option("wgrad_async", 0)
+    try:
+        d.call("msk_conv3d_fwd_ex", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk(), vp(stats), vp(xf))
+        got = t_to_ncdhw(yt)
+        assert rel_err(got, y_ref) < _conv_tol(cin * 125)
+        st = d.d2h(stats, (2 * cout,), np.float32)
+        yc = np.moveaxis(y_ref, 1, -1).reshape(-1, cout)
+        mean_ref, m2_ref = yc.mean(0), ((yc - yc.mean(0)) ** 2).sum(0)
+        assert np.abs(st[:cout] - mean_ref).max() < 1e-5 * (np.abs(mean_ref).max() + 1)
+        assert np.abs(st[cout:] - m2_ref).max() < 1e-5 * m2_ref.max()
+        nw = cout * cin * 125
+        dw1, dw2 = vec(np.zeros(nw, np.float32)), vec(np.zeros(nw, np.float32))
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dw1), None, 0)
+        d.call("msk_conv3d_wgrad_ex", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dw2), None, 0, vp(xf))
+        a1, a2 = d.d2h(dw1, (nw,), np.float32), d.d2h(dw2, (nw,), np.float32)
+        assert np.array_equal(a1, a2)
+    finally:
+        d.set_option("wgrad_async", 1)
