@@ -19,7 +19,7 @@ from ..datasets import DataLoader
 from ..device import to_tensor
 from ..optimizer import lr as lr_mod
 from ..parallel import DataParallel, ParallelEnv, init_parallel_env
-from ..utils import TimeAverager, calculate_eta, logger, loss_computation, resume, save
+from ..utils import TimeAverager, calculate_eta, logger, loss_computation, resume, save, train_profiler
 from .val import evaluate
 
 
@@ -46,7 +46,8 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
         logger.warning("VisualDL is not available in this build; --use_vdl is ignored.")
     dev = model.dev
 
-    pending = []  # (loss Scalar, [loss_i Scalars], per_channel_dice lazy) since the last log boundary
+    pending = []  # ring slots of the iterations since the last log boundary (_snapshot)
+    carry = None  # running sums of a log window that outgrew the ring
     iters_per_epoch = max(len(loader), 1)
     best_mean_dice = -1.0
     best_model_iter = -1
@@ -78,10 +79,15 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
             if isinstance(lr_sche, lr_mod.LRScheduler):
                 lr_sche.step()
             model.clear_gradients()
+            train_profiler.add_profiler_step(profiler_options, dev)   # reference core/train.py:153
 
             # values of this iteration (tiny device buffers) are fetched at the log boundary
             vals = _snapshot(dev, loss, loss_list, per_channel_dice)
             pending.append(vals)
+            if (len(pending) + 1) * max(len(vals[0]), 1) >= RING_DEPTH and it % log_iters != 0:
+                # log windows longer than the ring: fold what is pending into running sums before its slots are reused
+                carry = _fold_carry(carry, _reduce_pending(dev, pending), len(pending))
+                pending = []
             if it % log_iters == 0:
                 # the iterations of this window were only enqueued so far: their device time has to land inside the
                 # window's batch_cost / ips (recording before the sync under-reported the step by ~14 %)
@@ -89,8 +95,8 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
             batch_cost_averager.record(time.time() - batch_start, num_samples=batch_size)
 
             if it % log_iters == 0:
-                avg_loss, avg_loss_list, mdice = _reduce_pending(dev, pending)
-                pending = []
+                avg_loss, avg_loss_list, mdice = _unfold_carry(_fold_carry(carry, _reduce_pending(dev, pending), len(pending)))
+                pending, carry = [], None
                 if local_rank == 0:
                     remain_iters = iters - it
                     avg_train_batch_cost = batch_cost_averager.get_average()
@@ -129,22 +135,39 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
 
 
 def _snapshot(dev, loss, loss_list, per_channel_dice):
-    """Keep the device scalars of one iteration alive past the next arena reset by copying
-    them into a small persistent ring (async d2d, no sync)."""
-    node = loss.terms[0][1]
-    node.evaluate()
-    n = 2 + node.C
-    ptr = _ring_slot(dev, n)
-    dev.d2d(ptr, node.out_ptr, n * 4)
-    coefs = [(sum(c for c, _, w in l.terms if w == "ce"), sum(c for c, _, w in l.terms if w == "dice"))
-             for l in loss_list]
-    return ptr, node.C, coefs
+    """Keep the device scalars of one iteration alive past the next arena reset: the (2 + C)-float record
+    {CE, dice loss, per-class dice} of EVERY distinct loss node (one per model output: VNetDeepSup has four) is copied
+    into a small persistent ring (async d2d, no sync).  Returns (slots, terms, dsc_slot): terms = [(coef, slot index,
+    0 = CE | 1 = dice) per entry of loss_list], dsc_slot = the node per_channel_dice was taken from (the reference
+    reports the per-class dice of the LAST dice-bearing loss, utils/loss_utils.py:41-42)."""
+    nodes, index = [], {}
+    for l in loss_list:
+        for _, node, _ in l.terms:
+            if id(node) not in index:
+                index[id(node)] = len(nodes)
+                nodes.append(node)
+    slots = []
+    for node in nodes:
+        node.evaluate()
+        n = 2 + node.C
+        ptr = _ring_slot(dev, n)
+        dev.d2d(ptr, node.out_ptr, n * 4)
+        slots.append((ptr, node.C))
+    terms = [[(c, index[id(node)], 0 if w == "ce" else 1) for c, node, w in l.terms] for l in loss_list]
+    dsc_slot = None
+    if per_channel_dice is not None and hasattr(per_channel_dice, "ptr"):
+        for i, node in enumerate(nodes):
+            if node.out_ptr + 8 == per_channel_dice.ptr:
+                dsc_slot = i
+    return slots, terms, dsc_slot
 
 
-_RING = {"ptrs": [], "next": 0, "n": 0}
+_RING = {"ptrs": [], "next": 0, "n": 0, "depth": 0}
+RING_DEPTH = 4096
 
 
-def _ring_slot(dev, n, depth=4096):
+def _ring_slot(dev, n, depth=None):
+    depth = depth or RING_DEPTH
     if _RING["n"] < n or not _RING["ptrs"]:
         _RING["ptrs"] = [dev.malloc(depth * n * 4)]
         _RING["n"], _RING["next"], _RING["depth"] = n, 0, depth
@@ -154,12 +177,36 @@ def _ring_slot(dev, n, depth=4096):
 
 
 def _reduce_pending(dev, pending):
-    tot, per_loss, dsc = 0.0, None, 0.0
-    for ptr, Cn, coefs in pending:
-        v = dev.d2h(ptr, (2 + Cn,), np.float32).astype(np.float64)
-        li = [cc * v[0] + cd * v[1] for cc, cd in coefs]
+    """-> (mean loss, [mean of each weighted loss term], mean DSC in percent) over the pending iterations."""
+    tot, per_loss, dsc, ndsc = 0.0, None, 0.0, 0
+    for slots, terms, dsc_slot in pending:
+        vals = [dev.d2h(ptr, (2 + Cn,), np.float32).astype(np.float64) for ptr, Cn in slots]
+        li = [sum(c * vals[si][which] for c, si, which in t) for t in terms]
         tot += sum(li)
         per_loss = li if per_loss is None else [a + b for a, b in zip(per_loss, li)]
-        dsc += float(np.mean(v[2:])) * 100
+        if dsc_slot is not None:
+            dsc += float(np.mean(vals[dsc_slot][2:])) * 100
+            ndsc += 1
     k = max(len(pending), 1)
-    return tot / k, [p / k for p in (per_loss or [])], dsc / k
+    return tot / k, [p / k for p in (per_loss or [])], dsc / max(ndsc, 1)
+
+
+def _fold_carry(carry, red, k):
+    """Weighted running sums (count, loss, per-loss list, dsc) of partial window reductions."""
+    if k == 0:
+        return carry
+    avg, per, dsc = red
+    if carry is None:
+        return [k, avg * k, [p * k for p in per], dsc * k]
+    carry[0] += k
+    carry[1] += avg * k
+    carry[2] = [a + p * k for a, p in zip(carry[2], per)] if carry[2] else [p * k for p in per]
+    carry[3] += dsc * k
+    return carry
+
+
+def _unfold_carry(carry):
+    if carry is None:
+        return 0.0, [], 0.0
+    k = max(carry[0], 1)
+    return carry[1] / k, [p / k for p in carry[2]], carry[3] / k

@@ -18,6 +18,11 @@ np.set_printoptions(suppress=True)
 def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_roc=False, writer=None,
              save_dir=None):
     new_loss = {'types': [losses['types'][0]], 'coef': [losses['coef'][0]]}
+    if auc_roc:
+        logger.warning("evaluate(auc_roc=True): the AUC/ROC path of the reference (core/val.py:121-131, sklearn on host "
+                       "logits) is not built; mDice only.")
+    if writer is not None:
+        logger.warning("evaluate(writer=...): VisualDL logging is not built; the writer is ignored.")
     model.eval()
     from ..parallel import ParallelEnv
     env = ParallelEnv()

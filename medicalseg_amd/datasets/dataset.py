@@ -190,15 +190,35 @@ class DataLoader:
         import queue
         import threading
         q = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def put(item):
+            # bounded put that gives up when the consumer abandoned the iterator (otherwise the thread blocks forever)
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def work():
-            for b in batches:
-                q.put(self._load(b))
-            q.put(None)
+            try:
+                for b in batches:
+                    if not put(self._load(b)):
+                        return
+                put(None)
+            except BaseException as e:  # a bad file / shape mismatch / transform error must reach the training loop
+                put(e)
 
         threading.Thread(target=work, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is None:
-                return
-            yield item
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()

@@ -414,8 +414,9 @@ class Dropout3D(Layer):
                 raise ValueError(f"injected dropout mask must be [{x.n},{x.c}], got {m.shape}")
             dev.h2d(ptr, m)
         else:
+            # every data-parallel rank draws its own masks: the rank rides in the upper bits of the site id
             dev.call("msk_dropout_mask", C.c_uint64(Dropout3D.seed), C.c_uint64(Dropout3D.step),
-                     C.c_uint32(self.site), cnt, C.c_float(self.p), C.c_void_p(ptr))
+                     C.c_uint32(self.site | (dev.rank << 16)), cnt, C.c_float(self.p), C.c_void_p(ptr))
         return ptr
 
 

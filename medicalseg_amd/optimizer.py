@@ -125,16 +125,39 @@ class Momentum:
             sd[p.name + "_velocity_0"] = flat[p.offset:p.offset + p.size].reshape(p.shape).copy()
         if isinstance(self._learning_rate, _LR.LRScheduler):
             sd["LR_Scheduler"] = self._learning_rate.state_dict()
+        # not a Paddle key: the counter of the Dropout3D mask stream, so that a resumed run draws the masks an
+        # uninterrupted one would have drawn (Paddle's own optimizer state carries no RNG state either way)
+        from . import nn as _nn
+        sd["@msegk_dropout_step"] = np.array([_nn.Dropout3D.step], dtype=np.int64)
         return sd
 
     def set_state_dict(self, sd):
+        """Velocity keys are `<structured parameter name>_velocity_0` -- what this package's own `state_dict` writes.
+        A model.pdopt written by PADDLE names them after its internal parameter names (`conv3d_0.w_0_velocity_0`): those
+        match nothing here, the momentum restarts from zero, and this is reported rather than skipped silently
+        (model.pdparams interoperates both ways; model.pdopt only package -> package)."""
         dev = self.arena.dev
         flat = dev.d2h(self.velocity_ptr, (self.arena.count,), np.float32)
+        used, missing = set(), []
         for p in self.arena.params:
             k = p.name + "_velocity_0"
             if k in sd:
                 flat[p.offset:p.offset + p.size] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
+                used.add(k)
+            else:
+                missing.append(k)
         dev.h2d(self.velocity_ptr, flat)
+        unexpected = [k for k in sd if k not in used and k not in ("LR_Scheduler", "@msegk_dropout_step")]
+        if missing or unexpected:
+            from .utils import logger
+            logger.warning("optimizer state: %d velocity tensors missing (momentum restarts from zero for them), %d "
+                           "unexpected keys (e.g. %s)%s" % (len(missing), len(unexpected), unexpected[:2],
+                           " -- looks like a Paddle-written model.pdopt (internal parameter names)" if unexpected and
+                           not used else ""))
+        self.last_load = {"missing": missing, "unexpected": unexpected}
+        if "@msegk_dropout_step" in sd:
+            from . import nn as _nn
+            _nn.Dropout3D.step = int(np.asarray(sd["@msegk_dropout_step"]).ravel()[0])
         if "LR_Scheduler" in sd and isinstance(self._learning_rate, _LR.LRScheduler):
             self._learning_rate.set_state_dict(sd["LR_Scheduler"])
 

@@ -2,8 +2,10 @@
 (medicalseg/utils/utils.py:76-135, core/train.py:230-254).
 
 File format: ``model.pdparams`` / ``model.pdopt`` are pickles of {name: ndarray} -- the
-format paddle.save writes for state dicts -- so checkpoints are interchangeable in both
-directions (tensors in the reference's layouts and key names)."""
+format paddle.save writes for state dicts.  ``model.pdparams`` is interchangeable in both directions (tensors in
+the reference's layouts and structured key names).  ``model.pdopt`` round-trips between runs of THIS
+package; a Paddle-written one names its velocities after Paddle's internal parameter names, matches nothing here, and
+is reported as such by Momentum.set_state_dict (momentum then restarts from zero)."""
 import os
 import pickle
 
@@ -72,7 +74,10 @@ def resume(model, optimizer, resume_model):
     if not os.path.exists(resume_model):
         raise ValueError('Directory of the model needed to resume is not Found: {}'.format(resume_model))
     resume_model = os.path.normpath(resume_model)
-    model.set_state_dict(load(os.path.join(resume_model, 'model.pdparams')))
+    missing, unexpected = model.set_state_dict(load(os.path.join(resume_model, 'model.pdparams')))
+    if missing or unexpected:
+        logger.warning('resume: {} parameters missing from model.pdparams (e.g. {}), {} unexpected keys (e.g. {})'
+                       .format(len(missing), missing[:2], len(unexpected), unexpected[:2]))
     optimizer.set_state_dict(load(os.path.join(resume_model, 'model.pdopt')))
     return int(resume_model.split('_')[-1])
 

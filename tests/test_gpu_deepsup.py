@@ -110,3 +110,40 @@ def test_deepsup_forward_backward_step(cfg):
     for n in ("out_tr64.weight", "out_tr256.bias", "out_tr32.conv2.weight", "in_tr.conv1.weight"):
         assert np.abs(after[n].numpy() - om.p[n]).max() < 1e-4 * (np.abs(om.p[n]).max() + 1e-3), n
     dev().sync()
+
+
+def test_train_log_values_of_a_multi_output_model():
+    """core/train.py's deferred logging (`_snapshot` / `_reduce_pending`): for the 4-output VNetDeepSup the logged loss is
+    the weighted sum over ALL heads and the logged DSC is the per-class dice of the last dice-bearing loss, as
+    reference core/train.py:158-170 + utils/loss_utils.py:41-42 compute them (round-1 advisor finding: only output 0 was
+    snapshotted)."""
+    from medicalseg_amd.core import train as T
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNetDeepSup
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(3)
+    model = VNetDeepSup(elu=False, in_channels=1, num_classes=3)
+    model.train()
+    x = rng.standard_normal((1, 1, 16, 16, 16)).astype(np.float32)
+    y = rng.integers(0, 3, (1, 16, 16, 16)).astype(np.int32)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1]) for _ in range(4)], "coef": [0.25] * 4}
+    d = dev()
+    pending, want_loss, want_terms, want_dsc = [], [], [], []
+    for _ in range(3):
+        logits = model(x)
+        ll, per = loss_computation(logits, to_tensor(y), losses)
+        pending.append(T._snapshot(d, sum(ll), ll, per))
+        want_loss.append(float(sum(ll)))
+        want_terms.append([float(t) for t in ll])
+        want_dsc.append(float(np.mean(np.asarray(per))) * 100)
+    assert len(pending[0][0]) == 4 and len(want_terms[0]) == 8          # four loss nodes, CE + dice each
+    avg, per_loss, dsc = T._reduce_pending(d, pending)
+    assert abs(avg - np.mean(want_loss)) < 1e-5 * abs(np.mean(want_loss))
+    assert np.allclose(per_loss, np.mean(want_terms, axis=0), rtol=1e-5)
+    assert abs(dsc - np.mean(want_dsc)) < 1e-4
+    heads = np.array(want_terms[0]).reshape(4, 2).sum(1)
+    assert np.abs(heads - heads[0]).max() > 1e-4                         # the heads really differ: output 0 alone is wrong
+    # a log window longer than the ring folds into running sums
+    c = T._fold_carry(None, (2.0, [1.0, 1.0], 50.0), 3)
+    c = T._fold_carry(c, (4.0, [3.0, 1.0], 70.0), 1)
+    assert T._unfold_carry(c) == (2.5, [1.5, 1.0], 55.0)
