@@ -76,6 +76,8 @@ struct msk_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr;
   bool comm_pending = false;
+  bool host_transport = false;   // env MSEGK_DP_TRANSPORT=host: collectives through host staging + TCP (single-GPU test tier)
+  std::vector<int> host_fds;
   int rank = 0, world = 1;
   int num_cu = 256;
 };

@@ -3,9 +3,14 @@
 // (core/train.py:81-85, cvlibs/config.py:322).  All collectives are enqueued on the
 // context's compute stream so they order with the kernels that produce/consume them.
 #include <rccl/rccl.h>
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
 #include <unistd.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "msk_common.h"
 
@@ -34,6 +39,115 @@ struct StdoutToStderr {
     }
   }
 };
+// ---------------------------------------------------------------------------------------------------------
+// Host transport (env MSEGK_DP_TRANSPORT=host): the same collectives through pinned-less host staging and TCP sockets
+// in a star around rank 0, which reduces in rank order (deterministic).  It exists so that the N-rank code paths --
+// SyncBatchNorm exchanges, gradient buckets, 1/nranks, broadcast -- can run with SEVERAL PROCESSES ON ONE GPU (RCCL
+// refuses two ranks on one device), i.e. in the single-GPU test tier; it is never selected implicitly and is orders of
+// magnitude slower than RCCL over xGMI.
+// ---------------------------------------------------------------------------------------------------------
+bool send_all(int fd, const void* p, size_t n) {
+  const char* c = (const char*)p;
+  while (n > 0) {
+    const ssize_t k = send(fd, c, n, MSG_NOSIGNAL);
+    if (k <= 0) return false;
+    c += k;
+    n -= (size_t)k;
+  }
+  return true;
+}
+bool recv_all(int fd, void* p, size_t n) {
+  char* c = (char*)p;
+  while (n > 0) {
+    const ssize_t k = recv(fd, c, n, 0);
+    if (k <= 0) return false;
+    c += k;
+    n -= (size_t)k;
+  }
+  return true;
+}
+
+int host_connect(msk_ctx* ctx, int rank, int world) {
+  const char* pe = getenv("MASTER_PORT");
+  const char* ae = getenv("MASTER_ADDR");
+  const int port = (pe ? atoi(pe) : 29500) + 40;
+  sockaddr_in sa{};
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)port);
+  if (inet_pton(AF_INET, (ae && ae[0] && strcmp(ae, "localhost") != 0) ? ae : "127.0.0.1", &sa.sin_addr) != 1)
+    return msk_fail(ctx, __FILE__, __LINE__, "host transport", "MASTER_ADDR must be an IPv4 address");
+  ctx->host_fds.assign(world, -1);
+  const int one = 1;
+  if (rank == 0) {
+    const int srv = socket(AF_INET, SOCK_STREAM, 0);
+    setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (bind(srv, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(srv, world) != 0) {
+      close(srv);
+      return msk_fail(ctx, __FILE__, __LINE__, "host transport", "cannot listen on MASTER_PORT + 40");
+    }
+    for (int k = 1; k < world; ++k) {
+      const int fd = accept(srv, nullptr, nullptr);
+      int peer = -1;
+      if (fd < 0 || !recv_all(fd, &peer, sizeof(peer)) || peer <= 0 || peer >= world || ctx->host_fds[peer] >= 0) {
+        close(srv);
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "bad peer during connect");
+      }
+      setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      ctx->host_fds[peer] = fd;
+    }
+    close(srv);
+  } else {
+    int fd = -1;
+    for (int attempt = 0; attempt < 600 && fd < 0; ++attempt) {   // up to ~60 s for rank 0 to come up
+      fd = socket(AF_INET, SOCK_STREAM, 0);
+      if (connect(fd, (sockaddr*)&sa, sizeof(sa)) != 0) {
+        close(fd);
+        fd = -1;
+        usleep(100000);
+      }
+    }
+    if (fd < 0 || !send_all(fd, &rank, sizeof(rank)))
+      return msk_fail(ctx, __FILE__, __LINE__, "host transport", "cannot reach rank 0");
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    ctx->host_fds[0] = fd;
+  }
+  return 0;
+}
+
+// gather everybody's `count` floats on rank 0 ([world][count]); op 0: all-reduce sum in rank order, op 1: all-gather
+int host_collective(msk_ctx* ctx, const float* dsend, float* drecv, size_t count, int op, hipStream_t stream) {
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(stream));
+  const int W = ctx->world;
+  std::vector<float> mine(count), out(op == 0 ? count : count * W);
+  MSK_CHECK_HIP(ctx, hipMemcpy(mine.data(), dsend, count * sizeof(float), hipMemcpyDeviceToHost));
+  const size_t out_bytes = out.size() * sizeof(float);
+  const unsigned long long tag = (unsigned long long)count * 2 + (unsigned)op;  // travels ahead of every payload
+  if (ctx->rank == 0) {
+    std::vector<float> tmp(count);
+    if (op == 0) out = mine;
+    else memcpy(out.data(), mine.data(), count * sizeof(float));
+    for (int r = 1; r < W; ++r) {
+      unsigned long long peer_tag = 0;
+      if (!recv_all(ctx->host_fds[r], &peer_tag, sizeof(peer_tag)))
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during a collective");
+      if (peer_tag != tag)   // ranks disagree on the collective sequence: fail loudly instead of exchanging garbage
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "collective mismatch between ranks (kind or element count)");
+      if (!recv_all(ctx->host_fds[r], tmp.data(), count * sizeof(float)))
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during a collective");
+      if (op == 0) for (size_t i = 0; i < count; ++i) out[i] += tmp[i];
+      else memcpy(out.data() + (size_t)r * count, tmp.data(), count * sizeof(float));
+    }
+    for (int r = 1; r < W; ++r)
+      if (!send_all(ctx->host_fds[r], out.data(), out_bytes))
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during a collective");
+  } else {
+    if (!send_all(ctx->host_fds[0], &tag, sizeof(tag)) || !send_all(ctx->host_fds[0], mine.data(), count * sizeof(float)) ||
+        !recv_all(ctx->host_fds[0], out.data(), out_bytes))
+      return msk_fail(ctx, __FILE__, __LINE__, "host transport", "rank 0 closed during a collective");
+  }
+  MSK_CHECK_HIP(ctx, hipMemcpy(drecv, out.data(), out_bytes, hipMemcpyHostToDevice));
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -52,9 +166,20 @@ int msk_dp_unique_id(char* id128) {
 int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   MSK_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised");
   MSK_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+  MSK_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    const char* tr = getenv("MSEGK_DP_TRANSPORT");
+    if (tr && strcmp(tr, "host") == 0) {
+      ctx->rank = rank;
+      ctx->world = world;
+      if (world > 1 && host_connect(ctx, rank, world) != 0) return -1;
+      ctx->host_transport = true;
+      ctx->comm = (void*)ctx;   // non-null marker: "initialised"
+      return 0;
+    }
+  }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  MSK_CHECK_HIP(ctx, hipSetDevice(ctx->device));
   StdoutToStderr quiet;
   ncclComm_t comm;
   MSK_CHECK_NCCL(ctx, ncclCommInitRank(&comm, world, id, rank));
@@ -80,6 +205,7 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
 int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (msk_join_side_impl(ctx) != 0) return -1;  // the gradient arena includes side-stream weight gradients
+  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   msk_launch_scope ls(ctx, "rccl_allreduce");
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
@@ -88,7 +214,7 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
 int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (count == 0) return 0;
-  if (ctx->comm_grad == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);  // ncclCommSplit was not available
+  if (ctx->host_transport || ctx->comm_grad == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);  // no second communicator
   // the bucket's gradients come from the compute stream (data-gradient chain, bias/BN/PReLU gradients) and from the
   // weight-gradient side stream: wait for the current tail of both, block neither
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_main, ctx->stream));
@@ -108,6 +234,7 @@ int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
   // per-channel BatchNorm-backward sums: produced on the main stream, so the weight-gradient side stream
   // keeps running (msk_dp_allreduce_sum would join it 24 times per step and undo the overlap)
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   msk_launch_scope ls(ctx, "rccl_allreduce_stats");
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
@@ -115,6 +242,11 @@ int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
 
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  if (ctx->host_transport) {
+    if (ctx->world > 1) return host_collective(ctx, send, recv, count_per_rank, 1, ctx->stream);
+    MSK_CHECK_HIP(ctx, hipMemcpyAsync(recv, send, count_per_rank * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
   msk_launch_scope ls(ctx, "rccl_allgather");
   MSK_CHECK_NCCL(ctx, ncclAllGather(send, recv, count_per_rank, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
@@ -122,6 +254,24 @@ int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_
 
 int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  if (ctx->host_transport) {
+    if (ctx->world == 1) return 0;
+    MSK_REQUIRE(ctx, root == 0, "host transport broadcasts from rank 0 only");
+    // all-gather semantics reduced to "keep rank 0's copy": everybody contributes, rank 0's slice is what survives
+    std::vector<float> h(count);
+    MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->rank == 0) {
+      MSK_CHECK_HIP(ctx, hipMemcpy(h.data(), buf, count * sizeof(float), hipMemcpyDeviceToHost));
+      for (int r = 1; r < ctx->world; ++r)
+        if (!send_all(ctx->host_fds[r], h.data(), count * sizeof(float)))
+          return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during broadcast");
+    } else {
+      if (!recv_all(ctx->host_fds[0], h.data(), count * sizeof(float)))
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "rank 0 closed during broadcast");
+      MSK_CHECK_HIP(ctx, hipMemcpy(buf, h.data(), count * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+  }
   msk_launch_scope ls(ctx, "rccl_broadcast");
   MSK_CHECK_NCCL(ctx, ncclBroadcast(buf, buf, count, ncclFloat, root, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
@@ -131,12 +281,27 @@ int msk_dp_barrier(msk_ctx* ctx) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   float* tok = (float*)msk_workspace(ctx, 256);
   if (!tok) return -1;
+  if (ctx->host_transport) {
+    if (ctx->world > 1 && host_collective(ctx, tok, tok, 1, 0, ctx->stream) != 0) return -1;
+    MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
   MSK_CHECK_NCCL(ctx, ncclAllReduce(tok, tok, 1, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 int msk_dp_destroy(msk_ctx* ctx) {
+  if (ctx && ctx->host_transport) {
+    for (int fd : ctx->host_fds)
+      if (fd >= 0) close(fd);
+    ctx->host_fds.clear();
+    ctx->host_transport = false;
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+    return 0;
+  }
   if (ctx && ctx->comm_stream) {
     hipStreamSynchronize(ctx->comm_stream);
     if (ctx->comm_grad) ncclCommDestroy((ncclComm_t)ctx->comm_grad);

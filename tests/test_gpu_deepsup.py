@@ -117,7 +117,8 @@ def test_train_log_values_of_a_multi_output_model():
     the weighted sum over ALL heads and the logged DSC is the per-class dice of the last dice-bearing loss, as
     reference core/train.py:158-170 + utils/loss_utils.py:41-42 compute them (round-1 advisor finding: only output 0 was
     snapshotted)."""
-    from medicalseg_amd.core import train as T
+    import importlib
+    T = importlib.import_module("medicalseg_amd.core.train")
     from medicalseg_amd.device import to_tensor
     from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNetDeepSup
     from medicalseg_amd.utils import loss_computation

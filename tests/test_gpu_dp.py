@@ -116,3 +116,70 @@ def test_overlapped_gradient_buckets_world1(model_name):
             assert np.array_equal(outs[0][k], outs[2][k]), k
     finally:
         d.call("msk_dp_destroy")
+
+
+@pytest.mark.parametrize("C_,shape", [(32, (2, 8, 12, 12)), (256, (2, 4, 4, 4)), (3, (4, 5, 6, 7))])
+def test_syncbn_two_rank_arithmetic_on_one_gpu(C_, shape):
+    """The N-rank arithmetic of SyncBatchNorm (cvlibs/config.py:322; nn.ConvBNAct with world > 1), executed on ONE GPU:
+    the batch is cut in two "rank" halves; each half gets its own msk_bn_stats record, both records go through
+    msk_bn_finalize(world = 2) (the cross-rank Chan merge of bn_finalize_k), and the backward sums of the halves are ADDED
+    (what msk_dp_allreduce_stats does) before msk_affine_act_bwd_apply runs per half with the global count.  Reference
+    values: the float64 oracle on the CONCATENATED batch.  (Round-1 verdict: the world > 1 branches had never run.)"""
+    import ctypes as C
+    from helpers import rel_err, t_empty, t_from_ncdhw, t_to_ncdhw, vec, vec_back, vp
+    from oracle import vnet_numpy as O
+    d = dev()
+    N, D, H, W = shape
+    rng = np.random.default_rng(C_ + N)
+    x = (rng.standard_normal((N, C_, D, H, W)) * 2 + 10.0).astype(np.float32)
+    x[N // 2:] += 3.0                                       # the two ranks see different means
+    gamma, beta = rng.uniform(0.5, 1.5, C_).astype(np.float32), rng.standard_normal(C_).astype(np.float32)
+    alpha = rng.uniform(0.1, 0.4, C_).astype(np.float32)
+    dout = rng.standard_normal(x.shape).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref, xhat, mean, var, invstd = O.bn_train(f8(x), f8(gamma), f8(beta))
+    out_ref = O.prelu(y_ref, f8(alpha))
+    du, dalpha = O.prelu_bwd(f8(dout), y_ref, f8(alpha))
+    dx_ref, dg_ref, db_ref = O.bn_train_bwd(du, xhat, f8(gamma), invstd)
+
+    halves = [slice(0, N // 2), slice(N // 2, N)]
+    xs = [t_from_ncdhw(x[h]) for h in halves]
+    ds_ = [t_from_ncdhw(dout[h]) for h in halves]
+    Mh = (N // 2) * D * H * W
+    gathered = vec(np.zeros(2 * 2 * C_))
+    for r, xt in enumerate(xs):
+        d.call("msk_bn_stats", xt.msk(), vp(gathered + r * 2 * C_ * 4))
+    g, b_ = vec(gamma), vec(beta)
+    rm, rv = vec(np.zeros(C_)), vec(np.ones(C_))
+    sm, si, sc, sh = (vec(np.zeros(C_)) for _ in range(4))
+    d.call("msk_bn_finalize", vp(gathered), 2, C.c_double(Mh), C_, vp(g), vp(b_), C.c_float(1e-5), C.c_float(0.9),
+           vp(rm), vp(rv), vp(sm), vp(si), vp(sc), vp(sh))
+    assert np.abs(vec_back(sm, C_) - mean).max() < 2e-6 * np.abs(mean).max()
+    assert rel_err(vec_back(si, C_), invstd) < 2e-5
+    assert rel_err(vec_back(rv, C_), 0.9 * 1.0 + 0.1 * var) < 2e-5
+    al = vec(alpha)
+    sums = [vec(np.zeros(3 * C_)) for _ in range(2)]
+    for r in range(2):
+        ot = t_empty(N // 2, C_, D, H, W)
+        d.call("msk_affine_act_fwd", xs[r].msk(), vp(sc), vp(sh), d_null(), vp(al), ot.msk())
+        assert np.abs(t_to_ncdhw(ot) - out_ref[halves[r]]).max() < 5e-5 * np.abs(out_ref).max()
+        d.call("msk_affine_act_bwd_reduce", xs[r].msk(), vp(sc), vp(sh), d_null(), vp(al), vp(sm), vp(si), ds_[r].msk(),
+               vp(sums[r]))
+    total = vec_back(sums[0], 3 * C_) + vec_back(sums[1], 3 * C_)       # the all-reduce
+    assert rel_err(total[:C_], db_ref) < 1e-4 and rel_err(total[C_:2 * C_], dg_ref) < 1e-4
+    assert rel_err(total[2 * C_:], dalpha) < 1e-4
+    tot = vec(total)
+    for r in range(2):
+        dxt = t_empty(N // 2, C_, D, H, W)
+        d.call("msk_affine_act_bwd_apply", xs[r].msk(), vp(sc), vp(sh), d_null(), vp(al), vp(sm), vp(si), vp(g),
+               ds_[r].msk(), vp(tot), C.c_double(2 * Mh), 1, dxt.msk(), d_null(), 0)
+        assert rel_err(t_to_ncdhw(dxt), dx_ref[halves[r]]) < 2e-4
+    # and the rank-local alternative really differs (the test can tell the two apart)
+    loc = vec(np.zeros(2 * C_))
+    d.call("msk_bn_stats", xs[0].msk(), vp(loc))
+    assert np.abs(vec_back(loc, 2 * C_)[:C_] - mean).max() > 1.0
+
+
+def d_null():
+    from medicalseg_amd._lib import NULL_TENSOR
+    return NULL_TENSOR

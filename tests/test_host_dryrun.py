@@ -126,7 +126,7 @@ def test_gradient_buckets_partition_the_arena(fake_pkg):
     y = rng.integers(0, 3, (1, 16, 16, 16)).astype(np.int32)
     for cls, nout, min_buckets in ((VNet, 1, 4), (VNetDeepSup, 4, 3)):
         model = cls(num_classes=3)
-        ddp = parallel.DataParallel(model, force=True, bucket_bytes=16 << 20)
+        ddp = parallel.DataParallel(model, force=True, overlap=True, bucket_bytes=16 << 20)
         losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])] * nout, "coef": [1.0 / nout] * nout}
         for _ in range(2):                                  # the bookkeeping resets between steps
             ll, _ = loss_computation(ddp(x), to_tensor(y), losses)
