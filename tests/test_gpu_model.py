@@ -435,3 +435,128 @@ def test_fused_inference_matches_eval_forward(model_name):
         fused2 = model(to_tensor(x))[0].numpy()
     assert np.abs(plain2 - plain).max() > 1e-3 * scale
     assert np.abs(fused2 - plain2).max() <= 2e-5 * np.abs(plain2).max()
+
+
+def test_vnet_32cube_batch2_gradients_calibrated():
+    """Whole-net forward / backward at 32^3, batch 2 (every BatchNorm layer sees >= 16 values per channel) against the
+    float64 oracle, with the three kernel sets on identical weights and data.
+
+    Forward quantities are strict: logits 2e-5 of max|logit| (measured 2.7e-6), losses 2e-5, per-class dice 1e-5.
+    Gradients: this network amplifies per-layer rounding about 1000x on the way back (BatchNorm backward subtracts two
+    projections; the surviving signal is small) -- the float64 oracle re-run in FLOAT32 is itself 7.7e-4 (median
+    per-tensor rel-L2) away from float64, and the exact-fp32 direct kernels 4.9e-4 / 5.7e-3 (median / worst tensor).  A
+    per-tensor bound of 1e-3 is therefore not attainable by any fp32 implementation; what is asserted:
+      * every tensor rel-L2 <= 1.2e-2, median <= 5e-3 (measured: bf16x3 Winograd 3.0e-3 median / 6.5e-3 worst);
+      * the bf16x3 pipeline is no worse than the exact-fp32 Winograd kernels it replaced (measured 6.1e-3 / 8.8e-3);
+    a structural error (missing term, wrong scale) is O(1) and a 1 % systematic error doubles the worst tensor."""
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    shape, ncls, N = (32, 32, 32), 3, 2
+    K = S = ((2, 2, 2),) * 4
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+    params = O.init_params(2, 1, ncls, K, S)
+    om, lg_ref, ll_ref, per_ref, g_ref = _oracle_run(params, ncls, K, S, x, y, True, {}, np.float64)
+    d = dev()
+    stats = {}
+    for tag, opts in (("bf16x3", {}), ("fp32_wino", {"wino_bf3": 0}), ("fp32_direct", {"direct_conv": 1})):
+        for k_, v_ in opts.items():
+            d.set_option(k_, v_)
+        try:
+            model, _ = _build(ncls, K, S, seed=2)
+            model.train()
+            model.set_dropout_masks({})
+            d.prof_reset()
+            d.set_option("prof_only_halo", 0)
+            d.prof_enable(True)
+            logits = model(x)
+            lg = logits[0].numpy()
+            losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+            loss_list, per = loss_computation(logits, to_labels(y), losses)
+            model.clear_gradients()
+            sum(loss_list).backward()
+            d.sync()
+            d.prof_enable(False)
+            tags = d.prof_report()
+            ran_wbf = any(k.startswith("wbf_gemm_k") for k in tags) and any(k.startswith("wbf_wgrad_k") for k in tags)
+            assert ran_wbf == (tag == "bf16x3"), sorted(tags)
+            e_lg = rel_err(lg, lg_ref)
+            assert e_lg < 2e-5, (tag, e_lg)
+            assert abs(float(loss_list[0]) - ll_ref[0]) < 2e-5 * abs(ll_ref[0])
+            assert abs(float(loss_list[1]) - ll_ref[1]) < 2e-5
+            assert np.abs(np.asarray(per) - per_ref).max() < 1e-5
+            l2s = {}
+            for name, p in model.named_parameters():
+                ref = g_ref[name]
+                if np.abs(ref).max() < 1e-9:   # conv bias ahead of a train-mode BN: exactly 0 in exact arithmetic
+                    assert np.abs(p.grad_numpy()).max() < 1e-4
+                    continue
+                l2s[name] = _l2(p.grad_numpy(), ref)
+            worst = max(l2s, key=l2s.get)
+            stats[tag] = (float(np.median(list(l2s.values()))), l2s[worst])
+            print("32^3 N=2 %-11s logits %.2e | gradient rel-L2 median %.2e worst %.2e (%s)" %
+                  (tag, e_lg, stats[tag][0], l2s[worst], worst))
+            assert l2s[worst] < 1.2e-2 and stats[tag][0] < 7e-3, (tag, worst, l2s[worst])
+        finally:
+            for k_ in opts:
+                d.set_option(k_, 1 if k_ == "wino_bf3" else 0)
+    assert stats["bf16x3"][0] < 5e-3
+    assert stats["bf16x3"][0] <= 1.2 * stats["fp32_wino"][0] and stats["bf16x3"][1] <= 1.5 * stats["fp32_wino"][1]
+
+
+def test_training_trajectory_bf16x3_vs_exact_fp32_kernels():
+    """50 optimizer steps at 32^3, batch 2, from identical weights with (a) the bf16x3 Winograd pipeline (product default),
+    (b) the exact-fp32 Winograd kernels (wino_bf3 = 0), (c) the direct exact-fp32 kernels (direct_conv = 1), then the
+    eval-mode mDice of a held-out batch (core/val.py's metric).  north_star: "Dice within 1e-4".  Training is a chaotic
+    map, so two EXACT-fp32 implementations already drift apart; that drift (b vs c) is the noise band, and (a) must stay
+    inside max(1e-4, 2 x band) of (c) for mDice and the final losses."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(31)
+    N, S_ = 2, 32
+    xs = rng.standard_normal((4, N, 1, S_, S_, S_)).astype(np.float32)
+    # learnable labels: a smooth function of the input so that 50 steps move the Dice
+    ys = ((xs[:, :, 0] > 0.3).astype(np.int32) + (xs[:, :, 0] > 1.0).astype(np.int32))
+    xv = rng.standard_normal((N, 1, S_, S_, S_)).astype(np.float32)
+    yv = ((xv[:, 0] > 0.3).astype(np.int32) + (xv[:, 0] > 1.0).astype(np.int32))
+    d = dev()
+    res = {}
+    for tag, opts in (("bf16x3", {}), ("fp32_wino", {"wino_bf3": 0}), ("fp32_direct", {"direct_conv": 1})):
+        for k_, v_ in opts.items():
+            d.set_option(k_, v_)
+        try:
+            nn.seed(11)
+            model = VNet(num_classes=3)
+            model.train()
+            model.set_dropout_masks({})
+            opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+            losses = {"types": [MixedLoss([CrossEntropyLoss(weight=[1.0, 1.0, 1.0]), DiceLoss()], [1, 1])], "coef": [1]}
+            traj = []
+            for it in range(50):
+                logits = model(xs[it % 4])
+                ll, _ = loss_computation(logits, to_labels(ys[it % 4]), losses)
+                loss = sum(ll)
+                loss.backward()
+                opt.step()
+                model.clear_gradients()
+                if it % 10 == 9:
+                    traj.append(float(loss))
+            model.eval()
+            ll, per = loss_computation(model(xv), to_labels(yv), losses)
+            res[tag] = (np.array(traj), float(np.mean(np.asarray(per))), float(sum(ll)))
+        finally:
+            for k_ in opts:
+                d.set_option(k_, 1 if k_ == "wino_bf3" else 0)
+    (ta, ma, la), (tb, mb, lb), (tc, mc, lc) = res["bf16x3"], res["fp32_wino"], res["fp32_direct"]
+    band_m, band_l, band_t = abs(mb - mc), abs(lb - lc), np.abs(tb - tc).max()
+    print("mDice bf16x3 %.6f fp32-wino %.6f fp32-direct %.6f | |d| bf16x3-direct %.2e, fp32 band %.2e" %
+          (ma, mb, mc, abs(ma - mc), band_m))
+    print("eval loss |d| %.2e (band %.2e); train-loss trajectory |d| %.2e (band %.2e); losses %s" %
+          (abs(la - lc), band_l, np.abs(ta - tc).max(), band_t, ta))
+    assert ta[-1] < ta[0]                                  # it trains
+    assert abs(ma - mc) < max(1e-4, 2 * band_m)
+    assert abs(la - lc) < max(1e-4 * abs(lc), 2 * band_l)
+    assert np.abs(ta - tc).max() < max(1e-4 * np.abs(tc).max(), 2 * band_t)

@@ -1,7 +1,8 @@
 """Per-op parity: HIP kernels (through the C ABI) vs the numpy oracle, on the GPU.
 
 Tolerances (fp32 kernels vs float64 oracle, stated per the north-star's "fp32 tolerance"):
-  convolutions: max abs err <= 2e-5 * max|ref| * sqrt(K/1000 + 1)   (K = reduction length)
+  convolutions: max abs err <= 8e-6 * max|ref| * sqrt(K/1000 + 1)   (K = reduction length; about 3x the largest
+  error any kernel shows: direct fp32 MFMA ~5e-7, bf16x3 Winograd F(4,5) <= 2.7e-6, fp32 Winograd F(4,5) <= 4.5e-6)
   elementwise / BN / loss: 1e-5 relative to max|ref|.
 """
 import ctypes as C
@@ -51,7 +52,7 @@ CONV_CASES = [
 
 
 def _conv_tol(K):
-    return 2e-5 * np.sqrt(K / 1000.0 + 1.0)
+    return 8e-6 * np.sqrt(K / 1000.0 + 1.0)
 
 
 @pytest.mark.parametrize("impl", [0, 1, 7])
@@ -413,7 +414,7 @@ def _wino_variant(D, H, W):
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv5_winograd_f25_matches_oracle(case):
     """conv_halo_wino_k / conv_halo_wino4_k (1-D Winograd F(2,5) / F(4,5) along W, msk_conv_wino.hip) forward and data
-    gradient vs the float64 oracle.  Tolerance: the conv tolerance of this file (2e-5 * sqrt(K/1000 + 1) of max|ref|);
+    gradient vs the float64 oracle.  Tolerance: the conv tolerance of this file (8e-6 * sqrt(K/1000 + 1) of max|ref|);
     the transforms cost about one decimal digit relative to the direct fp32 kernel (measured ~1e-6 / ~4e-6 vs ~1e-7)."""
     cin, cout, (N, D, H, W) = case
     k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)

@@ -3,7 +3,7 @@ the float64 oracle, through the C ABI.
 
 The matrix stage multiplies fp32 operands that were split EXACTLY into three bf16 pieces with six bf16 products per
 fp32 product (fp32 accumulate); the claim under test is fp32-class accuracy: the same tolerance as every other
-convolution kernel of this repo (tests/test_gpu_ops.py: 2e-5 * sqrt(K/1000 + 1) of max|ref|), and in addition an
+convolution kernel of this repo (tests/test_gpu_ops.py: 8e-6 * sqrt(K/1000 + 1) of max|ref|), and in addition an
 error no larger than 1.5x that of the exact-fp32 Winograd kernels it replaces on the same inputs."""
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ def _desc(k, s, p):
 
 
 def _conv_tol(K):
-    return 2e-5 * np.sqrt(K / 1000.0 + 1.0)
+    return 8e-6 * np.sqrt(K / 1000.0 + 1.0)
 
 
 WBF_CASES = [
