@@ -259,7 +259,9 @@ def main():
     if os.path.exists(tpath) and S == 128 and B == 2:   # PMC pass of this exact workload (tools/summarize_rocprof.py)
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(DOM, {}).get("hbm_bytes_per_launch")
+            ent = [v for k, v in tj.items() if k.startswith(DOM) and isinstance(v, dict)]   # all tile variants of the kernel
+            nl = sum(v["launches"] for v in ent)
+            traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent) / nl) if nl else None
             traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                           "captured %s, NOT measured in this run" % tj.get("_captured", "in round 2")
         except Exception:
