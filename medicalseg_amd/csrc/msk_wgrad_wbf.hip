@@ -12,10 +12,10 @@
 // hands lane i channel i of the 4 positions (verified on hardware: tools/probes/tr16_probe.hip).  Two reads give the
 // 8-position fragment of v_mfma_f32_16x16x32_bf16 (M = 16 input channels, N = 16 output channels, K = 32 positions).
 //
-// Workgroup = 5 wavefronts = the 5 kd rows of the 25 taps; one 16-channel chunk of ci x 32 output channels; the V halo
-// tile (8+4) x (TH+4) and the Y tile 8 x TH of one (n, t) plane are staged once and serve all 25 taps.  A wavefront
-// keeps 5 (kh) x 2 (co halves) accumulators and walks the tile in K-steps of 32 positions; per K-step 42 transposing
-// reads feed 60 MFMAs.  The workgroup loops over its share of the position tiles (split-K over tiles, slabs reduced in
+// Workgroup = 4 wavefronts sharing the 25 taps (7 + 6 + 6 + 6); one 16-channel chunk of ci x 32 output channels; the V
+// halo tile (8+4) x (TH+4) and the Y tile 8 x TH of one (n, t) plane are staged once and serve all 25 taps.  A wavefront
+// keeps (6..7 taps) x 2 (co halves) accumulators and walks the tile in K-steps of 32 positions; per K-step 48..54
+// transposing reads feed 72..84 MFMAs.  The workgroup loops over its share of the position tiles (split-K over tiles, slabs reduced in
 // a fixed order) and writes its partial dU once.  Six bf16 products per fp32 product, as in the forward pipeline.
 #include "msk_wbf.h"
 
@@ -42,14 +42,14 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, unsigned byte_off
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0)
 
 template <int TH>
-__global__ void __launch_bounds__(320)
+__global__ void __launch_bounds__(256)
 wbf_wgrad_k(WgArgs a) {
   constexpr int TD = 8, HPt = TH + 4, NSV = (TD + 4) * HPt, NSY = TD * TH;
   constexpr int RV1 = (NSV + 63) / 64, RY1 = (NSY + 63) / 64;           // LDS-DMA rounds per plane
   constexpr int PSV = RV1 * 1024 + (TH == 16 ? 64 : 128);               // plane strides: the pad keeps the two khalf planes
   constexpr int PSY = RY1 * 1024 + 64;                                  //   of a transposing read on disjoint banks
   constexpr int YBASE = 6 * PSV;
-  constexpr int NRV = 6 * RV1, NRY = 12 * RY1, NR = NRV + NRY, RPW = (NR + 4) / 5;  // rounds per wavefront
+  constexpr int NRV = 6 * RV1, NRY = 12 * RY1, NR = NRV + NRY, RPW = (NR + 3) / 4;  // rounds per wavefront
   constexpr int KSTEPS = TD * TH / 32, ROWS_PER_STEP = 32 / TH;
   __shared__ __attribute__((aligned(16))) char lds[6 * PSV + 12 * PSY];
 
@@ -70,13 +70,13 @@ wbf_wgrad_k(WgArgs a) {
   const __amdgpu_buffer_rsrc_t yres =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (long)xi * a.y_xi), 0, 0xFFFFFFF0u, 0x00020000);
 
-  // LDS-DMA rounds of this wavefront: R = wave + 5 j.  V rounds first (plane pk, 64 slots each), then Y rounds
+  // LDS-DMA rounds of this wavefront: R = wave + 4 j.  V rounds first (plane pk, 64 slots each), then Y rounds
   // (chunk c, plane pk).  voff = byte offset inside the (n, t) block of the tensor, relative to the tile origin.
   unsigned voff[RPW];
   int ldst[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
-    const int R = wave + 5 * j;
+    const int R = wave + 4 * j;
     if (R < NRV) {
       const int pk = R / RV1, sub = R - pk * RV1;
       int slot = sub * 64 + lane;
@@ -98,14 +98,24 @@ wbf_wgrad_k(WgArgs a) {
   // per-lane LDS byte offsets of the transposing reads (position q = 8 g + 4 r + i/4 of the K-step, channel quad i%4)
   const int q0 = 8 * g + (i >> 2);
   const int khalf = (i & 3) >> 1, sub8 = (i & 1) * 8;
-  const unsigned va = (unsigned)(khalf * PSV + (((q0 / TH) + wave) * HPt + (q0 % TH)) * 16 + sub8);  // + kd = wave rows
+  const unsigned va = (unsigned)(khalf * PSV + ((q0 / TH) * HPt + (q0 % TH)) * 16 + sub8);
+  // taps of this wavefront: [tap0, tap0 + ntap) of the 25 (kd, kh) taps -- 7, 6, 6, 6.  (Five wavefronts, one kd row each,
+  // balanced the taps but not the SIMDs: a 5-wave workgroup takes 2 slots on one SIMD, the third resident workgroup often
+  // found no SIMD with room, and PMC showed half the expected wavefronts in flight and the matrix pipe 52 % busy.)
+  const int tap0 = wave == 0 ? 0 : 1 + 6 * wave, ntap = wave == 0 ? 7 : 6;
+  unsigned tapoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tp = min(tap0 + j, 24);
+    tapoff[j] = (unsigned)(((tp / 5) * HPt + (tp % 5)) * 16);   // wave-uniform
+  }
   const unsigned ya = (unsigned)(YBASE + khalf * PSY + ((q0 / TH) * TH + (q0 % TH)) * 16 + sub8);
 
-  f32x4 acc[5][2];
+  f32x4 acc[7][2];
 #pragma unroll
-  for (int kh = 0; kh < 5; ++kh)
+  for (int j = 0; j < 7; ++j)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) acc[kh][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 2; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int t0 = ks * a.tiles_per;
   const int t1 = min(a.ntiles, t0 + a.tiles_per);
@@ -119,7 +129,7 @@ wbf_wgrad_k(WgArgs a) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-      const int R = wave + 5 * j;
+      const int R = wave + 4 * j;
       if (R < NRV)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + ldst[j]), 16,
                                                  (int)voff[j], (int)vso, 0, 0);
@@ -142,35 +152,40 @@ wbf_wgrad_k(WgArgs a) {
           bq[c][p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh) {
-        s16x8 aq[3];
+      for (int j = 0; j < 7; ++j) {
+        if (j < ntap) {   // wave-uniform
+          s16x8 aq[3];
+          const unsigned vt = va + tapoff[j];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const unsigned o = va + (unsigned)(p * 2 * PSV + (kst * ROWS_PER_STEP * HPt + kh) * 16);
-          const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
-          aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+          for (int p = 0; p < 3; ++p) {
+            const unsigned o = vt + (unsigned)(p * 2 * PSV + kst * ROWS_PER_STEP * HPt * 16);
+            const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
+            aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          WGW_MFMA(acc[kh][c], aq[2], bq[c][0]);  // small terms first
-          WGW_MFMA(acc[kh][c], aq[0], bq[c][2]);
-          WGW_MFMA(acc[kh][c], aq[1], bq[c][1]);
-          WGW_MFMA(acc[kh][c], aq[1], bq[c][0]);
-          WGW_MFMA(acc[kh][c], aq[0], bq[c][1]);
-          WGW_MFMA(acc[kh][c], aq[0], bq[c][0]);
+          for (int c = 0; c < 2; ++c) {
+            WGW_MFMA(acc[j][c], aq[2], bq[c][0]);  // small terms first
+            WGW_MFMA(acc[j][c], aq[0], bq[c][2]);
+            WGW_MFMA(acc[j][c], aq[1], bq[c][1]);
+            WGW_MFMA(acc[j][c], aq[1], bq[c][0]);
+            WGW_MFMA(acc[j][c], aq[0], bq[c][1]);
+            WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
+          }
         }
       }
     }
   }
 
-  // partial dU[xi][ks][kci][cob][tap = wave*5 + kh][ci = 4 g + reg][co = c*16 + i]
-  float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * 25 + wave * 5) * 512;
+  // partial dU[xi][ks][kci][cob][tap = tap0 + j][ci = 4 g + reg][co = c*16 + i]
+  float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * 25 + tap0) * 512;
 #pragma unroll
-  for (int kh = 0; kh < 5; ++kh)
+  for (int j = 0; j < 7; ++j)
+    if (j < ntap) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pb[kh * 512 + (4 * g + r) * 32 + c * 16 + i] = acc[kh][c][r];
+        for (int r = 0; r < 4; ++r) pb[j * 512 + (4 * g + r) * 32 + c * 16 + i] = acc[j][c][r];
+    }
 }
 
 // dw[cb][ca][canonical tap(kd, kh, kw)] (+)= sum_xi G[xi][kw] * sum_ks P[xi][ks][ca/16][cb/32][kd*5+kh][ca%16][cb%32]
@@ -285,9 +300,15 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
       snprintf(buf, sizeof(buf), "wbf_wgrad_k[ca=%d,cb=%d,n=%d,dhw=%dx%dx%d,ks=%ld]", g.CA, g.CB, g.N, g.BD, g.BH, g.BW, ksplit);
       tag = msk_intern_tag(ctx, buf);
     }
+    if (getenv("MSEGK_DEBUG_OCC")) {
+      int nb16 = -1, nb8 = -1;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, wbf_wgrad_k<16>, 256, 0);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, wbf_wgrad_k<8>, 256, 0);
+      fprintf(stderr, "wbf_wgrad_k occupancy (workgroups per CU): TH16 %d, TH8 %d; blocks %ld ksplit %ld\n", nb16, nb8, nblk, ksplit);
+    }
     msk_launch_scope ls(ctx, tag);
-    if (TH == 16) hipLaunchKernelGGL(wbf_wgrad_k<16>, dim3((unsigned)nblk), dim3(320), 0, ctx->stream, wa);
-    else hipLaunchKernelGGL(wbf_wgrad_k<8>, dim3((unsigned)nblk), dim3(320), 0, ctx->stream, wa);
+    if (TH == 16) hipLaunchKernelGGL(wbf_wgrad_k<16>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
+    else hipLaunchKernelGGL(wbf_wgrad_k<8>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
     MSK_LAUNCH_CHECK(ctx);
   }
   {
