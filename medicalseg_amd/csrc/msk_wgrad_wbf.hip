@@ -189,9 +189,13 @@ wbf_wgrad_k(WgArgs a) {
 }
 
 // dw[cb][ca][canonical tap(kd, kh, kw)] (+)= sum_xi G[xi][kw] * sum_ks P[xi][ks][ca/16][cb/32][kd*5+kh][ca%16][cb%32]
+// Block = 32 consecutive outputs (one (row, ca), 32 cb: 128-byte lines of every slab) x 8 slices of the split-K slabs; a
+// thread adds its slices z = slice, slice + 8, ... in double, the 8 slices are combined through LDS in a fixed order
+// (deterministic).  (One thread per output walking all 8 * ksplit slabs alone took 0.87 ms per step: 25 K threads with
+// 384 dependent loads each for the 32-channel layers.)
 __global__ void __launch_bounds__(256)
-wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int KCA, int ncob, int CA, int CB, int tsd, int tsh, int tsw,
-                   float* __restrict__ dw, int accumulate) {
+wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int ncob, int CA, int CB, int tsd, int tsh,
+                   int tsw, float* __restrict__ dw, int accumulate) {
   const double G[8][5] = {{-1, 0, 0, 0, 0},
                           {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
                           {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
@@ -200,31 +204,50 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int KCA, int ncob, i
                           {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
                           {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
                           {0, 0, 0, 0, 1}};
-  const long total = 25L * CA * CB;
-  const long slab = (long)KCA * ncob * 25 * 512;  // floats per (xi, ks)
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int cb = (int)(idx % CB);
-    long r_ = idx / CB;
+  __shared__ double sh[8][8][32];  // [sub * NS + slice][xi][cb lane]
+  // NS = slices of the split-K range per output group (1, 2, 4 or 8: <= ksplit), SUB = 8 / NS groups per block
+  const int lane = threadIdx.x & 31, w8 = threadIdx.x >> 5, slice = w8 % NS, sub = w8 / NS, SUB = 8 / NS;
+  const long groups = 25L * CA * ncob;              // (row, ca, cob)
+  const long slab = (long)KCA * ncob * 25 * 512;    // floats per (xi, ks)
+  const long rounds = (groups + SUB - 1) / SUB;
+  for (long ri = blockIdx.x; ri < rounds; ri += gridDim.x) {
+    const long gi = ri * SUB + sub;
+    const bool live = gi < groups;
+    const int cob = (int)(gi % ncob);
+    long r_ = gi / ncob;
     const int ca = (int)(r_ % CA);
     const int row = (int)(r_ / CA);  // kd*5 + kh
-    const long off = ((((long)(ca >> 4) * ncob + (cb >> 5)) * 25 + row) * 16 + (ca & 15)) * 32 + (cb & 31);
-    double s[8];
+    const long off = ((((long)(ca >> 4) * ncob + cob) * 25 + row) * 16 + (ca & 15)) * 32 + lane;
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi) {
-      const float* p = P + (long)xi * ksplit * slab + off;
       double acc = 0.0;
-      for (int z = 0; z < ksplit; ++z) acc += (double)p[(long)z * slab];  // fixed order
-      s[xi] = acc;
+      if (live) {
+        const float* p = P + (long)xi * ksplit * slab + off;
+        for (int z = slice; z < ksplit; z += NS) acc += (double)p[(long)z * slab];
+      }
+      sh[w8][xi][lane] = acc;
     }
-    float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
+    __syncthreads();
+    if (slice == 0 && live) {
+      double s[8];
 #pragma unroll
-    for (int kw = 0; kw < 5; ++kw) {
-      double v = 0.0;
+      for (int xi = 0; xi < 8; ++xi) {
+        double t = sh[w8][xi][lane];
+        for (int k = 1; k < NS; ++k) t += sh[w8 + k][xi][lane];  // fixed order
+        s[xi] = t;
+      }
+      const int cb = cob * 32 + lane;
+      float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
 #pragma unroll
-      for (int xi = 0; xi < 8; ++xi) v += G[xi][kw] * s[xi];
-      float* q = o + kw * tsw;
-      *q = accumulate ? *q + (float)v : (float)v;
+      for (int kw = 0; kw < 5; ++kw) {
+        double v = 0.0;
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) v += G[xi][kw] * s[xi];
+        float* q = o + kw * tsw;
+        *q = accumulate ? *q + (float)v : (float)v;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -313,9 +336,10 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   }
   {
     msk_launch_scope ls(ctx, "wbf_wgrad_reduce");
-    long blocks = (25L * g.CA * g.CB + 255) / 256;
-    if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
-    hipLaunchKernelGGL(wbf_wgrad_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, KCA,
+    const int NS = ksplit >= 8 ? 8 : (ksplit >= 4 ? 4 : (ksplit >= 2 ? 2 : 1));
+    long blocks = (25L * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
+    if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
+    hipLaunchKernelGGL(wbf_wgrad_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, NS, KCA,
                        ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
