@@ -132,7 +132,10 @@ __device__ __forceinline__ void at8(const float e0, const float e1, const float 
 template <int MODE>
 __global__ void __launch_bounds__(256)
 wbf_tin_k(WbfTinArgs a) {
-  const int cgl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+  // lane mapping (A/B, option "wbf_tin_map"): 0 = 4 channel groups fastest (reads: full 128-byte lines per 4 lanes;
+  // stores: 4 runs of 256 B per wavefront), 1 = one channel group per wavefront (stores: one 1 KiB run; reads: 32 of
+  // every 128 bytes per lane, the rest of the line goes to the block's other wavefronts through L1/L2)
+  const int cgl = a.lane_map ? (threadIdx.x >> 6) : (threadIdx.x & 3), pl = a.lane_map ? (threadIdx.x & 63) : (threadIdx.x >> 2);
   const int ncgb = a.CK >> 5;
   const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
   const int pos = pb * 64 + pl;
@@ -546,7 +549,9 @@ void launch_gemm(msk_ctx* ctx, const GemmArgs& a, long nblk) {
 
 }  // namespace
 
-int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& ta) {
+int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& ta_in) {
+  WbfTinArgs ta = ta_in;
+  ta.lane_map = ctx->wbf_tin_map;
   const int pblocks = (ta.DP * ta.HP + 63) / 64;
   msk_launch_scope ls(ctx, mode == 0 ? "wbf_tin_k" : "wbf_ty_k");
   if (mode == 0)

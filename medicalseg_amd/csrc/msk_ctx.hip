@@ -320,6 +320,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf = value != 0;
     return 0;
   }
+  if (strcmp(key, "wbf_tin_map") == 0) {
+    ctx->wbf_tin_map = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_variant") == 0) {
     ctx->wbf_variant = value;
     return 0;

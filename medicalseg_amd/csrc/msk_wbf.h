@@ -32,6 +32,7 @@ struct WbfTinArgs {
   int DP, HP;
   char* V;
   long v_xi;  // bytes between xi planes
+  int lane_map;
 };
 int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& a);
 
