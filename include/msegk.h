@@ -85,8 +85,11 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *   "conv_impl": 1=VALU reference kernels everywhere, 3=reference wgrad only, 4=reference gather-conv only,
  *     5=no LDS wgrad, 6=no k==s scatter kernel, 7=scatter kernel at any size, 8=no tight-K kernel,
  *     9=one-voxel VALU kernel for 32->ncls, 10=Winograd forward kernel even for tiny grids, 11=direct (non-Winograd)
- *     forward/data-gradient kernels, 13=direct weight-gradient kernels, 14=Winograd F(2,5) instead of F(4,5),
- *     16=tap-row weight-gradient kernel for the kernel == stride convolutions;
+ *     forward/data-gradient kernels, 12=fp32 Winograd weight gradient forced, 13=direct weight-gradient kernels,
+ *     14=fp32 Winograd F(2,5) instead of F(4,5), 16=tap-row weight-gradient kernel for the kernel == stride convolutions,
+ *     20=fp32-MFMA Winograd kernels instead of the bf16x3 pipeline, 21=the same for the weight gradient only;
+ *   "wino_bf3" 0|1 (0 = fp32-MFMA Winograd kernels everywhere; also env MSEGK_WBF=0), "wbf_variant" (-1 auto | tile variant
+ *     of wbf_gemm_k), "wbf_tin_map" 0|1 (lane mapping of the transform kernel);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
  *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
  *   "direct_conv" 0|1 (1 = no Winograd kernels; also env MSEGK_DIRECT_CONV=1);
