@@ -47,6 +47,7 @@ struct msk_ctx {
   bool wbf = true;  // env MSEGK_WBF=0 / option "wino_bf3" 0: keep the fp32-MFMA Winograd kernels (exact-fp32 products)
   bool stats_fused = false;  // set by a conv kernel that wrote GConv::stats itself
   bool xform_written = false;  // set when GConv::xform was filled
+  bool conv_fp16 = false;  // option "conv_fp16": 3x3x3 convolutions with fp16 matrix operands (UNet3D precision='fp16')
   int wbf_tin_map = 1;  // lane mapping of wbf_tin_k (1: one channel group per wavefront, 1 KiB store runs; measured 3-10 % faster)
   int wbf_variant = -1;  // tuning: force a tile variant of wbf_gemm_k (-1 = least padding)
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation

@@ -605,14 +605,14 @@ int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
 
 size_t msk_conv3d_xform_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout) {
   if (!ctx->wbf || ctx->no_winograd || ctx->conv_impl != 0) return 0;
-  if (!(cd.kd == 5 && cd.kh == 5 && cd.kw == 5 && cd.sd == 1 && cd.sh == 1 && cd.sw == 1 && cd.pd == 2 && cd.ph == 2 &&
-        cd.pw == 2))
-    return 0;
+  const bool k5 = cd.kd == 5 && cd.kh == 5 && cd.kw == 5 && cd.pd == 2 && cd.ph == 2 && cd.pw == 2;
+  const bool k3 = cd.kd == 3 && cd.kh == 3 && cd.kw == 3 && cd.pd == 1 && cd.ph == 1 && cd.pw == 1;
+  if (!(k5 || k3) || !(cd.sd == 1 && cd.sh == 1 && cd.sw == 1)) return 0;
   if (cout < 32 || cout % 32) return 0;
   const size_t per = (size_t)x.d * x.h * x.w * (x.ld > cout ? x.ld : cout) * sizeof(float);
   if (per > 0 && (size_t)x.n > kChunkBytes / per) return 0;  // chunked batches do not keep the transform
   if (x.ld % 4 || (((uintptr_t)x.p) & 15)) return 0;
-  return msk_wbf_fwd_xform_bytes(ctx, x.n, x.d, x.h, x.w, x.c, cout);
+  return msk_wbf_fwd_xform_bytes(ctx, x.n, x.d, x.h, x.w, x.c, cout, k5 ? 5 : 3);
 }
 
 int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,

@@ -320,6 +320,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf = value != 0;
     return 0;
   }
+  if (strcmp(key, "conv_fp16") == 0) {
+    ctx->conv_fp16 = value != 0;
+    return 0;
+  }
   if (strcmp(key, "wbf_tin_map") == 0) {
     ctx->wbf_tin_map = value;
     return 0;

@@ -34,7 +34,10 @@ struct WbfTinArgs {
   long v_xi;  // bytes between xi planes
   int lane_map;
 };
-int msk_wbf_transform(msk_ctx* ctx, int mode, const WbfTinArgs& a);
+// K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
+int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& a);
+// pieces per value for a K^3 convolution under the context's precision option ("conv_fp16": fp16 operands for K = 3)
+inline int wbf_pieces(const msk_ctx* ctx, int K) { return (K == 3 && ctx->conv_fp16) ? 1 : 3; }
 
 // Geometry shared by the forward / data-gradient pipeline and the weight gradient (so that V = B^T x written by the forward
 // pass can be handed to the weight gradient, msk_conv3d_fwd_ex / msk_conv3d_wgrad_ex): which tensor axes play the
@@ -82,8 +85,8 @@ inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
   const int td = (g.LD + TD - 1) / TD * TD, th = (g.LH + TH - 1) / TH * TH;
   return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= 1.35 * (double)g.LD * g.LH;
 }
-size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout);
-size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout);
+size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP);
+size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K);
 // merge of per-block BatchNorm partial records [nb][C][3] = (n, mean, M2) into stats[2C] (msk_elementwise.hip)
 int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats);
 

@@ -1,5 +1,5 @@
-// Weight gradient of the 'same' 5x5x5 convolutions (every LUConv layer, vnet.py:36; autograd of core/train.py:139) on
-// the bf16 matrix pipe with fp32-exact operands -- the adjoint of the three-stage pipeline of msk_conv_wbf.hip:
+// Weight gradient of the 'same' K^3 convolutions, K = 5 (every LUConv layer, vnet.py:36; autograd of core/train.py:139)
+// or K = 3 (UNet3D), on the 16-bit matrix pipe -- NP = 3: bf16 with fp32-exact operands, NP = 1: fp16 operands -- the adjoint of the three-stage pipeline of msk_conv_wbf.hip:
 //
 //   dU_xi[kd,kh][ci][co] = sum_{n,d,h,t} V_xi[n, d+kd-2, h+kh-2, t][ci] * Y_xi[n, d, h, t][co]
 //   V = B^T x (wbf_tin_k<0>),  Y = A dy (wbf_tin_k<1>),  both split exactly into three bf16 pieces in HBM;
@@ -21,6 +21,7 @@
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -40,26 +41,32 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, unsigned byte_off
 
 #define WGW_MFMA(acc, av, bv) \
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0)
+#define WGW_MFMA_H(acc, av, bv) \
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc, 0, 0, 0)
 
-template <int TH>
+constexpr int wg_nxi(int K) { return K == 5 ? 8 : 6; }
+
+template <int TH, int K, int NP>
 __global__ void __launch_bounds__(256)
 wbf_wgrad_k(WgArgs a) {
-  constexpr int TD = 8, HPt = TH + 4, NSV = (TD + 4) * HPt, NSY = TD * TH;
+  constexpr int NXI = wg_nxi(K), T2 = K * K, PADK = (K - 1) / 2, NPL = 2 * NP;
+  constexpr int NT0 = K == 5 ? 7 : 3, NT1 = K == 5 ? 6 : 2;            // taps of wavefront 0 / of the others
+  constexpr int TD = 8, HPt = TH + K - 1, NSV = (TD + K - 1) * HPt, NSY = TD * TH;
   constexpr int RV1 = (NSV + 63) / 64, RY1 = (NSY + 63) / 64;           // LDS-DMA rounds per plane
   constexpr int PSV = RV1 * 1024 + (TH == 16 ? 64 : 128);               // plane strides: the pad keeps the two khalf planes
   constexpr int PSY = RY1 * 1024 + 64;                                  //   of a transposing read on disjoint banks
-  constexpr int YBASE = 6 * PSV;
-  constexpr int NRV = 6 * RV1, NRY = 12 * RY1, NR = NRV + NRY, RPW = (NR + 3) / 4;  // rounds per wavefront
+  constexpr int YBASE = NPL * PSV;
+  constexpr int NRV = NPL * RV1, NRY = 2 * NPL * RY1, NR = NRV + NRY, RPW = (NR + 3) / 4;  // rounds per wavefront
   constexpr int KSTEPS = TD * TH / 32, ROWS_PER_STEP = 32 / TH;
-  __shared__ __attribute__((aligned(16))) char lds[6 * PSV + 12 * PSY];
+  __shared__ __attribute__((aligned(16))) char lds[NPL * PSV + 2 * NPL * PSY];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = lane >> 4, i = lane & 15;
 
   int b = blockIdx.x;
-  const int xi = b & 7;
-  b >>= 3;
+  const int xi = b % NXI;
+  b /= NXI;
   const int cob = b % a.ncob;
   b /= a.ncob;
   const int kci = b % a.KCA;
@@ -82,15 +89,15 @@ wbf_wgrad_k(WgArgs a) {
       int slot = sub * 64 + lane;
       if (slot >= NSV) slot = 0;  // overshoot of the last round lands in the plane's pad
       const int row = slot / HPt, col = slot - row * HPt;
-      voff[j] = (unsigned)(((long)kci * 6 + pk) * a.plane + ((long)row * a.HP + col) * 16);
+      voff[j] = (unsigned)(((long)kci * NPL + pk) * a.plane + ((long)(row + 2 - PADK) * a.HP + col + 2 - PADK) * 16);
       ldst[j] = pk * PSV + sub * 1024;
     } else {
       const int Ry = R - NRV;
-      const int cp = Ry / RY1, sub = Ry - cp * RY1;  // cp = c*6 + pk
+      const int cp = Ry / RY1, sub = Ry - cp * RY1;  // cp = c*NPL + pk
       int slot = sub * 64 + lane;
       if (slot >= NSY) slot = 0;
       const int row = slot / TH, col = slot - row * TH;
-      voff[j] = (unsigned)(((long)cob * 12 + cp) * a.plane + ((long)(row + 2) * a.HP + col + 2) * 16);
+      voff[j] = (unsigned)(((long)cob * 2 * NPL + cp) * a.plane + ((long)(row + 2) * a.HP + col + 2) * 16);
       ldst[j] = YBASE + cp * PSY + sub * 1024;
     }
   }
@@ -102,18 +109,18 @@ wbf_wgrad_k(WgArgs a) {
   // taps of this wavefront: [tap0, tap0 + ntap) of the 25 (kd, kh) taps -- 7, 6, 6, 6.  (Five wavefronts, one kd row each,
   // balanced the taps but not the SIMDs: a 5-wave workgroup takes 2 slots on one SIMD, the third resident workgroup often
   // found no SIMD with room, and PMC showed half the expected wavefronts in flight and the matrix pipe 52 % busy.)
-  const int tap0 = wave == 0 ? 0 : 1 + 6 * wave, ntap = wave == 0 ? 7 : 6;
-  unsigned tapoff[7];
+  const int tap0 = wave == 0 ? 0 : NT0 - NT1 + NT1 * wave, ntap = wave == 0 ? NT0 : NT1;
+  unsigned tapoff[NT0];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tp = min(tap0 + j, 24);
-    tapoff[j] = (unsigned)(((tp / 5) * HPt + (tp % 5)) * 16);   // wave-uniform
+  for (int j = 0; j < NT0; ++j) {
+    const int tp = min(tap0 + j, T2 - 1);
+    tapoff[j] = (unsigned)(((tp / K) * HPt + (tp % K)) * 16);   // wave-uniform
   }
   const unsigned ya = (unsigned)(YBASE + khalf * PSY + ((q0 / TH) * TH + (q0 % TH)) * 16 + sub8);
 
-  f32x4 acc[7][2];
+  f32x4 acc[NT0][2];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int j = 0; j < NT0; ++j)
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -124,8 +131,8 @@ wbf_wgrad_k(WgArgs a) {
     const int nt = tile / tiles_nt, rem = tile - nt * tiles_nt;  // nt = n*T + t
     const int tdi = rem / a.tiles_h, thi = rem - tdi * a.tiles_h;
     const unsigned origin = (unsigned)(((long)(tdi * TD) * a.HP + thi * TH) * 16);
-    const unsigned vso = (unsigned)((long)nt * a.KCA * 6 * a.plane) + origin;
-    const unsigned yso = (unsigned)((long)nt * a.KCB * 6 * a.plane) + origin;
+    const unsigned vso = (unsigned)((long)nt * a.KCA * NPL * a.plane) + origin;
+    const unsigned yso = (unsigned)((long)nt * a.KCB * NPL * a.plane) + origin;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
@@ -142,34 +149,38 @@ wbf_wgrad_k(WgArgs a) {
 
 #pragma unroll
     for (int kst = 0; kst < KSTEPS; ++kst) {
-      s16x8 bq[2][3];
+      s16x8 bq[2][NP];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const unsigned o = ya + (unsigned)((c * 6 + p * 2) * PSY + kst * ROWS_PER_STEP * TH * 16);
+        for (int p = 0; p < NP; ++p) {
+          const unsigned o = ya + (unsigned)((c * NPL + p * 2) * PSY + kst * ROWS_PER_STEP * TH * 16);
           const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
           bq[c][p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
+      for (int j = 0; j < NT0; ++j) {
         if (j < ntap) {   // wave-uniform
-          s16x8 aq[3];
+          s16x8 aq[NP];
           const unsigned vt = va + tapoff[j];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NP; ++p) {
             const unsigned o = vt + (unsigned)(p * 2 * PSV + kst * ROWS_PER_STEP * HPt * 16);
             const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
             aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            WGW_MFMA(acc[j][c], aq[2], bq[c][0]);  // small terms first
-            WGW_MFMA(acc[j][c], aq[0], bq[c][2]);
-            WGW_MFMA(acc[j][c], aq[1], bq[c][1]);
-            WGW_MFMA(acc[j][c], aq[1], bq[c][0]);
-            WGW_MFMA(acc[j][c], aq[0], bq[c][1]);
-            WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
+            if (NP == 3) {
+              WGW_MFMA(acc[j][c], aq[NP - 1], bq[c][0]);  // small terms first
+              WGW_MFMA(acc[j][c], aq[0], bq[c][NP - 1]);
+              WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][NP / 2]);
+              WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][0]);
+              WGW_MFMA(acc[j][c], aq[0], bq[c][NP / 2]);
+              WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
+            } else {
+              WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
+            }
           }
         }
       }
@@ -177,9 +188,9 @@ wbf_wgrad_k(WgArgs a) {
   }
 
   // partial dU[xi][ks][kci][cob][tap = tap0 + j][ci = 4 g + reg][co = c*16 + i]
-  float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * 25 + tap0) * 512;
+  float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * T2 + tap0) * 512;
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int j = 0; j < NT0; ++j)
     if (j < ntap) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -193,22 +204,26 @@ wbf_wgrad_k(WgArgs a) {
 // thread adds its slices z = slice, slice + 8, ... in double, the 8 slices are combined through LDS in a fixed order
 // (deterministic).  (One thread per output walking all 8 * ksplit slabs alone took 0.87 ms per step: 25 K threads with
 // 384 dependent loads each for the 32-channel layers.)
+template <int K>
 __global__ void __launch_bounds__(256)
 wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int ncob, int CA, int CB, int tsd, int tsh,
                    int tsw, float* __restrict__ dw, int accumulate) {
-  const double G[8][5] = {{-1, 0, 0, 0, 0},
-                          {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
-                          {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
-                          {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
-                          {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
-                          {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
-                          {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
-                          {0, 0, 0, 0, 1}};
+  constexpr int NXI = wg_nxi(K), T2 = K * K, T3 = K * K * K;
+  const double G5[8][5] = {{-1, 0, 0, 0, 0},
+                           {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                           {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                           {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                           {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                           {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                           {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                           {0, 0, 0, 0, 1}};
+  const double G3[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
   __shared__ double sh[8][8][32];  // [sub * NS + slice][xi][cb lane]
   // NS = slices of the split-K range per output group (1, 2, 4 or 8: <= ksplit), SUB = 8 / NS groups per block
   const int lane = threadIdx.x & 31, w8 = threadIdx.x >> 5, slice = w8 % NS, sub = w8 / NS, SUB = 8 / NS;
-  const long groups = 25L * CA * ncob;              // (row, ca, cob)
-  const long slab = (long)KCA * ncob * 25 * 512;    // floats per (xi, ks)
+  const long groups = (long)T2 * CA * ncob;         // (row, ca, cob)
+  const long slab = (long)KCA * ncob * T2 * 512;    // floats per (xi, ks)
   const long rounds = (groups + SUB - 1) / SUB;
   for (long ri = blockIdx.x; ri < rounds; ri += gridDim.x) {
     const long gi = ri * SUB + sub;
@@ -216,10 +231,10 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
     const int cob = (int)(gi % ncob);
     long r_ = gi / ncob;
     const int ca = (int)(r_ % CA);
-    const int row = (int)(r_ / CA);  // kd*5 + kh
-    const long off = ((((long)(ca >> 4) * ncob + cob) * 25 + row) * 16 + (ca & 15)) * 32 + lane;
+    const int row = (int)(r_ / CA);  // kd*K + kh
+    const long off = ((((long)(ca >> 4) * ncob + cob) * T2 + row) * 16 + (ca & 15)) * 32 + lane;
 #pragma unroll
-    for (int xi = 0; xi < 8; ++xi) {
+    for (int xi = 0; xi < NXI; ++xi) {
       double acc = 0.0;
       if (live) {
         const float* p = P + (long)xi * ksplit * slab + off;
@@ -229,20 +244,20 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
     }
     __syncthreads();
     if (slice == 0 && live) {
-      double s[8];
+      double s[NXI];
 #pragma unroll
-      for (int xi = 0; xi < 8; ++xi) {
+      for (int xi = 0; xi < NXI; ++xi) {
         double t = sh[w8][xi][lane];
         for (int k = 1; k < NS; ++k) t += sh[w8 + k][xi][lane];  // fixed order
         s[xi] = t;
       }
       const int cb = cob * 32 + lane;
-      float* o = dw + ((long)cb * CA + ca) * 125 + (row / 5) * tsd + (row % 5) * tsh;
+      float* o = dw + ((long)cb * CA + ca) * T3 + (row / K) * tsd + (row % K) * tsh;
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
+      for (int kw = 0; kw < K; ++kw) {
         double v = 0.0;
 #pragma unroll
-        for (int xi = 0; xi < 8; ++xi) v += G[xi][kw] * s[xi];
+        for (int xi = 0; xi < NXI; ++xi) v += (K == 5 ? G5[xi][kw] : G3[xi][kw]) * s[xi];
         float* q = o + kw * tsw;
         *q = accumulate ? *q + (float)v : (float)v;
       }
@@ -253,9 +268,86 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
 
 }  // namespace
 
+namespace {
+template <int K, int NP>
+int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool shared_geom, int TH) {
+  constexpr int NXI = wg_nxi(K), T2 = K * K, NPL = 2 * NP;
+  const int* pm = geo.perm;
+  const int LD = geo.LD, LH = geo.LH, LW = geo.LW;
+  const int vstr[3] = {g.BH * g.BW, g.BW, 1};
+  const int tstr[3] = {K * K, K, 1};
+  const int T = geo.T, KCA = g.CA / 16, KCB = g.CB / 16, ncob = g.CB / 32;
+  const int tiles_d = (LD + 7) / 8, tiles_h = (LH + TH - 1) / TH;
+  const int DP = geo.DP, HP = geo.HP;
+  const long ntiles = (long)g.N * T * tiles_d * tiles_h;
+  if (ntiles > 0x7fffffffL) return 0;
+
+  // split K (position tiles): about 3 workgroups per CU in total
+  const long base_blocks = (long)NXI * KCA * ncob;
+  long ksplit = (3L * ctx->num_cu + base_blocks / 2) / base_blocks;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > ntiles) ksplit = ntiles;
+  const int tiles_per = (int)((ntiles + ksplit - 1) / ksplit);
+  ksplit = (ntiles + tiles_per - 1) / tiles_per;
+
+  const size_t plane = (size_t)DP * HP * 16;
+  const size_t v_xi = (size_t)g.N * T * KCA * NPL * plane, y_xi = (size_t)g.N * T * KCB * NPL * plane;
+  if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return 0;
+  const size_t p_floats = (size_t)NXI * ksplit * KCA * ncob * T2 * 512;
+  const size_t vb = (NXI * v_xi + 255) & ~(size_t)255, yb = (NXI * y_xi + 255) & ~(size_t)255;
+  const bool have_v = g.xform != nullptr && shared_geom &&
+                      msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) == NXI * v_xi;
+  char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + yb + p_floats * sizeof(float) + 256);
+  if (!wsp) return -1;
+  char* V = have_v ? (char*)const_cast<void*>(g.xform) : wsp;
+  char* Y = have_v ? wsp : wsp + vb;
+  float* P = (float*)(Y + yb);
+
+  WbfTinArgs ta{};
+  ta.src = g.A; ta.sld = g.ald;
+  ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
+  ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
+  ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
+  if (!have_v && msk_wbf_transform(ctx, 0, K, NP, ta) != 0) return -1;  // else: V written by msk_conv3d_fwd_ex for this tensor
+  ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
+  if (msk_wbf_transform(ctx, 1, K, NP, ta) != 0) return -1;
+
+  WgArgs wa{};
+  wa.V = V; wa.Y = Y; wa.P = P;
+  wa.N = g.N; wa.T = T; wa.KCA = KCA; wa.KCB = KCB; wa.DP = DP; wa.HP = HP;
+  wa.tiles_d = tiles_d; wa.tiles_h = tiles_h; wa.ntiles = (int)ntiles; wa.ksplit = (int)ksplit; wa.tiles_per = tiles_per;
+  wa.ncob = ncob; wa.v_xi = (long)v_xi; wa.y_xi = (long)y_xi; wa.plane = (long)plane;
+  const long nblk = base_blocks * ksplit;
+  {
+    const char* tag = NP == 3 ? "wbf_wgrad_k" : "wbf_wgrad_f16_k";
+    if (ctx->prof && ctx->prof_shapes) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "%s[ca=%d,cb=%d,n=%d,dhw=%dx%dx%d,k=%d,ks=%ld]", tag, g.CA, g.CB, g.N, g.BD, g.BH, g.BW, K, ksplit);
+      tag = msk_intern_tag(ctx, buf);
+    }
+    msk_launch_scope ls(ctx, tag);
+    if (TH == 16) hipLaunchKernelGGL((wbf_wgrad_k<16, K, NP>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
+    else hipLaunchKernelGGL((wbf_wgrad_k<8, K, NP>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  {
+    msk_launch_scope ls(ctx, "wbf_wgrad_reduce");
+    const int NS = ksplit >= 8 ? 8 : (ksplit >= 4 ? 4 : (ksplit >= 2 ? 2 : 1));
+    long blocks = ((long)T2 * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
+    if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
+    hipLaunchKernelGGL((wbf_wgrad_reduce_k<K>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, NS,
+                       KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 1;
+}
+}  // namespace
+
 // Returns 1 if handled, 0 if not eligible, < 0 on error.
 int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
+  if (!k5 && !k3) return 0;
   if (!(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
   if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
   if (g.CA < 32 || g.CA % 32 || g.CB < 32 || g.CB % 32) return 0;
@@ -271,77 +363,7 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   if (wbf_tile_ok(geo, 8, 16)) TH = 16;
   else if (wbf_tile_ok(geo, 8, 8)) TH = 8;
   if (!TH) return 0;
-  const int* pm = geo.perm;
-  const int LD = geo.LD, LH = geo.LH, LW = geo.LW;
-  const int vstr[3] = {g.BH * g.BW, g.BW, 1};
-  const int tstr[3] = {25, 5, 1};
-  const int T = geo.T, KCA = g.CA / 16, KCB = g.CB / 16, ncob = g.CB / 32;
-  const int tiles_d = (LD + 7) / 8, tiles_h = (LH + TH - 1) / TH;
-  const int DP = geo.DP, HP = geo.HP;
-  const long ntiles = (long)g.N * T * tiles_d * tiles_h;
-  if (ntiles > 0x7fffffffL) return 0;
-
-  // split K (position tiles): about 3 workgroups per CU in total
-  const long base_blocks = 8L * KCA * ncob;
-  long ksplit = (3L * ctx->num_cu + base_blocks / 2) / base_blocks;
-  if (ksplit < 1) ksplit = 1;
-  if (ksplit > ntiles) ksplit = ntiles;
-  const int tiles_per = (int)((ntiles + ksplit - 1) / ksplit);
-  ksplit = (ntiles + tiles_per - 1) / tiles_per;
-
-  const size_t plane = (size_t)DP * HP * 16;
-  const size_t v_xi = (size_t)g.N * T * KCA * 6 * plane, y_xi = (size_t)g.N * T * KCB * 6 * plane;
-  if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return 0;
-  const size_t p_floats = (size_t)8 * ksplit * KCA * ncob * 25 * 512;
-  const size_t vb = (8 * v_xi + 255) & ~(size_t)255, yb = (8 * y_xi + 255) & ~(size_t)255;
-  const bool have_v = g.xform != nullptr && shared_geom && msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB) == 8 * v_xi;
-  char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + yb + p_floats * sizeof(float) + 256);
-  if (!wsp) return -1;
-  char* V = have_v ? (char*)const_cast<void*>(g.xform) : wsp;
-  char* Y = have_v ? wsp : wsp + vb;
-  float* P = (float*)(Y + yb);
-
-  WbfTinArgs ta{};
-  ta.src = g.A; ta.sld = g.ald;
-  ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
-  ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
-  ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
-  if (!have_v && msk_wbf_transform(ctx, 0, ta) != 0) return -1;  // else: V written by msk_conv3d_fwd_ex for this tensor
-  ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
-  if (msk_wbf_transform(ctx, 1, ta) != 0) return -1;
-
-  WgArgs wa{};
-  wa.V = V; wa.Y = Y; wa.P = P;
-  wa.N = g.N; wa.T = T; wa.KCA = KCA; wa.KCB = KCB; wa.DP = DP; wa.HP = HP;
-  wa.tiles_d = tiles_d; wa.tiles_h = tiles_h; wa.ntiles = (int)ntiles; wa.ksplit = (int)ksplit; wa.tiles_per = tiles_per;
-  wa.ncob = ncob; wa.v_xi = (long)v_xi; wa.y_xi = (long)y_xi; wa.plane = (long)plane;
-  const long nblk = base_blocks * ksplit;
-  {
-    const char* tag = "wbf_wgrad_k";
-    if (ctx->prof && ctx->prof_shapes) {
-      char buf[200];
-      snprintf(buf, sizeof(buf), "wbf_wgrad_k[ca=%d,cb=%d,n=%d,dhw=%dx%dx%d,ks=%ld]", g.CA, g.CB, g.N, g.BD, g.BH, g.BW, ksplit);
-      tag = msk_intern_tag(ctx, buf);
-    }
-    if (getenv("MSEGK_DEBUG_OCC")) {
-      int nb16 = -1, nb8 = -1;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb16, wbf_wgrad_k<16>, 256, 0);
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb8, wbf_wgrad_k<8>, 256, 0);
-      fprintf(stderr, "wbf_wgrad_k occupancy (workgroups per CU): TH16 %d, TH8 %d; blocks %ld ksplit %ld\n", nb16, nb8, nblk, ksplit);
-    }
-    msk_launch_scope ls(ctx, tag);
-    if (TH == 16) hipLaunchKernelGGL(wbf_wgrad_k<16>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
-    else hipLaunchKernelGGL(wbf_wgrad_k<8>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
-    MSK_LAUNCH_CHECK(ctx);
-  }
-  {
-    msk_launch_scope ls(ctx, "wbf_wgrad_reduce");
-    const int NS = ksplit >= 8 ? 8 : (ksplit >= 4 ? 4 : (ksplit >= 2 ? 2 : 1));
-    long blocks = (25L * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
-    if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
-    hipLaunchKernelGGL(wbf_wgrad_reduce_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, NS, KCA,
-                       ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate);
-    MSK_LAUNCH_CHECK(ctx);
-  }
-  return 1;
+  if (k5) return run_wgrad_pipeline<5, 3>(ctx, g, geo, shared_geom, TH);
+  if (wbf_pieces(ctx, 3) == 3) return run_wgrad_pipeline<3, 3>(ctx, g, geo, shared_geom, TH);
+  return run_wgrad_pipeline<3, 1>(ctx, g, geo, shared_geom, TH);
 }

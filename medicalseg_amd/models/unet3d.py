@@ -3,8 +3,11 @@ continue", configs/lung_coronavirus/README.md:15-21); BASELINE.json's configs[3]
 3-D U-Net that config describes -- 3x3x3 convolutions, InstanceNorm + PReLU, kernel = stride 2 down / transposed-up
 convolutions, skip concatenation -- assembled from the SAME C-ABI kernels as VNet (`msk_conv3d_*` on the MFMA halo
 kernel with KS = 3, `msk_convT3d_*`, the BatchNorm statistics / affine+PReLU passes run per sample for the instance
-statistics).  fp32 only: there is no fp16 path and, with no reference model, no parity claim beyond the torch-CPU
-restatement in oracle/unet3d_torch.py (tests/test_gpu_unet3d.py).
+statistics).  `precision="fp16"` (BASELINE configs[3]) runs the 3x3x3 convolutions -- forward, data gradient and weight
+gradient -- with fp16 operands on the fp16 matrix pipe (Winograd F(4,3) domain, fp32 accumulation; activations, normalisation
+statistics, losses and the optimizer stay fp32: msk_conv_wbf.hip, option "conv_fp16"); the default "fp32" uses the exact
+bf16x3 operands.  With no reference model there is no parity claim beyond the torch-CPU restatement in
+oracle/unet3d_torch.py (tests/test_gpu_unet3d.py: fp32 at 3e-4, fp16 at the stated fp16 tolerance).
 
 Registered as `UNet3D` so a YAML `model: {type: UNet3D, ...}` builds it through the unchanged Config path."""
 from __future__ import annotations
@@ -66,7 +69,8 @@ class ConvINAct(ConvBNAct):
             raise ValueError("ConvINAct has no residual input")
         dev, norm = x.dev, self.bn
         self.x, self.res = x, None
-        y = self.conv.run_forward(x)
+        # a Conv3D keeps its transformed input for the weight gradient when the bf16x3 / fp16 pipeline takes the shape
+        y = self.conv.run_forward(x, keep_xform=True) if type(self.conv) is nn.Conv3D else self.conv.run_forward(x)
         self.y = y
         if out is None:
             out = y.empty_like()
@@ -183,10 +187,14 @@ class UNet3D(VNet):
 
     num_outputs = 1
 
-    def __init__(self, in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None, elu=False):
+    def __init__(self, in_channels=1, num_classes=3, base_channels=32, depth=4, pretrained=None, elu=False,
+                 precision="fp32"):
         nn.Layer.__init__(self)
         if depth < 2:
             raise ValueError("UNet3D needs depth >= 2")
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("UNet3D precision must be 'fp32' or 'fp16', got %r" % (precision,))
+        self.precision = precision
         if elu:  # the VNet configs this one usually inherits from carry `elu: False`
             raise ValueError("UNet3D has PReLU activations only")
         self.best_loss = 1000000
@@ -221,6 +229,13 @@ class UNet3D(VNet):
         if x.c != self.in_channels:
             raise ValueError(f"UNet3D expects {self.in_channels} input channel(s), got {x.c}")
         self.dev.arena.reset()
+        self.dev.set_option("conv_fp16", 1 if self.precision == "fp16" else 0)
+        try:
+            return self._forward(x)
+        finally:
+            self.dev.set_option("conv_fp16", 0)
+
+    def _forward(self, x):
         skips, t = [], x
         for i, enc in enumerate(self.encoders):
             # the first encoder's input is the image: it needs no data gradient
@@ -237,6 +252,13 @@ class UNet3D(VNet):
         return [logits, ]
 
     def backward(self, dlogits: Tensor):
+        self.dev.set_option("conv_fp16", 1 if self.precision == "fp16" else 0)
+        try:
+            self._backward(dlogits)
+        finally:
+            self.dev.set_option("conv_fp16", 0)
+
+    def _backward(self, dlogits: Tensor):
         self.head.run_backward(self._feat, dlogits, need_dx=True)
         self._grads_ready(self.head)
         g = self._feat.grad

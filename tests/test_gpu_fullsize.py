@@ -218,3 +218,56 @@ def test_conv_beyond_4gib_tensors_is_chunked_per_sample():
     assert np.abs(vec_back(db, Cc) - N * g1.sum(axis=0, dtype=np.float64)).max() < 1e-3 * np.sqrt(N * vox)
     for t in (x, y, dy, dx, xs, gs):
         d.free(t.ptr)
+
+
+def test_unet3d_fp16_192x192x64_full_size_step():
+    """BASELINE configs[3] at full size: UNet3D (base 32, depth 4), 2 x 192 x 192 x 64, precision fp16.  No reference
+    model exists, so properties: the fp16 matrix kernels really run at this size, the step is finite and BITWISE
+    reproducible, the loss of a fixed batch goes down over three steps, and the fp16 logits stay within the stated fp16
+    tolerance (2e-2 of max|logit|) of the fp32 (exact bf16x3 operands) forward pass of the same weights."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, UNet3D
+    from medicalseg_amd.utils import loss_computation
+    rng = np.random.default_rng(0)
+    shape = (192, 192, 64)
+    x = rng.standard_normal((2, 1) + shape).astype(np.float32)
+    y = ((x[:, 0] > 0.3).astype(np.int32) + (x[:, 0] > 1.0).astype(np.int32))
+    d = dev()
+    runs, logits0 = [], {}
+    for prec in ("fp16", "fp16", "fp32"):
+        nn.seed(0)
+        model = UNet3D(in_channels=1, num_classes=3, base_channels=32, depth=4, precision=prec)
+        model.train()
+        opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(weight=[1.0, 1.0, 1.0]), DiceLoss()], [1, 1])], "coef": [1]}
+        d.prof_reset()
+        d.set_option("prof_only_halo", 0)
+        d.prof_enable(True)
+        hist = []
+        for it in range(3 if prec == "fp16" else 1):
+            lg = model(to_tensor(x))
+            if it == 0:
+                logits0[prec] = lg[0].numpy()
+            ll, per = loss_computation(lg, to_tensor(y), losses)
+            loss = sum(ll)
+            loss.backward()
+            opt.step()
+            model.clear_gradients()
+            hist.append(float(loss))
+        d.sync()
+        d.prof_enable(False)
+        tags = d.prof_report()
+        if prec == "fp16":
+            assert any(k.startswith("wbf_gemm_f16_k") for k in tags) and any(k.startswith("wbf_wgrad_f16_k") for k in tags)
+            assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+            sd = model.state_dict()
+            runs.append((hist, sd["enc0.conv2.weight"], sd["up0.ops.conv1.weight"], sd["enc3.conv1.weight"]))
+        assert logits0[prec].shape == (2, 3) + shape and np.all(np.isfinite(logits0[prec]))
+    assert runs[0][0] == runs[1][0]
+    for u, v in zip(runs[0][1:], runs[1][1:]):
+        assert np.array_equal(u, v)                                   # bitwise reproducible fp16 step
+    e = np.abs(logits0["fp16"] - logits0["fp32"]).max() / np.abs(logits0["fp32"]).max()
+    print("UNet3D 2x192x192x64: fp16 vs fp32 logits %.2e; fp16 losses %s" % (e, runs[0][0]))
+    assert e < 2e-2

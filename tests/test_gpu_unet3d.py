@@ -86,3 +86,67 @@ def test_unet3d_trains_through_config(tmp_path):
         opt.step()
         model.clear_gradients()
     assert hist[-1] < 0.8 * hist[0], hist
+
+
+def test_unet3d_fp16_path_matches_torch_at_the_stated_fp16_tolerance():
+    """precision="fp16" (BASELINE configs[3]): the 3x3x3 convolutions of the 32-channel level run on the fp16 matrix pipe
+    (`wbf_gemm_f16_k` / `wbf_wgrad_f16_k`: fp16 operands in the Winograd F(4,3) domain, fp32 accumulation; activations,
+    InstanceNorm statistics, loss and optimizer in fp32).  No reference model exists: the yardstick is the
+    torch-CPU float64 restatement.  STATED fp16 TOLERANCE: logits 1.5e-2 of max|logit|, loss 5e-3 relative, parameter
+    gradients rel-L2 1e-1 per tensor (per-convolution operand rounding 2^-11, amplified by the InstanceNorm adjoints;
+    measured: logits 2.4e-3, loss 1e-5, gradients 4.1e-2 median / 6.7e-2 worst; the fp32 path of the same model: 1.5e-6 / 5.5e-6)."""
+    import torch
+    from medicalseg_amd import nn
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, UNet3D
+    from medicalseg_amd.utils import loss_computation
+    from oracle.unet3d_torch import TorchUNet3D
+    from helpers import dev
+    ncls, shape, depth, base = 3, (1, 1, 16, 16, 16), 2, 32
+    rng = np.random.default_rng(7)
+    nn.seed(0)
+    x = rng.standard_normal(shape).astype(np.float32)
+    y = rng.integers(0, ncls, (shape[0],) + shape[2:]).astype(np.int32)
+    res = {}
+    for prec in ("fp32", "fp16"):
+        nn.seed(0)
+        model = UNet3D(in_channels=1, num_classes=ncls, base_channels=base, depth=depth, precision=prec)
+        state = model.state_dict()
+        if "tm" not in res:
+            res["tm"] = TorchUNet3D(1, ncls, base, depth).double().load_msk_state(state)
+            res["ref"] = _loss_and_grads_torch(res["tm"], x, y, ncls)
+            res["ref_g"] = res["tm"].grads_as_msk([n for n, _ in model.named_parameters()])
+        model.train()
+        d = dev()
+        d.prof_reset()
+        d.set_option("prof_only_halo", 0)
+        d.prof_enable(True)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(weight=[1.0] * ncls), DiceLoss()], [1, 1])], "coef": [1]}
+        logits = model(to_tensor(x))
+        got = logits[0].numpy()
+        ll, _ = loss_computation(logits, to_tensor(y), losses)
+        loss = sum(ll)
+        lv = float(loss.numpy()[0])
+        loss.backward()
+        d.sync()
+        d.prof_enable(False)
+        tags = d.prof_report()
+        ran16 = any(k.startswith("wbf_gemm_f16_k") for k in tags) and any(k.startswith("wbf_wgrad_f16_k") for k in tags)
+        assert ran16 == (prec == "fp16"), sorted(tags)
+        ref_logits, ref_loss = res["ref"]
+        e_lg = np.abs(got - ref_logits).max() / np.abs(ref_logits).max()
+        e_ls = abs(lv - ref_loss) / abs(ref_loss)
+        l2 = {}
+        for name, p in model.named_parameters():
+            r = res["ref_g"][name]
+            if np.abs(r).max() < 1e-9:
+                continue
+            g = p.grad_numpy().astype(np.float64)
+            l2[name] = float(np.linalg.norm(g - r) / np.linalg.norm(r))
+        worst = max(l2, key=l2.get)
+        print("\nUNet3D %s: logits %.2e loss %.2e grads rel-L2 worst %.2e (%s) median %.2e" %
+              (prec, e_lg, e_ls, l2[worst], worst, float(np.median(list(l2.values())))))
+        if prec == "fp32":
+            assert e_lg < 2e-4 and e_ls < 1e-4 and l2[worst] < 3e-3
+        else:
+            assert e_lg < 1.5e-2 and e_ls < 5e-3 and l2[worst] < 1e-1

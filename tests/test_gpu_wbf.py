@@ -207,3 +207,64 @@ def test_conv3d_fwd_ex_stats_and_kept_transform(case):
         assert np.array_equal(a1, a2)
     finally:
         d.set_option("wgrad_async", 1)
+
+
+K3_CASES = [
+    # (Cin, Cout, (N, D, H, W))
+    (32, 32, (2, 16, 16, 16)),      # CN 32: 16 x 16 tiles
+    (64, 32, (1, 16, 32, 8)),
+    (32, 64, (1, 8, 16, 12)),       # CN 64: 8 x 16 tiles
+    (128, 128, (1, 8, 8, 8)),       # CN 128: 8 x 8 tiles, split K
+]
+
+
+@pytest.mark.parametrize("fp16", [0, 1])
+@pytest.mark.parametrize("case", K3_CASES)
+def test_wbf_3x3x3_pipeline(case, fp16):
+    """The same three-stage pipeline for 3 x 3 x 3 convolutions (Winograd F(4,3), 6 points; UNet3D's DoubleConvs):
+    forward, data gradient and weight gradient against the float64 oracle,
+      fp16 = 0: exact bf16x3 operands -> the fp32-class tolerance of every other convolution kernel;
+      fp16 = 1: option "conv_fp16" (the fp16 matrix path of BASELINE configs[3]): fp16 operands in the Winograd domain,
+                fp32 accumulate.  STATED fp16 TOLERANCE: 3e-3 of max|ref| (operand rounding 2^-11 ~ 4.9e-4 per value,
+                amplified ~3x by the output transform; measured 1.0e-3 .. 1.8e-3)."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    d = dev()
+    rng = np.random.default_rng(cin * 3 + cout + D + fp16)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 27)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    dw_ref, _ = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, yt, dyt = t_from_ncdhw(x), t_empty(N, cout, D, H, W, fill=7.0), t_from_ncdhw(dy)
+    dxt = t_empty(N, cin, D, H, W, fill=3.0)
+    wp, bp = vec(w.ravel()), vec(b)
+    nw = cout * cin * 27
+    dwp = vec(np.zeros(nw, np.float32))
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    d.set_option("wgrad_async", 0)
+    d.set_option("conv_fp16", fp16)
+    try:
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), None, 0)
+        e_f, e_d = rel_err(t_to_ncdhw(yt), y_ref), rel_err(t_to_ncdhw(dxt), dx_ref)
+        e_w = rel_err(d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape), dw_ref)
+        d.prof_enable(False)
+        rep = d.prof_report()
+        gk, wk = ("wbf_gemm_f16_k", "wbf_wgrad_f16_k") if fp16 else ("wbf_gemm_k", "wbf_wgrad_k")
+        assert rep.get(gk, (0, 0))[0] >= 1 and rep.get(wk, (0, 0))[0] == 1, rep
+    finally:
+        d.set_option("conv_fp16", 0)
+        d.set_option("wgrad_async", 1)
+    print(f"\nwbf 3^3 {case} fp16={fp16}: fwd {e_f:.2e} dgrad {e_d:.2e} wgrad {e_w:.2e}")
+    if fp16:
+        assert e_f < 3e-3 and e_d < 3e-3 and e_w < 3e-3
+    else:
+        assert e_f < _conv_tol(cin * 27) and e_d < _conv_tol(cout * 27) and e_w < _conv_tol(N * D * H * W) * 2

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="VNetDeepSup", choices=["VNet", "VNetDeepSup", "UNet3D"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"], help="UNet3D: fp16 = 3x3x3 convolutions on the fp16 matrix pipe")
     ap.add_argument("--shape", default="512,512,12")
     ap.add_argument("--num-classes", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
@@ -33,7 +34,7 @@ def main():
     S = [[2, 2, 2]] * 4 if a.iso else [[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]
     dev = get_device()
     if a.model == "UNet3D":   # builder-defined (no reference model): python tools/bench_workloads.py --model UNet3D --shape 192,192,64 --num-classes 3 --batch 2
-        model = models.UNet3D(num_classes=a.num_classes, base_channels=32, depth=4)
+        model = models.UNet3D(num_classes=a.num_classes, base_channels=32, depth=4, precision=a.precision)
     else:
         model = getattr(models, a.model)(num_classes=a.num_classes, kernel_size=K, stride_size=S)
     model.train()
