@@ -163,7 +163,7 @@ def test_unet3d_control_flow_and_config(fake_pkg):
     model = UNet3D(num_classes=3, base_channels=8, depth=3)
     names = [n for n, _ in model.named_parameters()]
     assert "enc0.norm1.scale" in names and "up0.up_conv.weight" in names and "head.bias" in names
-    ddp = parallel.DataParallel(model, force=True, bucket_bytes=1 << 10)
+    ddp = parallel.DataParallel(model, force=True, overlap=True, bucket_bytes=1 << 10)
     x = np.zeros((2, 1, 16, 16, 8), np.float32)
     out = ddp(x)[0]
     assert out.shape == (2, 3, 16, 16, 8)
