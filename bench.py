@@ -227,13 +227,24 @@ def main():
         prof_serial = dev.prof_report()
         dev.set_option("wgrad_async", 1)
 
-    # max over ranks
+    # max over ranks; per-rank time inside the RCCL collectives (HIP events on the stream each one is enqueued on: it
+    # includes waiting for the slowest peer), so that the first multi-GPU run is diagnosable
+    dp_info = None
     if world > 1:
         import ctypes as C
-        sp, rp = dev.small(1), dev.small(world)
-        dev.h2d(sp, np.array([elapsed], np.float32))
-        dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(1))
-        elapsed = max(elapsed, float(dev.d2h(rp, (world,), np.float32).max()))
+        tags = ("rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather")
+        mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags]
+        sp, rp = dev.small(len(mine)), dev.small(world * len(mine))
+        dev.h2d(sp, np.array(mine, np.float32))
+        dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(len(mine)))
+        allv = dev.d2h(rp, (world, len(mine)), np.float32)
+        elapsed = max(elapsed, float(allv[:, 0].max()))
+        dp_info = {"per_rank_step_ms": [round(float(v) / args.steps * 1e3, 3) for v in allv[:, 0]],
+                   "per_rank_collective_ms_per_step": {t: [round(float(v), 3) for v in allv[:, 1 + i]] for i, t in enumerate(tags)},
+                   "calls_per_step": {t: int(sum(v[0] for k, v in prof.items() if k == t) / args.steps) for t in tags},
+                   "overlap": os.environ.get("MSEGK_DP_OVERLAP", "default: off with SyncBatchNorm, on without"),
+                   "note": "rccl_allreduce = gradient arena (182 MB per step), rccl_allreduce_stats / rccl_allgather = "
+                           "SyncBatchNorm exchanges (2*C floats each)"}
 
     if rank != 0:
         return
@@ -299,6 +310,8 @@ def main():
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
                       "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn},
            "final_loss": round(loss_val, 6), "roofline": roofline}
+    if dp_info is not None:
+        out["dp"] = dp_info
     if args.profile_out:
         os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)) or ".", exist_ok=True)
         with open(args.profile_out, "w") as f:

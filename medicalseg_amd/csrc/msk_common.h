@@ -135,7 +135,8 @@ struct msk_launch_scope {
   // prof_prefix (option "prof_only_halo"): bracket only the launches whose tag starts with it -- two events
   // around EVERY launch cost ~4 % of the training step (packet-processor barriers between back-to-back kernels)
   msk_launch_scope(msk_ctx* c, const char* tag)
-      : ctx(c), on(c->prof && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0)) {
+      : ctx(c), on(c->prof && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0 ||
+                               strncmp(tag, "rccl_", 5) == 0)) {   // the (few) collectives are always bracketed
     if (on) msk_prof_begin(c, tag);
   }
   ~msk_launch_scope() { if (on) msk_prof_end(ctx); }

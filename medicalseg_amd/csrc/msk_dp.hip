@@ -205,8 +205,8 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
 int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (msk_join_side_impl(ctx) != 0) return -1;  // the gradient arena includes side-stream weight gradients
-  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   msk_launch_scope ls(ctx, "rccl_allreduce");
+  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
 }
@@ -234,20 +234,20 @@ int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
   // per-channel BatchNorm-backward sums: produced on the main stream, so the weight-gradient side stream
   // keeps running (msk_dp_allreduce_sum would join it 24 times per step and undo the overlap)
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
-  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   msk_launch_scope ls(ctx, "rccl_allreduce_stats");
+  if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
 }
 
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_launch_scope ls(ctx, "rccl_allgather");
   if (ctx->host_transport) {
     if (ctx->world > 1) return host_collective(ctx, send, recv, count_per_rank, 1, ctx->stream);
     MSK_CHECK_HIP(ctx, hipMemcpyAsync(recv, send, count_per_rank * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
   }
-  msk_launch_scope ls(ctx, "rccl_allgather");
   MSK_CHECK_NCCL(ctx, ncclAllGather(send, recv, count_per_rank, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
   return 0;
 }

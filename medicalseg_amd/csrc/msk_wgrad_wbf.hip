@@ -284,7 +284,8 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
 
   // split K (position tiles): about 3 workgroups per CU in total
   const long base_blocks = (long)NXI * KCA * ncob;
-  long ksplit = (3L * ctx->num_cu + base_blocks / 2) / base_blocks;
+  const long per_cu = ctx->wgrad_wino_rounds > 0 ? ctx->wgrad_wino_rounds : 3;   // tuning: option "wgrad_wino_rounds"
+  long ksplit = (per_cu * ctx->num_cu + base_blocks / 2) / base_blocks;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > ntiles) ksplit = ntiles;
   const int tiles_per = (int)((ntiles + ksplit - 1) / ksplit);

@@ -107,3 +107,29 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, overlap):
         name = k[2:]
         if name.endswith(("._mean", "._variance")):
             assert np.abs(r0[k] - om.p[name]).max() < 1e-4 * (np.abs(om.p[name]).max() + 1), name
+
+
+def test_bench_py_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's multi-rank path (env contract of `python -m torch.distributed.run`, barrier, max over ranks, the `dp`
+    object with per-rank collective times) executed with two processes on GPU 0 over the host transport."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MSEGK_DP_TRANSPORT="host")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2",
+                                       "--steps", "2", "--warmup", "1", "--size", "32", "--batch", "1", "--no-cpu-baseline",
+                                       "--skip-serialized"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e.decode(errors="replace")[-2000:]
+        outs.append(o.decode())
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]     # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["parallelism"] == "dp2"
+    assert j["value"] > 0 and len(j["dp"]["per_rank_step_ms"]) == 2
+    assert j["dp"]["calls_per_step"]["rccl_allgather"] == 24 and j["dp"]["calls_per_step"]["rccl_allreduce_stats"] == 24
+    assert j["dp"]["calls_per_step"]["rccl_allreduce"] == 1                                  # safe default: one all-reduce
