@@ -59,6 +59,9 @@ int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, in
 int msk_gconv_halo_tightk(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv 32 -> (<= 4) channels, two voxels per thread on the VALU (msk_conv_valu2.hip)
 int msk_gconv_halo_valu2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// 'same' 5^3 conv 32 -> (<= 3) channels on the fp32 matrix pipe, kd taps folded into the MFMA columns, marching along D
+// (msk_conv_foldn.hip); applies g.prelu in its epilogue (*act_fused)
+int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, bool* act_fused);
 // 'same' 5^3 conv with a 1-D Winograd F(2,5) transform along W (msk_conv_wino.hip)
 int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv as a three-stage Winograd F(4,5) pipeline with bf16x3 operands on the bf16 matrix pipe (msk_conv_wbf.hip)

@@ -259,6 +259,10 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     int r = ctx->conv_impl == 8 ? 0 : msk_gconv_halo_tightk(ctx, g, w, A, B, swap);  // 8 = A/B: skip the tight-K kernel
     if (r < 0) return r;
     if (r == 1) return 0;
+    // 22 = A/B: the VALU kernels instead of the folded-column MFMA kernel; 9 skips both (one-voxel VALU kernel)
+    r = (ctx->conv_impl == 22 || ctx->conv_impl == 9) ? 0 : msk_gconv_halo_foldn(ctx, g, w, A, B, swap, act_fused);
+    if (r < 0) return r;
+    if (r == 1) return 0;
     r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
     if (r < 0) return r;
     if (r == 1) return 0;

@@ -496,6 +496,59 @@ def test_wgrad_winograd_f25_matches_oracle(case):
     assert e1 < _conv_tol(M) * 2 and e2 < _conv_tol(M) * 2
 
 
+FOLDN_CASES = [
+    # (Cout, (N, D, H, W)): out_tr.conv1 class (32 -> ncls <= 3, 5^3 same) on conv_foldn_k
+    (3, (2, 20, 13, 37)),     # ragged (h, w) tiles, D split into segments
+    (3, (1, 4, 8, 16)),       # one tile, D at the minimum
+    (2, (1, 33, 8, 12)),      # narrowest W, odd D
+    (1, (2, 9, 24, 48)),
+    (3, (1, 64, 16, 16)),     # long march: many planes per workgroup
+]
+
+
+@pytest.mark.parametrize("case", FOLDN_CASES)
+def test_conv_foldn_out_tr_class(case):
+    """conv_foldn_k (kd taps folded into the MFMA columns, marching along D; msk_conv_foldn.hip) against the float64
+    oracle and against the VALU kernel it replaced (conv_impl 22), forward and accumulate... the data gradient of this
+    class never routes here (CK = ncls)."""
+    cout, (N, D, H, W) = case
+    d = dev()
+    rng = np.random.default_rng(100 * cout + D)
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    x = rng.standard_normal((N, 32, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, 32) + k) / np.sqrt(32 * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
+    xt = t_from_ncdhw(x)
+    wp, bp = vec(w.ravel()), vec(b)
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    out = {}
+    try:
+        for impl in (0, 22):
+            d.set_option("conv_impl", impl)
+            yt = t_empty(N, cout, D, H, W, fill=7.0)
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+            out[impl] = t_to_ncdhw(yt)
+            d.prof_enable(False)
+            rep = d.prof_report()
+            assert ("conv_foldn" in rep) == (impl == 0), rep
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    e0, e22 = rel_err(out[0], ref), rel_err(out[22], ref)
+    print("foldn %.2e  valu %.2e" % (e0, e22))
+    assert e0 < _conv_tol(32 * 125) and e22 < _conv_tol(32 * 125)
+    # a strided destination (channel slice of a wider tensor) keeps its neighbours
+    wide = t_empty(N, cout + 2, D, H, W, fill=5.0)
+    d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), wide.channel_slice(1, 1 + cout).msk())
+    got = wide.numpy()
+    assert rel_err(got[:, 1:1 + cout], ref) < _conv_tol(32 * 125)
+    assert np.all(got[:, 0] == 5.0) and np.all(got[:, -1] == 5.0)
+
+
 FOLD_CASES = [
     # (Cin, Cout, k, pad, (N, D, H, W), kernel that must run)
     (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue (fp32-MFMA kernels: wino_bf3 = 0 below)
@@ -504,6 +557,7 @@ FOLD_CASES = [
     (32, 24, 5, 2, (1, 16, 32, 12), "conv_halo_wino4_k"),     # permuted axes (transform along H)
     (128, 128, 5, 2, (1, 4, 8, 16), "conv_splitk_reduce"),    # few tiles -> split K: slope applied in the reduce
     (16, 8, 3, 1, (1, 6, 7, 9), "prelu_inplace"),             # no Winograd kernel: in-place pass after the conv
+    (32, 3, 5, 2, (1, 9, 11, 21), "conv_foldn"),              # out_tr.conv1: slope in the folded-column MFMA kernel's epilogue
 ]
 
 
