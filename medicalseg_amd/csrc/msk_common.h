@@ -54,6 +54,7 @@ struct msk_ctx {
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
   char prof_prefix[48] = {0};  // empty = profile every launch
   long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
+  int foldn_wgs = 0;          // conv_foldn_k: workgroups per CU targeted by the D segmentation (0 = 2)
   int wgrad_wino_rounds = 0;  // Winograd wgrad kernels: 0 = wave-fitting cost model, > 0 = that many half-waves
   int wgrad_rounds = 8;  // LDS wgrad: target workgroups per CU (split-K granularity)
   int poison = -1;    // debug: byte used to fill freshly (re)allocated scratch

@@ -14,8 +14,8 @@
 //     (DPP row_shr:1), so column (co, kd) always holds the partial sum of output plane d' + 2 - kd; what leaves
 //     kd = 4 is a finished output plane.  No 3-D halo: each input plane is staged ONCE per column, whole 128-byte
 //     voxels (all channels), halo only in (h, w): 12 x 20 / (8 x 16) = 1.9x, served by L2 between neighbouring columns.
-//   * LDS holds one input plane [quad][12 x 20 voxels][4] (conflict-free ds_read_b32 for the A operand: 16 consecutive
-//     voxels x 4 channels = 64 distinct banks); the next plane is prefetched into registers during the 200 MFMAs of
+//   * LDS holds one input plane (12 x 20 voxels x 32 channels, bank-spread layout below: conflict-free ds_read_b32 for
+//     the A operand); the next plane is prefetched into registers during the 200 MFMAs of
 //     the current one.  B operands (weights, 51 KB packed per lane) stream from L1/L2 as 16-byte loads.
 #include "msk_conv.h"
 
@@ -71,7 +71,13 @@ conv_foldn_k(FNArgs a) {
   constexpr int NLD = (NV * Q + 255) / 256;                               // 16-byte loads per thread and plane
   constexpr int QG = Q / 4;
   constexpr unsigned kOOB = 0xFFFFFFF0u;
-  __shared__ float4 lds[Q * NV];
+  // plane in LDS as dwords [quad: QS][channel pair of the quad: HS][voxel][2]: the half-wave (k = 0, 1 | k = 2, 3) of an A
+  // read covers 32 consecutive dwords, the two halves sit 32 banks apart (HS = 480 = 32 mod 64), and QS = 16 (mod 32)
+  // spreads the 8 quads x 8 voxels of a staging store over all banks (the first layout, [quad][voxel][4], measured 59 %
+  // of the LDS cycles in bank conflicts: a half-wave touched only dwords 0, 1 (mod 4))
+  constexpr int HS = 2 * NV, QS = 2 * HS + 16;
+  static_assert(HS % 64 == 32 && QS % 32 == 16, "bank spreading");
+  __shared__ __attribute__((aligned(16))) float lds[Q * QS + 64];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   int t = xcd_remap_fn(blockIdx.x, a.nblk);
@@ -98,7 +104,7 @@ conv_foldn_k(FNArgs a) {
     const bool ok = v < NV;
     const bool inb = ok && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
     st_off[j] = inb ? (unsigned)(((((long)n * a.D * a.H + gh) * a.W + gw) * a.sld + 4 * q) * 4) : kOOB;
-    st_lds[j] = ok ? q * NV + v : -1;
+    st_lds[j] = ok ? q * QS + v * 2 : -1;
   }
   const long plane_bytes = (long)a.H * a.W * a.sld * 4;
 
@@ -112,8 +118,8 @@ conv_foldn_k(FNArgs a) {
                     : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  const float* ldsf = reinterpret_cast<const float*>(lds);
-  const int abase = (2 * wave * HW + li) * 4 + lk;  // this lane's A element of tap (0, 0), quad 0, first row of the wave
+  const float* ldsf = lds;
+  const int abase = (lk >> 1) * HS + (2 * wave * HW + li) * 2 + (lk & 1);  // this lane's A element of tap (0, 0), quad 0, first row of the wave
   const float4* wbl = a.wb + lane;
 
   const int col_co = li / 5, col_kd = li - col_co * 5;
@@ -133,7 +139,10 @@ conv_foldn_k(FNArgs a) {
     if (live) {
 #pragma unroll
       for (int j = 0; j < NLD; ++j)
-        if (st_lds[j] >= 0) lds[st_lds[j]] = pre[j];
+        if (st_lds[j] >= 0) {
+          *reinterpret_cast<float2*>(lds + st_lds[j]) = make_float2(pre[j].x, pre[j].y);
+          *reinterpret_cast<float2*>(lds + st_lds[j] + HS) = make_float2(pre[j].z, pre[j].w);
+        }
     }
     __syncthreads();
     if (s + 1 < steps) fetch(dp + 1);
@@ -148,25 +157,46 @@ conv_foldn_k(FNArgs a) {
         acc[rr][r] = col_first ? 0.f : __int_as_float(sh);
       }
     if (live) {
+      // A and B operands one (kh, kw) step ahead of their MFMAs: the waits then cover loads issued 16 MFMAs earlier (the
+      // compiler's own schedule read LDS just in time).  The packed weights carry one padding tap and the LDS array a
+      // padding row for the step behind the last.
+      float4 bn[QG];
+      float an[2][Q];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) bn[g] = wbl[g * 64];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        an[0][q] = ldsf[abase + q * QS];
+        an[1][q] = ldsf[abase + q * QS + HW * 2];
+      }
 #pragma unroll 1
       for (int kh = 0; kh < 5; ++kh) {  // rolled: a fully unrolled plane (400 MFMAs) made the scheduler hoist loads into spills
-        const float* arow = ldsf + abase + kh * HW * 4;
+        const float* arow = ldsf + abase + kh * HW * 2;
         const float4* brow = wbl + kh * 5 * QG * 64;
 #pragma unroll
         for (int kw = 0; kw < 5; ++kw) {
           float4 b[QG];
+          float av[2][Q];
+          const int nxt = kw < 4 ? (kw + 1) * 2 : HW * 2;  // (kh, kw + 1) or (kh + 1, 0)
 #pragma unroll
-          for (int g = 0; g < QG; ++g) b[g] = brow[(kw * QG + g) * 64];
+          for (int g = 0; g < QG; ++g) {
+            b[g] = bn[g];
+            bn[g] = brow[((kw + 1) * QG + g) * 64];
+          }
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            av[0][q] = an[0][q];
+            av[1][q] = an[1][q];
+            an[0][q] = arow[q * QS + nxt];
+            an[1][q] = arow[q * QS + nxt + HW * 2];
+          }
 #pragma unroll
           for (int g = 0; g < QG; ++g) {
             const float bq[4] = {b[g].x, b[g].y, b[g].z, b[g].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int q = 4 * g + e;
-              const float a0 = arow[(q * NV + kw) * 4];
-              const float a1 = arow[(q * NV + HW + kw) * 4];
-              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[e], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[e], acc[1], 0, 0, 0);
+              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][4 * g + e], bq[e], acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][4 * g + e], bq[e], acc[1], 0, 0, 0);
             }
           }
         }
@@ -210,7 +240,7 @@ int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   constexpr int Q = 8, QG = Q / 4;
   const size_t sb = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
   if (sb >= 0xFFFFFFF0ull) return 0;
-  float* wb = (float*)msk_workspace2(ctx, (size_t)25 * QG * 64 * 4 * sizeof(float));
+  float* wb = (float*)msk_workspace2(ctx, (size_t)26 * QG * 64 * 4 * sizeof(float));  // + one padding tap (prefetched, never used)
   if (!wb) return -1;
   {
     msk_launch_scope ls(ctx, "pack_weights_foldn");
@@ -225,7 +255,8 @@ int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   a.tiles_h = msk_cdiv(a.H, 8); a.tiles_w = msk_cdiv(a.W, 16);
   const long cols = (long)a.N * a.tiles_h * a.tiles_w;
   // D segments: enough workgroups for two per CU, each segment re-walks 4 planes
-  int segs = (int)((2L * ctx->num_cu + cols - 1) / cols);
+  const long per_cu = ctx->foldn_wgs > 0 ? ctx->foldn_wgs : 2;  // tuning: option "foldn_wgs"
+  int segs = (int)((per_cu * ctx->num_cu + cols - 1) / cols);
   if (segs > a.D / 8) segs = a.D / 8;
   if (segs < 1) segs = 1;
   a.seg_len = msk_cdiv(a.D, segs);
