@@ -70,6 +70,8 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
 int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g);
 // kernel == stride transposed gather (up-convs, down-conv data gradients): taps folded into N (msk_conv_scatter.hip)
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// kernel == stride forward gather (down-convs, up-conv data gradients): flattened K, two operand batches in flight (msk_conv_ksfwd.hip)
+int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
 int msk_wgrad_cbs(msk_ctx* ctx, const WGrad& g); // <= 4 output channels, 5^3 same (msk_wgrad_cbs.hip)
 int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g);  // one input channel, 5^3 same (msk_wgrad_c1.hip)

@@ -288,6 +288,11 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
       if (r < 0) return r;
       if (r == 1) return 0;
     }
+    if (ctx->conv_impl != 6 && ctx->conv_impl != 7) {  // 6 / 7 = A/B: the general gather kernel
+      r = msk_gconv_ks_fwd(ctx, g, w, A, B, swap);
+      if (r < 0) return r;
+      if (r == 1) return 0;
+    }
     r = msk_gconv_gather_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;
     if (r == 1) return 0;

@@ -38,17 +38,21 @@ pack_scatter_weights_k(const float* __restrict__ w, int A, int B, int taps, int 
   }
 }
 
-constexpr int NTG = 4;   // N tiles (of 32 columns) per workgroup pass: 64 accumulator registers
 constexpr int KCB = 8;   // 8-channel chunks held in registers at a time (64 channels)
 
-__global__ void __launch_bounds__(256, 3)  // 172 registers without the bound: 4 over the three-wavefront limit
-convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad, int vec) {
+// D is produced TRANSPOSED: rows = (tap, cn) columns of the GEMM above (weights as the MFMA A operand), columns = the
+// wavefront's 32 source voxels (x as the B operand).  A lane then owns ONE source voxel -- one address decode instead of
+// sixteen -- and four consecutive rows of a register quad are four consecutive output channels of one tap: 16-byte
+// stores (and 16-byte loads for the accumulate) instead of 64 scalar ones per N tile group.
+template <int NTG>  // N tiles (of 32 rows) per workgroup pass: 16 accumulator registers each
+__global__ void __launch_bounds__(256, 3)
+convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const long M = (long)g.N * g.SD * g.SH * g.SW;
-  const long m = (long)blockIdx.x * 128 + wave * 32 + li;   // this lane's A row (source voxel)
+  const long m = (long)blockIdx.x * 128 + wave * 32 + li;   // this lane's source voxel
   const int nt0 = blockIdx.y * NTG;
-  const int ntiles = jpad / 32;
+  const bool mok = m < M;
 
   f32x16 acc[NTG];
 #pragma unroll
@@ -56,95 +60,68 @@ convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad, i
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-  const float* arow = g.src + (m < M ? m : 0) * g.sld;
+  const float* xrow = g.src + (mok ? m : 0) * g.sld + lh * 4;
+  const float4* wl = bf + (long)lh * jpad + nt0 * 32 + li;
   for (int kc0 = 0; kc0 < KC; kc0 += KCB) {
-    float4 a[KCB];
+    float4 xv[KCB];
 #pragma unroll
-    for (int i = 0; i < KCB; ++i) {
-      const int c0 = (kc0 + i) * 8 + lh * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && kc0 + i < KC && c0 < g.CK) {
-        if (vec) {
-          v = *reinterpret_cast<const float4*>(arow + c0);
-        } else {
-          v.x = arow[c0];
-          if (c0 + 1 < g.CK) v.y = arow[c0 + 1];
-          if (c0 + 2 < g.CK) v.z = arow[c0 + 2];
-          if (c0 + 3 < g.CK) v.w = arow[c0 + 3];
-        }
-      }
-      a[i] = v;
-    }
+    for (int i = 0; i < KCB; ++i)   // CK % 4 == 0: a quad is inside the voxel or not at all
+      xv[i] = (mok && (kc0 + i) * 8 + lh * 4 < g.CK) ? *reinterpret_cast<const float4*>(xrow + (kc0 + i) * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < KCB; ++i) {
       if (kc0 + i < KC) {  // wave-uniform
-        const float4* bk = bf + ((long)(kc0 + i) * 2 + lh) * jpad + li;
+        const float4* wk = wl + (long)(kc0 + i) * 2 * jpad;
+        float4 w4[NTG];
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) w4[t] = wk[t * 32];
 #pragma unroll
         for (int t = 0; t < NTG; ++t) {
-          if (nt0 + t < ntiles) {
-            const float4 b = bk[(nt0 + t) * 32];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[t], 0, 0, 0);
-          }
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[t].x, xv[i].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[t].y, xv[i].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[t].z, xv[i].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[t].w, xv[i].w, acc[t], 0, 0, 0);
         }
       }
     }
   }
+  if (!mok) return;
 
-  // D[row = source voxel][col = (tap, cn)] -> dst[(n, d*sd+a, h*sh+b, w*sw+c)][cn]
-  unsigned rowbase[16];
-  bool rowok[16];
-  const long mw = (long)blockIdx.x * 128 + wave * 32;
-  // The lane's first row is decoded with divisions, the other 15 follow by carries (rows advance by 1, 1, 1, 5):
-  // 64 run-time divisions per lane cost more than the MFMA loop of these k = s layers.
-  unsigned w_, h_, d_, n_;
+  // D[row = (tap, cn)][col = source voxel] -> dst[(n, d*sd+a, h*sh+b, w*sw+c)][cn .. cn+3]
+  unsigned base;
   {
-    const long m0 = mw + 4 * lh;
-    const unsigned r = (unsigned)(m0 < M ? m0 : 0);
+    const unsigned r = (unsigned)m;
     const unsigned t1 = r / (unsigned)g.SW, t2 = t1 / (unsigned)g.SH;
-    w_ = r - t1 * (unsigned)g.SW;
-    h_ = t1 - t2 * (unsigned)g.SH;
-    n_ = t2 / (unsigned)g.SD;
-    d_ = t2 - n_ * (unsigned)g.SD;
+    const unsigned w_ = r - t1 * (unsigned)g.SW, h_ = t1 - t2 * (unsigned)g.SH;
+    const unsigned n_ = t2 / (unsigned)g.SD, d_ = t2 - n_ * (unsigned)g.SD;
+    base = (((n_ * g.DD + d_ * g.sd) * g.DH + h_ * g.sh) * g.DW + w_ * g.sw) * g.dld;
   }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j > 0) {
-      w_ += (j & 3) ? 1u : 5u;
-      while (w_ >= (unsigned)g.SW) {
-        w_ -= (unsigned)g.SW;
-        if (++h_ >= (unsigned)g.SH) {
-          h_ = 0;
-          if (++d_ >= (unsigned)g.SD) {
-            d_ = 0;
-            ++n_;
-          }
-        }
-      }
-    }
-    const long mr = mw + (j & 3) + 8 * (j >> 2) + 4 * lh;
-    rowok[j] = mr < M;
-    rowbase[j] = (((n_ * g.DD + d_ * g.sd) * g.DH + h_ * g.sh) * g.DW + w_ * g.sw) * g.dld;
-  }
-  const int taps = g.kd * g.kh * g.kw;
+  const int khw = g.kh * g.kw;
 #pragma unroll
   for (int t = 0; t < NTG; ++t) {
-    const int col = (nt0 + t) * 32 + li;
-    if (nt0 + t < ntiles && col < taps * g.CN) {
-      const int tap = col / g.CN, cn = col - tap * g.CN;
-      const int ta = tap / (g.kh * g.kw), tb = (tap / g.kw) % g.kh, tc = tap % g.kw;
-      const unsigned tapoff = ((unsigned)(ta * g.DH + tb) * g.DW + tc) * g.dld + cn;
-      const float bv = g.bias ? g.bias[cn] : 0.f;
+    float4 old[4];
+    unsigned off[4];
+    bool ok[4];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (rowok[j]) {
-          float* o = g.dst + rowbase[j] + tapoff;
-          float v = acc[t][j] + bv;
-          if (g.accumulate) v += *o;
-          *o = v;
-        }
+    for (int q = 0; q < 4; ++q) {
+      const int row = (nt0 + t) * 32 + 8 * q + 4 * lh;  // the quad's first row; CN % 4 == 0: one tap per quad
+      const int tap = row / g.CN, cn = row - tap * g.CN;
+      const int ta = tap / khw, tb = (tap - ta * khw) / g.kw, tc = tap - ta * khw - tb * g.kw;
+      ok[q] = row < jpad && tap < g.kd * khw;
+      off[q] = base + ((unsigned)(ta * g.DH + tb) * g.DW + tc) * g.dld + cn;
+      old[q] = (g.accumulate && ok[q]) ? *reinterpret_cast<const float4*>(g.dst + off[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (ok[q]) {
+        const int row = (nt0 + t) * 32 + 8 * q + 4 * lh;
+        const int cn = row % g.CN;
+        const float4 bv = g.bias ? make_float4(g.bias[cn], g.bias[cn + 1], g.bias[cn + 2], g.bias[cn + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v;
+        v.x = acc[t][4 * q + 0] + bv.x + old[q].x;
+        v.y = acc[t][4 * q + 1] + bv.y + old[q].y;
+        v.z = acc[t][4 * q + 2] + bv.z + old[q].z;
+        v.w = acc[t][4 * q + 3] + bv.w + old[q].w;
+        *reinterpret_cast<float4*>(g.dst + off[q]) = v;
       }
     }
   }
@@ -159,6 +136,9 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   if (!(g.DD == g.SD * g.sd && g.DH == g.SH * g.sh && g.DW == g.SW * g.sw)) return 0;
   const int taps = g.kd * g.kh * g.kw;
   if (taps < 2) return 0;
+  // 16-byte accesses: channel counts, voxel strides and pointers aligned to 4 floats
+  if (g.CK % 4 || g.CN % 4 || g.sld % 4 || g.dld % 4 || ((uintptr_t)g.src) % 16 || ((uintptr_t)g.dst) % 16)
+    return 0;
   const long M = (long)g.N * g.SD * g.SH * g.SW;
   const unsigned long dst_elems = (unsigned long)g.N * g.DD * g.DH * g.DW * g.dld;
   if (M >= (1L << 31) || dst_elems >= (1UL << 32)) return 0;  // 32-bit row arithmetic in the epilogue
@@ -177,7 +157,6 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
                        g.CK, g.CN, KC, jpad, bf);
     MSK_LAUNCH_CHECK(ctx);
   }
-  const int vec = (g.CK % 4 == 0) && (g.sld % 4 == 0) && (((uintptr_t)g.src) % 16 == 0);
   const char* tag = "convT_scatter_mfma";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[160];
@@ -186,8 +165,14 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
     tag = msk_intern_tag(ctx, buf);
   }
   msk_launch_scope ls(ctx, tag);
-  dim3 grid((unsigned)((M + 127) / 128), (jpad / 32 + NTG - 1) / NTG);
-  hipLaunchKernelGGL(convT_scatter_mfma_k, grid, dim3(256), 0, ctx->stream, g, (const float4*)bf, KC, jpad, vec);
+  const int ntiles = jpad / 32;
+  const int ntg = ntiles % 4 == 0 ? 4 : (ntiles % 2 == 0 ? 2 : 1);
+  dim3 grid((unsigned)((M + 127) / 128), ntiles / ntg);
+  switch (ntg) {
+    case 4: hipLaunchKernelGGL((convT_scatter_mfma_k<4>), grid, dim3(256), 0, ctx->stream, g, (const float4*)bf, KC, jpad); break;
+    case 2: hipLaunchKernelGGL((convT_scatter_mfma_k<2>), grid, dim3(256), 0, ctx->stream, g, (const float4*)bf, KC, jpad); break;
+    default: hipLaunchKernelGGL((convT_scatter_mfma_k<1>), grid, dim3(256), 0, ctx->stream, g, (const float4*)bf, KC, jpad); break;
+  }
   MSK_LAUNCH_CHECK(ctx);
   return 1;
 }
