@@ -134,6 +134,22 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
                       msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/);
 int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
                         int accumulate, const void* xform /*nullable*/);
+/* Backward of one conv -> BatchNorm(batch statistics) -> PReLU unit (LUConv, vnet.py:36-41; autograd of core/train.py:139)
+ * in one call:   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1, no residual),
+ *                dx (+)= conv^T(dy, w)   (dx.p NULL -> skipped),   dw (+)= sum dy * x.
+ * When both gradients run on the transform pipeline (square 5^3 / 3^3 'same' layers; msk_conv3d_bwd_bnact_bytes() > 0) dy is
+ * evaluated inside the kernel that writes its two transforms and never reaches HBM: then `ybuf` (caller-owned,
+ * msk_conv3d_bwd_bnact_bytes() bytes, must stay untouched until the weight gradient -- possibly on the side stream -- has
+ * run, i.e. until the next msk_sync / optimizer step) receives the second transform and `dy_scratch` is not written.
+ * Otherwise (ybuf NULL, or the shape is not eligible) the three operations run one after the other with dy in `dy_scratch`
+ * (a tensor of y's shape, required either way).  xform as in msk_conv3d_wgrad_ex.  Results agree with the separate calls
+ * to fp32 rounding.                                                                                          */
+size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y);
+int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                         const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd,
+                         const float* gamma, msk_tensor dout, const float* sums_total, double M_total,
+                         msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
+                         const void* xform /*nullable*/, void* ybuf /*nullable*/);
 /* autograd of the above (core/train.py:139 loss.backward()):
  *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,

@@ -68,6 +68,8 @@ SIGNATURES = {
     "msk_conv3d_xform_bytes": (_sz, [_vp, _CD, _T, _i]),
     "msk_conv3d_fwd_ex": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp]),
     "msk_conv3d_wgrad_ex": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp]),
+    "msk_conv3d_bwd_bnact_bytes": (_sz, [_vp, _CD, _T, _T]),
+    "msk_conv3d_bwd_bnact": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i, _vp, _vp]),
     "msk_conv3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
     "msk_conv3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_convT3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),

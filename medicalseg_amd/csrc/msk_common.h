@@ -54,6 +54,7 @@ struct msk_ctx {
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table
   char prof_prefix[48] = {0};  // empty = profile every launch
   long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
+  int bwd_fuse = -1;          // msk_conv3d_bwd_bnact: -1 auto, 0 three calls, 1 one dual transform, 2 one transform per stream
   int foldn_wgs = 0;          // conv_foldn_k: workgroups per CU targeted by the D segmentation (0 = 2)
   int wgrad_wino_rounds = 0;  // Winograd wgrad kernels: 0 = wave-fitting cost model, > 0 = that many half-waves
   int wgrad_rounds = 8;  // LDS wgrad: target workgroups per CU (split-K granularity)
@@ -66,6 +67,7 @@ struct msk_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool wgrad_async = false;
   bool side_dirty = false;
+  bool fork_recorded = false;  // ev_fork already recorded at the point the next side scope has to wait for (msk_conv3d_bwd_bnact)
   // msk_h2d staging: two pinned buffers so that a batch upload neither synchronises the stream nor waits for the
   // previous step (the host may run one upload ahead)
   void* stage[2] = {nullptr, nullptr};
@@ -102,8 +104,10 @@ struct msk_side_scope {
   msk_ctx* ctx;
   bool active;
   explicit msk_side_scope(msk_ctx* c, bool want = true) : ctx(c), active(want && c->wgrad_async && c->side != nullptr) {
+    const bool forked = ctx->fork_recorded;  // an earlier fork point was recorded for this scope
+    ctx->fork_recorded = false;
     if (!active) return;
-    hipEventRecord(ctx->ev_fork, ctx->stream);
+    if (!forked) hipEventRecord(ctx->ev_fork, ctx->stream);
     hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
     std::swap(ctx->stream, ctx->side);
     std::swap(ctx->ws, ctx->ws_side);

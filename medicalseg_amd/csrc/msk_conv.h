@@ -2,6 +2,7 @@
 // VALU reference kernels) and msk_conv_mfma.hip (MFMA kernels).
 #pragma once
 #include "msk_common.h"
+struct WbfBnBwd;
 
 // "Gather convolution": every dst voxel gathers from src voxels
 //   transposed == 0:  spos = dpos*s - p + k                      (Conv3D forward, ConvT dgrad)
@@ -22,6 +23,7 @@ struct GConv {
   float* stats;       // msk_conv3d_fwd_ex: BatchNorm statistics (mean[CN], M2[CN]) of dst wanted; a kernel that produced them in
                       // its epilogue sets ctx->stats_fused, otherwise the caller runs msk_bn_stats
   void* xform;        // msk_conv3d_fwd_ex: caller-owned buffer that receives the transformed input (msk_conv3d_xform_bytes)
+  const struct WbfBnBwd* fuse;  // msk_conv3d_bwd_bnact: src is not read; the input transform evaluates dy from (y, dout) on the fly
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
 };
@@ -36,6 +38,8 @@ struct WGrad {
   int CA, CB;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   const void* xform;  // msk_conv3d_wgrad_ex: transformed A written by msk_conv3d_fwd_ex for the same tensor, or null
+  const void* yform;  // msk_conv3d_bwd_bnact: transformed B (A dy) already written by the dual transform, or null
+  const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
   // Winograd kernels only (filled by msk_wgrad_wino): BD/BH/BW are then LOGICAL dims, a permutation of the tensor's
@@ -66,8 +70,10 @@ int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int
 int msk_gconv_halo_wino(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv as a three-stage Winograd F(4,5) pipeline with bf16x3 operands on the bf16 matrix pipe (msk_conv_wbf.hip)
 int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+bool msk_gconv_wino_bf3_accepts(msk_ctx* ctx, const GConv& g);  // the same eligibility tests, nothing launched
 // weight gradient of the same layers on the bf16 matrix pipe (msk_wgrad_wbf.hip)
 int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g);
+bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes);  // see msk_conv3d_bwd_bnact
 // kernel == stride transposed gather (up-convs, down-conv data gradients): taps folded into N (msk_conv_scatter.hip)
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // kernel == stride forward gather (down-convs, up-conv data gradients): flattened K, two operand batches in flight (msk_conv_ksfwd.hip)

@@ -692,6 +692,98 @@ int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy
   return run_wgrad(ctx, g, dy, db, accumulate);
 }
 
+size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y) {
+  // the A dy transform has the layout of the transformed input of a conv over y's shape: same geometry by construction
+  if (x.c != y.c || x.d != y.d || x.h != y.h || x.w != y.w) return 0;
+  return msk_conv3d_xform_bytes(ctx, cd, y, y.c);
+}
+
+int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                         const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                         msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                         int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
+  MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
+  MSK_REQUIRE(ctx, dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
+                       dy_scratch.c == y.c, "dy_scratch must match y");
+  // ---- fused form: conditions under which BOTH gradient pipelines take pre-written transforms
+  bool fused = ctx->bwd_fuse != 0 && ybuf != nullptr && xform != nullptr && dx.p != nullptr && ctx->wbf && !ctx->no_winograd && ctx->conv_impl == 0 &&
+               x.c == y.c && y.ld % 4 == 0 && dout.ld % 4 == 0 && (((uintptr_t)y.p) & 15) == 0 && (((uintptr_t)dout.p) & 15) == 0;
+  const size_t per = (size_t)x.d * x.h * x.w * (x.ld > y.ld ? x.ld : y.ld) * sizeof(float);
+  if (per > 0 && (size_t)x.n > kChunkBytes / per) fused = false;  // chunked batches
+  WGrad gw{};
+  gw.A = (const float*)x.p; gw.ald = x.ld; gw.B = (const float*)dy_scratch.p; gw.bld = dy_scratch.ld;
+  gw.N = x.n; gw.AD = x.d; gw.AH = x.h; gw.AW = x.w; gw.BD = y.d; gw.BH = y.h; gw.BW = y.w;
+  gw.CA = x.c; gw.CB = y.c;
+  gw.kd = cd.kd; gw.kh = cd.kh; gw.kw = cd.kw; gw.sd = cd.sd; gw.sh = cd.sh; gw.sw = cd.sw;
+  gw.pd = cd.pd; gw.ph = cd.ph; gw.pw = cd.pw;
+  gw.dw = dw; gw.accumulate = dw_accumulate;
+  gw.xform = xform;
+  size_t y_bytes = 0;
+  if (fused && !msk_wgrad_wbf_fusable(ctx, gw, &y_bytes)) fused = false;
+  if (fused) {
+    GConv g{};
+    g.src = (const float*)dy_scratch.p; g.sld = dy_scratch.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
+    g.N = dx.n; g.SD = y.d; g.SH = y.h; g.SW = y.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
+    g.CK = y.c; g.CN = dx.c;
+    g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+    g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+    g.transposed = 1; g.bias = nullptr; g.accumulate = dx_accumulate; g.flip = 1;
+    WbfBnBwd bn{};
+    bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
+    bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
+    bn.invM = (float)(1.0 / M_total);
+    bn.Y = (char*)ybuf;
+    bn.y_xi = (long)(y_bytes / ((cd.kd == 5) ? 8 : 6));
+    // form 1 (one kernel writes both transforms; least traffic: best without a side stream) or form 2 (each stream's
+    // transform evaluates dy itself: the main stream -- the critical path -- moves 20 instead of 28 B per element, the
+    // weight-gradient stream 20 instead of 16).  Option "bwd_fuse": 0 = three calls, 1 / 2 = force a form, -1 = auto.
+    const bool side_on = ctx->wgrad_async && ctx->side != nullptr &&
+                         (ctx->wgrad_async_max_m <= 0 || msk_voxels(y) <= ctx->wgrad_async_max_m);
+    const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : (side_on ? 2 : 1);
+    if (form == 2) {
+      // nothing is launched unless both pipelines accept: the weight gradient was planned above, ask the data gradient
+      bn.Y = nullptr;
+      g.fuse = &bn;
+      if (msk_gconv_wino_bf3_accepts(ctx, g)) {
+        {
+          msk_side_scope side(ctx, side_on);
+          gw.yfuse = &bn;
+          const int rw = msk_wgrad_wbf(ctx, gw);
+          if (rw < 0) return rw;
+          if (rw == 0) return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_bwd_bnact", "weight-gradient pipeline declined a problem its plan accepted");
+        }
+        const int r = msk_gconv_wino_bf3(ctx, g, w, y.c, x.c, 0);
+        if (r < 0) return r;
+        if (r == 0) return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_bwd_bnact", "data-gradient pipeline declined a problem its plan accepted");
+        return 0;
+      }
+    } else {
+      g.fuse = &bn;
+      const int r = msk_gconv_wino_bf3(ctx, g, w, y.c, x.c, 0);   // launches nothing when it returns 0
+      if (r < 0) return r;
+      if (r == 1) {
+        msk_side_scope side(ctx, side_on);
+        gw.yform = ybuf;
+        const int rw = msk_wgrad_wbf(ctx, gw);
+        if (rw < 0) return rw;
+        if (rw == 0) return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_bwd_bnact", "weight-gradient pipeline declined a problem its plan accepted");
+        return 0;
+      }
+    }
+  }
+  // ---- three-kernel form: dy through HBM
+  (void)gamma;
+  if (int rc = msk_affine_act_bwd_apply(ctx, y, scale, shift, msk_tensor{}, alpha, mean, invstd, gamma, dout, sums_total, M_total, 1,
+                                        dy_scratch, msk_tensor{}, 0))
+    return rc;
+  // the weight gradient first: it forks to the side stream and overlaps the data gradient enqueued behind it
+  if (int rc = msk_conv3d_wgrad_ex(ctx, cd, x, dy_scratch, dw, nullptr, dw_accumulate, xform)) return rc;
+  if (dx.p) return msk_conv3d_dgrad(ctx, cd, dy_scratch, w, dx, dx_accumulate);
+  return 0;
+}
+
 int msk_convT3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y) {
   if (check_conv_shapes(ctx, cd, x, y, true) != 0) return -1;
   GConv g{};

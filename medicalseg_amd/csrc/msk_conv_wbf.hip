@@ -284,6 +284,169 @@ wbf_tin_k(WbfTinArgs a) {
   }
 }
 
+// Both transforms of dy = BatchNorm/PReLU-backward(y, dout) (WbfBnBwd, msk_wbf.h) in one pass: the thread mapping and
+// the sliding window of wbf_tin_k<0> (one 8-channel group per wavefront, so the per-channel coefficients are scalar
+// registers), dy evaluated as the window is filled, tile t's own four positions (window slots PADW .. PADW+3) feed the
+// A dy transform.  Reads 8 B and writes 2 x 12 B per element instead of 12 + 16 + 16 B of the three-kernel form.
+struct DualArgs {
+  WbfTinArgs t;
+  const float* y;
+  int yld;
+  const float* dout;
+  int dld;
+  const float *scale, *shift, *alpha, *mean, *invstd, *sums;
+  float invM;
+  int C;
+  char* Y;
+  long y_xi;
+};
+
+template <int K, int NP>
+__device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8][8], int xi) {
+  if (NP == 3) {
+    uint4 hi, mid, lo;
+    wbf_split3_pair(v[0][xi], v[1][xi], hi.x, mid.x, lo.x);
+    wbf_split3_pair(v[2][xi], v[3][xi], hi.y, mid.y, lo.y);
+    wbf_split3_pair(v[4][xi], v[5][xi], hi.z, mid.z, lo.z);
+    wbf_split3_pair(v[6][xi], v[7][xi], hi.w, mid.w, lo.w);
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 2 * plane) = mid;
+    *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
+  } else {
+    uint4 hv;
+    hv.x = pack_f16_pair(v[0][xi], v[1][xi]);
+    hv.y = pack_f16_pair(v[2][xi], v[3][xi]);
+    hv.z = pack_f16_pair(v[4][xi], v[5][xi]);
+    hv.w = pack_f16_pair(v[6][xi], v[7][xi]);
+    *reinterpret_cast<uint4*>(o) = hv;
+  }
+}
+
+template <int K, int NP, bool WV, bool WY>  // which of the two transforms are written (each stream may take its own)
+__global__ void __launch_bounds__(256)
+wbf_tin_dual_k(DualArgs b) {
+  constexpr int NXI = nxi_of(K), WIN = K + 3, PADW = (K - 1) / 2, KEEP = WIN - 4;
+  const WbfTinArgs& a = b.t;
+  const int cgl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pl = threadIdx.x & 63;
+  const int ncgb = a.CK >> 5;
+  const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
+  const int pos = pb * 64 + pl;
+  const int n = blockIdx.y;
+  const int cg = cgb * 4 + cgl, kc = cg >> 1, khalf = cg & 1;
+  // per-channel coefficients of this wavefront's 8 channels: wave-uniform -> scalar registers
+  float sc[8], sf[8], al[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    sc[j] = b.scale[c];
+    sf[j] = b.shift[c];
+    al[j] = b.alpha ? b.alpha[c] : 1.f;
+    mu[j] = b.mean[c];
+    is[j] = b.invstd[c];
+    s1[j] = b.sums[c] * b.invM;
+    s2[j] = b.sums[b.C + c] * b.invM;
+  }
+  if (pos >= a.DP * a.HP) return;
+  const int dp = pos / a.HP, hp = pos - dp * a.HP;
+  const int d = dp - 2, h = hp - 2;
+  const bool live = d >= 0 && d < a.LD && h >= 0 && h < a.LH;
+  const long plane = (long)a.DP * a.HP * 16;
+  const long voff = (((long)n * a.T * a.KC + kc) * 2 * NP + khalf) * plane + (long)pos * 16;
+  char* vb = a.V + voff;
+  char* yb2 = b.Y + voff;
+  const long tstep = (long)a.KC * 2 * NP * plane;
+  const long vox0 = (long)n * a.svn + (long)d * a.svd + (long)h * a.svh;
+  const float* xb = b.y + vox0 * b.yld + cg * 8;
+  const float* gb = b.dout + vox0 * b.dld + cg * 8;
+  const long xstep = (long)a.svw * b.yld, gstep = (long)a.svw * b.dld;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // dy of 8 channels at logical position w (zero outside the volume)
+  auto dy_at = [&](int w, float4& o0, float4& o1) {
+    if (!(live && w >= 0 && w < a.LW)) {
+      o0 = o1 = z4;
+      return;
+    }
+    const float4* px = reinterpret_cast<const float4*>(xb + w * xstep);
+    const float4* pg = reinterpret_cast<const float4*>(gb + w * gstep);
+    const float4 x0 = px[0], x1 = px[1], g0 = pg[0], g1 = pg[1];
+    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dd = gv[j];
+      const float u = fmaf(xv[j], sc[j], sf[j]);
+      if (!(u > 0.f)) dd *= al[j];
+      const float xh = (xv[j] - mu[j]) * is[j];
+      r[j] = sc[j] * (dd - s1[j] - xh * s2[j]);
+    }
+    o0 = make_float4(r[0], r[1], r[2], r[3]);
+    o1 = make_float4(r[4], r[5], r[6], r[7]);
+  };
+
+  float4 win[WIN][2];
+#pragma unroll
+  for (int j = 0; j < WIN; ++j) dy_at(j - PADW, win[j][0], win[j][1]);
+  for (int t = 0; t < a.T; ++t) {
+    float4 nxt[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = 4 * (t + 1) + KEEP - PADW + j;  // the part of tile t + 1 not yet in registers
+      if (t + 1 < a.T) dy_at(w, nxt[j][0], nxt[j][1]);
+      else nxt[j][0] = nxt[j][1] = z4;
+    }
+    float v[8][8];  // [channel][xi]
+    if (WV) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float wx[8], wy[8], wz[8], ww[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 e = j < WIN ? win[j < WIN ? j : 0][q] : z4;
+          wx[j] = e.x; wy[j] = e.y; wz[j] = e.z; ww[j] = e.w;
+        }
+        tin_transform<0, K>(wx, v[q * 4 + 0]);
+        tin_transform<0, K>(wy, v[q * 4 + 1]);
+        tin_transform<0, K>(wz, v[q * 4 + 2]);
+        tin_transform<0, K>(ww, v[q * 4 + 3]);
+      }
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(vb + t * tstep + (long)xi * a.v_xi, plane, v, xi);
+    }
+    if (WY) {
+      // A dy of the tile's own positions 4t .. 4t+3 = window slots PADW .. PADW+3
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float wx[8], wy[8], wz[8], ww[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 e = win[PADW + j][q];
+          wx[j] = e.x; wy[j] = e.y; wz[j] = e.z; ww[j] = e.w;
+        }
+#pragma unroll
+        for (int j = 4; j < 8; ++j) wx[j] = wy[j] = wz[j] = ww[j] = 0.f;
+        tin_transform<1, K>(wx, v[q * 4 + 0]);
+        tin_transform<1, K>(wy, v[q * 4 + 1]);
+        tin_transform<1, K>(wz, v[q * 4 + 2]);
+        tin_transform<1, K>(ww, v[q * 4 + 3]);
+      }
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(yb2 + t * tstep + (long)xi * b.y_xi, plane, v, xi);
+    }
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+      win[j][0] = win[j + 4][0];
+      win[j][1] = win[j + 4][1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      win[KEEP + j][0] = nxt[j][0];
+      win[KEEP + j][1] = nxt[j][1];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // stage 2: per-xi 2-D convolution as an implicit GEMM on the 16-bit matrix pipe
 // ---------------------------------------------------------------------------------------------------------
@@ -652,7 +815,7 @@ void launch_gemm_variant(msk_ctx* ctx, int variant, const GemmArgs& ga, long nbl
 }
 
 template <int K, int NP>
-int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, const WbfGeom& geo, const Var* bv) {
+int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, const WbfGeom& geo, const Var* bv, bool dry) {
   constexpr int NXI = nxi_of(K), NPL = 2 * NP;
   const int TD = bv->TD, TH = bv->TH, variant = bv->id;
   const int* pm = geo.perm;
@@ -683,6 +846,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   if (v_xi >= 0xFFFFFFF0ull) return 0;                     // 32-bit offsets inside one xi plane
   const size_t u_xi = (size_t)K * K * KC * NPL * g.CN * 16;
   if (u_xi >= 0xFFFFFFF0ull) return 0;
+  if (dry) return 1;  // every eligibility test passed; nothing launched
   const size_t v_bytes = (NXI * v_xi + 255) & ~(size_t)255, m_bytes = ((size_t)ksplit * NXI * m_xi * sizeof(float) + 255) & ~(size_t)255;
   long tout_blocks = ((long)m_xi / 4 + 255) / 256;
   if (tout_blocks > 16L * ctx->num_cu) tout_blocks = 16L * ctx->num_cu;
@@ -712,7 +876,17 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     ta.svn = (long)g.DD * g.DH * g.DW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
     ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CK; ta.KC = KC;
     ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
-    if (msk_wbf_transform(ctx, 0, K, NP, ta) != 0) return -1;
+    if (g.fuse) {
+      if (msk_wbf_transform_dual(ctx, K, NP, ta, *g.fuse, true) != 0) return -1;
+      // one-kernel form: the weight gradient (side stream) may start as soon as both transforms are written: fork here,
+      // not after the GEMM
+      if (g.fuse->Y && ctx->wgrad_async && ctx->side != nullptr) {
+        hipEventRecord(ctx->ev_fork, ctx->stream);
+        ctx->fork_recorded = true;
+      }
+    } else if (msk_wbf_transform(ctx, 0, K, NP, ta) != 0) {
+      return -1;
+    }
   }
   {
     GemmArgs ga{};
@@ -777,6 +951,32 @@ int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& t
   return 0;
 }
 
+int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in, const WbfBnBwd& bn, bool write_v) {
+  DualArgs da{};
+  da.t = ta_in;
+  da.t.lane_map = 1;
+  da.y = bn.y; da.yld = bn.yld; da.dout = bn.dout; da.dld = bn.dld;
+  da.scale = bn.scale; da.shift = bn.shift; da.alpha = bn.alpha; da.mean = bn.mean; da.invstd = bn.invstd; da.sums = bn.sums;
+  da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi;
+  const bool write_y = bn.Y != nullptr;
+  if (!write_v && !write_y) return 0;
+  const int pblocks = (da.t.DP * da.t.HP + 63) / 64;
+  const dim3 grid((unsigned)(pblocks * (da.t.CK / 32)), da.t.N);
+  msk_launch_scope ls(ctx, write_v ? (write_y ? "wbf_tin_dual_k" : "wbf_tin_bn_k") : "wbf_ty_bn_k");
+#define WBF_DUAL_LAUNCH(K_, P_)                                                                                        \
+  do {                                                                                                                 \
+    if (write_v && write_y) hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, true, true>), grid, dim3(256), 0, ctx->stream, da);   \
+    else if (write_v) hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, true, false>), grid, dim3(256), 0, ctx->stream, da);        \
+    else hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, false, true>), grid, dim3(256), 0, ctx->stream, da);                     \
+  } while (0)
+  if (K == 5) WBF_DUAL_LAUNCH(5, 3);
+  else if (NP == 3) WBF_DUAL_LAUNCH(3, 3);
+  else WBF_DUAL_LAUNCH(3, 1);
+#undef WBF_DUAL_LAUNCH
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 // Bytes of the transformed input V of a 'same' K^3 convolution over a [n, d, h, w, c] tensor in the shared geometry, or 0
 // when the tensor is not eligible.
 size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP) {
@@ -798,7 +998,7 @@ size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, i
 }
 
 // Returns 1 if handled, 0 if the problem is not eligible, < 0 on error.
-int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+static int wino_bf3_impl(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, bool dry) {
   const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
   const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
   if (!k5 && !k3) return 0;
@@ -817,7 +1017,12 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
   if (!wbf_pick_geom(g.DD, g.DH, g.DW, mtd, mth, &geo)) return 0;
   const Var* bv = pick_variant(ctx, geo, g.CN, K);
   if (!bv) return 0;
-  if (K == 5) return run_pipeline<5, 3>(ctx, g, w_canon, A, B, swap, geo, bv);
-  if (wbf_pieces(ctx, 3) == 3) return run_pipeline<3, 3>(ctx, g, w_canon, A, B, swap, geo, bv);
-  return run_pipeline<3, 1>(ctx, g, w_canon, A, B, swap, geo, bv);
+  if (K == 5) return run_pipeline<5, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
+  if (wbf_pieces(ctx, 3) == 3) return run_pipeline<3, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
+  return run_pipeline<3, 1>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
 }
+int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+  return wino_bf3_impl(ctx, g, w_canon, A, B, swap, false);
+}
+// would msk_gconv_wino_bf3 run this problem?  (launches nothing)
+bool msk_gconv_wino_bf3_accepts(msk_ctx* ctx, const GConv& g) { return wino_bf3_impl(ctx, g, nullptr, 0, 0, 0, true) == 1; }

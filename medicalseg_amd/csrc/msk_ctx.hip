@@ -336,6 +336,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->no_winograd = value != 0;
     return 0;
   }
+  if (strcmp(key, "bwd_fuse") == 0) {
+    ctx->bwd_fuse = value < 0 ? -1 : (value > 2 ? 2 : value);
+    return 0;
+  }
   if (strcmp(key, "foldn_wgs") == 0) {
     ctx->foldn_wgs = value > 0 ? value : 0;
     return 0;

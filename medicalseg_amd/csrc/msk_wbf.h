@@ -36,6 +36,24 @@ struct WbfTinArgs {
 };
 // K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
 int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& a);
+
+// Backward of conv -> BatchNorm (batch statistics) -> PReLU fused into the transforms of dy (msk_conv3d_bwd_bnact):
+// dy = scale * (du - sums[c]/M - xhat * sums[C + c]/M), du = dout * (u > 0 ? 1 : alpha), u = scale*y + shift,
+// xhat = (y - mean) * invstd  -- the arithmetic of msk_affine_act_bwd_apply (bn_mode 1, no residual) -- is evaluated in the
+// registers of ONE kernel that writes both transforms of dy, B^T dy (data gradient) and A dy (weight gradient): dy itself
+// never reaches HBM.
+struct WbfBnBwd {
+  const float* y;     // convolution output (pre-BatchNorm), voxel stride yld
+  int yld;
+  const float* dout;  // gradient w.r.t. the unit's output, voxel stride dld
+  int dld;
+  const float *scale, *shift, *alpha, *mean, *invstd, *sums;  // [C] each, sums [2C]
+  float invM;
+  char* Y;            // second output: the A dy transform in the layout of the first (null: not written)
+  long y_xi;
+};
+// writes B^T dy to a.V when write_v and A dy to bn.Y when that is non-null
+int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& a, const WbfBnBwd& bn, bool write_v);
 // pieces per value for a K^3 convolution under the context's precision option ("conv_fp16": fp16 operands for K = 3)
 inline int wbf_pieces(const msk_ctx* ctx, int K) { return (K == 3 && ctx->conv_fp16) ? 1 : 3; }
 

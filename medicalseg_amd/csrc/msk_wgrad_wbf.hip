@@ -298,11 +298,13 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   const size_t vb = (NXI * v_xi + 255) & ~(size_t)255, yb = (NXI * y_xi + 255) & ~(size_t)255;
   const bool have_v = g.xform != nullptr && shared_geom &&
                       msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) == NXI * v_xi;
-  char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + yb + p_floats * sizeof(float) + 256);
+  const bool have_y = g.yform != nullptr;  // A dy already written by the dual transform (msk_conv3d_bwd_bnact checked the geometry)
+  if ((have_y || g.yfuse) && !(have_v && shared_geom)) return 0;
+  char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + (have_y ? 0 : yb) + p_floats * sizeof(float) + 256);
   if (!wsp) return -1;
   char* V = have_v ? (char*)const_cast<void*>(g.xform) : wsp;
-  char* Y = have_v ? wsp : wsp + vb;
-  float* P = (float*)(Y + yb);
+  char* Y = have_y ? (char*)const_cast<void*>(g.yform) : (have_v ? wsp : wsp + vb);
+  float* P = (float*)(have_y ? (have_v ? wsp : wsp + vb) : Y + yb);
 
   WbfTinArgs ta{};
   ta.src = g.A; ta.sld = g.ald;
@@ -311,7 +313,14 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
   if (!have_v && msk_wbf_transform(ctx, 0, K, NP, ta) != 0) return -1;  // else: V written by msk_conv3d_fwd_ex for this tensor
   ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
-  if (msk_wbf_transform(ctx, 1, K, NP, ta) != 0) return -1;
+  if (g.yfuse) {
+    WbfBnBwd bn = *g.yfuse;
+    bn.Y = Y;
+    bn.y_xi = (long)y_xi;
+    if (msk_wbf_transform_dual(ctx, K, NP, ta, bn, false) != 0) return -1;
+  } else if (!have_y && msk_wbf_transform(ctx, 1, K, NP, ta) != 0) {
+    return -1;
+  }
 
   WgArgs wa{};
   wa.V = V; wa.Y = Y; wa.P = P;
@@ -368,3 +377,31 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   if (wbf_pieces(ctx, 3) == 3) return run_wgrad_pipeline<3, 3>(ctx, g, geo, shared_geom, TH);
   return run_wgrad_pipeline<3, 1>(ctx, g, geo, shared_geom, TH);
 }
+
+// Would msk_wgrad_wbf run this problem from two PRE-WRITTEN transforms (V = g.xform in the geometry the forward pass
+// used, Y = the dual transform's second output)?  *y_bytes = size of that Y.  Launches nothing.
+bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes) {
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
+  if (!k5 && !k3) return false;
+  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1)) return false;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return false;
+  if (g.CA < 32 || g.CA % 32 || g.CB < 32 || g.CB % 32) return false;
+  if (g.xform == nullptr) return false;
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(g.CB, &mtd, &mth);
+  if (!wbf_pick_geom(g.BD, g.BH, g.BW, mtd, mth, &geo)) return false;
+  if (!wbf_tile_ok(geo, 8, 16) && !wbf_tile_ok(geo, 8, 8)) return false;
+  const int K = k5 ? 5 : 3, NP = wbf_pieces(ctx, K), NPL = 2 * NP;
+  const int NXI = K == 5 ? 8 : 6;
+  const long ntiles = (long)g.N * geo.T * ((geo.LD + 7) / 8) * ((geo.LH + 7) / 8);
+  if (ntiles > 0x7fffffffL) return false;
+  const size_t plane = (size_t)geo.DP * geo.HP * 16;
+  const size_t v_xi = (size_t)g.N * geo.T * (g.CA / 16) * NPL * plane, y_xi = (size_t)g.N * geo.T * (g.CB / 16) * NPL * plane;
+  if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return false;
+  if (msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) != NXI * v_xi) return false;
+  *y_bytes = NXI * y_xi;
+  return true;
+}
+

@@ -13,6 +13,7 @@ adjoint needs.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -448,6 +449,10 @@ def _fp(ptr):
     return C.c_void_p(ptr) if ptr else None
 
 
+# A/B switch (env MSEGK_BWD_FUSE=0): conv -> BN -> PReLU units run their backward as three calls (apply, dgrad, wgrad)
+FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
+
+
 class ConvBNAct:
     """conv (or convT) -> BatchNorm -> (+ residual) -> PReLU, forward and adjoint.
 
@@ -541,6 +546,27 @@ class ConvBNAct:
         dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
                  _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
         dy = y.empty_like()
+        if (FUSE_BN_BACKWARD and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and need_dx
+                and self.conv.cin == self.conv.cout):
+            # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
+            # of dy (msk_conv3d_bwd_bnact); dy itself reaches HBM only when the shape is not eligible
+            conv, x = self.conv, self.x
+            xf = getattr(conv, "_xform", None)
+            xfp = xf[0] if (xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen) else None
+            ybuf = None
+            if xfp is not None:
+                nbytes = int(dev.lib.msk_conv3d_bwd_bnact_bytes(dev.ctx, conv.desc(), x.msk(), y.msk()))
+                if nbytes > 0:
+                    ybuf = dev.arena.alloc(nbytes)
+            dx = x.ensure_grad()
+            dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                     _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
+                     _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,
+                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf))
+            x.grad_written = True
+            conv._xform = None
+            self.dy = dy if ybuf is None else None
+            return
         dres = NULL_TENSOR
         dres_acc = 0
         if res is not None and res_needs_grad and res.c == y.c:

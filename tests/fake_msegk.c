@@ -37,9 +37,10 @@ int msk_prof_report(void* c, char* buf, int n, int* len) { (void)c; if (buf && n
 int msk_set_option(void* c, const char* k, int v) { (void)c; (void)k; (void)v; return 0; }
 int msk_dp_unique_id(char* id) { memset(id, 7, 128); return 0; }
 size_t msk_conv3d_xform_bytes() { return 0; }
+size_t msk_conv3d_bwd_bnact_bytes() { return 0; }
 #define NOOP(name) int name() { ++g_calls; return 0; }
 NOOP(msk_ncdhw_to_ndhwc) NOOP(msk_ndhwc_to_ncdhw)
-NOOP(msk_conv3d_fwd) NOOP(msk_conv_fold_bn) NOOP(msk_conv3d_fwd_act) NOOP(msk_conv3d_fwd_ex) NOOP(msk_conv3d_wgrad_ex) NOOP(msk_conv3d_dgrad) NOOP(msk_conv3d_wgrad)
+NOOP(msk_conv3d_fwd) NOOP(msk_conv_fold_bn) NOOP(msk_conv3d_fwd_act) NOOP(msk_conv3d_fwd_ex) NOOP(msk_conv3d_wgrad_ex) NOOP(msk_conv3d_bwd_bnact) NOOP(msk_conv3d_dgrad) NOOP(msk_conv3d_wgrad)
 NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
 NOOP(msk_bn_stats) NOOP(msk_bn_finalize) NOOP(msk_bn_eval_coeffs)
 NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)

@@ -268,3 +268,99 @@ def test_wbf_3x3x3_pipeline(case, fp16):
         assert e_f < 3e-3 and e_d < 3e-3 and e_w < 3e-3
     else:
         assert e_f < _conv_tol(cin * 27) and e_d < _conv_tol(cout * 27) and e_w < _conv_tol(N * D * H * W) * 2
+
+
+@pytest.mark.parametrize("case", [(32, 5, (2, 16, 32, 16)), (64, 5, (1, 8, 16, 16)), (128, 5, (1, 8, 16, 8)), (32, 3, (2, 16, 16, 16)),
+                                  (32, 5, (1, 30, 60, 8)), (16, 5, (1, 8, 8, 8))])
+def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
+    """msk_conv3d_bwd_bnact (backward of a LUConv unit, vnet.py:36-41): the fused form -- BatchNorm/PReLU backward evaluated
+    inside wbf_tin_dual_k, which writes both transforms of dy; dy never stored -- against (a) the same entry point without
+    `ybuf` (msk_affine_act_bwd_apply -> msk_conv3d_dgrad -> msk_conv3d_wgrad_ex through HBM) and (b) the float64 oracle of
+    the three operations.  The last case (16 channels) is not eligible: bytes() = 0 and the call takes the three-call form."""
+    import ctypes as C
+    c, K, (N, D, H, W) = case
+    k, s_, p = (K,) * 3, (1, 1, 1), (K // 2,) * 3
+    d = dev()
+    rng = np.random.default_rng(c + K + D)
+    f8 = lambda a: a.astype(np.float64)
+    x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((c, c) + k) / np.sqrt(c * K ** 3)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    dout = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), (0.3 * rng.standard_normal(c)).astype(np.float32)
+    alpha = rng.uniform(0.05, 0.5, c).astype(np.float32)
+    y = O.conv3d(f8(x), f8(w), f8(b), s_, p).astype(np.float32)
+    # training-mode BatchNorm coefficients of y and the reduced sums of its backward, in float64
+    yc = np.moveaxis(f8(y), 1, -1).reshape(-1, c)
+    M = yc.shape[0]
+    mean, var = yc.mean(0), yc.var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    scale, shift = f8(gamma) * invstd, f8(beta) - mean * f8(gamma) * invstd
+    u = yc * scale + shift
+    du = np.moveaxis(f8(dout), 1, -1).reshape(-1, c) * np.where(u > 0, 1.0, f8(alpha))
+    xhat = (yc - mean) * invstd
+    sums = np.concatenate([du.sum(0), (du * xhat).sum(0)])
+    dy_ref = scale * (du - sums[:c] / M - xhat * sums[c:] / M)
+    dy_ref = np.moveaxis(dy_ref.reshape(N, D, H, W, c), -1, 1)
+    dx_ref = O.conv3d_dgrad(dy_ref, f8(w), x.shape, s_, p)
+    dw_ref, _ = O.conv3d_wgrad(dy_ref, f8(x), k, s_, p)
+
+    xt, yt, dot = t_from_ncdhw(x), t_from_ncdhw(y), t_from_ncdhw(dout)
+    wp, bp = vec(w.ravel()), vec(b)
+    cv = {n_: vec(v.astype(np.float32)) for n_, v in dict(scale=scale, shift=shift, alpha=alpha, mean=mean, invstd=invstd,
+                                                            gamma=gamma, sums=sums).items()}
+    desc = _desc(k, s_, p)
+    nx = int(d.lib.msk_conv3d_xform_bytes(d.ctx, desc, xt.msk(), c))
+    nb = int(d.lib.msk_conv3d_bwd_bnact_bytes(d.ctx, desc, xt.msk(), yt.msk()))
+    assert (nb > 0) == (c >= 32) and (nx > 0) == (c >= 32)
+    xf = d.malloc(nx) if nx else None
+    ybuf = d.malloc(nb) if nb else None
+    ytmp = t_empty(N, c, D, H, W, fill=0.0)
+    d.call("msk_conv3d_fwd_ex", desc, xt.msk(), vp(wp), vp(bp), ytmp.msk(), None, vp(xf))   # fills xf for x
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    res = {}
+    try:
+        for form, opt in (("one", 1), ("split", 2), ("three", 0)):
+            d.set_option("bwd_fuse", opt)
+            dyt = t_empty(N, c, D, H, W, fill=9.0)
+            dxt = t_empty(N, c, D, H, W, fill=3.0)
+            dw = vec(np.full(w.size, 0.5, np.float32))
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_bwd_bnact", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
+                   vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
+                   dyt.msk(), dxt.msk(), 0, vp(dw), 0, vp(xf), vp(ybuf))
+            d.sync()
+            d.prof_enable(False)
+            rep = d.prof_report()
+            res[form] = (t_to_ncdhw(dxt), d.d2h(dw, (w.size,), np.float32).reshape(w.shape), t_to_ncdhw(dyt), rep)
+    finally:
+        d.prof_enable(False)
+        d.set_option("bwd_fuse", -1)
+    eligible = c >= 32
+    (dx3, dw3, dy3, rep3) = res["three"]
+    assert "affine_act_bwd_apply" in rep3 and not any(t.startswith("wbf_tin_dual") or t.endswith("_bn_k") for t in rep3), rep3
+    assert rel_err(dy3, dy_ref) < 2e-6
+    tol = _conv_tol(c * K ** 3)
+    for form, tags in (("one", ("wbf_tin_dual_k",)), ("split", ("wbf_tin_bn_k", "wbf_ty_bn_k"))):
+        dxf, dwf, dyf, repf = res[form]
+        assert all((t in repf) == eligible for t in tags), (form, repf)
+        assert ("affine_act_bwd_apply" in repf) == (not eligible), (form, repf)
+        if eligible:
+            assert np.all(dyf == 9.0)                       # dy never written in the fused forms
+        print("%s: dx err %.2e (three %.2e) | dw err %.2e (three %.2e)" % (form, rel_err(dxf, dx_ref), rel_err(dx3, dx_ref),
+                                                                         rel_err(dwf, dw_ref), rel_err(dw3, dw_ref)))
+        assert rel_err(dxf, dx_ref) < tol and rel_err(dwf, dw_ref) < 2 * _conv_tol(M)
+        assert rel_err(dxf, dx3) < 2e-6 and rel_err(dwf, dw3) < 2e-6     # the forms agree to fp32 rounding
+    assert rel_err(dx3, dx_ref) < tol and rel_err(dw3, dw_ref) < 2 * _conv_tol(M)
+    # accumulate semantics of both outputs
+    dxt = t_from_ncdhw(dx_ref.astype(np.float32))
+    dw = vec(dw_ref.astype(np.float32).ravel())
+    dyt = t_empty(N, c, D, H, W, fill=9.0)
+    d.call("msk_conv3d_bwd_bnact", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
+           vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
+           dyt.msk(), dxt.msk(), 1, vp(dw), 1, vp(xf), vp(ybuf))
+    d.sync()
+    assert rel_err(t_to_ncdhw(dxt), 2 * dx_ref) < tol
+    assert rel_err(d.d2h(dw, (w.size,), np.float32).reshape(w.shape), 2 * dw_ref) < 2 * _conv_tol(M)
