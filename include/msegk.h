@@ -83,16 +83,20 @@ int msk_prof_reset(msk_ctx* ctx);
 int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
 /* knobs (debugging / A-B measurements; 0 = the product dispatch):
  *   "conv_impl": 1=VALU reference kernels everywhere, 3=reference wgrad only, 4=reference gather-conv only,
- *     5=no LDS wgrad, 6=no k==s scatter kernel, 7=scatter kernel at any size, 8=no tight-K kernel,
+ *     5=no LDS wgrad, 6=no k==s scatter / forward-gather kernels, 7=scatter kernel at any size and the general gather
+ *     kernel for the k==s forward convs, 8=no tight-K kernel,
  *     9=one-voxel VALU kernel for 32->ncls, 10=Winograd forward kernel even for tiny grids, 11=direct (non-Winograd)
  *     forward/data-gradient kernels, 12=fp32 Winograd weight gradient forced, 13=direct weight-gradient kernels,
  *     14=fp32 Winograd F(2,5) instead of F(4,5), 16=tap-row weight-gradient kernel for the kernel == stride convolutions,
- *     20=fp32-MFMA Winograd kernels instead of the bf16x3 pipeline, 21=the same for the weight gradient only;
+ *     20=fp32-MFMA Winograd kernels instead of the bf16x3 pipeline, 21=the same for the weight gradient only,
+ *     22=VALU kernel instead of the folded-column MFMA kernel for 32->ncls (conv_foldn_k);
  *   "wino_bf3" 0|1 (0 = fp32-MFMA Winograd kernels everywhere; also env MSEGK_WBF=0), "wbf_variant" (-1 auto | tile variant
  *     of wbf_gemm_k), "wbf_tin_map" 0|1 (lane mapping of the transform kernel);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
  *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
  *   "direct_conv" 0|1 (1 = no Winograd kernels; also env MSEGK_DIRECT_CONV=1);
+ *   "bwd_fuse" -1|0|1|2 (msk_conv3d_bwd_bnact: auto | three calls | one dual transform | one transform per stream),
+ *     "foldn_wgs" (workgroups per CU targeted by the D segmentation of conv_foldn_k, 0 = 2);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
  *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels; "wgrad_wino_rounds" 0 = pick the
  *   split count that fills whole waves of resident workgroups, the default) */
