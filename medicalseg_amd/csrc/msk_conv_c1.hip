@@ -1,0 +1,158 @@
+// 'Same' 5^3 convolution with ONE input channel (in_tr.conv1, 1 -> 16, vnet.py:67) on the fp32 matrix pipe:
+//     y[v][co] = bias[co] + sum_tap x[v + tap] * W[co][tap]
+// The GEMM has K = 125 taps (padded to 128), N = CN <= 16 output channels, M = voxels.  The one-voxel-per-thread VALU
+// kernel (conv_halo_valu_k) took 0.39 ms for 2 x 128^3 -- 16.8 GFLOP are 0.11 ms of fp32 MFMA, the 268 MB of output
+// 0.06 ms of HBM.  Here (mirror of wgrad_c1_mfma_k):
+//   * the 1-channel x halo of a 4 x 8 x 32 voxel tile sits in LDS (13.8 KB);
+//   * v_mfma_f32_16x16x4_f32 with D TRANSPOSED: A = weights (rows = output channels, the lane's 32 values -- all 125 taps --
+//     stay in registers for the whole kernel), B = x gathered from LDS at (voxel + tap offset); the lane's 32 tap offsets
+//     are registers too, so a K step is one ds_read_b32 + one MFMA;
+//   * a lane ends up with 4 consecutive output channels of one voxel: a wavefront's store covers 16 voxels x 64 B = 1 KiB
+//     of contiguous output.
+#include "msk_conv.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOBc = 0xFFFFFFF0u;
+
+struct C1Args {
+  const float* src;
+  int sld;
+  float* dst;
+  int dld;
+  int N, D, H, W, CN;
+  const float* w;  // canonical [CN][1][125]
+  const float* bias;
+  int flip;
+  int tiles_d, tiles_h, tiles_w, ntiles;
+  unsigned src_bytes;
+};
+
+__global__ void __launch_bounds__(256)
+conv_c1_mfma_k(C1Args a) {
+  constexpr int KS = 5, TD = 4, TH = 8, TW = 32, P = 2;
+  constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
+  constexpr int NV = HD * HH * HW;  // 8 x 12 x 36 = 3456 floats
+  constexpr int TAPS = 125, KSTEPS = 32;
+  __shared__ float xs[NV];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+
+  // K step s consumes taps 4s .. 4s+3; this lane supplies tap 4s + lk of both operands
+  float wreg[KSTEPS];
+  int toff[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int tap = 4 * s + lk;
+    const bool live = tap < TAPS;
+    const int st = a.flip ? TAPS - 1 - tap : tap;
+    wreg[s] = (live && li < a.CN) ? a.w[(long)li * TAPS + st] : 0.f;
+    // the three padding taps (zero weight) re-read tap 0's voxel: a finite operand that belongs to this output anyway
+    toff[s] = live ? ((tap / (KS * KS)) * HH + (tap / KS) % KS) * HW + tap % KS : 0;
+  }
+  const int cq = 4 * lk;  // this lane's output-channel quad
+  float bq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bq[j] = (a.bias && cq + j < a.CN) ? a.bias[cq + j] : 0.f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int t_ = tile;
+    const int twi = t_ % a.tiles_w;
+    t_ /= a.tiles_w;
+    const int thi = t_ % a.tiles_h;
+    t_ /= a.tiles_h;
+    const int tdi = t_ % a.tiles_d;
+    const int n = t_ / a.tiles_d;
+    const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
+    __syncthreads();  // the previous tile's readers are done
+    for (int hv = tid; hv < NV; hv += 256) {
+      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+      const bool in = (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+      xs[hv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                   rs, (int)(in ? (unsigned)((((n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld) * 4u : kOOBc), 0, 0));
+    }
+    __syncthreads();
+    // a wavefront owns plane d0 + wave: 8 rows x 2 column tiles of 16 voxels
+    const int gd = d0 + wave;
+    if (gd < a.D) {
+#pragma unroll 1
+      for (int rt = 0; rt < TH * 2; rt += 2) {  // two independent accumulator chains per trip
+        const int h = rt >> 1;
+        const int gh = h0 + h;
+        if (gh >= a.H) break;
+        // two accumulators per column tile (even / odd K steps): four independent MFMA chains and shorter fp32 sums
+        f32x4 acc0 = {bq[0], bq[1], bq[2], bq[3]}, acc1 = acc0;
+        f32x4 odd0 = {0.f, 0.f, 0.f, 0.f}, odd1 = odd0;
+        const int b0 = (wave * HH + h) * HW + li, b1 = b0 + 16;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xs[b0 + toff[s]], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xs[b1 + toff[s]], acc1, 0, 0, 0);
+          odd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xs[b0 + toff[s + 1]], odd0, 0, 0, 0);
+          odd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xs[b1 + toff[s + 1]], odd1, 0, 0, 0);
+        }
+        acc0 += odd0;
+        acc1 += odd1;
+        // D[row = co = 4*lk + j][col = voxel li]
+        if (cq < a.CN) {
+          const long rowv = (((long)n * a.D + gd) * a.H + gh) * a.W;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int gw = w0 + c * 16 + li;
+            if (gw < a.W) {
+              float* o = a.dst + (rowv + gw) * a.dld + cq;
+              const f32x4 v = c == 0 ? acc0 : acc1;
+              if (cq + 3 < a.CN) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  if (cq + j < a.CN) o[j] = v[j];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// returns 1 when handled, 0 when not eligible, < 0 on error
+int msk_gconv_c1_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
+  if (!(g.CK == 1 && g.CN >= 1 && g.CN <= 16) || g.accumulate) return 0;
+  if (g.DW < 16) return 0;                                   // narrow slabs keep the VALU kernel's tiles
+  // canonical w[a][b][tap] with (k, n) = swap ? (b, a) : (a, b); CK = 1 -> both read w[n*125 + tap]
+  (void)A; (void)B; (void)swap;
+  if (g.dld % 4 || (((uintptr_t)g.dst) & 15)) return 0;
+  const size_t sb = (size_t)g.N * g.SD * g.SH * g.SW * g.sld * sizeof(float);
+  if (sb >= 0xFFFFFFF0ull) return 0;
+  C1Args a{};
+  a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
+  a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CN = g.CN;
+  a.w = w_canon; a.bias = g.bias; a.flip = g.transposed ? 1 : 0;
+  a.tiles_d = msk_cdiv(a.D, 4); a.tiles_h = msk_cdiv(a.H, 8); a.tiles_w = msk_cdiv(a.W, 32);
+  const long ntiles = (long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+  if (ntiles > 0x7fffffff) return 0;
+  a.ntiles = (int)ntiles;
+  a.src_bytes = (unsigned)sb;
+  long blocks = 4L * ctx->num_cu;  // persistent: the 64 weight / offset registers are loaded once per workgroup
+  if (blocks > ntiles) blocks = ntiles;
+  const char* tag = "conv_c1_mfma";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "conv_c1_mfma[cn=%d,n=%d,dhw=%dx%dx%d]", g.CN, g.N, g.DD, g.DH, g.DW);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
+  hipLaunchKernelGGL(conv_c1_mfma_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+  MSK_LAUNCH_CHECK(ctx);
+  return 1;
+}

@@ -549,6 +549,40 @@ def test_conv_foldn_out_tr_class(case):
     assert np.all(got[:, 0] == 5.0) and np.all(got[:, -1] == 5.0)
 
 
+@pytest.mark.parametrize("case", [(16, (2, 9, 13, 37)), (16, (1, 4, 8, 32)), (12, (1, 6, 8, 16)), (5, (2, 5, 9, 40))])
+def test_conv_c1_mfma_in_tr_class(case):
+    """conv_c1_mfma_k (1 -> <= 16 channels, 5^3 same: in_tr.conv1, vnet.py:67) against the float64 oracle and the VALU kernel it
+    replaced (conv_impl 23), incl. output-channel counts that are not a multiple of 4 and a strided destination."""
+    cout, (N, D, H, W) = case
+    d = dev()
+    rng = np.random.default_rng(cout + D)
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    x = rng.standard_normal((N, 1, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, 1) + k) / np.sqrt(125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
+    xt, wp, bp = t_from_ncdhw(x), vec(w.ravel()), vec(b)
+    ld = (cout + 3) // 4 * 4 + 4
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    try:
+        for impl in (0, 23):
+            d.set_option("conv_impl", impl)
+            yt = t_empty(N, cout, D, H, W, ld=ld, fill=7.0)
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+            got = yt.numpy()
+            d.prof_enable(False)
+            assert ("conv_c1_mfma" in d.prof_report()) == (impl == 0)
+            assert rel_err(got, ref) < _conv_tol(125)
+            full = d.d2h(yt.ptr, (N, D, H, W, ld), np.float32)
+            assert np.all(full[..., cout:] == 7.0)          # the padding channels of the strided destination are untouched
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+
+
 FOLD_CASES = [
     # (Cin, Cout, k, pad, (N, D, H, W), kernel that must run)
     (32, 32, 5, 2, (2, 8, 16, 16), "conv_halo_wino4_k"),      # F(4,5) epilogue (fp32-MFMA kernels: wino_bf3 = 0 below)
