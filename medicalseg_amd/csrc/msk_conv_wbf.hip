@@ -505,12 +505,13 @@ __device__ __forceinline__ void frag_pos(int r, int& a, int& b) {
 // used by MR*6 (or MR) MFMAs), A fragments from the LDS halo tile (TD+K-1) x (TH+K-1) that the whole workgroup shares
 // and every one of the K*K taps re-reads.  The tile is filled by LDS-DMA (buffer_load ... lds, 16 B per lane), no registers.
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WM * WN * 64)
 wbf_gemm_k(GemmArgs a) {
-  static_assert(WM * WN == 4 && WM * MR * 32 == TD * TH, "tile shape");
+  static_assert((WM * WN == 4 || WM * WN == 2) && WM * MR * 32 == TD * TH, "tile shape");
+  constexpr int NT = WM * WN * 64;  // workgroup size: 4 wavefronts, or 2 with twice the row fragments each (half the B loads per MFMA)
   constexpr int NXI = nxi_of(K), T2 = K * K, PADK = (K - 1) / 2;
-  constexpr int HDt = TD + K - 1, HPt = TH + K - 1, NSLOT = HDt * HPt, NPL = 2 * NP, NIT = NPL * NSLOT, ROUNDS = (NIT + 255) / 256;
-  __shared__ uint4 lds[ROUNDS * 256];
+  constexpr int HDt = TD + K - 1, HPt = TH + K - 1, NSLOT = HDt * HPt, NPL = 2 * NP, NIT = NPL * NSLOT, ROUNDS = (NIT + NT - 1) / NT;
+  __shared__ uint4 lds[ROUNDS * NT];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -530,11 +531,11 @@ wbf_gemm_k(GemmArgs a) {
   const int n = b % a.N;
   const int ks = b / a.N;
 
-  // LDS-DMA: item it = r*256 + tid -> (plane pk = piece*2 + khalf, slot); slot = row*HPt + col of the halo tile
+  // LDS-DMA: item it = r*NT + tid -> (plane pk = piece*2 + khalf, slot); slot = row*HPt + col of the halo tile
   unsigned voff[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    int it = r * 256 + tid;
+    int it = r * NT + tid;
     if (it >= NIT) it = 0;  // the last round overshoots: re-read item 0 into the unused tail of the image
     const int pk = it / NSLOT, slot = it - pk * NSLOT;
     const int row = slot / HPt, col = slot - row * HPt;
@@ -572,7 +573,7 @@ wbf_gemm_k(GemmArgs a) {
     const unsigned vsoff = (unsigned)(kc * NPL * a.v_plane);
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * 256 + wave * 64), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * NT + wave * 64), 16,
                                                (int)voff[r], (int)vsoff, 0, 0);
     const unsigned ukc = (unsigned)kc * uchunk;
     uint4 bq[2][NP];
@@ -817,7 +818,7 @@ wbf_tout_k(ToutArgs a) {
 
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
 void launch_gemm(msk_ctx* ctx, const GemmArgs& a, long nblk) {
-  hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP>), dim3((unsigned)nblk), dim3(WM * WN * 64), 0, ctx->stream, a);
 }
 
 // tile variants {id, MR, WM, WN, TD, TH} by output channels (first = preferred)
@@ -825,15 +826,17 @@ struct Var { int id, MR, WM, WN, TD, TH; };
 // Measured (tools/bench_conv.py, 2 x 128^3 .. 2 x 16^3): the MR = 2 variants win everywhere (32ch@128^3 3.06 vs 3.13 ms,
 // 128ch@32^3 0.60 vs 0.85 ms, 256ch@16^3 0.32 vs 0.45 ms): smaller LDS tiles -> 3-4 workgroups per CU hide the
 // staging barriers; the MR = 4 variants halve the B-fragment traffic and stay selectable ("wbf_variant", K = 5 only).
-const Var kVars[6] = {{4, 2, 4, 1, 16, 16}, {0, 4, 4, 1, 16, 32},    // CN == 32
+const Var kVars[7] = {{4, 2, 4, 1, 16, 16}, {0, 4, 4, 1, 16, 32},    // CN == 32
                       {5, 2, 2, 2, 8, 16},  {1, 4, 2, 2, 16, 16},    // CN == 64
-                      {3, 2, 1, 4, 8, 8},   {2, 4, 1, 4, 8, 16}};    // CN % 128 == 0
+                      {3, 2, 1, 4, 8, 8},   {2, 4, 1, 4, 8, 16},     // CN % 128 == 0
+                      {6, 4, 2, 1, 16, 16}};                         // CN == 32, two wavefronts x 4 row fragments ("wbf_variant" 6)
 const Var* pick_variant(const msk_ctx* ctx, const WbfGeom& geo, int CN, int K) {
   int v0;
   if (CN == 32) v0 = 0;
   else if (CN == 64) v0 = 2;
   else if (CN >= 128 && CN % 128 == 0) v0 = 4;
   else return nullptr;
+  if (K == 5 && CN == 32 && ctx->wbf_variant == 6 && wbf_tile_ok(geo, 16, 16)) return &kVars[6];
   for (int c = v0; c < v0 + (K == 5 ? 2 : 1); ++c) {
     const Var& v = kVars[c];
     if (K == 5 && ctx->wbf_variant >= 0 && ctx->wbf_variant != v.id) continue;  // tuning knob "wbf_variant"
@@ -850,7 +853,8 @@ void launch_gemm_variant(msk_ctx* ctx, int variant, const GemmArgs& ga, long nbl
     case 5: launch_gemm<2, 2, 2, 8, 16, K, NP>(ctx, ga, nblk); break;
     default:
       if constexpr (K == 5) {
-        if (variant == 0) launch_gemm<4, 4, 1, 16, 32, 5, NP>(ctx, ga, nblk);
+        if (variant == 6) launch_gemm<4, 2, 1, 16, 16, 5, NP>(ctx, ga, nblk);
+        else if (variant == 0) launch_gemm<4, 4, 1, 16, 32, 5, NP>(ctx, ga, nblk);
         else if (variant == 1) launch_gemm<4, 2, 2, 16, 16, 5, NP>(ctx, ga, nblk);
         else launch_gemm<4, 1, 4, 8, 16, 5, NP>(ctx, ga, nblk);
       }
