@@ -43,10 +43,14 @@ def vnet_lu_layers(d, h, w):
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
 WINO_F45_MAC_RATIO = 0.4        # 1-D Winograd F(4,5): 8 multiplications per 4 outputs instead of 20
-BF16X3_PRODUCTS = 6             # bf16 products per fp32 product (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
+# 16-bit products per fp32 product: fp16 two-piece operands (option "conv_split" 2, the product default: hi*hi, hi*lo, lo*hi)
+# or exact bf16 three-piece operands (conv_split 3: hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi)
+SPLIT_PRODUCTS = {2: 3, 3: 6}
+GEMM_TAGS = {2: "wbf_gemm_h2_k", 3: "wbf_gemm_k"}
+WGRAD_TAGS = {2: "wbf_wgrad_h2_k", 3: "wbf_wgrad_k"}
 
 
-def lu_conv_work(n, d, h, w):
+def lu_conv_work(n, d, h, w, products=6):
     """Per training step, for the 5^3 LUConv layers: algorithmic FLOPs (SURVEY 8 d3's
     direct-convolution count, 2*125*Cin*Cout per output voxel), the FLOPs the bf16 matrix pipe EXECUTES for them in the
     three-stage Winograd F(4,5) x bf16x3 pipeline (0.4 x 6 = 2.4 bf16 MACs per algorithmic MAC), algorithmic HBM bytes
@@ -62,7 +66,7 @@ def lu_conv_work(n, d, h, w):
             e[0] += passes * f
             e[1] += passes * by
             e[2] += passes
-            e[3] += passes * f * WINO_F45_MAC_RATIO * BF16X3_PRODUCTS
+            e[3] += passes * f * WINO_F45_MAC_RATIO * products
     return work
 
 
@@ -257,9 +261,10 @@ def main():
     #   achieved = bf16 FLOPs the matrix pipe EXECUTES for it per second  (<= peak: a true fraction of the roof)
     #   algorithmic_tflops = SURVEY 8 d3's direct-convolution FLOPs per second (what the work is worth; the pipeline executes
     #   0.4 x 6 = 2.4 bf16 MACs per algorithmic MAC, so this can exceed the fp32 peak but never 2500 / 2.4)
-    work = lu_conv_work(B, S, S, S)
-    DOM = "wbf_gemm_k"
-    flops_step, bytes_step, launches_step, exec_step = work[DOM]
+    split = 2 if any(k.startswith("wbf_gemm_h2_k") for k in list(prof) + list(prof_serial)) else 3
+    work = lu_conv_work(B, S, S, S, SPLIT_PRODUCTS[split])
+    DOM = GEMM_TAGS[split]
+    flops_step, bytes_step, launches_step, exec_step = work["wbf_gemm_k"]
     line = _kernel_line(prof, DOM, flops_step, exec_step, args.steps) or {"achieved": 0.0, "frac": 0.0,
                                                                           "algorithmic_tflops": 0.0, "launches": 0,
                                                                           "avg_launch_ms": 0.0}
@@ -270,7 +275,8 @@ def main():
     if os.path.exists(tpath) and S == 128 and B == 2:   # PMC pass of this exact workload (tools/summarize_rocprof.py)
         try:
             tj = json.load(open(tpath))
-            ent = [v for k, v in tj.items() if k.startswith(DOM) and isinstance(v, dict)]   # all tile variants of the kernel
+            # all tile variants of the kernel template with this operand split (its last template argument)
+            ent = [v for k, v in tj.items() if k.startswith("wbf_gemm_k<") and k.rstrip(">").endswith(", %d" % split) and isinstance(v, dict)]
             nl = sum(v["launches"] for v in ent)
             traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent) / nl) if nl else None
             traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
@@ -285,7 +291,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": DOM, "achieved": line["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": line["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "launches": line["launches"], "avg_launch_ms": line["avg_launch_ms"],
-                "executed_bf16_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
+                "executed_16bit_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
                 "algorithmic_flop_per_launch": round(flops_step / max(launches_step, 1), 1),
                 "algorithmic_tflops": line["algorithmic_tflops"],
                 "algorithmic_speedup_vs_fp32_mfma_peak": round(line["algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -293,8 +299,9 @@ def main():
                 "kernel_share_of_step": round(kms / max(elapsed * 1e3, 1e-9), 4),  # of wall time (streams overlap)
                 "serialized": _kernel_line(prof_serial, DOM, flops_step, exec_step, 2,
                                            "same launches, weight-gradient stream disabled (untimed extra pass of 2 steps)"),
-                "wgrad_kernel": _kernel_line(prof_serial, "wbf_wgrad_k", work["wbf_wgrad_k"][0], work["wbf_wgrad_k"][3], 2,
-                                             "wbf_wgrad_k in the same untimed pass (it runs on the side stream in the timed region)"),
+                "operand_split": "fp16 x 2 pieces, 3 MFMAs per fp32 product" if split == 2 else "bf16 x 3 pieces, 6 MFMAs per fp32 product",
+                "wgrad_kernel": _kernel_line(prof_serial, WGRAD_TAGS[split], work["wbf_wgrad_k"][0], work["wbf_wgrad_k"][3], 2,
+                                             WGRAD_TAGS[split] + " in the same untimed pass (it runs on the side stream in the timed region)"),
                 # fraction of the step the EXECUTED work would take at the hardware peaks (bf16 pipe for the LUConv
                 # layers, fp32 MFMA peak for the remaining convolutions); <= 1
                 "step_executed_frac": round(t_floor / (ms_per_step * 1e-3), 4),
@@ -303,8 +310,9 @@ def main():
     out = {"metric": "3D-voxels/sec fwd+bwd, VNet 128^3 fp32", "value": round(value, 1), "unit": "voxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "dtype_note": "fp32 tensors end to end; the LUConv matrix products run as six bf16 MFMA products of exactly split "
-                         "fp32 operands with fp32 accumulation (fp32-class error, tests/test_gpu_wbf.py)",
+           "dtype_note": "fp32 tensors end to end; the LUConv matrix products run on the 16-bit matrix pipe with fp32 operands split "
+                         "into 16-bit pieces and fp32 accumulation (roofline.operand_split; fp32-class error against the float64 "
+                         "oracle, tests/test_gpu_wbf.py)",
            "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes (BASELINE configs[%d])"
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,

@@ -96,6 +96,9 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
  *   "prof_shapes" 0|1, "prof_only_halo" 0|1 (profile only the 5^3 halo-conv kernels), "poison_scratch" byte|-1;
  *   "direct_conv" 0|1 (1 = no Winograd kernels; also env MSEGK_DIRECT_CONV=1);
+ *   "conv_split" 3|2: operand split of the Winograd pipelines: 3 = three bf16 pieces (exact fp32 operands, six MFMAs per
+ *     product), 2 = two fp16 pieces with a scaled residual (22 significand bits, three MFMAs per product; gradients are
+ *     scaled by a power of two derived on the device, forward activations must stay below 3000 in magnitude);
  *   "bwd_fuse" -1|0|1|2 (msk_conv3d_bwd_bnact: auto | three calls | one dual transform | one transform per stream),
  *     "foldn_wgs" (workgroups per CU targeted by the D segmentation of conv_foldn_k, 0 = 2);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
@@ -154,7 +157,8 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd,
                          const float* gamma, msk_tensor dout, const float* sums_total, double M_total,
                          msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
-                         const void* xform /*nullable*/, void* ybuf /*nullable*/);
+                         const void* xform /*nullable*/, void* ybuf /*nullable*/,
+                         const float* maxes /*nullable: msk_affine_act_bwd_reduce_ex's, needed by the fused forms under "conv_split" 2*/);
 /* autograd of the above (core/train.py:139 loss.backward()):
  *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,
@@ -202,6 +206,12 @@ int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const flo
 int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
                               msk_tensor res, const float* alpha, const float* mean,
                               const float* invstd, msk_tensor dout, float* sums);
+/* the same; maxes (nullable, device float[2]) additionally receives max |du| and max |xhat| over the tensor -- the bound
+ * msk_conv3d_bwd_bnact needs to scale dy into fp16 range when option "conv_split" is 2.  Requires C % 4 == 0, voxel
+ * strides % 4 == 0 and 16-byte aligned tensors.                                                              */
+int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
+                                 msk_tensor res, const float* alpha, const float* mean,
+                                 const float* invstd, msk_tensor dout, float* sums, float* maxes /*nullable*/);
 /* backward pass 2: dx = BN-backward(du) and dres (+)= du.
  *   bn_mode 0: no BN (dx = du); 1: training BN (uses sums, total count M over all
  *   ranks); 2: eval BN (dx = scale*du).  dres.p NULL -> skipped; dres_acc adds.   */

@@ -23,6 +23,7 @@ struct GConv {
   float* stats;       // msk_conv3d_fwd_ex: BatchNorm statistics (mean[CN], M2[CN]) of dst wanted; a kernel that produced them in
                       // its epilogue sets ctx->stats_fused, otherwise the caller runs msk_bn_stats
   void* xform;        // msk_conv3d_fwd_ex: caller-owned buffer that receives the transformed input (msk_conv3d_xform_bytes)
+  const float* in_amax;  // NP = 2 pipelines: device scalar bounding max |src| (scales the source transform, undone in the output stage); NULL = unscaled
   const struct WbfBnBwd* fuse;  // msk_conv3d_bwd_bnact: src is not read; the input transform evaluates dy from (y, dout) on the fly
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
@@ -39,6 +40,7 @@ struct WGrad {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   const void* xform;  // msk_conv3d_wgrad_ex: transformed A written by msk_conv3d_fwd_ex for the same tensor, or null
   const void* yform;  // msk_conv3d_bwd_bnact: transformed B (A dy) already written by the dual transform, or null
+  const float* y_amax;  // NP = 2: device scalar bounding max |B| when yform is given
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
@@ -89,5 +91,11 @@ int msk_wgrad_wino(msk_ctx* ctx, const WGrad& g);
 
 // split-K reducer shared by both wgrad implementations:
 // dw[cb][ca][tap] (+)= sum_s P[s][tap][ca][cb]
+// max |x| of a tensor into dst (device float) or, dst == NULL, into a fresh device scalar of the context's ring (NP = 2
+// pipelines); returns the scalar's address, NULL on error
+const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels, float* dst = nullptr);
+// n zeroed device scalars from the same ring (valid until ~1000 later requests)
+float* msk_scalar_slots(msk_ctx* ctx, int n);
+const float* msk_bn_bwd_bound(msk_ctx* ctx, int C, const float* scale, const float* sums, double M_total, const float* maxes);
 int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
                      int accumulate);

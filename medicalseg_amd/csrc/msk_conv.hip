@@ -704,14 +704,15 @@ size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, 
 int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
                          msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
-                         int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf) {
+                         int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
   MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
   MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
   MSK_REQUIRE(ctx, dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
                        dy_scratch.c == y.c, "dy_scratch must match y");
   // ---- fused form: conditions under which BOTH gradient pipelines take pre-written transforms
-  bool fused = ctx->bwd_fuse != 0 && ybuf != nullptr && xform != nullptr && dx.p != nullptr && ctx->wbf && !ctx->no_winograd && ctx->conv_impl == 0 &&
+  const bool split2 = wbf_pieces(ctx, cd.kd) == 2;
+  bool fused = ctx->bwd_fuse != 0 && (!split2 || maxes != nullptr) && ybuf != nullptr && xform != nullptr && dx.p != nullptr && ctx->wbf && !ctx->no_winograd && ctx->conv_impl == 0 &&
                x.c == y.c && y.ld % 4 == 0 && dout.ld % 4 == 0 && (((uintptr_t)y.p) & 15) == 0 && (((uintptr_t)dout.p) & 15) == 0;
   const size_t per = (size_t)x.d * x.h * x.w * (x.ld > y.ld ? x.ld : y.ld) * sizeof(float);
   if (per > 0 && (size_t)x.n > kChunkBytes / per) fused = false;  // chunked batches
@@ -739,6 +740,10 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     bn.invM = (float)(1.0 / M_total);
     bn.Y = (char*)ybuf;
     bn.y_xi = (long)(y_bytes / ((cd.kd == 5) ? 8 : 6));
+    if (split2) {  // fp16 pieces: dy is scaled by a power of two from a device-side bound of its maximum
+      bn.amax = msk_bn_bwd_bound(ctx, y.c, scale, sums_total, M_total, maxes);
+      if (!bn.amax) return -1;
+    }
     // form 1 (one kernel writes both transforms; least traffic: best without a side stream) or form 2 (each stream's
     // transform evaluates dy itself: the main stream -- the critical path -- moves 20 instead of 28 B per element, the
     // weight-gradient stream 20 instead of 16).  Option "bwd_fuse": 0 = three calls, 1 / 2 = force a form, -1 = auto.
@@ -769,6 +774,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
       if (r == 1) {
         msk_side_scope side(ctx, side_on);
         gw.yform = ybuf;
+        gw.y_amax = bn.amax;
         const int rw = msk_wgrad_wbf(ctx, gw);
         if (rw < 0) return rw;
         if (rw == 0) return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_bwd_bnact", "weight-gradient pipeline declined a problem its plan accepted");

@@ -70,7 +70,8 @@ __device__ __forceinline__ double g_coef(int K, int xi, int kw) {
 template <int K, int NP>
 __global__ void __launch_bounds__(256)
 wbf_pack_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int tsd, int tsh,
-                   int tsw, unsigned short* __restrict__ out, long xi_stride /*elements*/) {
+                   int tsw, unsigned short* __restrict__ out, long xi_stride /*elements*/, const float* __restrict__ w_amax) {
+  const double wsc = NP == 2 ? (double)wbf_scale_of(w_amax) : 1.0;  // NP = 2: power-of-two scale into fp16 range
   constexpr int NXI = nxi_of(K), T2 = K * K, T3 = K * K * K;
   // one thread per (tap row, k, n): reads its K kw taps once, writes NXI x NP values
   const long total = (long)T2 * KC * 16 * CN;
@@ -111,6 +112,11 @@ wbf_pack_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip
         o[0] = hi;
         o[pstep] = mid;
         o[2 * pstep] = lo;
+      } else if (NP == 2) {
+        const double v = s_ * wsc;
+        const _Float16 h = (_Float16)v;
+        o[0] = __builtin_bit_cast(unsigned short, h);
+        o[pstep] = __builtin_bit_cast(unsigned short, (_Float16)(v - (double)(float)h));
       } else {
         o[0] = __builtin_bit_cast(unsigned short, (_Float16)(float)s_);
       }
@@ -209,6 +215,8 @@ wbf_tin_k(WbfTinArgs a) {
   const float* xb = a.src + ((long)n * a.svn + (long)d * a.svd + (long)h * a.svh) * a.sld + cg * 8;
   const long wstep = (long)a.svw * a.sld;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float sc2 = NP == 2 ? wbf_scale_of(a.amax) : 1.f;
+  (void)sc2;
 
   float4 win[WIN][2];
 #pragma unroll
@@ -262,6 +270,14 @@ wbf_tin_k(WbfTinArgs a) {
         *reinterpret_cast<uint4*>(o) = hi;
         *reinterpret_cast<uint4*>(o + 2 * plane) = mid;
         *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
+      } else if (NP == 2) {
+        uint4 hi, lo;
+        wbf_split2h_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
+        wbf_split2h_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
+        wbf_split2h_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
+        wbf_split2h_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
+        *reinterpret_cast<uint4*>(o) = hi;
+        *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
       } else {
         uint4 hv;
         hv.x = pack_f16_pair(v[0][xi], v[1][xi]);
@@ -299,10 +315,11 @@ struct DualArgs {
   int C;
   char* Y;
   long y_xi;
+  const float* amax;
 };
 
 template <int K, int NP>
-__device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8][8], int xi) {
+__device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8][8], int xi, float sc2) {
   if (NP == 3) {
     uint4 hi, mid, lo;
     wbf_split3_pair(v[0][xi], v[1][xi], hi.x, mid.x, lo.x);
@@ -312,6 +329,14 @@ __device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8
     *reinterpret_cast<uint4*>(o) = hi;
     *reinterpret_cast<uint4*>(o + 2 * plane) = mid;
     *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
+  } else if (NP == 2) {
+    uint4 hi, lo;
+    wbf_split2h_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
+    wbf_split2h_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
+    wbf_split2h_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
+    wbf_split2h_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
+    *reinterpret_cast<uint4*>(o) = hi;
+    *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
   } else {
     uint4 hv;
     hv.x = pack_f16_pair(v[0][xi], v[1][xi]);
@@ -360,6 +385,8 @@ wbf_tin_dual_k(DualArgs b) {
   const float* gb = b.dout + vox0 * b.dld + cg * 8;
   const long xstep = (long)a.svw * b.yld, gstep = (long)a.svw * b.dld;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float sc2 = NP == 2 ? wbf_scale_of(b.amax) : 1.f;
+  (void)sc2;
 
   // dy of 8 channels at logical position w (zero outside the volume)
   auto dy_at = [&](int w, float4& o0, float4& o1) {
@@ -412,7 +439,7 @@ wbf_tin_dual_k(DualArgs b) {
         tin_transform<0, K>(ww, v[q * 4 + 3]);
       }
 #pragma unroll
-      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(vb + t * tstep + (long)xi * a.v_xi, plane, v, xi);
+      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(vb + t * tstep + (long)xi * a.v_xi, plane, v, xi, sc2);
     }
     if (WY) {
       // A dy of the tile's own positions 4t .. 4t+3 = window slots PADW .. PADW+3
@@ -432,7 +459,7 @@ wbf_tin_dual_k(DualArgs b) {
         tin_transform<1, K>(ww, v[q * 4 + 3]);
       }
 #pragma unroll
-      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(yb2 + t * tstep + (long)xi * b.y_xi, plane, v, xi);
+      for (int xi = 0; xi < NXI; ++xi) store_xi<K, NP>(yb2 + t * tstep + (long)xi * b.y_xi, plane, v, xi, sc2);
     }
 #pragma unroll
     for (int j = 0; j < KEEP; ++j) {
@@ -633,6 +660,14 @@ wbf_gemm_k(GemmArgs a) {
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP / 2]);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+      } else if (NP == 2) {
+        // small terms first: lo*hi, hi*lo, hi*hi
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
       } else {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
@@ -671,6 +706,9 @@ struct ToutArgs {
   const float* bias;
   const float* prelu;
   int accumulate;
+  const float* in_amax; // NP = 2: the device scalars the input transform and the weight pack scaled by (wbf_scale_of)
+  const float* w_amax;
+  int scaled;           // NP = 2
   float* stat_partial;  // STATS: per-block BatchNorm records [gridDim.x][CN][3] = (n, mean, M2) of the stored values
 };
 
@@ -718,6 +756,7 @@ wbf_tout_k(ToutArgs a) {
   const int c4n = a.CN >> 2;
   float sk[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   float cnt = 0.f;
+  const float osc = a.scaled ? 1.f / (wbf_scale_of(a.in_amax) * wbf_scale_of(a.w_amax)) : 1.f;  // power of two: exact
   const long total = (long)a.N * a.T * a.LD * a.LH * c4n;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
@@ -755,7 +794,7 @@ wbf_tout_k(ToutArgs a) {
     for (int i = 0; i < 4; ++i) {
       if (4 * t + i < a.LW) {
         float4* op = reinterpret_cast<float4*>(o + (long)i * a.dvw * a.dld);
-        float4 r = make_float4(yx[i] + bv.x, yy[i] + bv.y, yz[i] + bv.z, yw[i] + bv.w);
+        float4 r = make_float4(fmaf(yx[i], osc, bv.x), fmaf(yy[i], osc, bv.y), fmaf(yz[i], osc, bv.z), fmaf(yw[i], osc, bv.w));
         if (a.accumulate) {
           const float4 e = *op;
           r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;
@@ -903,11 +942,21 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   const size_t s_bytes = fuse_stats ? (size_t)tout_blocks * g.CN * 3 * sizeof(float) : 0;
   char* wsp = (char*)msk_workspace(ctx, (g.xform ? 0 : v_bytes) + m_bytes + s_bytes + 256);
   if (!wsp) return -1;
-  char* V = g.xform ? (char*)g.xform : wsp;
+  char* V = g.xform ? (char*)g.xform + kWbfXformHeader : wsp;
   float* M = (float*)(g.xform ? wsp : wsp + v_bytes);
   float* SP = (float*)((char*)M + m_bytes);
   char* U = (char*)msk_workspace2(ctx, NXI * u_xi);
   if (!U) return -1;
+  // NP = 2: every operand is scaled into fp16 range by a power of two derived on the device from (a bound of) its maximum:
+  // the source tensor (kept in the xform header for the weight gradient), the weights
+  const float *in_amax = nullptr, *w_amax = nullptr;
+  if (NP == 2) {
+    if (g.fuse) in_amax = g.fuse->amax;
+    else if (g.in_amax) in_amax = g.in_amax;
+    else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
+    w_amax = msk_absmax(ctx, w_canon, 4, 4, ((long)K * K * K * g.CK * g.CN + 3) / 4);
+    if (!in_amax || !w_amax) return -1;
+  }
 
   {
     msk_launch_scope ls(ctx, "wbf_pack_weights");
@@ -915,7 +964,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
     hipLaunchKernelGGL((wbf_pack_weights_k<K, NP>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
                        g.transposed ? 1 : 0, g.CK, g.CN, KC, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], (unsigned short*)U,
-                       (long)(u_xi / 2));
+                       (long)(u_xi / 2), w_amax);
     MSK_LAUNCH_CHECK(ctx);
   }
   {
@@ -924,6 +973,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     ta.svn = (long)g.DD * g.DH * g.DW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
     ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CK; ta.KC = KC;
     ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
+    ta.amax = in_amax;
     if (g.fuse) {
       if (msk_wbf_transform_dual(ctx, K, NP, ta, *g.fuse, true) != 0) return -1;
       // one-kernel form: the weight gradient (side stream) may start as soon as both transforms are written: fork here,
@@ -942,7 +992,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     ga.N = g.N; ga.T = T; ga.KC = KC; ga.CN = g.CN; ga.LD = LD; ga.LH = LH; ga.DP = DP; ga.HP = HP;
     ga.tiles_d = tiles_d; ga.tiles_h = tiles_h; ga.ngrp = ngrp; ga.ksplit = ksplit; ga.kc_per = kc_per;
     ga.v_xi = (long)v_xi; ga.v_plane = (long)v_plane; ga.u_xi = (long)u_xi; ga.m_xi = (long)m_xi;
-    const char* tag = NP == 3 ? "wbf_gemm_k" : "wbf_gemm_f16_k";
+    const char* tag = NP == 3 ? "wbf_gemm_k" : (NP == 2 ? "wbf_gemm_h2_k" : "wbf_gemm_f16_k");
     if (ctx->prof && ctx->prof_shapes) {
       char buf[200];
       snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,k=%d,ks=%d]", tag, g.CK, g.CN, g.N, g.DD, g.DH, g.DW, K, ksplit);
@@ -960,6 +1010,9 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     oa.dvn = (long)g.DD * g.DH * g.DW; oa.dvd = vstr[pm[0]]; oa.dvh = vstr[pm[1]]; oa.dvw = vstr[pm[2]];
     oa.bias = g.bias; oa.prelu = g.prelu; oa.accumulate = g.accumulate;
     oa.stat_partial = SP;
+    oa.in_amax = in_amax;
+    oa.w_amax = w_amax;
+    oa.scaled = NP == 2 ? 1 : 0;
     {
       msk_launch_scope ls(ctx, "wbf_tout_k");
       if (fuse_stats) hipLaunchKernelGGL((wbf_tout_k<true, K>), dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);
@@ -984,9 +1037,15 @@ int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& t
   const dim3 grid((unsigned)(pblocks * (ta.CK / 32)), ta.N);
   msk_launch_scope ls(ctx, mode == 0 ? "wbf_tin_k" : "wbf_ty_k");
 #define WBF_TIN_LAUNCH(M_, K_, P_) hipLaunchKernelGGL((wbf_tin_k<M_, K_, P_>), grid, dim3(256), 0, ctx->stream, ta)
-  if (K == 5) {
+  if (K == 5 && NP == 2) {
+    if (mode == 0) WBF_TIN_LAUNCH(0, 5, 2);
+    else WBF_TIN_LAUNCH(1, 5, 2);
+  } else if (K == 5) {
     if (mode == 0) WBF_TIN_LAUNCH(0, 5, 3);
     else WBF_TIN_LAUNCH(1, 5, 3);
+  } else if (NP == 2) {
+    if (mode == 0) WBF_TIN_LAUNCH(0, 3, 2);
+    else WBF_TIN_LAUNCH(1, 3, 2);
   } else if (NP == 3) {
     if (mode == 0) WBF_TIN_LAUNCH(0, 3, 3);
     else WBF_TIN_LAUNCH(1, 3, 3);
@@ -1005,7 +1064,7 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   da.t.lane_map = 1;
   da.y = bn.y; da.yld = bn.yld; da.dout = bn.dout; da.dld = bn.dld;
   da.scale = bn.scale; da.shift = bn.shift; da.alpha = bn.alpha; da.mean = bn.mean; da.invstd = bn.invstd; da.sums = bn.sums;
-  da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi;
+  da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax;
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;
@@ -1017,7 +1076,9 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
     else if (write_v) hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, true, false>), grid, dim3(256), 0, ctx->stream, da);        \
     else hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, false, true>), grid, dim3(256), 0, ctx->stream, da);                     \
   } while (0)
-  if (K == 5) WBF_DUAL_LAUNCH(5, 3);
+  if (K == 5 && NP == 2) WBF_DUAL_LAUNCH(5, 2);
+  else if (K == 5) WBF_DUAL_LAUNCH(5, 3);
+  else if (NP == 2) WBF_DUAL_LAUNCH(3, 2);
   else if (NP == 3) WBF_DUAL_LAUNCH(3, 3);
   else WBF_DUAL_LAUNCH(3, 1);
 #undef WBF_DUAL_LAUNCH
@@ -1034,7 +1095,7 @@ size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, i
   if (c < 32 || c % 32 || !wbf_pick_geom(d, h, w, mtd, mth, &geo)) return 0;
   const size_t v_xi = (size_t)n * geo.T * (c / 16) * 2 * NP * geo.DP * geo.HP * 16;
   if (v_xi >= 0xFFFFFFF0ull) return 0;
-  return (size_t)nxi_of(K) * v_xi;
+  return (size_t)nxi_of(K) * v_xi + kWbfXformHeader;
 }
 // the same, 0 unless msk_gconv_wino_bf3 will run the forward convolution c -> cout of that tensor
 size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K) {
@@ -1065,8 +1126,10 @@ static int wino_bf3_impl(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   if (!wbf_pick_geom(g.DD, g.DH, g.DW, mtd, mth, &geo)) return 0;
   const Var* bv = pick_variant(ctx, geo, g.CN, K);
   if (!bv) return 0;
-  if (K == 5) return run_pipeline<5, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
-  if (wbf_pieces(ctx, 3) == 3) return run_pipeline<3, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
+  const int np = wbf_pieces(ctx, K);
+  if (K == 5) return np == 2 ? run_pipeline<5, 2>(ctx, g, w_canon, A, B, swap, geo, bv, dry) : run_pipeline<5, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
+  if (np == 3) return run_pipeline<3, 3>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
+  if (np == 2) return run_pipeline<3, 2>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
   return run_pipeline<3, 1>(ctx, g, w_canon, A, B, swap, geo, bv, dry);
 }
 int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {

@@ -121,6 +121,9 @@ int msk_ctx_create(int device, msk_ctx** out) {
     ctx->no_winograd = e && e[0] && e[0] != '0';
     const char* f = getenv("MSEGK_WBF");
     if (f && f[0] == '0') ctx->wbf = false;
+    const char* sp = getenv("MSEGK_CONV_SPLIT");  // operand split of the Winograd pipelines (option "conv_split")
+    if (sp && sp[0] == '2') ctx->conv_split = 2;
+    if (sp && sp[0] == '3') ctx->conv_split = 3;
   }
   MSK_CHECK_HIP(ctx, hipSetDevice(device));
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -153,6 +156,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->ws_side) hipFree(ctx->ws_side);
+  if (ctx->scalar_ring) hipFree(ctx->scalar_ring);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
   for (int b = 0; b < 2; ++b) {
     if (ctx->stage_ev[b]) hipEventDestroy(ctx->stage_ev[b]);
@@ -309,7 +313,7 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     return 0;
   }
   if (strcmp(key, "prof_only_halo") == 0) {  // per-kernel profile restricted to the MFMA halo convs (bench.py roofline)
-    snprintf(ctx->prof_prefix, sizeof(ctx->prof_prefix), "%s", value ? (ctx->wbf ? "wbf_gemm_k" : "conv_halo_") : "");
+    snprintf(ctx->prof_prefix, sizeof(ctx->prof_prefix), "%s", value ? (ctx->wbf ? "wbf_gemm_" : "conv_halo_") : "");
     return 0;
   }
   if (strcmp(key, "wgrad_async_max_m") == 0) {
@@ -334,6 +338,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "direct_conv") == 0) {  // 1 = no Winograd kernels (same as env MSEGK_DIRECT_CONV=1)
     ctx->no_winograd = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "conv_split") == 0) {
+    ctx->conv_split = value == 2 ? 2 : 3;
     return 0;
   }
   if (strcmp(key, "bwd_fuse") == 0) {

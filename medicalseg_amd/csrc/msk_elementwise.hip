@@ -418,6 +418,12 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
   }
 }
 
+__device__ __forceinline__ void wave_atomic_max_f(unsigned* slot, float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
 // float4 variant: a thread owns one channel QUAD and every VL-th voxel (a wavefront reads 1 KiB
 // contiguous), two voxels in flight per iteration.  The scalar kernel above moved 4 bytes per
 // lane per load and reached ~1.2 TB/s on the 128^3 layers.
@@ -432,9 +438,11 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
                            const float* __restrict__ alpha, const float* __restrict__ mean,
                            const float* __restrict__ invstd, const float* __restrict__ dout, int ldd, long voxels,
                            int C, int QCB, int VL, float* __restrict__ da, int ldda, float* __restrict__ db,
-                           int lddb, int db_acc, float* __restrict__ partial /*[nb][NQ][4*QCB]*/) {
+                           int lddb, int db_acc, float* __restrict__ partial /*[nb][NQ][4*QCB]*/,
+                           unsigned* __restrict__ maxes /*[2] or null: max |du|, max |xhat| (bits of non-negative floats)*/) {
   __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
   constexpr int NQ = JOIN ? 1 : 3;
+  float m_du = 0.f, m_xh = 0.f;
   __shared__ float sh[NQ * 4][kThreads];
   const int t = threadIdx.x;
   const int cq = t % QCB, vl = t / QCB;
@@ -469,8 +477,11 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
         }
         du[j] = g;
         if (!JOIN) {
+          const float xh = (xv[j] - mu[j]) * is[j];
           s_du[j] += g;
-          s_dux[j] = fmaf(g, (xv[j] - mu[j]) * is[j], s_dux[j]);
+          s_dux[j] = fmaf(g, xh, s_dux[j]);
+          m_du = fmaxf(m_du, fabsf(g));
+          m_xh = fmaxf(m_xh, fabsf(xh));
         }
       }
       if (JOIN) {
@@ -504,6 +515,10 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
     if (v < v1)
       body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
            load_res(v));
+  }
+  if (!JOIN && maxes) {  // wave-uniform
+    wave_atomic_max_f(maxes, m_du);
+    wave_atomic_max_f(maxes + 1, m_xh);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -970,10 +985,20 @@ int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const flo
 int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
                               const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
                               float* sums) {
+  return msk_affine_act_bwd_reduce_ex(ctx, x, scale, shift, res, alpha, mean, invstd, dout, sums, nullptr);
+}
+
+int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                                 const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
+                                 float* sums, float* maxes) {
   MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
   const long voxels = msk_voxels(x);
   const bool v4 = x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x) && vec4_ok(dout) &&
                   (res.p == nullptr || res.c != x.c || vec4_ok(res));
+  if (maxes) {
+    MSK_REQUIRE(ctx, v4, "maxes are produced by the float4 kernel only: channel count and strides multiples of 4, 16-byte aligned tensors");
+    MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * sizeof(float), ctx->stream));
+  }
   if (v4) {
     const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
     const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
@@ -984,7 +1009,7 @@ int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, co
       hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<false>, dim3(nb), dim3(kThreads), 0, ctx->stream,
                          (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean, invstd,
                          (const float*)dout.p, dout.ld, voxels, x.c, QCB, VL, (float*)nullptr, 0, (float*)nullptr, 0, 0,
-                         partial);
+                         partial, (unsigned*)maxes);
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "sums_merge");
@@ -1067,7 +1092,7 @@ int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha
     hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<true>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p,
                        a.ld, (const float*)nullptr, (const float*)nullptr, (const float*)b.p, b.ld, b.c, alpha,
                        (const float*)nullptr, (const float*)nullptr, (const float*)dout.p, dout.ld, voxels, a.c, QCB, VL,
-                       (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial);
+                       (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial, (unsigned*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
   }
   msk_launch_scope ls(ctx, "sums_merge");
@@ -1152,3 +1177,118 @@ int msk_argmax_c(msk_ctx* ctx, msk_tensor x, int32_t* out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// device scalars for the fp16 two-piece pipelines (msk_wbf.h, NP = 2): max |x| of a tensor
+// ---------------------------------------------------------------------------
+namespace {
+// one atomic per BLOCK (thousands of wavefronts hammering one address took 0.16 ms per launch)
+__device__ __forceinline__ void block_atomic_max(unsigned* slot, float m) {
+  __shared__ float shm[kThreads / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, shm[i]);
+    if (m > 0.f) atomicMax(slot, __float_as_uint(m));  // non-negative floats order like their bits
+  }
+}
+__global__ void __launch_bounds__(kThreads)
+absmax_k(const float* __restrict__ x, int ld, int C, long voxels, unsigned* __restrict__ slot) {
+  float m = 0.f;
+  if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
+    const int c4 = C >> 2;
+    const long total = voxels * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long v = i / c4;
+      const int c = (int)(i - v * c4) * 4;
+      const float4 q = *reinterpret_cast<const float4*>(x + v * ld + c);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+  } else {
+    const long total = voxels * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long v = i / C;
+      m = fmaxf(m, fabsf(x[v * ld + (i - v * C)]));
+    }
+  }
+  block_atomic_max(slot, m);
+}
+// amax[0] = bound of max |dy| of the BatchNorm/PReLU backward (WbfBnBwd):
+//   |dy| <= max_c |scale_c| * (max|du| + max_c |s1_c| + max|xhat| * max_c |s2_c|)
+__global__ void bn_bwd_bound_k(int C, const float* __restrict__ scale, const float* __restrict__ sums, float invM,
+                               const float* __restrict__ maxes /*[2] = max|du|, max|xhat|*/, float* __restrict__ out) {
+  __shared__ float sh[3][64];
+  float a = 0.f, b = 0.f, c_ = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) {
+    a = fmaxf(a, fabsf(scale[c]));
+    b = fmaxf(b, fabsf(sums[c] * invM));
+    c_ = fmaxf(c_, fabsf(sums[C + c] * invM));
+  }
+  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c_;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 64; ++i) {
+      a = fmaxf(a, sh[0][i]); b = fmaxf(b, sh[1][i]); c_ = fmaxf(c_, sh[2][i]);
+    }
+    out[0] = a * (maxes[0] + b + maxes[1] * c_);
+  }
+}
+}  // namespace
+
+float* msk_scalar_slots(msk_ctx* ctx, int n) {
+  constexpr int kRing = 1024;
+  if (!ctx->scalar_ring) {
+    if (hipMalloc((void**)&ctx->scalar_ring, kRing * sizeof(float)) != hipSuccess) {
+      msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMalloc failed");
+      return nullptr;
+    }
+  }
+  if (ctx->scalar_next + n > kRing) ctx->scalar_next = 0;
+  float* p = ctx->scalar_ring + ctx->scalar_next;
+  ctx->scalar_next += n;
+  if (hipMemsetAsync(p, 0, n * sizeof(float), ctx->stream) != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMemsetAsync failed");
+    return nullptr;
+  }
+  return p;
+}
+
+const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels, float* dst) {
+  float* slot = dst;
+  if (slot) {
+    if (hipMemsetAsync(slot, 0, sizeof(float), ctx->stream) != hipSuccess) {
+      msk_fail(ctx, __FILE__, __LINE__, "absmax", "hipMemsetAsync failed");
+      return nullptr;
+    }
+  } else {
+    slot = msk_scalar_slots(ctx, 1);
+  }
+  if (!slot) return nullptr;
+  msk_launch_scope ls(ctx, "absmax");
+  long ab = (voxels * C / 4 + kThreads - 1) / kThreads;
+  if (ab > 4L * ctx->num_cu) ab = 4L * ctx->num_cu;
+  if (ab < 1) ab = 1;
+  hipLaunchKernelGGL(absmax_k, dim3((unsigned)ab), dim3(kThreads), 0, ctx->stream, x, ld, C, voxels,
+                     (unsigned*)slot);
+  if (hipGetLastError() != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "absmax", "kernel launch");
+    return nullptr;
+  }
+  return slot;
+}
+
+// bound of max |dy| for msk_conv3d_bwd_bnact's NP = 2 form from the maxima msk_affine_act_bwd_reduce_ex left in maxes[2]
+const float* msk_bn_bwd_bound(msk_ctx* ctx, int C, const float* scale, const float* sums, double M_total, const float* maxes) {
+  float* slot = msk_scalar_slots(ctx, 1);
+  if (!slot) return nullptr;
+  msk_launch_scope ls(ctx, "bn_bwd_bound");
+  hipLaunchKernelGGL(bn_bwd_bound_k, dim3(1), dim3(64), 0, ctx->stream, C, scale, sums, (float)(1.0 / M_total), maxes, slot);
+  if (hipGetLastError() != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "bn_bwd_bound", "kernel launch");
+    return nullptr;
+  }
+  return slot;
+}
+

@@ -19,6 +19,37 @@ __device__ __forceinline__ void wbf_split3_pair(float x0, float x1, unsigned& hi
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
+// NP = 2: fp16 two-piece split  x*s = h + l,  h = fp16(x*s), l = fp16(x*s - h)  (22 significand bits where l is a normal
+// fp16 number).  A product then is  a*b = ha*hb + ha*lb + la*hb + O(2^-22):  THREE fp16 MFMAs into the SAME fp32 accumulator
+// instead of six bf16 ones.  fp16's exponent range is managed per TENSOR: s is a power of two derived on the device from
+// (an upper bound of) the tensor's max |value| (wbf_scale_of: the max lands at 2^9..2^10, the Winograd transforms amplify by
+// <= 21.25, fp16 overflows at 2^16); elements more than 2^12 below the max get a subnormal l, i.e. an ABSOLUTE error of
+// 2^-25 in scaled units = 2^-35 of the tensor's max -- far below the fp32 rounding of the sums they enter.  The results are
+// divided by the product of the operand scales in the output stage (exact: powers of two).
+typedef _Float16 wbf_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wbf_split2h_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  f32x2 x = {x0, x1};
+  const wbf_f16x2 h = __builtin_convertvector(x, wbf_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  f32x2 r = {x0 - hf.x, x1 - hf.y};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wbf_f16x2));
+}
+// A caller-owned transformed-input buffer (msk_conv3d_fwd_ex's xform) starts with a header of kWbfXformHeader bytes whose
+// first float is the max |x| the transform was scaled by (NP = 2; unused otherwise): the weight gradient that consumes the
+// buffer later undoes that scale.
+constexpr int kWbfXformHeader = 256;
+// Power-of-two scale of a tensor from (an upper bound of) its max |value| on the DEVICE (no host round trip): amax * scale
+// lands in [2^9, 2^10), the Winograd transforms amplify by <= 21.25, fp16 overflows at 65504 = 2^16.  NULL / 0 / inf -> 1.
+__device__ __forceinline__ float wbf_scale_of(const float* amax) {
+  if (!amax) return 1.f;
+  const float a = *amax;
+  if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 10 - e);
+}
+
 // Stage 1 (wbf_tin_k<MODE>): MODE 0  V = B^T x  (8 transformed values per 4 inputs, sliding 8-wide window along w)
 //                            MODE 1  Y = A dy   (8 values per 4 output gradients: the adjoint of the output transform)
 // both split into three bf16 pieces and written as V[xi][n][t][kc][piece][khalf][DP][HP] (16-byte slots of 8 channels,
@@ -33,6 +64,7 @@ struct WbfTinArgs {
   char* V;
   long v_xi;  // bytes between xi planes
   int lane_map;
+  const float* amax;  // NP = 2: device scalar, (bound of) max |value| of the source tensor -> wbf_scale_of; NULL = unscaled
 };
 // K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
 int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& a);
@@ -50,12 +82,14 @@ struct WbfBnBwd {
   const float *scale, *shift, *alpha, *mean, *invstd, *sums;  // [C] each, sums [2C]
   float invM;
   char* Y;            // second output: the A dy transform in the layout of the first (null: not written)
+  const float* amax;  // NP = 2: device scalar bounding max |dy| (msk_bn_bwd_bound), else NULL
   long y_xi;
 };
 // writes B^T dy to a.V when write_v and A dy to bn.Y when that is non-null
 int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& a, const WbfBnBwd& bn, bool write_v);
 // pieces per value for a K^3 convolution under the context's precision option ("conv_fp16": fp16 operands for K = 3)
-inline int wbf_pieces(const msk_ctx* ctx, int K) { return (K == 3 && ctx->conv_fp16) ? 1 : 3; }
+// and "conv_split" 2: the fp16 two-piece split above)
+inline int wbf_pieces(const msk_ctx* ctx, int K) { return (K == 3 && ctx->conv_fp16) ? 1 : (ctx->conv_split == 2 ? 2 : 3); }
 
 // Geometry shared by the forward / data-gradient pipeline and the weight gradient (so that V = B^T x written by the forward
 // pass can be handed to the weight gradient, msk_conv3d_fwd_ex / msk_conv3d_wgrad_ex): which tensor axes play the

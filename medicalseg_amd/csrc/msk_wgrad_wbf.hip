@@ -178,6 +178,10 @@ wbf_wgrad_k(WgArgs a) {
               WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][0]);
               WGW_MFMA(acc[j][c], aq[0], bq[c][NP / 2]);
               WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
+            } else if (NP == 2) {
+              WGW_MFMA_H(acc[j][c], aq[NP - 1], bq[c][0]);  // small terms first
+              WGW_MFMA_H(acc[j][c], aq[0], bq[c][NP - 1]);
+              WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
             } else {
               WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
             }
@@ -207,7 +211,8 @@ wbf_wgrad_k(WgArgs a) {
 template <int K>
 __global__ void __launch_bounds__(256)
 wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int ncob, int CA, int CB, int tsd, int tsh,
-                   int tsw, float* __restrict__ dw, int accumulate) {
+                   int tsw, float* __restrict__ dw, int accumulate, const float* __restrict__ y_amax,
+                   const float* __restrict__ v_amax, int scaled) {
   constexpr int NXI = wg_nxi(K), T2 = K * K, T3 = K * K * K;
   const double G5[8][5] = {{-1, 0, 0, 0, 0},
                            {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -220,6 +225,7 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
   const double G3[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
   __shared__ double sh[8][8][32];  // [sub * NS + slice][xi][cb lane]
+  const double oscale = scaled ? 1.0 / ((double)wbf_scale_of(y_amax) * (double)wbf_scale_of(v_amax)) : 1.0;  // NP = 2: the operands' power-of-two scales
   // NS = slices of the split-K range per output group (1, 2, 4 or 8: <= ksplit), SUB = 8 / NS groups per block
   const int lane = threadIdx.x & 31, w8 = threadIdx.x >> 5, slice = w8 % NS, sub = w8 / NS, SUB = 8 / NS;
   const long groups = (long)T2 * CA * ncob;         // (row, ca, cob)
@@ -258,6 +264,7 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
         double v = 0.0;
 #pragma unroll
         for (int xi = 0; xi < NXI; ++xi) v += (K == 5 ? G5[xi][kw] : G3[xi][kw]) * s[xi];
+        v *= oscale;
         float* q = o + kw * tsw;
         *q = accumulate ? *q + (float)v : (float)v;
       }
@@ -297,12 +304,14 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   const size_t p_floats = (size_t)NXI * ksplit * KCA * ncob * T2 * 512;
   const size_t vb = (NXI * v_xi + 255) & ~(size_t)255, yb = (NXI * y_xi + 255) & ~(size_t)255;
   const bool have_v = g.xform != nullptr && shared_geom &&
-                      msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) == NXI * v_xi;
+                      msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) == NXI * v_xi + kWbfXformHeader;
   const bool have_y = g.yform != nullptr;  // A dy already written by the dual transform (msk_conv3d_bwd_bnact checked the geometry)
   if ((have_y || g.yfuse) && !(have_v && shared_geom)) return 0;
   char* wsp = (char*)msk_workspace(ctx, (have_v ? 0 : vb) + (have_y ? 0 : yb) + p_floats * sizeof(float) + 256);
   if (!wsp) return -1;
-  char* V = have_v ? (char*)const_cast<void*>(g.xform) : wsp;
+  char* V = have_v ? (char*)const_cast<void*>(g.xform) + kWbfXformHeader : wsp;
+  const float* v_amax = nullptr;  // NP = 2: the scale of the A operand (from the xform header, or computed here)
+  if (NP == 2 && have_v) v_amax = (const float*)g.xform;
   char* Y = have_y ? (char*)const_cast<void*>(g.yform) : (have_v ? wsp : wsp + vb);
   float* P = (float*)(have_y ? (have_v ? wsp : wsp + vb) : Y + yb);
 
@@ -311,15 +320,31 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
   ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
   ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
-  if (!have_v && msk_wbf_transform(ctx, 0, K, NP, ta) != 0) return -1;  // else: V written by msk_conv3d_fwd_ex for this tensor
+  if (!have_v) {  // else: V written by msk_conv3d_fwd_ex for this tensor
+    if (NP == 2) {
+      v_amax = msk_absmax(ctx, g.A, g.ald, g.CA, (long)g.N * g.AD * g.AH * g.AW);
+      if (!v_amax) return -1;
+      ta.amax = v_amax;
+    }
+    if (msk_wbf_transform(ctx, 0, K, NP, ta) != 0) return -1;
+  }
   ta.src = g.B; ta.sld = g.bld; ta.CK = g.CB; ta.KC = KCB; ta.V = Y; ta.v_xi = (long)y_xi;
+  const float* y_amax = nullptr;  // NP = 2: the gradient operand is scaled by a power of two (fp16 range), undone in the reduce
   if (g.yfuse) {
     WbfBnBwd bn = *g.yfuse;
     bn.Y = Y;
     bn.y_xi = (long)y_xi;
+    y_amax = bn.amax;
     if (msk_wbf_transform_dual(ctx, K, NP, ta, bn, false) != 0) return -1;
-  } else if (!have_y && msk_wbf_transform(ctx, 1, K, NP, ta) != 0) {
-    return -1;
+  } else if (have_y) {
+    y_amax = g.y_amax;
+  } else {
+    if (NP == 2) {
+      y_amax = msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);
+      if (!y_amax) return -1;
+    }
+    ta.amax = y_amax;
+    if (msk_wbf_transform(ctx, 1, K, NP, ta) != 0) return -1;
   }
 
   WgArgs wa{};
@@ -329,7 +354,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   wa.ncob = ncob; wa.v_xi = (long)v_xi; wa.y_xi = (long)y_xi; wa.plane = (long)plane;
   const long nblk = base_blocks * ksplit;
   {
-    const char* tag = NP == 3 ? "wbf_wgrad_k" : "wbf_wgrad_f16_k";
+    const char* tag = NP == 3 ? "wbf_wgrad_k" : (NP == 2 ? "wbf_wgrad_h2_k" : "wbf_wgrad_f16_k");
     if (ctx->prof && ctx->prof_shapes) {
       char buf[200];
       snprintf(buf, sizeof(buf), "%s[ca=%d,cb=%d,n=%d,dhw=%dx%dx%d,k=%d,ks=%ld]", tag, g.CA, g.CB, g.N, g.BD, g.BH, g.BW, K, ksplit);
@@ -346,7 +371,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
     long blocks = ((long)T2 * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
     hipLaunchKernelGGL((wbf_wgrad_reduce_k<K>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, NS,
-                       KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate);
+                       KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate, y_amax, v_amax, NP == 2 ? 1 : 0);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 1;
@@ -373,8 +398,10 @@ int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   if (wbf_tile_ok(geo, 8, 16)) TH = 16;
   else if (wbf_tile_ok(geo, 8, 8)) TH = 8;
   if (!TH) return 0;
-  if (k5) return run_wgrad_pipeline<5, 3>(ctx, g, geo, shared_geom, TH);
-  if (wbf_pieces(ctx, 3) == 3) return run_wgrad_pipeline<3, 3>(ctx, g, geo, shared_geom, TH);
+  const int np = wbf_pieces(ctx, k5 ? 5 : 3);
+  if (k5) return np == 2 ? run_wgrad_pipeline<5, 2>(ctx, g, geo, shared_geom, TH) : run_wgrad_pipeline<5, 3>(ctx, g, geo, shared_geom, TH);
+  if (np == 3) return run_wgrad_pipeline<3, 3>(ctx, g, geo, shared_geom, TH);
+  if (np == 2) return run_wgrad_pipeline<3, 2>(ctx, g, geo, shared_geom, TH);
   return run_wgrad_pipeline<3, 1>(ctx, g, geo, shared_geom, TH);
 }
 
@@ -400,8 +427,8 @@ bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes) {
   const size_t plane = (size_t)geo.DP * geo.HP * 16;
   const size_t v_xi = (size_t)g.N * geo.T * (g.CA / 16) * NPL * plane, y_xi = (size_t)g.N * geo.T * (g.CB / 16) * NPL * plane;
   if (v_xi >= 0xFFFFFFF0ull || y_xi >= 0xFFFFFFF0ull) return false;
-  if (msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) != NXI * v_xi) return false;
-  *y_bytes = NXI * y_xi;
+  if (msk_wbf_xform_bytes(g.N, g.AD, g.AH, g.AW, g.CA, g.CB, K, NP) != NXI * v_xi + kWbfXformHeader) return false;
+  *y_bytes = NXI * y_xi;  // (without the header of msk_wbf_xform_bytes)
   return true;
 }
 

@@ -348,12 +348,12 @@ class BatchNorm3D(Layer):
         sums[3C] sums_total[3C]."""
         if self._scratch is None or self._scratch["world"] != dev.world:
             Cn, W = self.num_features, dev.world
-            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn
+            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn + 4
             base = dev.small(total)
             o = 0
             s = {"world": W}
             for name, cnt in (("stats", 2 * Cn), ("gathered", W * 2 * Cn), ("scale", Cn), ("shift", Cn),
-                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn)):
+                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn), ("maxes", 4)):
                 s[name] = base + 4 * o
                 o += cnt
             self._scratch = s
@@ -536,8 +536,16 @@ class ConvBNAct:
         y, res = self.y, self.res
         alpha = self.act._weight.ptr if self.act is not None else None
         resm = res.msk() if res is not None else NULL_TENSOR
-        dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
-                 _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
+        fuse = (FUSE_BN_BACKWARD and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and need_dx
+                and self.conv.cin == self.conv.cout)
+        # the maxima of |du| and |xhat| ride along when the fused backward may need to scale dy into fp16 range
+        want_maxes = fuse and Cn % 4 == 0 and y.ld % 4 == 0 and dout.ld % 4 == 0 and y.ptr % 16 == 0 and dout.ptr % 16 == 0
+        if want_maxes:
+            dev.call("msk_affine_act_bwd_reduce_ex", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                     _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]), _fp(sc["maxes"]))
+        else:
+            dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                     _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
         sums_total, m_total = sc["sums"], float(y.voxels)
         if self.bn_mode == 1 and dev.world > 1 and BatchNorm3D.sync:
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
@@ -546,8 +554,7 @@ class ConvBNAct:
         dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
                  _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
         dy = y.empty_like()
-        if (FUSE_BN_BACKWARD and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and need_dx
-                and self.conv.cin == self.conv.cout):
+        if fuse:
             # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
             # of dy (msk_conv3d_bwd_bnact); dy itself reaches HBM only when the shape is not eligible
             conv, x = self.conv, self.x
@@ -562,7 +569,7 @@ class ConvBNAct:
             dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
                      _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
                      _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,
-                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf))
+                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(sc["maxes"]) if want_maxes else None)
             x.grad_written = True
             conv._xform = None
             self.dy = dy if ybuf is None else None

@@ -482,7 +482,8 @@ def test_vnet_32cube_batch2_gradients_calibrated():
             d.sync()
             d.prof_enable(False)
             tags = d.prof_report()
-            ran_wbf = any(k.startswith("wbf_gemm_k") for k in tags) and any(k.startswith("wbf_wgrad_k") for k in tags)
+            ran_wbf = (any(k.startswith(("wbf_gemm_k", "wbf_gemm_h2_k")) for k in tags)
+                       and any(k.startswith(("wbf_wgrad_k", "wbf_wgrad_h2_k")) for k in tags))
             assert ran_wbf == (tag == "bf16x3"), sorted(tags)
             e_lg = rel_err(lg, lg_ref)
             assert e_lg < 2e-5, (tag, e_lg)

@@ -12,6 +12,16 @@ from helpers import dev, rel_err, t_empty, t_from_ncdhw, t_to_ncdhw, vec, vp
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _operand_split():
+    """The tests of this file address the exact bf16x3 pipeline ("conv_split" 3) unless they select the fp16 two-piece
+    format themselves; every test leaves the context in the product configuration (conv_split 2)."""
+    dev().set_option("conv_split", 3)
+    yield
+    dev().set_option("conv_split", 2)
+    dev().set_option("bwd_fuse", -1)
+
 from oracle import vnet_numpy as O  # noqa: E402
 
 
@@ -270,13 +280,16 @@ def test_wbf_3x3x3_pipeline(case, fp16):
         assert e_f < _conv_tol(cin * 27) and e_d < _conv_tol(cout * 27) and e_w < _conv_tol(N * D * H * W) * 2
 
 
+@pytest.mark.parametrize("split", [3, 2])
 @pytest.mark.parametrize("case", [(32, 5, (2, 16, 32, 16)), (64, 5, (1, 8, 16, 16)), (128, 5, (1, 8, 16, 8)), (32, 3, (2, 16, 16, 16)),
                                   (32, 5, (1, 30, 60, 8)), (16, 5, (1, 8, 8, 8))])
-def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
+def test_conv3d_bwd_bnact_fused_equals_three_call_form(case, split):
     """msk_conv3d_bwd_bnact (backward of a LUConv unit, vnet.py:36-41): the fused form -- BatchNorm/PReLU backward evaluated
     inside wbf_tin_dual_k, which writes both transforms of dy; dy never stored -- against (a) the same entry point without
     `ybuf` (msk_affine_act_bwd_apply -> msk_conv3d_dgrad -> msk_conv3d_wgrad_ex through HBM) and (b) the float64 oracle of
-    the three operations.  The last case (16 channels) is not eligible: bytes() = 0 and the call takes the three-call form."""
+    the three operations.  The last case (16 channels) is not eligible: bytes() = 0 and the call takes the three-call form.
+    split = 2: the fp16 two-piece operand format ("conv_split"); dout is scaled to 1e-6 (real gradient magnitudes: far below
+    fp16's normal range) so that the device-side power-of-two scaling from the reduce pass's maxima is what makes it work."""
     import ctypes as C
     c, K, (N, D, H, W) = case
     k, s_, p = (K,) * 3, (1, 1, 1), (K // 2,) * 3
@@ -286,10 +299,12 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
     x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
     w = (rng.standard_normal((c, c) + k) / np.sqrt(c * K ** 3)).astype(np.float32)
     b = rng.standard_normal(c).astype(np.float32)
-    dout = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    dout = (rng.standard_normal((N, c, D, H, W)) * (1e-6 if split == 2 else 1.0)).astype(np.float32)
     gamma, beta = rng.uniform(0.5, 1.5, c).astype(np.float32), (0.3 * rng.standard_normal(c)).astype(np.float32)
     alpha = rng.uniform(0.05, 0.5, c).astype(np.float32)
     y = O.conv3d(f8(x), f8(w), f8(b), s_, p).astype(np.float32)
+    d = dev()
+    d.set_option("conv_split", split)
     # training-mode BatchNorm coefficients of y and the reduced sums of its backward, in float64
     yc = np.moveaxis(f8(y), 1, -1).reshape(-1, c)
     M = yc.shape[0]
@@ -317,6 +332,16 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
     ybuf = d.malloc(nb) if nb else None
     ytmp = t_empty(N, c, D, H, W, fill=0.0)
     d.call("msk_conv3d_fwd_ex", desc, xt.msk(), vp(wp), vp(bp), ytmp.msk(), None, vp(xf))   # fills xf for x
+    # the reduce pass the backward always starts with: its maxima bound |dy| (needed by the fused forms under split 2)
+    maxes, sums_dev = (vec(np.zeros(4, np.float32)), vec(np.zeros(3 * c, np.float32))) if c % 4 == 0 else (None, None)
+    if maxes:
+        from medicalseg_amd._lib import NULL_TENSOR
+        d.call("msk_affine_act_bwd_reduce_ex", yt.msk(), vp(cv["scale"]), vp(cv["shift"]), NULL_TENSOR, vp(cv["alpha"]),
+               vp(cv["mean"]), vp(cv["invstd"]), dot.msk(), vp(sums_dev), vp(maxes))
+        mx = d.d2h(maxes, (2,), np.float32)
+        assert abs(mx[0] - np.abs(du).max()) <= 1e-6 * np.abs(du).max() and abs(mx[1] - np.abs(xhat).max()) < 1e-4 * np.abs(xhat).max()
+        got_sums = d.d2h(sums_dev, (2 * c,), np.float32)
+        assert np.abs(got_sums - sums).max() < 1e-4 * np.abs(sums).max()
     d.set_option("prof_shapes", 0)
     d.set_option("prof_only_halo", 0)
     res = {}
@@ -330,7 +355,7 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
             d.prof_enable(True)
             d.call("msk_conv3d_bwd_bnact", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
                    vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
-                   dyt.msk(), dxt.msk(), 0, vp(dw), 0, vp(xf), vp(ybuf))
+                   dyt.msk(), dxt.msk(), 0, vp(dw), 0, vp(xf), vp(ybuf), vp(maxes))
             d.sync()
             d.prof_enable(False)
             rep = d.prof_report()
@@ -343,6 +368,7 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
     assert "affine_act_bwd_apply" in rep3 and not any(t.startswith("wbf_tin_dual") or t.endswith("_bn_k") for t in rep3), rep3
     assert rel_err(dy3, dy_ref) < 2e-6
     tol = _conv_tol(c * K ** 3)
+    tag_sfx = "_h2" if split == 2 and eligible else ""
     for form, tags in (("one", ("wbf_tin_dual_k",)), ("split", ("wbf_tin_bn_k", "wbf_ty_bn_k"))):
         dxf, dwf, dyf, repf = res[form]
         assert all((t in repf) == eligible for t in tags), (form, repf)
@@ -353,6 +379,8 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
                                                                          rel_err(dwf, dw_ref), rel_err(dw3, dw_ref)))
         assert rel_err(dxf, dx_ref) < tol and rel_err(dwf, dw_ref) < 2 * _conv_tol(M)
         assert rel_err(dxf, dx3) < 2e-6 and rel_err(dwf, dw3) < 2e-6     # the forms agree to fp32 rounding
+        if eligible:
+            assert ("wbf_gemm%s_k" % tag_sfx) in repf and ("wbf_wgrad%s_k" % tag_sfx) in repf, repf
     assert rel_err(dx3, dx_ref) < tol and rel_err(dw3, dw_ref) < 2 * _conv_tol(M)
     # accumulate semantics of both outputs
     dxt = t_from_ncdhw(dx_ref.astype(np.float32))
@@ -360,7 +388,55 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case):
     dyt = t_empty(N, c, D, H, W, fill=9.0)
     d.call("msk_conv3d_bwd_bnact", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
            vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
-           dyt.msk(), dxt.msk(), 1, vp(dw), 1, vp(xf), vp(ybuf))
+           dyt.msk(), dxt.msk(), 1, vp(dw), 1, vp(xf), vp(ybuf), vp(maxes))
     d.sync()
     assert rel_err(t_to_ncdhw(dxt), 2 * dx_ref) < tol
     assert rel_err(d.d2h(dw, (w.size,), np.float32).reshape(w.shape), 2 * dw_ref) < 2 * _conv_tol(M)
+
+
+@pytest.mark.parametrize("case", [(32, 5, (2, 16, 32, 16), 1.0), (64, 5, (1, 8, 16, 16), 1e-6), (128, 5, (1, 8, 16, 8), 1e3),
+                                  (32, 3, (2, 16, 16, 16), 1e-7)])
+def test_wbf_fp16_two_piece_split_matches_oracle(case):
+    """Option "conv_split" 2 (msk_wbf.h): operands as two fp16 pieces with a scaled residual, three MFMAs per fp32 product.
+    Forward on O(1) activations; data and weight gradients on dy of the given magnitude (1e-7 .. 1e3) -- the pipelines scale dy
+    by a power of two derived from its device-side maximum, so the result must be as accurate as for O(1) values, inside the
+    tolerance of every other convolution kernel; the bf16x3 pipeline on the same inputs is printed next to it."""
+    c, K, (N, D, H, W), mag = case
+    k, s_, p = (K,) * 3, (1, 1, 1), (K // 2,) * 3
+    d = dev()
+    rng = np.random.default_rng(c + K)
+    f8 = lambda a: a.astype(np.float64)
+    x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    x = np.where(x > 0, x, 0.25 * x).astype(np.float32)
+    w = (rng.standard_normal((c, c) + k) * np.sqrt(2.0 / (c * K ** 3))).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    dy = (rng.standard_normal((N, c, D, H, W)) * mag).astype(np.float32)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    dw_ref, _ = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, dyt, wp, bp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel()), vec(b)
+    desc = _desc(k, s_, p)
+    M = N * D * H * W
+    errs = {}
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    for split in (3, 2):
+        d.set_option("conv_split", split)
+        yt, dxt = t_empty(N, c, D, H, W, fill=7.0), t_empty(N, c, D, H, W, fill=3.0)
+        dw = vec(np.zeros(w.size, np.float32))
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", desc, xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.call("msk_conv3d_dgrad", desc, dyt.msk(), vp(wp), dxt.msk(), 0)
+        d.call("msk_conv3d_wgrad", desc, xt.msk(), dyt.msk(), vp(dw), None, 0)
+        d.sync()
+        d.prof_enable(False)
+        rep = d.prof_report()
+        sfx = "_h2" if split == 2 else ""
+        assert rep.get("wbf_gemm%s_k" % sfx, (0, 0))[0] == 2 and rep.get("wbf_wgrad%s_k" % sfx, (0, 0))[0] == 1, rep
+        errs[split] = (rel_err(t_to_ncdhw(yt), y_ref), rel_err(t_to_ncdhw(dxt), dx_ref),
+                       rel_err(d.d2h(dw, (w.size,), np.float32).reshape(w.shape), dw_ref))
+    print("c=%d K=%d |dy|~%g: fwd/dgrad/wgrad err  bf16x3 %.2e %.2e %.2e | fp16x2 %.2e %.2e %.2e" % ((c, K, mag) + errs[3] + errs[2]))
+    for split in (3, 2):
+        assert errs[split][0] < _conv_tol(c * K ** 3) and errs[split][1] < _conv_tol(c * K ** 3)
+        assert errs[split][2] < 2 * _conv_tol(M)
