@@ -206,7 +206,8 @@ int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const flo
 int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
                               msk_tensor res, const float* alpha, const float* mean,
                               const float* invstd, msk_tensor dout, float* sums);
-/* the same; maxes (nullable, device float[2]) additionally receives max |du| and max |xhat| over the tensor -- the bound
+/* the same; maxes (nullable, device float[2][64]: two "amax arrays" -- the maximum of each row counts, the kernel spreads
+ * its atomics over the entries) additionally receives max |du| and max |xhat| over the tensor -- the bound
  * msk_conv3d_bwd_bnact needs to scale dy into fp16 range when option "conv_split" is 2.  Requires C % 4 == 0, voxel
  * strides % 4 == 0 and 16-byte aligned tensors.                                                              */
 int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,

@@ -23,6 +23,7 @@ struct GConv {
   float* stats;       // msk_conv3d_fwd_ex: BatchNorm statistics (mean[CN], M2[CN]) of dst wanted; a kernel that produced them in
                       // its epilogue sets ctx->stats_fused, otherwise the caller runs msk_bn_stats
   void* xform;        // msk_conv3d_fwd_ex: caller-owned buffer that receives the transformed input (msk_conv3d_xform_bytes)
+  const float* w_amax;   // NP = 2 pipelines: amax array of the weights if the caller has it (else taken here)
   const float* in_amax;  // NP = 2 pipelines: device scalar bounding max |src| (scales the source transform, undone in the output stage); NULL = unscaled
   const struct WbfBnBwd* fuse;  // msk_conv3d_bwd_bnact: src is not read; the input transform evaluates dy from (y, dout) on the fly
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The

@@ -740,6 +740,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     bn.invM = (float)(1.0 / M_total);
     bn.Y = (char*)ybuf;
     bn.y_xi = (long)(y_bytes / ((cd.kd == 5) ? 8 : 6));
+    if (split2) g.w_amax = (const float*)xform + kWbfAmaxWays;  // max |w| of this layer, left there by the forward pass
     if (split2) {  // fp16 pieces: dy is scaled by a power of two from a device-side bound of its maximum
       bn.amax = msk_bn_bwd_bound(ctx, y.c, scale, sums_total, M_total, maxes);
       if (!bn.amax) return -1;

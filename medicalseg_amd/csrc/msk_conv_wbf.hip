@@ -954,7 +954,9 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     if (g.fuse) in_amax = g.fuse->amax;
     else if (g.in_amax) in_amax = g.in_amax;
     else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
-    w_amax = msk_absmax(ctx, w_canon, 4, 4, ((long)K * K * K * g.CK * g.CN + 3) / 4);
+    w_amax = g.w_amax ? g.w_amax
+                      : msk_absmax(ctx, w_canon, 4, 4, ((long)K * K * K * g.CK * g.CN + 3) / 4,
+                                   g.xform ? (float*)g.xform + kWbfAmaxWays : nullptr);
     if (!in_amax || !w_amax) return -1;
   }
 

@@ -418,10 +418,19 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
   }
 }
 
-__device__ __forceinline__ void wave_atomic_max_f(unsigned* slot, float m) {
+// max of a block folded into an amax array (msk_wbf.h: kWbfAmaxWays floats, bits of non-negative floats): ONE atomic per
+// block, on the way blockIdx % ways, nothing waits for it (per-wavefront atomics on a single address cost 0.2 ms per step)
+__device__ __forceinline__ void block_atomic_max(unsigned* amax, float m) {
+  __shared__ float shm_amax[kThreads / 64];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));  // non-negative floats order like their bits
+  __syncthreads();  // a second call reuses the array
+  if ((threadIdx.x & 63) == 0) shm_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, shm_amax[i]);
+    if (m > 0.f) (void)atomicMax(amax + (blockIdx.x + blockIdx.y * 7u) % kWbfAmaxWays, __float_as_uint(m));
+  }
 }
 
 // float4 variant: a thread owns one channel QUAD and every VL-th voxel (a wavefront reads 1 KiB
@@ -516,9 +525,9 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
       body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
            load_res(v));
   }
-  if (!JOIN && maxes) {  // wave-uniform
-    wave_atomic_max_f(maxes, m_du);
-    wave_atomic_max_f(maxes + 1, m_xh);
+  if (!JOIN && maxes) {  // uniform
+    block_atomic_max(maxes, m_du);
+    block_atomic_max(maxes + kWbfAmaxWays, m_xh);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -997,7 +1006,7 @@ int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale,
                   (res.p == nullptr || res.c != x.c || vec4_ok(res));
   if (maxes) {
     MSK_REQUIRE(ctx, v4, "maxes are produced by the float4 kernel only: channel count and strides multiples of 4, 16-byte aligned tensors");
-    MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * sizeof(float), ctx->stream));
+    MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
   }
   if (v4) {
     const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
@@ -1182,30 +1191,23 @@ int msk_argmax_c(msk_ctx* ctx, msk_tensor x, int32_t* out) {
 // device scalars for the fp16 two-piece pipelines (msk_wbf.h, NP = 2): max |x| of a tensor
 // ---------------------------------------------------------------------------
 namespace {
-// one atomic per BLOCK (thousands of wavefronts hammering one address took 0.16 ms per launch)
-__device__ __forceinline__ void block_atomic_max(unsigned* slot, float m) {
-  __shared__ float shm[kThreads / 64];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, shm[i]);
-    if (m > 0.f) atomicMax(slot, __float_as_uint(m));  // non-negative floats order like their bits
-  }
-}
 __global__ void __launch_bounds__(kThreads)
 absmax_k(const float* __restrict__ x, int ld, int C, long voxels, unsigned* __restrict__ slot) {
   float m = 0.f;
   if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
     const int c4 = C >> 2;
-    const long total = voxels * c4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long total = voxels * c4, stride = (long)gridDim.x * blockDim.x;
+    auto at = [&](long i) {
       const long v = i / c4;
-      const int c = (int)(i - v * c4) * 4;
-      const float4 q = *reinterpret_cast<const float4*>(x + v * ld + c);
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+      return *reinterpret_cast<const float4*>(x + v * ld + (int)(i - v * c4) * 4);
+    };
+    auto fold = [&](const float4 q) { m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w))); };
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < total; i += 4 * stride) {  // four loads in flight
+      const float4 a = at(i), b = at(i + stride), c = at(i + 2 * stride), d = at(i + 3 * stride);
+      fold(a); fold(b); fold(c); fold(d);
     }
+    for (; i < total; i += stride) fold(at(i));
   } else {
     const long total = voxels * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1218,7 +1220,7 @@ absmax_k(const float* __restrict__ x, int ld, int C, long voxels, unsigned* __re
 // amax[0] = bound of max |dy| of the BatchNorm/PReLU backward (WbfBnBwd):
 //   |dy| <= max_c |scale_c| * (max|du| + max_c |s1_c| + max|xhat| * max_c |s2_c|)
 __global__ void bn_bwd_bound_k(int C, const float* __restrict__ scale, const float* __restrict__ sums, float invM,
-                               const float* __restrict__ maxes /*[2] = max|du|, max|xhat|*/, float* __restrict__ out) {
+                               const float* __restrict__ maxes /*two amax arrays: max|du|, max|xhat|*/, float* __restrict__ out) {
   __shared__ float sh[3][64];
   float a = 0.f, b = 0.f, c_ = 0.f;
   for (int c = threadIdx.x; c < C; c += 64) {
@@ -1232,13 +1234,14 @@ __global__ void bn_bwd_bound_k(int C, const float* __restrict__ scale, const flo
     for (int i = 1; i < 64; ++i) {
       a = fmaxf(a, sh[0][i]); b = fmaxf(b, sh[1][i]); c_ = fmaxf(c_, sh[2][i]);
     }
-    out[0] = a * (maxes[0] + b + maxes[1] * c_);
+    out[0] = a * (wbf_amax_of(maxes) + b + wbf_amax_of(maxes + kWbfAmaxWays) * c_);
   }
 }
 }  // namespace
 
 float* msk_scalar_slots(msk_ctx* ctx, int n) {
-  constexpr int kRing = 1024;
+  constexpr int kRing = 1024 * kWbfAmaxWays;  // 1024 amax arrays
+  n *= kWbfAmaxWays;
   if (!ctx->scalar_ring) {
     if (hipMalloc((void**)&ctx->scalar_ring, kRing * sizeof(float)) != hipSuccess) {
       msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMalloc failed");
@@ -1258,7 +1261,7 @@ float* msk_scalar_slots(msk_ctx* ctx, int n) {
 const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels, float* dst) {
   float* slot = dst;
   if (slot) {
-    if (hipMemsetAsync(slot, 0, sizeof(float), ctx->stream) != hipSuccess) {
+    if (hipMemsetAsync(slot, 0, kWbfAmaxWays * sizeof(float), ctx->stream) != hipSuccess) {
       msk_fail(ctx, __FILE__, __LINE__, "absmax", "hipMemsetAsync failed");
       return nullptr;
     }
@@ -1268,7 +1271,7 @@ const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels
   if (!slot) return nullptr;
   msk_launch_scope ls(ctx, "absmax");
   long ab = (voxels * C / 4 + kThreads - 1) / kThreads;
-  if (ab > 4L * ctx->num_cu) ab = 4L * ctx->num_cu;
+  if (ab > 8L * ctx->num_cu) ab = 8L * ctx->num_cu;
   if (ab < 1) ab = 1;
   hipLaunchKernelGGL(absmax_k, dim3((unsigned)ab), dim3(kThreads), 0, ctx->stream, x, ld, C, voxels,
                      (unsigned*)slot);

@@ -36,14 +36,28 @@ __device__ __forceinline__ void wbf_split2h_pair(float x0, float x1, unsigned& h
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wbf_f16x2));
 }
 // A caller-owned transformed-input buffer (msk_conv3d_fwd_ex's xform) starts with a header of kWbfXformHeader bytes whose
-// first float is the max |x| the transform was scaled by (NP = 2; unused otherwise): the weight gradient that consumes the
-// buffer later undoes that scale.
-constexpr int kWbfXformHeader = 256;
+// two amax arrays hold the max |x| the transform was scaled by and the max |w| of the layer's weights (NP = 2; unused
+// otherwise): the weight gradient that consumes the buffer later undoes the first, the data gradient of the same step reuses
+// the second (msk_conv3d_bwd_bnact: the weights have not changed since the forward pass).
+constexpr int kWbfXformHeader = 512;  // two amax arrays: max |x| and max |w| the forward pass scaled by
 // Power-of-two scale of a tensor from (an upper bound of) its max |value| on the DEVICE (no host round trip): amax * scale
 // lands in [2^9, 2^10), the Winograd transforms amplify by <= 21.25, fp16 overflows at 65504 = 2^16.  NULL / 0 / inf -> 1.
+// An "amax" is an array of kWbfAmaxWays floats whose maximum counts: producers spread their atomics over the ways by block
+// index (a thousand blocks updating ONE address cost as much as the pass they ride on), consumers take the max of all.
+constexpr int kWbfAmaxWays = 64;
+__device__ __forceinline__ float wbf_amax_of(const float* amax) {
+  const float4* p = reinterpret_cast<const float4*>(amax);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWbfAmaxWays / 4; ++i) {
+    const float4 q = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+  }
+  return m;
+}
 __device__ __forceinline__ float wbf_scale_of(const float* amax) {
   if (!amax) return 1.f;
-  const float a = *amax;
+  const float a = wbf_amax_of(amax);
   if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
   int e;
   (void)frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)

@@ -348,12 +348,12 @@ class BatchNorm3D(Layer):
         sums[3C] sums_total[3C]."""
         if self._scratch is None or self._scratch["world"] != dev.world:
             Cn, W = self.num_features, dev.world
-            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn + 4
+            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn + 128
             base = dev.small(total)
             o = 0
             s = {"world": W}
             for name, cnt in (("stats", 2 * Cn), ("gathered", W * 2 * Cn), ("scale", Cn), ("shift", Cn),
-                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn), ("maxes", 4)):
+                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn), ("maxes", 128)):   # maxes: two amax arrays of 64 floats (msk_affine_act_bwd_reduce_ex)
                 s[name] = base + 4 * o
                 o += cnt
             self._scratch = s
