@@ -483,6 +483,7 @@ struct GemmArgs {
   float* M;
   int N, T, KC, CN, LD, LH, DP, HP;
   int tiles_d, tiles_h, ngrp, ksplit, kc_per;
+  int tpb, nblk;       // tiles per workgroup, total tiles
   long v_xi, v_plane;  // bytes
   long u_xi;           // bytes
   long m_xi;           // floats between xi planes of M (= N*T*LD*LH*CN); split slabs are NXI*m_xi apart
@@ -544,7 +545,13 @@ wbf_gemm_k(GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  int b = blockIdx.x;
+  // a workgroup walks `tpb` tiles, b = blockIdx.x + i * gridDim.x (gridDim.x is a multiple of 8: the Winograd point and with
+  // it the XCD stay the same): 32 768 five-microsecond workgroups per launch were paying for their dispatch
+#pragma unroll 1
+  for (int rep = 0; rep < a.tpb; ++rep) {
+  int b = blockIdx.x + rep * gridDim.x;
+  if (b >= a.nblk) break;
+  if (rep > 0) __syncthreads();  // the previous tile's LDS reads are done (the chunk loop opens with a barrier as well)
   const int xi = b % NXI;  // block b runs on XCD b % 8: with 8 points one Winograd point per XCD, its weights stay in that L2
   b /= NXI;
   const int grp = b % a.ngrp;
@@ -689,6 +696,7 @@ wbf_gemm_k(GemmArgs a) {
       if (d < a.LD && h < a.LH) mbase[((long)d * a.LH + h) * a.CN] = acc[mr][j];
     }
   }
+  }  // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -857,7 +865,15 @@ wbf_tout_k(ToutArgs a) {
 
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
 void launch_gemm(msk_ctx* ctx, const GemmArgs& a, long nblk) {
-  hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP>), dim3((unsigned)nblk), dim3(WM * WN * 64), 0, ctx->stream, a);
+  GemmArgs b = a;
+  b.nblk = (int)nblk;
+  // tiles per workgroup: keep >= ~6 workgroups per CU in the grid (tuning knob "wbf_tpb")
+  int tpb = ctx->wbf_tpb > 0 ? ctx->wbf_tpb : 1;
+  while (tpb > 1 && nblk / tpb < 6L * ctx->num_cu) tpb >>= 1;
+  long grid = (nblk + tpb - 1) / tpb;
+  grid = (grid + 7) & ~7L;
+  b.tpb = (int)((nblk + grid - 1) / grid);
+  hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP>), dim3((unsigned)grid), dim3(WM * WN * 64), 0, ctx->stream, b);
 }
 
 // tile variants {id, MR, WM, WN, TD, TH} by output channels (first = preferred)

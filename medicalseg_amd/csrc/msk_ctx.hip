@@ -340,6 +340,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->no_winograd = value != 0;
     return 0;
   }
+  if (strcmp(key, "wbf_tpb") == 0) {
+    ctx->wbf_tpb = value > 0 ? value : 0;
+    return 0;
+  }
   if (strcmp(key, "conv_split") == 0) {
     ctx->conv_split = value == 2 ? 2 : 3;
     return 0;
