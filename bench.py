@@ -8,7 +8,7 @@ already resident in HBM (BASELINE.json configs[1]; configs[2] at --gpus 8).
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is
 not imported).  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (wbf_gemm_k: the matrix stage of the 5x5x5 convs and their data gradients),
+  roofline     -- the dominant kernel (wbf_gemm_h2_k / wbf_gemm_k: the matrix stage of the 5x5x5 convs and their data gradients),
                   HIP-event time over the timed region; achieved/frac = EXECUTED bf16 FLOPs against the 2.5 PFLOP/s
                   dense bf16 MFMA peak, the algorithmic (direct-convolution) rate under its own keys;
   cpu_baseline -- the CPU oracle timed on the host cores on a bounded sample (rank 0, N=1).
@@ -222,6 +222,7 @@ def main():
     prof_serial = {}
     if not args.skip_serialized:
         dev.set_option("wgrad_async", 0)
+        dev.set_option("prof_only_halo", 0)     # untimed: bracket every launch (the weight-gradient kernel's line comes from here)
         dev.prof_reset()
         dev.prof_enable(True)
         for _ in range(2):
