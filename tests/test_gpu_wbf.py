@@ -440,3 +440,39 @@ def test_wbf_fp16_two_piece_split_matches_oracle(case):
     for split in (3, 2):
         assert errs[split][0] < _conv_tol(c * K ** 3) and errs[split][1] < _conv_tol(c * K ** 3)
         assert errs[split][2] < 2 * _conv_tol(M)
+
+
+@pytest.mark.parametrize("mag", [1e-30, 1e-12, 1e6, 1e15, 0.0])
+def test_wbf_fp16_two_piece_split_scale_invariance(mag):
+    """The fp16 two-piece pipelines scale every operand by a power of two taken from its device-side maximum, so a
+    convolution of (mag * x, w / mag-ish weights) must be as accurate as at magnitude 1: activations, weights and gradients
+    of 1e-30 ... 1e15 (far outside fp16's 6e-8 ... 65504), and an all-zero tensor (amax = 0 -> scale 1, exact zeros out)."""
+    c, K, (N, D, H, W) = 32, 5, (1, 16, 16, 16)
+    k, s_, p = (K,) * 3, (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", 2)
+    rng = np.random.default_rng(5)
+    f8 = lambda a: a.astype(np.float64)
+    x = (rng.standard_normal((N, c, D, H, W)) * mag).astype(np.float32)
+    wmag = 1e-3 if mag >= 1 else 1e3
+    w = (rng.standard_normal((c, c) + k) * wmag).astype(np.float32)
+    dy = (rng.standard_normal((N, c, D, H, W)) * mag).astype(np.float32)
+    y_ref = O.conv3d(f8(x), f8(w), None, s_, p)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    dw_ref, _ = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, dyt, wp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel())
+    desc = _desc(k, s_, p)
+    yt, dxt = t_empty(N, c, D, H, W, fill=7.0), t_empty(N, c, D, H, W, fill=3.0)
+    dw = vec(np.full(w.size, 9.0, np.float32))
+    d.call("msk_conv3d_fwd", desc, xt.msk(), vp(wp), None, yt.msk())
+    d.call("msk_conv3d_dgrad", desc, dyt.msk(), vp(wp), dxt.msk(), 0)
+    d.call("msk_conv3d_wgrad", desc, xt.msk(), dyt.msk(), vp(dw), None, 0)
+    d.sync()
+    got = (t_to_ncdhw(yt), t_to_ncdhw(dxt), d.d2h(dw, (w.size,), np.float32).reshape(w.shape))
+    if mag == 0.0:
+        assert all(np.all(g == 0.0) for g in got)
+        return
+    assert all(np.all(np.isfinite(g)) for g in got)
+    errs = [rel_err(got[0], y_ref), rel_err(got[1], dx_ref), rel_err(got[2], dw_ref)]
+    print("mag %g: fwd / dgrad / wgrad err %.2e %.2e %.2e" % ((mag,) + tuple(errs)))
+    assert errs[0] < _conv_tol(c * K ** 3) and errs[1] < _conv_tol(c * K ** 3) and errs[2] < 2 * _conv_tol(N * D * H * W)
