@@ -525,7 +525,7 @@ def test_conv_foldn_out_tr_class(case):
     d.set_option("prof_only_halo", 0)
     out = {}
     try:
-        for impl in (0, 22):
+        for impl in (0, 22, 24):             # product (fp16 two-piece MFMA), VALU kernel, fp32-MFMA form of the folded kernel
             d.set_option("conv_impl", impl)
             yt = t_empty(N, cout, D, H, W, fill=7.0)
             d.prof_reset()
@@ -534,13 +534,14 @@ def test_conv_foldn_out_tr_class(case):
             out[impl] = t_to_ncdhw(yt)
             d.prof_enable(False)
             rep = d.prof_report()
-            assert ("conv_foldn" in rep) == (impl == 0), rep
+            assert any(k.startswith("conv_foldn") for k in rep) == (impl != 22), rep
+            assert ("conv_foldn_h2" in rep) == (impl == 0), rep
     finally:
         d.prof_enable(False)
         d.set_option("conv_impl", 0)
-    e0, e22 = rel_err(out[0], ref), rel_err(out[22], ref)
-    print("foldn %.2e  valu %.2e" % (e0, e22))
-    assert e0 < _conv_tol(32 * 125) and e22 < _conv_tol(32 * 125)
+    e0, e22, e24 = rel_err(out[0], ref), rel_err(out[22], ref), rel_err(out[24], ref)
+    print("foldn fp16x2 %.2e  fp32-MFMA %.2e  valu %.2e" % (e0, e24, e22))
+    assert e0 < _conv_tol(32 * 125) and e22 < _conv_tol(32 * 125) and e24 < _conv_tol(32 * 125)
     # a strided destination (channel slice of a wider tensor) keeps its neighbours
     wide = t_empty(N, cout + 2, D, H, W, fill=5.0)
     d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), wide.channel_slice(1, 1 + cout).msk())
@@ -591,7 +592,7 @@ FOLD_CASES = [
     (32, 24, 5, 2, (1, 16, 32, 12), "conv_halo_wino4_k"),     # permuted axes (transform along H)
     (128, 128, 5, 2, (1, 4, 8, 16), "conv_splitk_reduce"),    # few tiles -> split K: slope applied in the reduce
     (16, 8, 3, 1, (1, 6, 7, 9), "prelu_inplace"),             # no Winograd kernel: in-place pass after the conv
-    (32, 3, 5, 2, (1, 9, 11, 21), "conv_foldn"),              # out_tr.conv1: slope in the folded-column MFMA kernel's epilogue
+    (32, 3, 5, 2, (1, 9, 11, 21), "conv_foldn_h2"),           # out_tr.conv1: slope in the folded-column MFMA kernel's epilogue
 ]
 
 

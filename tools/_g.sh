@@ -1,2 +1,3 @@
-for t in 1 2 4 8; do echo tpb $t; for c in 32 64 128; do s=$((4096/c)); python tools/bench_conv.py --c $c --size $s --iters 10 --profile --opt wbf_tpb=$t 2>&1 | grep "wbf_gemm"; done; done
-python -m pytest tests/test_gpu_wbf.py -q -x 2>&1 | tail -1
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -x 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+python tools/bench_infer.py 2>&1 | tail -2
