@@ -750,7 +750,9 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     // weight-gradient stream 20 instead of 16).  Option "bwd_fuse": 0 = three calls, 1 / 2 = force a form, -1 = auto.
     const bool side_on = ctx->wgrad_async && ctx->side != nullptr &&
                          (ctx->wgrad_async_max_m <= 0 || msk_voxels(y) <= ctx->wgrad_async_max_m);
-    const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : (side_on ? 2 : 1);
+    // auto: with the two-piece fp16 operands the one-kernel form wins even with the side stream on (24.1 vs 24.7 ms per
+    // step: its transforms are a third cheaper); with the exact bf16 x 3 split form 2 does (30.1-30.2 vs 30.3-30.4)
+    const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : ((side_on && !split2) ? 2 : 1);
     if (form == 2) {
       // nothing is launched unless both pipelines accept: the weight gradient was planned above, ask the data gradient
       bn.Y = nullptr;
