@@ -305,6 +305,16 @@ int msk_bn_bias_grad(msk_ctx* ctx, int C, const float* sums, const float* scale,
  * tensors with C % 4 == 0.                                                              */
 int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha, msk_tensor dout,
                     msk_tensor da, msk_tensor db, int db_accumulate, float* dalpha);
+/* The residual join right behind a conv -> BatchNorm -> PReLU unit (vnet.py:107-111, 150-154: the last LUConv of a stage and
+ * relu2(add(out, down))) in ONE pass over the convolution output y, without materialising the unit's activation:
+ *   out = prelu(prelu(scale*y + shift, alpha_inner) + res, alpha_outer)            (saves 8 bytes per element of traffic)
+ * and its backward: da = gradient w.r.t. the unit's (never stored) activation, dres (+)= the same, dalpha_outer += ...;
+ * the unit's own backward (msk_affine_act_bwd_reduce / msk_conv3d_bwd_bnact with dout = da) follows unchanged.        */
+int msk_affine_act_join_fwd(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, msk_tensor out);
+int msk_add_act_join_bwd(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                         msk_tensor res, const float* alpha_outer, msk_tensor dout, msk_tensor da, msk_tensor dres,
+                         int dres_accumulate, float* dalpha_outer);
 
 /* ---- deep supervision (models/vnet_deepsup.py:266-277) -------------- */
 /* F.interpolate(d, size=x.shape[2:], mode='trilinear') of a conv3^3 head: align_corners=

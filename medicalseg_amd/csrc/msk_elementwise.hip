@@ -279,7 +279,8 @@ template <int V>
 __global__ void __launch_bounds__(kThreads)
 affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                  const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
-                 const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C) {
+                 const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C,
+                 const float* __restrict__ alpha_in) {
   const int cv = C / V;
   const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
@@ -294,6 +295,7 @@ affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__
     for (int j = 0; j < V; ++j) {
       float u = xv[j];
       if (scale) u = fmaf(u, scale[c + j], shift[c + j]);
+      if (alpha_in && !(u > 0.f)) u *= alpha_in[c + j];  // msk_affine_act_join_fwd: the unit's own PReLU ahead of the join
       o[j] = u;
     }
     if (res) {
@@ -322,16 +324,18 @@ affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__
 __global__ void __launch_bounds__(kThreads)
 affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
-                    const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift) {
+                    const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift,
+                    const float* __restrict__ alpha_in) {
   const long g = (long)blockIdx.x * kThreads + threadIdx.x;
   const int c = (int)(g & ((C >> 2) - 1)) * 4;
   const long vstride = ((long)gridDim.x * kThreads) >> cshift;
-  float sc[4], sf[4], al[4];
+  float sc[4], sf[4], al[4], ai[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     sc[j] = scale ? scale[c + j] : 1.f;
     sf[j] = scale ? shift[c + j] : 0.f;
     al[j] = alpha ? alpha[c + j] : 1.f;
+    ai[j] = alpha_in ? alpha_in[c + j] : 1.f;
   }
   auto load_res = [&](long v) {
     if (!res) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -344,7 +348,9 @@ affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restric
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float u = fmaf(xv[j], sc[j], sf[j]) + rv[j];
+      float t = fmaf(xv[j], sc[j], sf[j]);
+      if (alpha_in && !(t > 0.f)) t *= ai[j];  // the unit's own PReLU ahead of the join (msk_affine_act_join_fwd)
+      const float u = t + rv[j];
       o[j] = (alpha && !(u > 0.f)) ? al[j] * u : u;
     }
     *reinterpret_cast<float4*>(out + v * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -448,7 +454,8 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
                            const float* __restrict__ invstd, const float* __restrict__ dout, int ldd, long voxels,
                            int C, int QCB, int VL, float* __restrict__ da, int ldda, float* __restrict__ db,
                            int lddb, int db_acc, float* __restrict__ partial /*[nb][NQ][4*QCB]*/,
-                           unsigned* __restrict__ maxes /*[2] or null: max |du|, max |xhat| (bits of non-negative floats)*/) {
+                           unsigned* __restrict__ maxes /*[2] or null: max |du|, max |xhat| (bits of non-negative floats)*/,
+                           const float* __restrict__ alpha_in /*JOIN: inner PReLU of the first operand, or null*/) {
   __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
   constexpr int NQ = JOIN ? 1 : 3;
   float m_du = 0.f, m_xh = 0.f;
@@ -463,12 +470,13 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
   if (v1 > voxels) v1 = voxels;
   float s_du[4] = {0.f, 0.f, 0.f, 0.f}, s_dux[4] = {0.f, 0.f, 0.f, 0.f}, s_da[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    float sc[4], sf[4], al[4], mu[4], is[4];
+    float sc[4], sf[4], al[4], mu[4], is[4], ai[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       sc[j] = scale ? scale[c + j] : 1.f;
       sf[j] = scale ? shift[c + j] : 0.f;
       al[j] = alpha ? alpha[c + j] : 1.f;
+      ai[j] = (JOIN && alpha_in) ? alpha_in[c + j] : 1.f;
       mu[j] = mean ? mean[c + j] : 0.f;
       is[j] = mean ? invstd[c + j] : 0.f;
     }
@@ -478,7 +486,9 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
       float du[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float u = fmaf(xv[j], sc[j], sf[j]) + rv[j];
+        float t = fmaf(xv[j], sc[j], sf[j]);
+        if (JOIN && alpha_in && !(t > 0.f)) t *= ai[j];
+        const float u = t + rv[j];
         float g = dv[j];
         if (alpha && !(u > 0.f)) {
           g = al[j] * dv[j];
@@ -963,8 +973,8 @@ int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* bet
   return 0;
 }
 
-int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
-                       const float* alpha, msk_tensor out) {
+static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                               const float* alpha, msk_tensor out, const float* alpha_in) {
   MSK_REQUIRE(ctx, same_shape(x, out), "x/out shape mismatch");
   MSK_REQUIRE(ctx, (scale == nullptr) == (shift == nullptr), "scale and shift go together");
   if (res.p) MSK_REQUIRE(ctx, res.c > 0 && (res.c == x.c || x.c % res.c == 0), "residual channels must tile");
@@ -977,18 +987,30 @@ int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const flo
     while ((1 << cshift) < cq) ++cshift;
     hipLaunchKernelGGL(affine_act_fwd_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
                        (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, (float*)out.p,
-                       out.ld, voxels, x.c, cshift);
+                       out.ld, voxels, x.c, cshift, alpha_in);
   } else if (v4) {
     hipLaunchKernelGGL(affine_act_fwd_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
-                       alpha, (float*)out.p, out.ld, voxels, x.c);
+                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in);
   } else {
     hipLaunchKernelGGL(affine_act_fwd_k<1>, dim3(ew_blocks(voxels * x.c, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
-                       alpha, (float*)out.p, out.ld, voxels, x.c);
+                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in);
   }
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                       const float* alpha, msk_tensor out) {
+  return affine_act_fwd_impl(ctx, x, scale, shift, res, alpha, out, nullptr);
+}
+
+int msk_affine_act_join_fwd(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, msk_tensor out) {
+  MSK_REQUIRE(ctx, scale && shift && alpha_inner && alpha_outer && res.p, "join of a conv -> BN -> PReLU unit with a residual");
+  MSK_REQUIRE(ctx, res.c == y.c, "the residual has the unit's channel count");
+  return affine_act_fwd_impl(ctx, y, scale, shift, res, alpha_outer, out, alpha_inner);
 }
 
 int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
@@ -1018,7 +1040,7 @@ int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale,
       hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<false>, dim3(nb), dim3(kThreads), 0, ctx->stream,
                          (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean, invstd,
                          (const float*)dout.p, dout.ld, voxels, x.c, QCB, VL, (float*)nullptr, 0, (float*)nullptr, 0, 0,
-                         partial, (unsigned*)maxes);
+                         partial, (unsigned*)maxes, (const float*)nullptr);
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "sums_merge");
@@ -1085,8 +1107,9 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
   return 0;
 }
 
-int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da,
-                    msk_tensor db, int db_accumulate, float* dalpha) {
+static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, const float* shift, const float* alpha_in,
+                           msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da, msk_tensor db, int db_accumulate,
+                           float* dalpha) {
   MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && same_shape(a, db), "shape mismatch");
   MSK_REQUIRE(ctx, alpha != nullptr && dalpha != nullptr, "join needs alpha and its gradient");
   MSK_REQUIRE(ctx, a.c % 4 == 0 && a.c / 4 <= kThreads && vec4_ok(a) && vec4_ok(b) && vec4_ok(dout) && vec4_ok(da) &&
@@ -1099,15 +1122,27 @@ int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha
   {
     msk_launch_scope ls(ctx, "add_act_bwd");
     hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<true>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p,
-                       a.ld, (const float*)nullptr, (const float*)nullptr, (const float*)b.p, b.ld, b.c, alpha,
+                       a.ld, scale, shift, (const float*)b.p, b.ld, b.c, alpha,
                        (const float*)nullptr, (const float*)nullptr, (const float*)dout.p, dout.ld, voxels, a.c, QCB, VL,
-                       (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial, (unsigned*)nullptr);
+                       (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial, (unsigned*)nullptr, alpha_in);
     MSK_LAUNCH_CHECK(ctx);
   }
   msk_launch_scope ls(ctx, "sums_merge");
   hipLaunchKernelGGL(sums_merge_k, dim3(a.c), dim3(64), 0, ctx->stream, partial, nb, a.c, 4 * QCB, 1, dalpha, 1);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+int msk_add_act_bwd(msk_ctx* ctx, msk_tensor a, msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da,
+                    msk_tensor db, int db_accumulate, float* dalpha) {
+  return add_act_bwd_impl(ctx, a, nullptr, nullptr, nullptr, b, alpha, dout, da, db, db_accumulate, dalpha);
+}
+
+int msk_add_act_join_bwd(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                         msk_tensor res, const float* alpha_outer, msk_tensor dout, msk_tensor da, msk_tensor dres,
+                         int dres_accumulate, float* dalpha_outer) {
+  MSK_REQUIRE(ctx, scale && shift && alpha_inner, "the unit's BatchNorm coefficients and PReLU slope");
+  return add_act_bwd_impl(ctx, y, scale, shift, alpha_inner, res, alpha_outer, dout, da, dres, dres_accumulate, dalpha_outer);
 }
 
 int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma, float* dbeta, float* dalpha,

@@ -6,6 +6,8 @@ forward(x[N,C,D,H,W]) -> [logits]; the backward pass is explicit (VNet.backward)
 entered from the loss (``loss.backward()``, core/train.py:139)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .. import nn
@@ -29,6 +31,28 @@ class LUConv(nn.Layer):
 
     def backward(self, dout):
         self._unit.backward(dout)
+
+
+def _join_fusable(t, res):
+    """msk_affine_act_join_fwd / msk_add_act_join_bwd take float4-aligned tensors of equal channel count"""
+    return (t.c % 4 == 0 and res.c == t.c and all(x.ld % 4 == 0 and x.ptr % 16 == 0 for x in (t, res))
+            and os.environ.get("MSEGK_JOIN_FUSE", "1") != "0")
+
+
+def _run_ops(ops, x, res):
+    """The LUConv chain of a stage; the LAST unit leaves its BatchNorm apply + PReLU to the residual join that follows
+    (vnet.py:107-111, 150-154): returns (its output tensor -- unwritten in that case --, the unit or None)."""
+    ops = list(ops)
+    out = x
+    for op in ops[:-1]:
+        out = op(out)
+    if not ops:
+        return out, None
+    last = ops[-1]
+    if isinstance(last, LUConv) and _join_fusable(out, res):
+        out = last._unit.forward(out, defer_act=True)
+        return out, (last._unit if last._unit.deferred else None)
+    return last(out), None
 
 
 def _make_nConv(nchan, depth, elu):
@@ -83,10 +107,9 @@ class DownTransition(nn.Layer):
             out = down
         self._dropped = out
         self._t_down = down
-        for op in self.ops:
-            out = op(out)
+        out, unit = _run_ops(self.ops, out, down)
         self._t_ops = out
-        return self._join.forward(out, down)
+        return self._join.forward(out, down, unit=unit)
 
     def backward(self, dout):
         down = self._t_down
@@ -138,10 +161,8 @@ class UpTransition(nn.Layer):
         self._up.forward(xin, out=xcat.channel_slice(0, half))
         copy_scale(skipx, self._m2, xcat.channel_slice(half, self.outChans))
         self._xcat = xcat
-        out = xcat
-        for op in self.ops:
-            out = op(out)
-        return self._join.forward(out, xcat)
+        out, unit = _run_ops(self.ops, xcat, xcat)
+        return self._join.forward(out, xcat, unit=unit)
 
     def backward(self, dout):
         xcat, half = self._xcat, self.outChans // 2

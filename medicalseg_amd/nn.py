@@ -487,8 +487,12 @@ class ConvBNAct:
         self.x, self.res, self.y, self.out, self.bn_mode = x, None, None, out, 3   # 3: no backward through this
         return out
 
-    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None, defer_act=False) -> Tensor:
+        """defer_act: stop after the BatchNorm coefficients; the caller (AddAct.forward with unit=self) applies BN + PReLU
+        inside the residual join that follows (msk_affine_act_join_fwd) -- the returned tensor is allocated (it carries the
+        gradient in backward) but never written."""
         dev = x.dev
+        self.deferred = False
         if (_FUSED_INFERENCE["on"] and not self.bn.training and res is None and type(self.conv) is Conv3D
                 and (self.act is None or isinstance(self.act, PReLU))):
             return self._forward_folded(x, out)
@@ -520,8 +524,11 @@ class ConvBNAct:
         if out is None:
             out = y.empty_like()
         alpha = self.act._weight.ptr if self.act is not None else None
-        dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
-                 res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
+        if defer_act and res is None and alpha is not None:
+            self.deferred = True
+        else:
+            dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                     res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
         self.out = out
         return out
 
@@ -600,10 +607,18 @@ class AddAct:
         self.act = act
         self._sums = None
 
-    def forward(self, a: Tensor, b: Tensor) -> Tensor:
+    def forward(self, a: Tensor, b: Tensor, unit: "ConvBNAct | None" = None) -> Tensor:
+        """unit: the conv -> BN -> PReLU unit that produced `a` with defer_act=True: its BatchNorm apply + PReLU run inside
+        this join, on the convolution output (one pass instead of two, `a` is never written)."""
         self.a, self.b = a, b
+        self.unit = unit if (unit is not None and getattr(unit, "deferred", False)) else None
         out = a.empty_like()
-        a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), _fp(self.act._weight.ptr), out.msk())
+        if self.unit is not None:
+            u, sc = self.unit, self.unit.bn.scratch(a.dev)
+            a.dev.call("msk_affine_act_join_fwd", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
+                       b.msk(), _fp(self.act._weight.ptr), out.msk())
+        else:
+            a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), _fp(self.act._weight.ptr), out.msk())
         return out
 
     def backward(self, dout: Tensor):
@@ -616,7 +631,11 @@ class AddAct:
         ga, gb = a.ensure_grad(), b.ensure_grad()
         if a.grad_written:
             raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
-        if Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
+        if getattr(self, "unit", None) is not None:
+            u, sc = self.unit, self.unit.bn.scratch(dev)
+            dev.call("msk_add_act_join_bwd", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr), b.msk(),
+                     alpha, dout.msk(), ga.msk(), gb.msk(), 1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr))
+        elif Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
             # one pass: both data gradients and the alpha-gradient sum (a join has no BatchNorm)
             dev.call("msk_add_act_bwd", a.msk(), b.msk(), alpha, dout.msk(), ga.msk(), gb.msk(),
                      1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr))

@@ -743,3 +743,39 @@ def test_conv3_winograd_f43_matches_oracle(case):
         d.set_option("conv_impl", 0)
     print("F(4,3) rel err fwd %.2e dgrad %.2e" % (e_f, e_d))
     assert e_f < _conv_tol(cin * 27) and e_d < _conv_tol(cout * 27) and e_acc < _conv_tol(cout * 27), (e_f, e_d, e_acc)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 10), (1, 64, 3, 5, 7), (1, 12, 4, 4, 5)])
+def test_affine_act_join_fwd_bwd(shape):
+    """msk_affine_act_join_fwd / msk_add_act_join_bwd: the residual join fused with the BatchNorm apply + PReLU of the unit
+    in front of it (vnet.py:107-111, 150-154), against numpy float64 of the two-step form
+        a = prelu(scale*y + shift, alpha_in);  out = prelu(a + res, alpha_out)
+    and its adjoint (da, dres (+)=, dalpha_out +=)."""
+    from medicalseg_amd._lib import NULL_TENSOR  # noqa: F401
+    N, Cn, D, H, W = shape
+    d = dev()
+    rng = np.random.default_rng(Cn)
+    f8 = lambda a: a.astype(np.float64)
+    y = rng.standard_normal(shape).astype(np.float32)
+    res = rng.standard_normal(shape).astype(np.float32)
+    dout = rng.standard_normal(shape).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, Cn).astype(np.float32), rng.standard_normal(Cn).astype(np.float32)
+    ai, ao = rng.uniform(0.05, 0.5, Cn).astype(np.float32), rng.uniform(-0.2, 0.5, Cn).astype(np.float32)
+    sh = (1, Cn, 1, 1, 1)
+    u = f8(y) * f8(scale).reshape(sh) + f8(shift).reshape(sh)
+    a = np.where(u > 0, u, u * f8(ai).reshape(sh))
+    s_ = a + f8(res)
+    out_ref = np.where(s_ > 0, s_, s_ * f8(ao).reshape(sh))
+    ds = f8(dout) * np.where(s_ > 0, 1.0, f8(ao).reshape(sh))
+    dao_ref = (f8(dout) * s_ * (s_ <= 0)).sum(axis=(0, 2, 3, 4))
+    yt, rt, dt = t_from_ncdhw(y), t_from_ncdhw(res), t_from_ncdhw(dout)
+    ot = t_empty(N, Cn, D, H, W, fill=7.0)
+    sc, sf, pai, pao = vec(scale), vec(shift), vec(ai), vec(ao)
+    d.call("msk_affine_act_join_fwd", yt.msk(), vp(sc), vp(sf), vp(pai), rt.msk(), vp(pao), ot.msk())
+    assert rel_err(t_to_ncdhw(ot), out_ref) < 1e-6
+    da, dres = t_empty(N, Cn, D, H, W, fill=5.0), t_from_ncdhw(np.full(shape, 0.5, np.float32))
+    dao = vec(np.full(Cn, 0.25, np.float32))
+    d.call("msk_add_act_join_bwd", yt.msk(), vp(sc), vp(sf), vp(pai), rt.msk(), vp(pao), dt.msk(), da.msk(), dres.msk(), 1, vp(dao))
+    assert rel_err(t_to_ncdhw(da), ds) < 1e-6
+    assert rel_err(t_to_ncdhw(dres), ds + 0.5) < 1e-6
+    assert rel_err(vec_back(dao, Cn), dao_ref + 0.25) < 2e-5
