@@ -315,6 +315,13 @@ int msk_affine_act_join_fwd(msk_ctx* ctx, msk_tensor y, const float* scale, cons
 int msk_add_act_join_bwd(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
                          msk_tensor res, const float* alpha_outer, msk_tensor dout, msk_tensor da, msk_tensor dres,
                          int dres_accumulate, float* dalpha_outer);
+/* the same pass additionally leaves the UNIT's backward sums (what msk_affine_act_bwd_reduce_ex(y, ..., dout = da) would
+ * compute: unit_sums[0..3C) = sum du, sum du*xhat, d alpha_inner; unit_sums needs 4*C floats) and maxes (nullable, as in
+ * msk_affine_act_bwd_reduce_ex): the unit's reduce pass is not needed afterwards.                                      */
+int msk_add_act_join_bwd_ex(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, const float* mean, const float* invstd, msk_tensor dout,
+                            msk_tensor da, msk_tensor dres, int dres_accumulate, float* dalpha_outer, float* unit_sums,
+                            float* maxes /*nullable*/);
 
 /* ---- deep supervision (models/vnet_deepsup.py:266-277) -------------- */
 /* F.interpolate(d, size=x.shape[2:], mode='trilinear') of a conv3^3 head: align_corners=

@@ -86,6 +86,7 @@ SIGNATURES = {
     "msk_add_act_bwd": (_i, [_vp, _T, _T, _vp, _T, _T, _T, _i, _vp]),
     "msk_affine_act_join_fwd": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _T]),
     "msk_add_act_join_bwd": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _T, _T, _T, _i, _vp]),
+    "msk_add_act_join_bwd_ex": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _vp, _vp, _T, _T, _T, _i, _vp, _vp, _vp]),
     "msk_bn_bias_grad": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
     "msk_copy_scale": (_i, [_vp, _T, _vp, _T, _i]),
     "msk_dropout_mask": (_i, [_vp, _u64, _u64, _u32, _i, _f, _vp]),

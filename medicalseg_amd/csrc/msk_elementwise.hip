@@ -443,10 +443,14 @@ __device__ __forceinline__ void block_atomic_max(unsigned* amax, float m) {
 // contiguous), two voxels in flight per iteration.  The scalar kernel above moved 4 bytes per
 // lane per load and reached ~1.2 TB/s on the 128^3 layers.
 //   JOIN = false: the three BatchNorm/PReLU sums of a ConvBNAct unit
-//   JOIN = true : the residual join out = prelu(a + b) in ONE pass: writes da (and db, optionally
+//   MODE 1 (JOIN): the residual join out = prelu(a + b) in ONE pass: writes da (and db, optionally
 //                 accumulating) while reducing the alpha-gradient sum -- the data gradient of a
 //                 join does not depend on any sum, so the separate reduce pass is not needed.
-template <bool JOIN>
+//   MODE 2:       the join fused with the unit in front of it (msk_add_act_join_bwd_ex): as MODE 1 with
+//                 a = prelu(scale*x + shift, alpha_in), and in the same pass the unit's OWN three BatchNorm/PReLU
+//                 sums (and maxima) of du = da * prelu'(.) -- the unit's reduce pass disappears.
+//                 partial quantities: [0] sum du, [1] sum du*xhat, [2] d alpha_in, [3] d alpha (join)
+template <int MODE>
 __global__ void __launch_bounds__(kThreads)
 affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                            const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
@@ -457,7 +461,8 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
                            unsigned* __restrict__ maxes /*[2] or null: max |du|, max |xhat| (bits of non-negative floats)*/,
                            const float* __restrict__ alpha_in /*JOIN: inner PReLU of the first operand, or null*/) {
   __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
-  constexpr int NQ = JOIN ? 1 : 3;
+  constexpr bool JOIN = MODE != 0, UNIT = MODE == 2;
+  constexpr int NQ = MODE == 0 ? 3 : (MODE == 1 ? 1 : 4);
   float m_du = 0.f, m_xh = 0.f;
   __shared__ float sh[NQ * 4][kThreads];
   const int t = threadIdx.x;
@@ -469,6 +474,7 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
   long v1 = v0 + per;
   if (v1 > voxels) v1 = voxels;
   float s_du[4] = {0.f, 0.f, 0.f, 0.f}, s_dux[4] = {0.f, 0.f, 0.f, 0.f}, s_da[4] = {0.f, 0.f, 0.f, 0.f};
+  float s_dai[4] = {0.f, 0.f, 0.f, 0.f};  // MODE 2: gradient of the unit's own slope
   if (c < C) {
     float sc[4], sf[4], al[4], mu[4], is[4], ai[4];
 #pragma unroll
@@ -487,19 +493,26 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float t = fmaf(xv[j], sc[j], sf[j]);
+        const float tin = t;
         if (JOIN && alpha_in && !(t > 0.f)) t *= ai[j];
         const float u = t + rv[j];
+        t = tin;  // pre-activation of the unit (MODE 2 below)
         float g = dv[j];
         if (alpha && !(u > 0.f)) {
           g = al[j] * dv[j];
           s_da[j] = fmaf(dv[j], u, s_da[j]);
         }
         du[j] = g;
-        if (!JOIN) {
+        if (!JOIN || UNIT) {
+          float gu = g;  // gradient w.r.t. the BatchNorm output of the unit
+          if (UNIT && !(t > 0.f)) {
+            gu = g * ai[j];
+            s_dai[j] = fmaf(g, fmaf(xv[j], sc[j], sf[j]), s_dai[j]);
+          }
           const float xh = (xv[j] - mu[j]) * is[j];
-          s_du[j] += g;
-          s_dux[j] = fmaf(g, xh, s_dux[j]);
-          m_du = fmaxf(m_du, fabsf(g));
+          s_du[j] += gu;
+          s_dux[j] = fmaf(gu, xh, s_dux[j]);
+          m_du = fmaxf(m_du, fabsf(gu));
           m_xh = fmaxf(m_xh, fabsf(xh));
         }
       }
@@ -535,18 +548,19 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
       body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
            load_res(v));
   }
-  if (!JOIN && maxes) {  // uniform
+  if ((!JOIN || UNIT) && maxes) {  // uniform
     block_atomic_max(maxes, m_du);
     block_atomic_max(maxes + kWbfAmaxWays, m_xh);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (JOIN) {
+    if (MODE == 1) {
       sh[j][t] = s_da[j];
     } else {
       sh[j][t] = s_du[j];
       sh[4 + j][t] = s_dux[j];
-      sh[8 + j][t] = s_da[j];
+      sh[8 + j][t] = UNIT ? s_dai[j] : s_da[j];
+      if (UNIT) sh[(NQ - 1) * 4 + j][t] = s_da[j];
     }
   }
   __syncthreads();
@@ -1037,7 +1051,7 @@ int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale,
     if (!partial) return -1;
     {
       msk_launch_scope ls(ctx, "affine_act_bwd_reduce");
-      hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<false>, dim3(nb), dim3(kThreads), 0, ctx->stream,
+      hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<0>, dim3(nb), dim3(kThreads), 0, ctx->stream,
                          (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean, invstd,
                          (const float*)dout.p, dout.ld, voxels, x.c, QCB, VL, (float*)nullptr, 0, (float*)nullptr, 0, 0,
                          partial, (unsigned*)maxes, (const float*)nullptr);
@@ -1109,7 +1123,8 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
 
 static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, const float* shift, const float* alpha_in,
                            msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da, msk_tensor db, int db_accumulate,
-                           float* dalpha) {
+                           float* dalpha, const float* mean = nullptr, const float* invstd = nullptr, float* unit_sums = nullptr,
+                           float* maxes = nullptr) {
   MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && same_shape(a, db), "shape mismatch");
   MSK_REQUIRE(ctx, alpha != nullptr && dalpha != nullptr, "join needs alpha and its gradient");
   MSK_REQUIRE(ctx, a.c % 4 == 0 && a.c / 4 <= kThreads && vec4_ok(a) && vec4_ok(b) && vec4_ok(dout) && vec4_ok(da) &&
@@ -1117,11 +1132,31 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
   const long voxels = msk_voxels(a);
   const int QCB = pow2ceil(a.c / 4), VL = kThreads / QCB;
   const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+  if (unit_sums) {  // the unit's BatchNorm/PReLU sums in the same pass
+    float* partial4 = (float*)msk_workspace(ctx, (size_t)nb * 4 * 4 * QCB * sizeof(float));
+    if (!partial4) return -1;
+    if (maxes) MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
+    {
+      msk_launch_scope ls(ctx, "add_act_bwd_unit");
+      hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<2>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p, a.ld, scale,
+                         shift, (const float*)b.p, b.ld, b.c, alpha, mean, invstd, (const float*)dout.p, dout.ld, voxels, a.c, QCB,
+                         VL, (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial4, (unsigned*)maxes, alpha_in);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "sums_merge");
+    // quantities 0..2 -> unit_sums[3C] (overwritten), quantity 3 -> dalpha of the join (accumulated)
+    hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0);
+    MSK_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(param_grads_k, dim3(msk_cdiv(a.c, 64)), dim3(64), 0, ctx->stream, a.c, (const float*)(unit_sums + a.c),
+                       (float*)nullptr, (float*)nullptr, dalpha, 1);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   float* partial = (float*)msk_workspace(ctx, (size_t)nb * 4 * QCB * sizeof(float));
   if (!partial) return -1;
   {
     msk_launch_scope ls(ctx, "add_act_bwd");
-    hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<true>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p,
+    hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p,
                        a.ld, scale, shift, (const float*)b.p, b.ld, b.c, alpha,
                        (const float*)nullptr, (const float*)nullptr, (const float*)dout.p, dout.ld, voxels, a.c, QCB, VL,
                        (float*)da.p, da.ld, (float*)db.p, db.ld, db_accumulate, partial, (unsigned*)nullptr, alpha_in);
@@ -1143,6 +1178,15 @@ int msk_add_act_join_bwd(msk_ctx* ctx, msk_tensor y, const float* scale, const f
                          int dres_accumulate, float* dalpha_outer) {
   MSK_REQUIRE(ctx, scale && shift && alpha_inner, "the unit's BatchNorm coefficients and PReLU slope");
   return add_act_bwd_impl(ctx, y, scale, shift, alpha_inner, res, alpha_outer, dout, da, dres, dres_accumulate, dalpha_outer);
+}
+
+int msk_add_act_join_bwd_ex(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, const float* mean, const float* invstd, msk_tensor dout,
+                            msk_tensor da, msk_tensor dres, int dres_accumulate, float* dalpha_outer, float* unit_sums,
+                            float* maxes) {
+  MSK_REQUIRE(ctx, scale && shift && alpha_inner && mean && invstd && unit_sums, "the unit's BatchNorm coefficients, statistics and sums buffer");
+  return add_act_bwd_impl(ctx, y, scale, shift, alpha_inner, res, alpha_outer, dout, da, dres, dres_accumulate, dalpha_outer, mean,
+                          invstd, unit_sums, maxes);
 }
 
 int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma, float* dbeta, float* dalpha,

@@ -348,12 +348,12 @@ class BatchNorm3D(Layer):
         sums[3C] sums_total[3C]."""
         if self._scratch is None or self._scratch["world"] != dev.world:
             Cn, W = self.num_features, dev.world
-            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 6 * Cn + 128
+            total = 2 * Cn + W * 2 * Cn + 4 * Cn + 7 * Cn + 128
             base = dev.small(total)
             o = 0
             s = {"world": W}
             for name, cnt in (("stats", 2 * Cn), ("gathered", W * 2 * Cn), ("scale", Cn), ("shift", Cn),
-                              ("mean", Cn), ("invstd", Cn), ("sums", 3 * Cn), ("sums_total", 3 * Cn), ("maxes", 128)):   # maxes: two amax arrays of 64 floats (msk_affine_act_bwd_reduce_ex)
+                              ("mean", Cn), ("invstd", Cn), ("sums", 4 * Cn), ("sums_total", 3 * Cn), ("maxes", 128)):   # maxes: two amax arrays of 64 floats (msk_affine_act_bwd_reduce_ex)
                 s[name] = base + 4 * o
                 o += cnt
             self._scratch = s
@@ -547,7 +547,10 @@ class ConvBNAct:
                 and self.conv.cin == self.conv.cout)
         # the maxima of |du| and |xhat| ride along when the fused backward may need to scale dy into fp16 range
         want_maxes = fuse and Cn % 4 == 0 and y.ld % 4 == 0 and dout.ld % 4 == 0 and y.ptr % 16 == 0 and dout.ptr % 16 == 0
-        if want_maxes:
+        if getattr(self, "presummed", False):     # the join behind this unit already reduced (msk_add_act_join_bwd_ex)
+            self.presummed = False
+            want_maxes = fuse
+        elif want_maxes:
             dev.call("msk_affine_act_bwd_reduce_ex", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                      _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]), _fp(sc["maxes"]))
         else:
@@ -632,9 +635,13 @@ class AddAct:
         if a.grad_written:
             raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
         if getattr(self, "unit", None) is not None:
+            # one pass: the join's data gradients and slope gradient AND the sums (and maxima) the unit's own backward starts
+            # with -- its reduce pass is skipped (ConvBNAct.backward, presummed)
             u, sc = self.unit, self.unit.bn.scratch(dev)
-            dev.call("msk_add_act_join_bwd", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr), b.msk(),
-                     alpha, dout.msk(), ga.msk(), gb.msk(), 1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr))
+            dev.call("msk_add_act_join_bwd_ex", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr), b.msk(),
+                     alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(), 1 if b.grad_written else 0,
+                     _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(sc["maxes"]))
+            u.presummed = True
         elif Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
             # one pass: both data gradients and the alpha-gradient sum (a join has no BatchNorm)
             dev.call("msk_add_act_bwd", a.msk(), b.msk(), alpha, dout.msk(), ga.msk(), gb.msk(),

@@ -43,7 +43,7 @@ NOOP(msk_ncdhw_to_ndhwc) NOOP(msk_ndhwc_to_ncdhw)
 NOOP(msk_conv3d_fwd) NOOP(msk_conv_fold_bn) NOOP(msk_conv3d_fwd_act) NOOP(msk_conv3d_fwd_ex) NOOP(msk_conv3d_wgrad_ex) NOOP(msk_conv3d_bwd_bnact) NOOP(msk_conv3d_dgrad) NOOP(msk_conv3d_wgrad)
 NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
 NOOP(msk_bn_stats) NOOP(msk_bn_finalize) NOOP(msk_bn_eval_coeffs)
-NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_reduce_ex) NOOP(msk_affine_act_join_fwd) NOOP(msk_add_act_join_bwd) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)
+NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_reduce_ex) NOOP(msk_affine_act_join_fwd) NOOP(msk_add_act_join_bwd) NOOP(msk_add_act_join_bwd_ex) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)
 NOOP(msk_add_act_bwd) NOOP(msk_bn_bias_grad) NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c)
 NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum)
 NOOP(msk_resample3d) NOOP(msk_hu_norm) NOOP(msk_minmax_norm) NOOP(msk_max_norm) NOOP(msk_label_remap)

@@ -779,3 +779,20 @@ def test_affine_act_join_fwd_bwd(shape):
     assert rel_err(t_to_ncdhw(da), ds) < 1e-6
     assert rel_err(t_to_ncdhw(dres), ds + 0.5) < 1e-6
     assert rel_err(vec_back(dao, Cn), dao_ref + 0.25) < 2e-5
+    # the _ex form: the same outputs plus the unit's own backward sums (what msk_affine_act_bwd_reduce_ex(y, dout = da) gives)
+    if Cn % 4 == 0:
+        mean, invstd = rng.standard_normal(Cn).astype(np.float32), rng.uniform(0.5, 2.0, Cn).astype(np.float32)
+        da2, dres2 = t_empty(N, Cn, D, H, W, fill=5.0), t_from_ncdhw(np.full(shape, 0.5, np.float32))
+        dao2, sums4, maxes = vec(np.full(Cn, 0.25, np.float32)), vec(np.zeros(4 * Cn, np.float32)), vec(np.zeros(128, np.float32))
+        d.call("msk_add_act_join_bwd_ex", yt.msk(), vp(sc), vp(sf), vp(pai), rt.msk(), vp(pao), vp(vec(mean)), vp(vec(invstd)),
+               dt.msk(), da2.msk(), dres2.msk(), 1, vp(dao2), vp(sums4), vp(maxes))
+        assert rel_err(t_to_ncdhw(da2), ds) < 1e-6 and rel_err(t_to_ncdhw(dres2), ds + 0.5) < 1e-6
+        assert rel_err(vec_back(dao2, Cn), dao_ref + 0.25) < 2e-5
+        du = ds * np.where(u > 0, 1.0, f8(ai).reshape(sh))
+        xhat = (f8(y) - f8(mean).reshape(sh)) * f8(invstd).reshape(sh)
+        ref_sums = np.concatenate([du.sum(axis=(0, 2, 3, 4)), (du * xhat).sum(axis=(0, 2, 3, 4)), (ds * u * (u <= 0)).sum(axis=(0, 2, 3, 4))])
+        got = vec_back(sums4, 3 * Cn)
+        assert np.abs(got - ref_sums).max() < 2e-5 * np.abs(ref_sums).max()
+        mx = d.d2h(maxes, (2, 64), np.float32).max(axis=1)
+        assert abs(mx[0] - np.abs(du).max()) < 1e-6 * np.abs(du).max() and abs(mx[1] - np.abs(xhat).max()) < 1e-5 * np.abs(xhat).max()
+
