@@ -90,7 +90,8 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *     14=fp32 Winograd F(2,5) instead of F(4,5), 16=tap-row weight-gradient kernel for the kernel == stride convolutions,
  *     20=fp32-MFMA Winograd kernels instead of the bf16x3 pipeline, 21=the same for the weight gradient only,
  *     22=VALU kernel instead of the folded-column MFMA kernel for 32->ncls (conv_foldn_k), 23=VALU kernel instead of
- *     conv_c1_mfma_k for 1->16, 24=fp32-MFMA form of conv_foldn_k instead of the fp16 two-piece form;
+ *     conv_c1_mfma_k for 1->16, 24=fp32-MFMA form of conv_foldn_k instead of the fp16 two-piece form,
+ *     25=fp32-MFMA tight-K kernel instead of conv_tk_h2_k for ncls->32;
  *   "wino_bf3" 0|1 (0 = fp32-MFMA Winograd kernels everywhere; also env MSEGK_WBF=0), "wbf_variant" (-1 auto | tile variant
  *     of wbf_gemm_k), "wbf_tin_map" 0|1 (lane mapping of the transform kernel);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);

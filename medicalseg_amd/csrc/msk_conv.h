@@ -64,6 +64,8 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
 int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv with <= 4 reduction channels: (tap, channel) pairs enumerated tightly along K (msk_conv_tightk.hip)
 int msk_gconv_halo_tightk(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// the same class (CK <= 4 -> 32 channels) with fp16 two-piece operands, kd folded into K, marching along D (msk_conv_tightk.hip)
+int msk_gconv_tk_h2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv with ONE input channel (in_tr.conv1) on the fp32 matrix pipe, weights and tap offsets in registers (msk_conv_c1.hip)
 int msk_gconv_c1_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv 32 -> (<= 4) channels, two voxels per thread on the VALU (msk_conv_valu2.hip)

@@ -259,7 +259,10 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     int r = ctx->conv_impl == 23 ? 0 : msk_gconv_c1_mfma(ctx, g, w, A, B, swap);  // 23 = A/B: VALU kernel for 1 -> 16
     if (r < 0) return r;
     if (r == 1) return 0;
-    r = ctx->conv_impl == 8 ? 0 : msk_gconv_halo_tightk(ctx, g, w, A, B, swap);  // 8 = A/B: skip the tight-K kernel
+    r = ctx->conv_impl == 8 ? 0 : msk_gconv_tk_h2(ctx, g, w, A, B, swap);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+    r = ctx->conv_impl == 8 ? 0 : msk_gconv_halo_tightk(ctx, g, w, A, B, swap);  // 8 = A/B: skip the tight-K kernels
     if (r < 0) return r;
     if (r == 1) return 0;
     // 22 = A/B: the VALU kernels instead of the folded-column MFMA kernel; 9 skips both (one-voxel VALU kernel)

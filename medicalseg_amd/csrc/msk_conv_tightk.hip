@@ -9,8 +9,10 @@
 // ([channel][voxel], odd pitch) so every A operand is a conflict-free ds_read_b32 at
 // voxel + tap_offset[t], the offsets coming from a small LDS table.
 #include "msk_conv.h"
+#include "msk_wbf.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 tk_f16x8 __attribute__((ext_vector_type(8)));
+ __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -169,7 +171,229 @@ int launch_tk(msk_ctx* ctx, TKArgs& a, int CK, int ntn, const char* tag) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same problem class with fp16 two-piece operands (msk_wbf.h, option "conv_split" 2) for CN = 32 (out_tr.conv1's data
+// gradient): the kd taps are folded into the K dimension of v_mfma_f32_16x16x32_f16 -- K = (kd 0..4, channel 0..3) = 20 of
+// 32 -- so one instruction per (kh, kw) tap, output-channel tile and piece product covers all five kd taps: 150 instead of
+// 188 x 4 MFMA issue slots per 32 positions, on a pipe 16x faster.  A workgroup owns a 16 x 16 (h, w) column and marches
+// along D; the last planes of the (tiny: <= 4 channels) source live in an LDS ring of 8 slots as [piece][voxel][4 x fp16],
+// so a lane's A fragment is two 8-byte reads (planes kd = 2 kg, 2 kg + 1; the padding lanes read a zero slot).  D is
+// produced transposed (weights as the A operand): a lane ends up with 4 consecutive output channels of one position.
+struct TKH2Args {
+  const float* src;
+  int sld;
+  float* dst;
+  int dld;
+  int N, D, H, W, CK;
+  const uint4* wb;  // [tap 25][n tile 2][piece 2][lane 64]: A fragment (8 fp16: K = 8*(lane/16) .. +7) of output channel 16*nt + lane%16
+  int accumulate;
+  int tiles_h, tiles_w, segs, seg_len, nblk;
+  const float* x_amax;
+  const float* w_amax;
+};
+
+// K index k = kd*4 + c (kd < 5, c < CK), zero elsewhere
+__global__ void __launch_bounds__(256)
+pack_tkh2_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, const float* __restrict__ w_amax,
+                    unsigned short* __restrict__ out) {
+  const float sw = wbf_scale_of(w_amax);
+  const int total = 25 * 2 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, nt = (idx >> 9) & 1, tap2 = idx >> 10;
+    const int n = nt * 16 + (lane & 15), k = 8 * (lane >> 4) + e;
+    const int kd = k >> 2, c = k & 3;
+    float v = 0.f;
+    if (kd < 5 && c < CK) {
+      int tap = kd * 25 + tap2;
+      if (flip) tap = 124 - tap;
+      const int ia = swap ? n : c, ib = swap ? c : n;
+      v = w[((long)ia * B + ib) * 125 + tap] * sw;
+    }
+    const _Float16 h = (_Float16)v;
+    out[(((tap2 * 2 + nt) * 2 + 0) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+    out[(((tap2 * 2 + nt) * 2 + 1) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+  }
+}
+
+__global__ void __launch_bounds__(256, 3)
+conv_tk_h2_k(TKH2Args a) {
+  constexpr int TH = 16, TW = 16, HH = TH + 4, HW = TW + 4, NV = HH * HW;  // 20 x 20 = 400 voxels per plane
+  constexpr int RING = 8, SLOT = 2 * NV;                                    // 8-byte units per ring slot: [piece][voxel]
+  __shared__ uint2 lds[RING * SLOT + 2];                                    // + one zero unit for the padding lanes
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  int t = xcd_remap_tk(blockIdx.x, a.nblk);
+  const int twi = t % a.tiles_w;
+  t /= a.tiles_w;
+  const int thi = t % a.tiles_h;
+  t /= a.tiles_h;
+  const int seg = t % a.segs;
+  const int n = t / a.segs;
+  const int h0 = thi * TH, w0 = twi * TW;
+  const int d_begin = seg * a.seg_len;
+  const int d_end = min(a.D, d_begin + a.seg_len);
+  const float sx = wbf_scale_of(a.x_amax);
+  const float osc = 1.f / (sx * wbf_scale_of(a.w_amax));
+  constexpr int ZERO = RING * SLOT;
+  if (tid == 0) lds[ZERO] = make_uint2(0u, 0u);
+
+  // staging: a thread owns up to two voxels of the plane tile
+  long st_off[2];
+  int st_v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int v = tid + 256 * j;
+    const int hh = v / HW, ww = v % HW;
+    const int gh = h0 - 2 + hh, gw = w0 - 2 + ww;
+    const bool inb = v < NV && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    st_off[j] = inb ? ((((long)n * a.D) * a.H + gh) * a.W + gw) * a.sld : -1;
+    st_v[j] = v < NV ? v : -1;
+  }
+  const long plane = (long)a.H * a.W * a.sld;
+  auto stage = [&](int p) {  // plane p (may lie outside the volume: zeros) -> ring slot p & 7
+    uint2* sl = lds + (p & (RING - 1)) * SLOT;
+    const bool live = p >= 0 && p < a.D;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (st_v[j] < 0) continue;
+      float c[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live && st_off[j] >= 0) {
+        const float* sp = a.src + st_off[j] + (long)p * plane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < a.CK) c[q] = sp[q] * sx;
+      }
+      uint2 hv, lv;
+      wbf_split2h_pair(c[0], c[1], hv.x, lv.x);
+      wbf_split2h_pair(c[2], c[3], hv.y, lv.y);
+      sl[st_v[j]] = hv;
+      sl[NV + st_v[j]] = lv;
+    }
+  };
+
+  f32x4 acc[4][2];  // [row of the wave][output-channel tile]
+  const int steps = (d_end - d_begin) + 4;
+  // planes d_begin-2 .. d_begin+1 first, then one new plane per output plane
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) stage(d_begin - 2 + s);
+#pragma unroll 1
+  for (int s = 4; s < steps; ++s) {
+    const int d = d_begin + s - 4;  // output plane: needs planes d-2 .. d+2
+    __syncthreads();                // the previous plane's reads of the slot about to be overwritten are done
+    stage(d + 2);
+    __syncthreads();
+    // slots of this lane's two planes (kd = 2 lk, 2 lk + 1); padding lanes read the zero unit
+    const int s0 = lk < 3 ? ((d - 2 + 2 * lk) & (RING - 1)) * SLOT : -1;
+    const int s1 = lk < 2 ? ((d - 1 + 2 * lk) & (RING - 1)) * SLOT : -1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int tap = kh * 5 + kw;
+        uint4 wf[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) wf[nt][pc] = a.wb[((tap * 2 + nt) * 2 + pc) * 64 + lane];
+        uint4 xh[4], xl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int vox = (4 * wave + r + kh) * HW + li + kw;
+          const uint2 h0v = lds[s0 >= 0 ? s0 + vox : ZERO], h1v = lds[s1 >= 0 ? s1 + vox : ZERO];
+          const uint2 l0v = lds[s0 >= 0 ? s0 + NV + vox : ZERO], l1v = lds[s1 >= 0 ? s1 + NV + vox : ZERO];
+          xh[r] = make_uint4(h0v.x, h0v.y, h1v.x, h1v.y);
+          xl[r] = make_uint4(l0v.x, l0v.y, l1v.x, l1v.y);
+        }
+        // the three piece products as three sweeps over the eight accumulators: consecutive MFMAs never share one
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][1]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xl[r]), acc[r][nt], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
+      }
+    }
+    // D[row = output channel 16 nt + 4 lk + e][col = position li]
+    if (d < d_end) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gh = h0 + 4 * wave + r, gw = w0 + li;
+        if (gh < a.H && gw < a.W) {
+          float* o = a.dst + ((((long)n * a.D + d) * a.H + gh) * a.W + gw) * a.dld + 4 * lk;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            float4 v = make_float4(acc[r][nt][0] * osc, acc[r][nt][1] * osc, acc[r][nt][2] * osc, acc[r][nt][3] * osc);
+            float4* op = reinterpret_cast<float4*>(o + 16 * nt);
+            if (a.accumulate) {
+              const float4 e = *op;
+              v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+            }
+            *op = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int msk_gconv_tk_h2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
+  if (ctx->conv_split != 2 || ctx->conv_impl == 25) return 0;  // 25 = A/B: the fp32-MFMA tight-K kernel
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
+  if (g.CK < 1 || g.CK > 4 || g.CN != 32 || g.bias || g.prelu) return 0;
+  if (g.DW < 12 || g.DH < 8 || g.DD < 4) return 0;
+  if (g.dld % 4 || (((uintptr_t)g.dst) & 15)) return 0;
+  unsigned short* wb = (unsigned short*)msk_workspace2(ctx, (size_t)25 * 2 * 2 * 64 * 8 * sizeof(unsigned short));
+  if (!wb) return -1;
+  const float* x_amax = g.in_amax ? g.in_amax : msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW);
+  const float* w_amax = msk_absmax(ctx, w_canon, 4, 4, (125L * g.CK * g.CN + 3) / 4);
+  if (!x_amax || !w_amax) return -1;
+  {
+    msk_launch_scope ls(ctx, "pack_weights_tightk");
+    hipLaunchKernelGGL(pack_tkh2_weights_k, dim3(100), dim3(256), 0, ctx->stream, w_canon, A, B, swap, g.transposed ? 1 : 0, g.CK, w_amax, wb);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  TKH2Args a{};
+  a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
+  a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CK = g.CK;
+  a.wb = (const uint4*)wb; a.accumulate = g.accumulate;
+  a.tiles_h = msk_cdiv(a.H, 16); a.tiles_w = msk_cdiv(a.W, 16);
+  const long cols = (long)a.N * a.tiles_h * a.tiles_w;
+  const long per_cu = ctx->foldn_wgs > 0 ? ctx->foldn_wgs : 3;  // tuning: option "foldn_wgs" (shared with conv_foldn_k)
+  int segs = (int)((per_cu * ctx->num_cu + cols - 1) / cols);
+  if (segs > a.D / 8) segs = a.D / 8;
+  if (segs < 1) segs = 1;
+  a.seg_len = msk_cdiv(a.D, segs);
+  a.segs = msk_cdiv(a.D, a.seg_len);
+  const long nblk = cols * a.segs;
+  if (nblk > 0x7fffffff) return 0;
+  a.nblk = (int)nblk;
+  a.x_amax = x_amax; a.w_amax = w_amax;
+  const char* tag = "conv_tk_h2";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "conv_tk_h2[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,acc=%d]", g.CK, g.CN, g.N, g.DD, g.DH, g.DW, g.accumulate);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
+  hipLaunchKernelGGL(conv_tk_h2_k, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, a);
+  MSK_LAUNCH_CHECK(ctx);
+  return 1;
+}
 
 int msk_gconv_halo_tightk(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
   const int ks = g.kd;

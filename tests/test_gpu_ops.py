@@ -796,3 +796,41 @@ def test_affine_act_join_fwd_bwd(shape):
         mx = d.d2h(maxes, (2, 64), np.float32).max(axis=1)
         assert abs(mx[0] - np.abs(du).max()) < 1e-6 * np.abs(du).max() and abs(mx[1] - np.abs(xhat).max()) < 1e-5 * np.abs(xhat).max()
 
+
+
+@pytest.mark.parametrize("case", [(3, (2, 20, 16, 37)), (3, (1, 4, 8, 12)), (2, (1, 33, 24, 16)), (4, (1, 9, 17, 48)), (1, (2, 8, 8, 16))])
+def test_conv_tk_h2_out_tr_dgrad_class(case):
+    """conv_tk_h2_k (data gradient of out_tr.conv1, ncls <= 4 -> 32 channels, vnet.py:165: fp16 two-piece operands, kd folded
+    into the MFMA K dimension, ring of dy planes in LDS, marching along D) against the float64 oracle and against the fp32-MFMA
+    tight-K kernel (conv_impl 25), plain and accumulating, gradient magnitudes 1e-6."""
+    ncls, (N, D, H, W) = case
+    d = dev()
+    rng = np.random.default_rng(50 * ncls + D)
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    w = (rng.standard_normal((ncls, 32) + k) / np.sqrt(32 * 125)).astype(np.float32)
+    dy = (rng.standard_normal((N, ncls, D, H, W)) * 1e-6).astype(np.float32)
+    ref = O.conv3d_dgrad(dy.astype(np.float64), w.astype(np.float64), (N, 32, D, H, W), s_, p)
+    dyt, wp = t_from_ncdhw(dy), vec(w.ravel())
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    out = {}
+    try:
+        for impl in (0, 25):
+            d.set_option("conv_impl", impl)
+            dxt = t_empty(N, 32, D, H, W, fill=3.0)
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+            out[impl] = t_to_ncdhw(dxt)
+            d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+            acc = t_to_ncdhw(dxt)
+            d.prof_enable(False)
+            rep = d.prof_report()
+            assert ("conv_tk_h2" in rep) == (impl == 0), rep
+            assert rel_err(acc, 2 * ref) < _conv_tol(ncls * 125)
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    e0, e25 = rel_err(out[0], ref), rel_err(out[25], ref)
+    print("tk fp16x2 %.2e  fp32-MFMA %.2e" % (e0, e25))
+    assert e0 < _conv_tol(ncls * 125) and e25 < _conv_tol(ncls * 125)
