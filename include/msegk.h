@@ -253,6 +253,15 @@ int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
                  int ignore_index, const double* stats, float coef_ce, float coef_dice,
                  msk_tensor dlogits);
 
+/* DiceLoss(sigmoid_norm=False) and DiceLoss(weight=...) (losses/dice_loss.py:36-43,68-69): dice_softmax != 0
+ * normalises the dice term's probabilities with softmax over the classes instead of the sigmoid; dice_weight
+ * (device, [C], or NULL) multiplies each class's intersection.  The CE term is unchanged. */
+int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                    int ignore_index, int dice_softmax, const float* dice_weight, float* out, double* stats);
+int msk_loss_bwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                    int ignore_index, int dice_softmax, const float* dice_weight, const double* stats,
+                    float coef_ce, float coef_dice, msk_tensor dlogits);
+
 /* ---- optimizer --------------------------------------------------------------- */
 /* paddle.optimizer.Momentum(momentum, weight_decay=L2) over one flat arena
  * (cvlibs/config.py:212-214): g += wd*p; v = mu*v + g; p -= lr*v.
@@ -260,6 +269,14 @@ int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
 int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity,
                      size_t count, float lr, float momentum, float weight_decay,
                      float grad_scale);
+
+/* paddle.optimizer.Adam(beta1, beta2, epsilon, weight_decay=L2) over one flat arena (cvlibs/config.py:214-216):
+ * g = grad_scale*grad + wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr sqrt(1-beta2_pow)/(1-beta1_pow) * m / (sqrt(v) + epsilon sqrt(1-beta2_pow));
+ * beta*_pow = beta*^t of THIS step (t = 1 on the first call); the caller keeps the powers. */
+int msk_adam(msk_ctx* ctx, float* param, const float* grad, float* moment1, float* moment2,
+             size_t count, float lr, float beta1, float beta2, float epsilon, double beta1_pow,
+             double beta2_pow, float weight_decay, float grad_scale);
 
 /* ---- preprocessing (tools/preprocess_utils) ----------------------------------- */
 /* geometry.py:31-69 resample == scipy.ndimage.zoom(order 0|1, grid_mode=False):

@@ -95,7 +95,10 @@ SIGNATURES = {
     "msk_class_weights": (_i, [_vp, _T, _vp]),
     "msk_loss_fwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _vp]),
     "msk_loss_bwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _f, _f, _T]),
+    "msk_loss_fwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "msk_loss_bwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _T]),
     "msk_sgd_momentum": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f]),
+    "msk_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _d, _d, _f, _f]),
     "msk_resample3d": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "msk_crop_resample3d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "msk_flip3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),

@@ -3,13 +3,41 @@ import collections.abc
 import ctypes as C
 
 from .. import nn
-from ..device import IntTensor
+from ..device import IntTensor, Tensor
+
+
+def get_reverse_list(ori_shape, transforms):
+    """infer.py:21-40: [('resize', shape before that Resize3D), ...] in application order."""
+    reverse_list = []
+    d, h, w = ori_shape[0], ori_shape[1], ori_shape[2]
+    for op in (transforms or []):
+        if op.__class__.__name__ in ['Resize3D']:
+            reverse_list.append(('resize', (d, h, w)))
+            d, h, w = op.size[0], op.size[1], op.size[2]
+    return reverse_list
+
+
+def reverse_transform(pred, ori_shape, transforms, mode='trilinear'):
+    """infer.py:43-59: undo the Resize3D ops of the val transforms on the logits, last one first, with
+    F.interpolate(mode='trilinear', align_corners=False) -- the resize kernel of the deep-supervision heads
+    (msk_interp_trilinear_fwd).  The reference's own call site passes mode='bilinear', which Paddle rejects for
+    5-D input; the function's default mode is what is built, and 'bilinear' is read as it."""
+    if mode not in ('trilinear', 'bilinear'):
+        raise ValueError("reverse_transform supports mode='trilinear' only, got %r" % (mode,))
+    for kind, (d, h, w) in get_reverse_list(ori_shape, transforms)[::-1]:
+        if kind != 'resize':
+            raise Exception("Unexpected info '{}' in im_info".format(kind))
+        if (d, h, w) == (pred.d, pred.h, pred.w):
+            continue
+        out = Tensor.empty(pred.dev, pred.n, int(d), int(h), int(w), pred.c)
+        pred.dev.call("msk_interp_trilinear_fwd", pred.msk(), out.msk())
+        pred = out
+    return pred
 
 
 def inference(model, im, ori_shape=None, transforms=None):
-    """Returns (pred int32 [N,1,D,H,W] on device, logits Tensor).  Reverse-resize of the
-    reference (infer.py:43-59,88-90) is only reachable with Resize3D in the val transforms,
-    which no shipped config uses (and which fails upstream): it raises here.
+    """Returns (pred int32 [N,1,D,H,W] on device, logits Tensor); with `ori_shape` different from the logits' and
+    Resize3D ops in `transforms`, the logits are resized back first (infer.py:88-90).
 
     An eval-mode model runs its conv -> BN -> PReLU units as single folded convolutions here
     (nn.fused_inference); a model left in training mode runs the ordinary kernels."""
@@ -20,7 +48,7 @@ def inference(model, im, ori_shape=None, transforms=None):
                         "But received {}".format(type(logits)))
     logit = logits[0]
     if ori_shape is not None and tuple(ori_shape) != tuple(logit.shape[2:]):
-        raise NotImplementedError("reverse_transform (Resize3D in val transforms) is not built")
+        logit = reverse_transform(logit, ori_shape, transforms, mode='bilinear')
     dev = logit.dev
     ptr = dev.arena.alloc(logit.voxels * 4)
     dev.call("msk_argmax_c", logit.msk(), C.c_void_p(ptr))

@@ -28,7 +28,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kThreads)
 loss_stats_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels,
              const float* __restrict__ weights, int ignore_index, long voxels, int C, int CB,
-             float* __restrict__ partial /*[nb][NQ][CB]*/) {
+             float* __restrict__ partial /*[nb][NQ][CB]*/, int dice_softmax) {
   constexpr int NQ = MODE == 0 ? 1 : 5;
   __shared__ float sh[NQ][kThreads];
   const int t = threadIdx.x;
@@ -54,7 +54,14 @@ loss_stats_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ la
       acc[0] += e / se;
     } else {
       const int y = labels[v];
-      const float s = 1.f / (1.f + expf(-zc));
+      float s;
+      if (dice_softmax) {  // dice_loss.py:42-43 nn.Softmax(axis=1) of the raw logits (no EPS: that is the CE term's)
+        const float m2 = group_reduce(live ? zc : -INFINITY, CB, [](float a, float b) { return fmaxf(a, b); });
+        const float e2 = live ? expf(zc - m2) : 0.f;
+        s = e2 / group_reduce(e2, CB, [](float a, float b) { return a + b; });
+      } else {
+        s = 1.f / (1.f + expf(-zc));
+      }
       const bool hit = live && (y == c);
       if (live) {
         acc[1] = fmaf(s, s, acc[1]);
@@ -96,7 +103,7 @@ __global__ void class_weights_final_k(const float* __restrict__ partial, int nb,
 }
 
 __global__ void loss_final_k(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ out,
-                             double* __restrict__ stats /*[3C+2]*/) {
+                             double* __restrict__ stats /*[3C+2]*/, const float* __restrict__ dice_weight) {
   // one wavefront: the 64 lanes stride over the block partials of every (class, quantity) pair and are combined with a
   // fixed-order shuffle tree (the first version let thread c walk all nb partials of class c alone: 0.4 ms at C = 3)
   __shared__ double q[64][5];
@@ -118,7 +125,8 @@ __global__ void loss_final_k(const float* __restrict__ partial, int nb, int C, i
       stats[C + c] = q[c][1];
       stats[2 * C + c] = q[c][2];
       const double den = q[c][1] + q[c][2];
-      const double per = 2.0 * q[c][0] / (den > 1e-6 ? den : 1e-6);  // dice_loss.py:74 clip(min=1e-6)
+      const double wI = dice_weight ? (double)dice_weight[c] * q[c][0] : q[c][0];  // dice_loss.py:68-69
+      const double per = 2.0 * wI / (den > 1e-6 ? den : 1e-6);  // dice_loss.py:74 clip(min=1e-6)
       out[2 + c] = (float)per;
       sp += per;
       sn += q[c][3];
@@ -134,7 +142,8 @@ __global__ void loss_final_k(const float* __restrict__ partial, int nb, int C, i
 __global__ void __launch_bounds__(kThreads)
 loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels,
            const float* __restrict__ weights, int ignore_index, const double* __restrict__ stats,
-           float coef_ce, float coef_dice, float* __restrict__ dz, int lddz, long voxels, int C, int CB) {
+           float coef_ce, float coef_dice, float* __restrict__ dz, int lddz, long voxels, int C, int CB,
+           int dice_softmax, const float* __restrict__ dice_weight) {
   const int t = threadIdx.x;
   const int c = t % CB, vl = t / CB, VPB = kThreads / CB;
   const bool live = c < C;
@@ -143,8 +152,9 @@ loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labe
   if (live) {
     double I = stats[c], den = stats[C + c] + stats[2 * C + c];
     double dc = den > 1e-6 ? den : 1e-6;
-    a_t = (float)(2.0 / dc);                                   // d per / d s  (t term)
-    a_s = (float)(den > 1e-6 ? 4.0 * I / (dc * dc) : 0.0);     // clip passes gradient only above min
+    const double wd_ = dice_weight ? (double)dice_weight[c] : 1.0;  // per = 2 w I / den
+    a_t = (float)(wd_ * 2.0 / dc);                                   // d per / d s  (t term)
+    a_s = (float)(den > 1e-6 ? wd_ * 4.0 * I / (dc * dc) : 0.0);     // clip passes gradient only above min
   }
   const double cden = stats[3 * C + 1];
   const float inv_den = cden != 0 ? (float)(1.0 / cden) : 0.f;
@@ -158,14 +168,26 @@ loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labe
     const float m = group_reduce(zs, CB, [](float a, float b) { return fmaxf(a, b); });
     const float e = (live && ok) ? expf(zs - m) : 0.f;
     const float se = group_reduce(e, CB, [](float a, float b) { return a + b; });
+    const int y = ok ? labels[v] : -1;
+    const float tt = (y == c) ? 1.f : 0.f;
+    float g_d;
+    if (dice_softmax) {
+      // p = softmax(z): dL/dz_k = p_k (g_k - sum_j g_j p_j) with g = dL/dp
+      const float m2 = group_reduce((live && ok) ? zc : -INFINITY, CB, [](float a, float b) { return fmaxf(a, b); });
+      const float e2 = (live && ok) ? expf(zc - m2) : 0.f;
+      const float se2 = group_reduce(e2, CB, [](float a, float b) { return a + b; });
+      const float pd = ok ? e2 / se2 : 0.f;
+      const float gp = (live && ok) ? kd * (a_t * tt - a_s * pd) : 0.f;
+      const float dot = group_reduce(gp * pd, CB, [](float a, float b) { return a + b; });
+      g_d = pd * (gp - dot);
+    } else {
+      const float s = 1.f / (1.f + expf(-zc));
+      g_d = kd * (a_t * tt - a_s * s) * s * (1.f - s);
+    }
     if (live && ok) {
-      const int y = labels[v];
       const float p = e / se;
-      const float tt = (y == c) ? 1.f : 0.f;
       float g_ce = 0.f;
       if (y != ignore_index && y >= 0 && y < C) g_ce = (p - tt) * weights[y] * inv_den;
-      const float s = 1.f / (1.f + expf(-zc));
-      const float g_d = kd * (a_t * tt - a_s * s) * s * (1.f - s);
       dz[v * lddz + c] = coef_ce * g_ce + g_d;
     }
   }
@@ -196,6 +218,24 @@ sgd_momentum_k(float* __restrict__ p, const float* __restrict__ g, float* __rest
   }
 }
 
+// paddle.optimizer.Adam (cvlibs/config.py:214-216; Paddle's adam kernel, which is not part of the reference tree):
+//   g += wd * p (float weight_decay = L2Decay);  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//   p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps sqrt(1 - b2^t))
+__global__ void __launch_bounds__(kThreads)
+adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, size_t n,
+       float lr_t, float b1, float b2, float eps_t, float wd, float gs) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float pp = p[i];
+    const float gg = fmaf(wd, pp, g[i] * gs);
+    const float a = fmaf(b1, m1[i], (1.f - b1) * gg);
+    const float b = fmaf(b2, m2[i], (1.f - b2) * gg * gg);
+    m1[i] = a;
+    m2[i] = b;
+    p[i] = pp - lr_t * (a / (sqrtf(b) + eps_t));
+  }
+}
+
 inline int stat_blocks(long voxels, int VPB, int num_cu) {
   long want = (voxels + (long)VPB * 32 - 1) / ((long)VPB * 32);
   long cap = (long)num_cu * 8;
@@ -219,7 +259,7 @@ int msk_class_weights(msk_ctx* ctx, msk_tensor logits, float* weights) {
   {
     msk_launch_scope ls(ctx, "loss_class_weights");
     hipLaunchKernelGGL(loss_stats_k<0>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
-                       logits.ld, (const int32_t*)nullptr, (const float*)nullptr, 0, voxels, C, CB, partial);
+                       logits.ld, (const int32_t*)nullptr, (const float*)nullptr, 0, voxels, C, CB, partial, 0);
     MSK_LAUNCH_CHECK(ctx);
   }
   {
@@ -231,8 +271,8 @@ int msk_class_weights(msk_ctx* ctx, msk_tensor logits, float* weights) {
   return 0;
 }
 
-int msk_loss_fwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
-                 int ignore_index, float* out, double* stats) {
+int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                    int ignore_index, int dice_softmax, const float* dice_weight, float* out, double* stats) {
   const int C = logits.c;
   MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
   const int CB = pow2ceil(C);
@@ -243,19 +283,25 @@ int msk_loss_fwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
   {
     msk_launch_scope ls(ctx, "loss_fwd_stats");
     hipLaunchKernelGGL(loss_stats_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
-                       logits.ld, labels, weights, ignore_index, voxels, C, CB, partial);
+                       logits.ld, labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax);
     MSK_LAUNCH_CHECK(ctx);
   }
   {
     msk_launch_scope ls(ctx, "loss_fwd_final");
-    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(64), 0, ctx->stream, partial, nb, C, CB, out, stats);
+    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(64), 0, ctx->stream, partial, nb, C, CB, out, stats, dice_weight);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 0;
 }
 
-int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
-                 int ignore_index, const double* stats, float coef_ce, float coef_dice, msk_tensor dlogits) {
+int msk_loss_fwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, float* out, double* stats) {
+  return msk_loss_fwd_ex(ctx, logits, labels, weights, ignore_index, 0, nullptr, out, stats);
+}
+
+int msk_loss_bwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                    int ignore_index, int dice_softmax, const float* dice_weight, const double* stats, float coef_ce,
+                    float coef_dice, msk_tensor dlogits) {
   const int C = logits.c;
   MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
   MSK_REQUIRE(ctx, dlogits.c == C && msk_voxels(dlogits) == msk_voxels(logits), "dlogits shape mismatch");
@@ -267,9 +313,14 @@ int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
   msk_launch_scope ls(ctx, "loss_bwd");
   hipLaunchKernelGGL(loss_bwd_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
                      logits.ld, labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p,
-                     dlogits.ld, voxels, C, CB);
+                     dlogits.ld, voxels, C, CB, dice_softmax, dice_weight);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const float* weights,
+                 int ignore_index, const double* stats, float coef_ce, float coef_dice, msk_tensor dlogits) {
+  return msk_loss_bwd_ex(ctx, logits, labels, weights, ignore_index, 0, nullptr, stats, coef_ce, coef_dice, dlogits);
 }
 
 int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
@@ -286,6 +337,25 @@ int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* veloc
   msk_launch_scope ls(ctx, "sgd_momentum");
   hipLaunchKernelGGL(sgd_momentum_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, velocity, n4,
                      count, lr, momentum, weight_decay, grad_scale);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_adam(msk_ctx* ctx, float* param, const float* grad, float* moment1, float* moment2, size_t count, float lr,
+             float beta1, float beta2, float epsilon, double beta1_pow, double beta2_pow, float weight_decay,
+             float grad_scale) {
+  if (count == 0) return 0;
+  if (msk_join_side_impl(ctx) != 0) return -1;  // weight gradients may still be running on the side stream
+  MSK_REQUIRE(ctx, beta1_pow < 1.0 && beta2_pow < 1.0 && beta1_pow >= 0.0 && beta2_pow >= 0.0, "beta powers must be in [0, 1)");
+  const double c2 = sqrt(1.0 - beta2_pow);
+  const float lr_t = (float)((double)lr * c2 / (1.0 - beta1_pow));
+  const float eps_t = (float)((double)epsilon * c2);
+  long blocks = (long)((count + kThreads - 1) / kThreads);
+  const long cap = (long)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  msk_launch_scope ls(ctx, "adam");
+  hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, moment1, moment2, count, lr_t,
+                     beta1, beta2, eps_t, weight_decay, grad_scale);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }

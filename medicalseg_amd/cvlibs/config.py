@@ -206,6 +206,8 @@ class Config(object):
         kind = args.pop('type')
         if kind == 'sgd':  # the reference maps sgd to Momentum (config.py:212-214)
             cls = optim.Momentum
+        elif kind == 'adam':  # config.py:214-216
+            cls = optim.Adam
         elif kind in optim.__all__:
             cls = getattr(optim, kind)
         else:

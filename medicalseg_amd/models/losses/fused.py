@@ -22,12 +22,14 @@ class LossNode:
         self.C = logits.c
         self.weights_ptr = None
         self.ignore_index = 255
+        self.dice_softmax = False      # DiceLoss(sigmoid_norm=False)
+        self.dice_weight_ptr = None    # DiceLoss(weight=[...]) on the device
         self.out_ptr = None
         self.stats_ptr = None
         self.evaluated_with = None
 
     def evaluate(self):
-        key = self.weights_ptr
+        key = (self.weights_ptr, self.dice_softmax, self.dice_weight_ptr)
         if self.evaluated_with == (key, self.ignore_index) and self.out_ptr is not None:
             return
         dev, Cn = self.dev, self.C
@@ -39,8 +41,9 @@ class LossNode:
             w = dev.arena.alloc(Cn * 4)
             dev.h2d(w, np.ones(Cn, dtype=np.float32))
             self._dummy_w = w
-        dev.call("msk_loss_fwd", self.logits.msk(), C.c_void_p(self.labels.ptr), C.c_void_p(w),
-                 int(self.ignore_index), C.c_void_p(self.out_ptr), C.c_void_p(self.stats_ptr))
+        dev.call("msk_loss_fwd_ex", self.logits.msk(), C.c_void_p(self.labels.ptr), C.c_void_p(w),
+                 int(self.ignore_index), int(self.dice_softmax), C.c_void_p(self.dice_weight_ptr),
+                 C.c_void_p(self.out_ptr), C.c_void_p(self.stats_ptr))
         self.evaluated_with = (key, self.ignore_index)
 
     def backward(self, coef_ce: float, coef_dice: float):
@@ -48,9 +51,9 @@ class LossNode:
         dev = self.dev
         w = self.weights_ptr if self.weights_ptr is not None else self._dummy_w
         dz = self.logits.empty_like()
-        dev.call("msk_loss_bwd", self.logits.msk(), C.c_void_p(self.labels.ptr), C.c_void_p(w),
-                 int(self.ignore_index), C.c_void_p(self.stats_ptr), C.c_float(coef_ce), C.c_float(coef_dice),
-                 dz.msk())
+        dev.call("msk_loss_bwd_ex", self.logits.msk(), C.c_void_p(self.labels.ptr), C.c_void_p(w),
+                 int(self.ignore_index), int(self.dice_softmax), C.c_void_p(self.dice_weight_ptr),
+                 C.c_void_p(self.stats_ptr), C.c_float(coef_ce), C.c_float(coef_dice), dz.msk())
         self.logits.grad = dz
         self.logits.grad_written = True
         return dz

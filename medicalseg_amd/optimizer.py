@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-__all__ = ["Momentum", "SGD", "lr"]
+__all__ = ["Momentum", "SGD", "Adam", "lr"]
 
 
 class _LR:
@@ -165,3 +165,102 @@ class Momentum:
 class SGD(Momentum):
     def __init__(self, learning_rate=0.001, parameters=None, weight_decay=None, **kw):
         super().__init__(learning_rate, 0.0, parameters, weight_decay)
+
+
+class Adam:
+    """paddle.optimizer.Adam(lr, beta1=0.9, beta2=0.999, epsilon=1e-8, parameters, weight_decay: float = L2) as the
+    reference's `optimizer: {type: adam}` branch builds it (cvlibs/config.py:214-216): one kernel over the flat arena,
+    bias-corrected with the running powers beta^t that Paddle keeps as `*_beta{1,2}_pow_acc_0` (here two host doubles,
+    identical for every tensor because all tensors step together)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, parameters=None, weight_decay=None,
+                 **kw):
+        if not parameters:
+            raise ValueError("parameters must be a non-empty list")
+        parameters = [p for p in parameters if not getattr(p, "frozen", False)]
+        arenas = {id(p.arena): p.arena for p in parameters}
+        if len(arenas) != 1 or None in [p.arena for p in parameters]:
+            raise ValueError("all parameters must belong to one built model (one ParamArena)")
+        self.arena = next(iter(arenas.values()))
+        self._learning_rate = learning_rate
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self.weight_decay = float(weight_decay) if weight_decay else 0.0
+        self._parameter_list = list(parameters)
+        self.beta1_pow, self.beta2_pow = self.beta1, self.beta2  # the powers the NEXT step uses (t = 1)
+        dev = self.arena.dev
+        n = max(self.arena.count, 4) * 4
+        self.moment1_ptr, self.moment2_ptr = dev.malloc(n), dev.malloc(n)
+        dev.memset(self.moment1_ptr, 0, n)
+        dev.memset(self.moment2_ptr, 0, n)
+
+    get_lr = Momentum.get_lr
+    set_lr = Momentum.set_lr
+
+    def step(self):
+        a = self.arena
+        a.dev.call("msk_adam", C.c_void_p(a.value_ptr), C.c_void_p(a.grad_ptr), C.c_void_p(self.moment1_ptr),
+                   C.c_void_p(self.moment2_ptr), C.c_size_t(a.count), C.c_float(self.get_lr()), C.c_float(self.beta1),
+                   C.c_float(self.beta2), C.c_float(self.epsilon), C.c_double(self.beta1_pow),
+                   C.c_double(self.beta2_pow), C.c_float(self.weight_decay), C.c_float(a.grad_scale))
+        self.beta1_pow *= self.beta1
+        self.beta2_pow *= self.beta2
+
+    def clear_grad(self):
+        self.arena.zero_grad()
+
+    clear_gradients = clear_grad
+
+    def state_dict(self):
+        dev = self.arena.dev
+        m1 = dev.d2h(self.moment1_ptr, (self.arena.count,), np.float32)
+        m2 = dev.d2h(self.moment2_ptr, (self.arena.count,), np.float32)
+        sd = {}
+        for p in self.arena.params:
+            sd[p.name + "_moment1_0"] = m1[p.offset:p.offset + p.size].reshape(p.shape).copy()
+            sd[p.name + "_moment2_0"] = m2[p.offset:p.offset + p.size].reshape(p.shape).copy()
+            sd[p.name + "_beta1_pow_acc_0"] = np.array([self.beta1_pow], dtype=np.float32)
+            sd[p.name + "_beta2_pow_acc_0"] = np.array([self.beta2_pow], dtype=np.float32)
+        sd["@msegk_beta_pows"] = np.array([self.beta1_pow, self.beta2_pow], dtype=np.float64)
+        if isinstance(self._learning_rate, _LR.LRScheduler):
+            sd["LR_Scheduler"] = self._learning_rate.state_dict()
+        from . import nn as _nn
+        sd["@msegk_dropout_step"] = np.array([_nn.Dropout3D.step], dtype=np.int64)
+        return sd
+
+    def set_state_dict(self, sd):
+        dev = self.arena.dev
+        m1 = dev.d2h(self.moment1_ptr, (self.arena.count,), np.float32)
+        m2 = dev.d2h(self.moment2_ptr, (self.arena.count,), np.float32)
+        used, missing = set(), []
+        for p in self.arena.params:
+            for buf, suffix in ((m1, "_moment1_0"), (m2, "_moment2_0")):
+                k = p.name + suffix
+                if k in sd:
+                    buf[p.offset:p.offset + p.size] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
+                    used.add(k)
+                else:
+                    missing.append(k)
+            for suffix in ("_beta1_pow_acc_0", "_beta2_pow_acc_0"):
+                if p.name + suffix in sd:
+                    used.add(p.name + suffix)
+        dev.h2d(self.moment1_ptr, m1)
+        dev.h2d(self.moment2_ptr, m2)
+        if "@msegk_beta_pows" in sd:
+            self.beta1_pow, self.beta2_pow = [float(v) for v in np.asarray(sd["@msegk_beta_pows"]).ravel()[:2]]
+        else:
+            first = self.arena.params[0].name
+            if first + "_beta1_pow_acc_0" in sd:
+                self.beta1_pow = float(np.asarray(sd[first + "_beta1_pow_acc_0"]).ravel()[0])
+                self.beta2_pow = float(np.asarray(sd[first + "_beta2_pow_acc_0"]).ravel()[0])
+        unexpected = [k for k in sd if k not in used and k not in ("LR_Scheduler", "@msegk_dropout_step",
+                                                                   "@msegk_beta_pows")]
+        if missing or unexpected:
+            from .utils import logger
+            logger.warning("optimizer state: %d moment tensors missing (they restart from zero), %d unexpected keys "
+                           "(e.g. %s)" % (len(missing), len(unexpected), unexpected[:2]))
+        self.last_load = {"missing": missing, "unexpected": unexpected}
+        if "@msegk_dropout_step" in sd:
+            from . import nn as _nn
+            _nn.Dropout3D.step = int(np.asarray(sd["@msegk_dropout_step"]).ravel()[0])
+        if "LR_Scheduler" in sd and isinstance(self._learning_rate, _LR.LRScheduler):
+            self._learning_rate.set_state_dict(sd["LR_Scheduler"])

@@ -609,9 +609,12 @@ def cross_entropy(logit, label, weight, ignore_index=255, eps=1e-8):
     return loss, dz
 
 
-def dice(logit, label, epsilon=1e-6):
-    """losses/dice_loss.py:45-102: sigmoid-normalised V-Net dice with squared
-    denominator.  Returns (loss, per_channel_dice, dL/dlogit)."""
+def dice(logit, label, epsilon=1e-6, sigmoid_norm=True, weight=None):
+    """losses/dice_loss.py:45-102: V-Net dice with squared denominator; probabilities from the sigmoid
+    (dice_loss.py:40-41) or the softmax over classes (:42-43), optional per-class weight on the intersection
+    (:68-69).  Returns (loss, per_channel_dice, dL/dlogit)."""
+    if not sigmoid_norm or weight is not None:
+        return _dice_general(logit, label, epsilon, sigmoid_norm, weight)
     C = logit.shape[1]
     s = 1.0 / (1.0 + np.exp(-logit))
     t = np.moveaxis(np.eye(C, dtype=logit.dtype)[label.astype(np.int64)], -1, 1)
@@ -626,6 +629,41 @@ def dice(logit, label, epsilon=1e-6):
     dper_ds = 2.0 * t / r(denc) - r(2.0 * inter / denc ** 2 * dden) * 2.0 * s
     dz = -(1.0 / C) * dper_ds * s * (1.0 - s)
     return loss, per, dz
+
+
+def _dice_general(logit, label, epsilon, sigmoid_norm, weight):
+    C = logit.shape[1]
+    p = 1.0 / (1.0 + np.exp(-logit)) if sigmoid_norm else softmax(logit, 1)
+    t = np.moveaxis(np.eye(C, dtype=logit.dtype)[label.astype(np.int64)], -1, 1)
+    ax = (0, 2, 3, 4)
+    w = np.ones(C, dtype=logit.dtype) if weight is None else np.asarray(weight, dtype=logit.dtype)
+    inter = w * (p * t).sum(axis=ax)
+    den = (p * p).sum(axis=ax) + (t * t).sum(axis=ax)
+    denc = np.maximum(den, epsilon)
+    per = 2.0 * inter / denc
+    loss = 1.0 - per.mean()
+    r = lambda v: v.reshape(1, -1, 1, 1, 1)
+    dden = np.where(den > epsilon, 1.0, 0.0)
+    dper_dp = 2.0 * r(w) * t / r(denc) - r(2.0 * inter / denc ** 2 * dden) * 2.0 * p
+    g = -(1.0 / C) * dper_dp  # dL/dp
+    if sigmoid_norm:
+        dz = g * p * (1.0 - p)
+    else:
+        dz = p * (g - (g * p).sum(axis=1, keepdims=True))
+    return loss, per, dz
+
+
+def adam_step(params, grads, m1, m2, t, lr, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0, names=None):
+    """paddle.optimizer.Adam with a float weight_decay (= L2Decay added to the gradient), step t = 1, 2, ...:
+    the bias-corrected update in the form Paddle's kernel evaluates it (epsilon scaled by sqrt(1 - beta2^t));
+    algebraically torch.optim.Adam's update, against which tests/test_oracle.py checks it."""
+    c2 = np.sqrt(1.0 - beta2 ** t)
+    lr_t = lr * c2 / (1.0 - beta1 ** t)
+    for n in (names if names is not None else grads.keys()):
+        g = grads[n] + weight_decay * params[n]
+        m1[n] = beta1 * m1.get(n, 0.0) + (1.0 - beta1) * g
+        m2[n] = beta2 * m2.get(n, 0.0) + (1.0 - beta2) * g * g
+        params[n] = params[n] - lr_t * (m1[n] / (np.sqrt(m2[n]) + epsilon * c2))
 
 
 class MixedLossOracle:

@@ -563,3 +563,75 @@ def test_training_trajectory_bf16x3_vs_exact_fp32_kernels():
     assert abs(ma - mc) < max(1e-4, 2 * band_m)
     assert abs(la - lc) < max(1e-4 * abs(lc), 2 * band_l)
     assert np.abs(ta - tc).max() < max(1e-4 * np.abs(tc).max(), 2 * band_t)
+
+
+def test_adam_and_dice_options_trajectory_matches_oracle():
+    """`optimizer: {type: adam}` (cvlibs/config.py:214-216) with MixedLoss([CE, DiceLoss(sigmoid_norm=False, weight)])
+    (dice_loss.py:36-43,68-69): three eval-mode-BN steps through the product's classes against the float64 oracle."""
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    shape, ncls, K, S, N = CFGS[0]
+    dw = np.array([0.5, 2.0, 1.25][:ncls] + [1.0] * max(0, ncls - 3))
+    rng = np.random.default_rng(21)
+    model, params = _build(ncls, K, S, seed=6)
+    om = O.VNetOracle(params, 1, ncls, K, S)
+    m1, m2, ce_w = {}, {}, None
+    opt = optim.Adam(1e-4, parameters=model.parameters(), weight_decay=1e-4)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss(sigmoid_norm=False, weight=list(dw))], [1, 1])],
+              "coef": [1]}
+    model.eval()
+    for step in range(3):
+        x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+        y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+        z = om.forward(x, train=False)
+        if ce_w is None:
+            ce_w = O.class_weights(z)
+        ce, dce = O.cross_entropy(z, y, ce_w, 255)
+        dl, per_ref, ddl = O.dice(z, y, sigmoid_norm=False, weight=dw)
+        grads = om.backward(dce + ddl)
+        O.adam_step(om.p, grads, m1, m2, step + 1, 1e-4, weight_decay=1e-4, names=om.trainable)
+        logits = model(x)
+        loss_list, per = loss_computation(logits, to_labels(y), losses)
+        loss = sum(loss_list)
+        loss.backward()
+        opt.step()
+        model.clear_gradients()
+        assert abs(float(loss) - (ce + dl)) < 5e-5 * abs(ce + dl), (step, float(loss), ce + dl)
+        assert np.abs(np.asarray(per) - per_ref).max() < 1e-4
+    sd = model.state_dict()
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size: tensors whose gradient is at the
+    # fp32 noise level (sign flips) may differ by 2*lr per step; everything else follows the oracle closely
+    worst = max(np.abs(sd[k] - om.p[k]).max() for k in om.trainable)
+    med = np.median([np.abs(sd[k] - om.p[k]).mean() for k in om.trainable])
+    print("adam trajectory: worst %.2e  median of means %.2e" % (worst, med))
+    assert worst <= 3 * 2 * 1e-4 + 1e-6 and med < 2e-5
+
+
+def test_reverse_transform_resizes_logits_back():
+    """core/infer.py:43-59,88-90: with a Resize3D among the val transforms the logits are brought back to the original
+    shape (trilinear, align_corners=False) before the argmax."""
+    from medicalseg_amd import models
+    from medicalseg_amd.core import infer
+    from medicalseg_amd.device import to_tensor
+
+    class Resize3D:  # get_reverse_list matches on the class name and reads .size (infer.py:36-38)
+        def __init__(self, size):
+            self.size = size
+
+    rng = np.random.default_rng(9)
+    model = models.VNet(num_classes=3)
+    model.eval()
+    x = rng.standard_normal((1, 1, 16, 16, 16)).astype(np.float32)
+    _, logit = infer.inference(model, to_tensor(x))
+    small = logit.numpy()
+    pred, back = infer.inference(model, to_tensor(x), ori_shape=(24, 20, 31), transforms=[Resize3D((16, 16, 16))])
+    assert tuple(back.shape) == (1, 3, 24, 20, 31) and tuple(pred.shape) == (1, 1, 24, 20, 31)
+    ref = O.trilinear_resize(small.astype(np.float64), (24, 20, 31))
+    assert np.abs(back.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    top2 = np.sort(ref, axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 1e-4 * np.abs(ref).max()
+    assert np.array_equal(pred.numpy()[:, 0][clear], ref.argmax(1)[clear])
+    # unchanged shape: no resize
+    _, same = infer.inference(model, to_tensor(x), ori_shape=(16, 16, 16), transforms=[Resize3D((16, 16, 16))])
+    assert np.array_equal(same.numpy(), small)

@@ -319,6 +319,61 @@ def test_sgd_momentum():
     assert rel_err(vec_back(pp, n), p - 0.01 * v2) < 1e-6
 
 
+def test_adam():
+    """msk_adam (paddle.optimizer.Adam, cvlibs/config.py:214-216) over five steps against the float64 oracle."""
+    d = dev()
+    rng = np.random.default_rng(4)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    pp, m1p, m2p = vec(p), vec(np.zeros(n)), vec(np.zeros(n))
+    params, m1, m2 = {"p": p.astype(np.float64)}, {}, {}
+    # the kernel holds beta1 / beta2 as fp32 like Paddle's (1 - float(0.999) differs from 0.001 by 4.7e-5 relative):
+    # the oracle runs on the same rounded constants
+    b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+    b1p, b2p = b1, b2
+    for t in range(1, 6):
+        g = rng.standard_normal(n).astype(np.float32)
+        gp = vec(g)
+        d.call("msk_adam", vp(pp), vp(gp), vp(m1p), vp(m2p), C.c_size_t(n), C.c_float(2e-3), C.c_float(0.9),
+               C.c_float(0.999), C.c_float(1e-8), C.c_double(b1p), C.c_double(b2p), C.c_float(1e-4), C.c_float(0.5))
+        b1p, b2p = b1p * b1, b2p * b2
+        O.adam_step(params, {"p": 0.5 * g.astype(np.float64)}, m1, m2, t, 2e-3, b1, b2, 1e-8, float(np.float32(1e-4)))
+        assert rel_err(vec_back(pp, n), params["p"]) < 1e-6
+    assert rel_err(vec_back(m1p, n), m1["p"]) < 1e-6 and rel_err(vec_back(m2p, n), m2["p"]) < 1e-6
+
+
+@pytest.mark.parametrize("sigmoid_norm,weighted", [(False, False), (True, True), (False, True)])
+@pytest.mark.parametrize("ncls,shape", [(3, (2, 5, 6, 7)), (2, (1, 4, 8, 9)), (5, (1, 3, 4, 5))])
+def test_dice_options(ncls, shape, sigmoid_norm, weighted):
+    """DiceLoss(sigmoid_norm=False) and DiceLoss(weight=...) (dice_loss.py:36-43,68-69) through msk_loss_fwd_ex /
+    msk_loss_bwd_ex against the float64 oracle; the CE term beside it is unchanged."""
+    d = dev()
+    N, D, H, W = shape
+    rng = np.random.default_rng(ncls + 7)
+    z = (rng.standard_normal((N, ncls, D, H, W)) * 2).astype(np.float32)
+    y = rng.integers(0, ncls, (N, D, H, W)).astype(np.int32)
+    zt = t_from_ncdhw(z)
+    yp = d.malloc(y.nbytes)
+    d.h2d(yp, y)
+    w_ce = O.class_weights(z.astype(np.float64))
+    wv = vec(w_ce)
+    dw = rng.uniform(0.5, 2.0, ncls) if weighted else None
+    dwp = vec(dw) if weighted else None
+    out, stats = vec(np.zeros(2 + ncls)), d.malloc((3 * ncls + 2) * 8)
+    d.call("msk_loss_fwd_ex", zt.msk(), vp(yp), vp(wv), 255, int(not sigmoid_norm), vp(dwp) if weighted else None,
+           vp(out), vp(stats))
+    z64 = z.astype(np.float64)
+    ce_ref, dce = O.cross_entropy(z64, y, w_ce, 255)
+    dl_ref, per_ref, ddl = O.dice(z64, y, sigmoid_norm=sigmoid_norm, weight=dw)
+    o = vec_back(out, 2 + ncls)
+    assert abs(o[0] - ce_ref) < 2e-5 * abs(ce_ref)
+    assert abs(o[1] - dl_ref) < 2e-6 and rel_err(o[2:], per_ref) < 2e-6
+    dz = t_empty(N, ncls, D, H, W)
+    d.call("msk_loss_bwd_ex", zt.msk(), vp(yp), vp(wv), 255, int(not sigmoid_norm), vp(dwp) if weighted else None,
+           vp(stats), C.c_float(0.7), C.c_float(1.3), dz.msk())
+    assert rel_err(t_to_ncdhw(dz), 0.7 * dce + 1.3 * ddl) < 5e-6
+
+
 def test_dropout_mask_statistics():
     d = dev()
     m = vec(np.zeros(4096))

@@ -61,6 +61,41 @@ def test_full_step_control_flow(fake_pkg, tmp_path):
     assert resume(model, opt, str(tmp_path / "out" / "iter_3")) == 3
 
 
+def test_adam_and_dice_options_control_flow(fake_pkg, tmp_path):
+    """`optimizer: {type: adam}` (cvlibs/config.py:214-216) and DiceLoss(sigmoid_norm=False, weight=...)
+    (dice_loss.py:36-43) drive a full iteration, checkpoint and resume through the real host stack."""
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.core import train
+    from medicalseg_amd.datasets import SyntheticCT
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import resume
+    model = VNet(num_classes=3)
+    opt = optim.Adam(1e-3, parameters=model.parameters(), weight_decay=1e-4)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss(sigmoid_norm=False, weight=[1.0, 2.0, 0.5])], [1, 1])],
+              "coef": [1]}
+    ds = SyntheticCT(num_samples=2, shape=(16, 16, 16), num_classes=3)
+    train(model, ds, optimizer=opt, save_dir=str(tmp_path / "o"), iters=2, batch_size=1, save_interval=2, log_iters=1,
+          losses=losses)
+    assert abs(opt.beta1_pow - 0.9 ** 3) < 1e-12 and abs(opt.beta2_pow - 0.999 ** 3) < 1e-12
+    sd = opt.state_dict()
+    assert "in_tr.conv1.weight_moment1_0" in sd and "in_tr.conv1.weight_beta2_pow_acc_0" in sd
+    opt2 = optim.Adam(1e-3, parameters=model.parameters())
+    assert resume(model, opt2, str(tmp_path / "o" / "iter_2")) == 2
+    assert abs(opt2.beta1_pow - 0.9 ** 3) < 1e-12 and not opt2.last_load["missing"]
+    with pytest.raises(ValueError):
+        DiceLoss(weight=[1.0, 2.0])(_logits(model), _labels())  # two weights for three classes
+
+
+def _logits(model):
+    from medicalseg_amd.device import to_tensor
+    return model(to_tensor(np.zeros((1, 1, 16, 16, 16), np.float32)))[0]
+
+
+def _labels():
+    from medicalseg_amd.device import to_tensor
+    return to_tensor(np.zeros((1, 16, 16, 16), np.int32))
+
+
 def test_mri_config_shapes(fake_pkg):
     """Anisotropic MRI kernels: spatial chain 512x512x12 -> ... (vnet.py:258-265 comments),
     checked here at 1/8 scale in-plane."""

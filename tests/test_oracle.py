@@ -179,3 +179,48 @@ def test_preprocess_restatement_vs_reference_goldens():
     assert np.array_equal(P.label_remap(g["lr_in"], {1: 2, 2: 3}), g["lr_out_chain"])
     ct, _ = P.resample(P.HUnorm(g["pipe_ct_in"]), [16, 16, 16], 1)
     assert np.abs(ct - g["pipe_ct_out"]).max() < 1e-4
+
+
+def test_adam_vs_torch():
+    """oracle adam_step (Paddle's kernel form, cvlibs/config.py:214-216) == torch.optim.Adam with L2 weight decay."""
+    rng = np.random.default_rng(5)
+    p0 = rng.standard_normal(64)
+    tp = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.Adam([tp], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    params, m1, m2 = {"p": p0.copy()}, {}, {}
+    for t in range(1, 6):
+        g = rng.standard_normal(64)
+        tp.grad = torch.tensor(g)
+        opt.step()
+        O.adam_step(params, {"p": g}, m1, m2, t, 2e-3, 0.9, 0.999, 1e-8, 1e-4)
+        assert np.abs(tp.detach().numpy() - params["p"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("sigmoid_norm,weighted", [(False, False), (True, True), (False, True)])
+def test_dice_options_vs_torch_autograd(sigmoid_norm, weighted):
+    """DiceLoss(sigmoid_norm=False) / DiceLoss(weight=...) (dice_loss.py:36-43,68-69) restated in the oracle against
+    torch autograd of the same formula."""
+    rng = np.random.default_rng(11)
+    z = rng.standard_normal((2, 3, 3, 4, 5))
+    y = rng.integers(0, 3, (2, 3, 4, 5))
+    w = np.array([0.5, 2.0, 1.25]) if weighted else None
+    loss, per, dz = O.dice(z, y, sigmoid_norm=sigmoid_norm, weight=w)
+    zt = torch.tensor(z, requires_grad=True)
+    p = torch.sigmoid(zt) if sigmoid_norm else torch.softmax(zt, 1)
+    t = torch.nn.functional.one_hot(torch.tensor(y), 3).permute(0, 4, 1, 2, 3).double()
+    pf, tf = p.transpose(0, 1).reshape(3, -1), t.transpose(0, 1).reshape(3, -1)
+    inter = (pf * tf).sum(-1)
+    if w is not None:
+        inter = torch.tensor(w) * inter
+    tper = 2 * inter / torch.clamp((pf * pf).sum(-1) + (tf * tf).sum(-1), min=1e-6)
+    tl = 1 - tper.mean()
+    tl.backward()
+    assert abs(loss - tl.item()) < 1e-14
+    assert np.abs(per - tper.detach().numpy()).max() < 1e-14
+    assert np.abs(dz - zt.grad.numpy()).max() < 1e-15
+    if sigmoid_norm and not weighted:
+        pass
+    # the default arguments still take the original code path
+    l0, p0, d0 = O.dice(z, y)
+    l1, p1, d1 = O._dice_general(z, y, 1e-6, True, None)
+    assert abs(l0 - l1) < 1e-15 and np.abs(d0 - d1).max() < 1e-16
