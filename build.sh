@@ -10,11 +10,15 @@ OBJS=""
 for f in medicalseg_amd/csrc/*.hip; do
   o=build/$(basename ${f%.hip}).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ include/msegk.h -nt $o ] || [ medicalseg_amd/csrc/msk_common.h -nt $o ] || [ medicalseg_amd/csrc/msk_conv.h -nt $o ] || [ medicalseg_amd/csrc/msk_wbf.h -nt $o ]; then
+    rm -f $o   # a failed compile must not leave the previous object behind (the jobs run in the background)
     hipcc $FLAGS $EXTRA -c $f -o $o &
   fi
   OBJS="$OBJS $o"
 done
 wait
+for o in $OBJS; do
+  if [ ! -f $o ]; then echo "build failed: $o was not produced" >&2; exit 1; fi
+done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsegk.so $OBJS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/libmsegk.so"
 if [ -f oracle/c/Makefile ]; then make -s -C oracle/c; fi

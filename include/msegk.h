@@ -91,7 +91,8 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *     20=fp32-MFMA Winograd kernels instead of the bf16x3 pipeline, 21=the same for the weight gradient only,
  *     22=VALU kernel instead of the folded-column MFMA kernel for 32->ncls (conv_foldn_k), 23=VALU kernel instead of
  *     conv_c1_mfma_k for 1->16, 24=fp32-MFMA form of conv_foldn_k instead of the fp16 two-piece form,
- *     25=fp32-MFMA tight-K kernel instead of conv_tk_h2_k for ncls->32;
+ *     25=fp32-MFMA tight-K kernel instead of conv_tk_h2_k for ncls->32,
+ *     26=fp32-MFMA (tap, class)-row weight gradient instead of wgrad_cbs_h2_k for 32->ncls;
  *   "wino_bf3" 0|1 (0 = fp32-MFMA Winograd kernels everywhere; also env MSEGK_WBF=0), "wbf_variant" (-1 auto | tile variant
  *     of wbf_gemm_k), "wbf_tin_map" 0|1 (lane mapping of the transform kernel);
  *   "wgrad_async" 0|1 (weight gradients on the side stream), "wgrad_async_max_m" (voxel limit for it, 0 = all);
@@ -133,7 +134,9 @@ int msk_conv3d_fwd_act(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float
  *                    the convolution's output stage when the kernel supports it (no second read of y), else by msk_bn_stats;
  *       xform (nullable): caller-owned device buffer of msk_conv3d_xform_bytes() bytes that receives the transformed input
  *                    (Winograd B^T x, split into bf16 pieces) the convolution computes anyway; it stays valid while x is
- *                    unchanged.  Pass it only when msk_conv3d_xform_bytes() > 0.
+ *                    unchanged.  Pass it only when msk_conv3d_xform_bytes() > 0.  For the 32 -> ncls <= 3 class
+ *                    (out_tr.conv1, vnet.py:165) the buffer is 512 bytes: only max |x|, which the fp16 two-piece forward
+ *                    kernel measures anyway, travels to the weight gradient.
  *   msk_conv3d_wgrad_ex: as msk_conv3d_wgrad; xform (nullable) = the buffer msk_conv3d_fwd_ex filled for the SAME x,
  *                    which saves recomputing the transform of x (the layer input kept for backward, vnet.py:41).
  *   msk_conv3d_xform_bytes: size of that buffer for input x and cout output channels; 0 = the convolution does not

@@ -42,6 +42,7 @@ struct WGrad {
   const void* xform;  // msk_conv3d_wgrad_ex: transformed A written by msk_conv3d_fwd_ex for the same tensor, or null
   const void* yform;  // msk_conv3d_bwd_bnact: transformed B (A dy) already written by the dual transform, or null
   const float* y_amax;  // NP = 2: device scalar bounding max |B| when yform is given
+  const float* b_amax;  // NP = 2, small-channel kernels: max |B| when the caller already has it (amax array), or null
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
@@ -86,6 +87,7 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
 // kernel == stride forward gather (down-convs, up-conv data gradients): flattened K, two operand batches in flight (msk_conv_ksfwd.hip)
 int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
+bool msk_gconv_foldn_h2_accepts(const msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout);
 int msk_wgrad_cbs(msk_ctx* ctx, const WGrad& g); // <= 4 output channels, 5^3 same (msk_wgrad_cbs.hip)
 int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g);  // one input channel, 5^3 same (msk_wgrad_c1.hip)
 int msk_wgrad_ks(msk_ctx* ctx, const WGrad& g);  // kernel == stride, no padding (msk_wgrad_ks.hip)

@@ -579,6 +579,38 @@ int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* d
   return 0;
 }
 
+// msk_conv3d_wgrad_ex / msk_conv3d_dgrad with the maximum |dy| the caller may already hold (an amax array, msk_wbf.h)
+int conv3d_wgrad_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
+                      const void* xform, const float* dy_amax) {
+  if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
+  msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);
+  WGrad g{};
+  g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
+  g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
+  g.CA = x.c; g.CB = dy.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.dw = dw; g.accumulate = accumulate;
+  g.xform = xform;
+  g.b_amax = dy_amax;
+  return run_wgrad(ctx, g, dy, db, accumulate);
+}
+
+int conv3d_dgrad_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate,
+                      const float* dy_amax) {
+  if (check_conv_shapes(ctx, cd, dx, dy, false) != 0) return -1;
+  GConv g{};
+  g.src = (const float*)dy.p; g.sld = dy.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
+  g.N = dx.n; g.SD = dy.d; g.SH = dy.h; g.SW = dy.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
+  g.CK = dy.c; g.CN = dx.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 1; g.bias = nullptr; g.accumulate = accumulate; g.flip = 1;
+  g.in_amax = dy_amax;
+  // w[Cout][Cin][tap]: k = Cout = a, n = Cin = b -> no swap
+  return run_gconv(ctx, g, w, dy.c, dx.c, 0, "conv3d_dgrad_direct");
+}
+
 extern "C" {
 
 int msk_conv_fold_bn(msk_ctx* ctx, const float* w, const float* bias, const float* scale, const float* shift, int cout,
@@ -623,9 +655,11 @@ size_t msk_conv3d_xform_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int 
   const bool k5 = cd.kd == 5 && cd.kh == 5 && cd.kw == 5 && cd.pd == 2 && cd.ph == 2 && cd.pw == 2;
   const bool k3 = cd.kd == 3 && cd.kh == 3 && cd.kw == 3 && cd.pd == 1 && cd.ph == 1 && cd.pw == 1;
   if (!(k5 || k3) || !(cd.sd == 1 && cd.sh == 1 && cd.sw == 1)) return 0;
-  if (cout < 32 || cout % 32) return 0;
   const size_t per = (size_t)x.d * x.h * x.w * (x.ld > cout ? x.ld : cout) * sizeof(float);
   if (per > 0 && (size_t)x.n > kChunkBytes / per) return 0;  // chunked batches do not keep the transform
+  // out_tr.conv1 class (32 -> ncls <= 3): only the header -- max |x| travels from conv_foldn_h2_k to wgrad_cbs_h2_k
+  if (msk_gconv_foldn_h2_accepts(ctx, cd, x, cout)) return kWbfXformHeader;
+  if (cout < 32 || cout % 32) return 0;
   if (x.ld % 4 || (((uintptr_t)x.p) & 15)) return 0;
   return msk_wbf_fwd_xform_bytes(ctx, x.n, x.d, x.h, x.w, x.c, cout, k5 ? 5 : 3);
 }
@@ -659,30 +693,11 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
 
 int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
                         const void* xform) {
-  if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
-  msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);
-  WGrad g{};
-  g.A = (const float*)x.p; g.ald = x.ld; g.B = (const float*)dy.p; g.bld = dy.ld;
-  g.N = x.n; g.AD = x.d; g.AH = x.h; g.AW = x.w; g.BD = dy.d; g.BH = dy.h; g.BW = dy.w;
-  g.CA = x.c; g.CB = dy.c;
-  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
-  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
-  g.dw = dw; g.accumulate = accumulate;
-  g.xform = xform;
-  return run_wgrad(ctx, g, dy, db, accumulate);
+  return conv3d_wgrad_impl(ctx, cd, x, dy, dw, db, accumulate, xform, nullptr);
 }
 
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate) {
-  if (check_conv_shapes(ctx, cd, dx, dy, false) != 0) return -1;
-  GConv g{};
-  g.src = (const float*)dy.p; g.sld = dy.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
-  g.N = dx.n; g.SD = dy.d; g.SH = dy.h; g.SW = dy.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
-  g.CK = dy.c; g.CN = dx.c;
-  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
-  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
-  g.transposed = 1; g.bias = nullptr; g.accumulate = accumulate; g.flip = 1;
-  // w[Cout][Cin][tap]: k = Cout = a, n = Cin = b -> no swap
-  return run_gconv(ctx, g, w, dy.c, dx.c, 0, "conv3d_dgrad_direct");
+  return conv3d_dgrad_impl(ctx, cd, dy, w, dx, accumulate, nullptr);
 }
 
 int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
@@ -793,9 +808,15 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
   if (int rc = msk_affine_act_bwd_apply(ctx, y, scale, shift, msk_tensor{}, alpha, mean, invstd, gamma, dout, sums_total, M_total, 1,
                                         dy_scratch, msk_tensor{}, 0))
     return rc;
+  // out_tr.conv1 class with fp16 two-piece operands: both gradient kernels scale dy by its maximum -- taken once here
+  const float* dy_amax = nullptr;
+  if (ctx->conv_split == 2 && ctx->conv_impl == 0 && y.c <= 4 && cd.kd == 5 && cd.kh == 5 && cd.kw == 5) {
+    dy_amax = msk_absmax(ctx, (const float*)dy_scratch.p, dy_scratch.ld, dy_scratch.c, msk_voxels(dy_scratch));
+    if (!dy_amax) return -1;
+  }
   // the weight gradient first: it forks to the side stream and overlaps the data gradient enqueued behind it
-  if (int rc = msk_conv3d_wgrad_ex(ctx, cd, x, dy_scratch, dw, nullptr, dw_accumulate, xform)) return rc;
-  if (dx.p) return msk_conv3d_dgrad(ctx, cd, dy_scratch, w, dx, dx_accumulate);
+  if (int rc = conv3d_wgrad_impl(ctx, cd, x, dy_scratch, dw, nullptr, dw_accumulate, xform, dy_amax)) return rc;
+  if (dx.p) return conv3d_dgrad_impl(ctx, cd, dy_scratch, w, dx, dx_accumulate, dy_amax);
   return 0;
 }
 

@@ -428,6 +428,19 @@ conv_foldn_h2_k(FNH2Args a) {
 
 }  // namespace
 
+// Will msk_conv3d_fwd_ex route this problem to conv_foldn_h2_k?  Then the caller may keep a kWbfXformHeader-byte "xform"
+// whose first amax array receives max |x| for the layer's weight gradient (wgrad_cbs_h2_k).  Mirrors the checks below and
+// the dispatch order in run_gconv_one (conv_impl 0 only).
+bool msk_gconv_foldn_h2_accepts(const msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout) {
+  if (ctx->conv_split != 2 || ctx->conv_impl != 0) return false;
+  if (!(cd.kd == 5 && cd.kh == 5 && cd.kw == 5 && cd.sd == 1 && cd.sh == 1 && cd.sw == 1 && cd.pd == 2 && cd.ph == 2 && cd.pw == 2)) return false;
+  if (!(x.c == 32 && cout >= 1 && 5 * cout <= 16)) return false;
+  if (x.w < 12 || x.d < 4) return false;
+  if (x.ld % 4 || (((uintptr_t)x.p) & 15)) return false;
+  if ((size_t)x.n * x.d * x.h * x.w * x.ld * sizeof(float) >= 0xFFFFFFF0ull) return false;
+  return true;
+}
+
 int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, bool* act_fused) {
   if (!(g.kd == 5 && g.kh == 5 && g.kw == 5)) return 0;
   if (!(g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
@@ -441,9 +454,12 @@ int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   if (ctx->conv_split == 2 && ctx->conv_impl != 24) {  // 24 = A/B: the fp32-MFMA form
     unsigned short* wb2 = (unsigned short*)msk_workspace2(ctx, (size_t)25 * 2 * 64 * 8 * sizeof(unsigned short));
     if (!wb2) return -1;
-    const float* x_amax = g.in_amax ? g.in_amax : msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW);
+    // a caller-kept xform (msk_conv3d_fwd_ex): max |x| goes into its header for the layer's weight gradient
+    const float* x_amax = g.in_amax ? g.in_amax
+                                    : msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
     const float* w_amax = msk_absmax(ctx, w_canon, 4, 4, (125L * g.CK * g.CN + 3) / 4);
     if (!x_amax || !w_amax) return -1;
+    if (g.xform && !g.in_amax) ctx->xform_written = true;
     {
       msk_launch_scope ls(ctx, "pack_weights_foldn");
       hipLaunchKernelGGL(pack_foldn_h2_weights_k, dim3(50), dim3(256), 0, ctx->stream, w_canon, A, B, swap, g.transposed ? 1 : 0, g.CN,

@@ -889,3 +889,44 @@ def test_conv_tk_h2_out_tr_dgrad_class(case):
     e0, e25 = rel_err(out[0], ref), rel_err(out[25], ref)
     print("tk fp16x2 %.2e  fp32-MFMA %.2e" % (e0, e25))
     assert e0 < _conv_tol(ncls * 125) and e25 < _conv_tol(ncls * 125)
+
+
+@pytest.mark.parametrize("case", [(3, 32, (2, 20, 16, 37)), (3, 32, (1, 4, 8, 12)), (2, 16, (1, 9, 24, 40)), (4, 32, (1, 9, 17, 48)),
+                                  (1, 8, (2, 8, 8, 16)), (3, 24, (1, 6, 10, 33))])
+def test_wgrad_cbs_h2_out_tr_class(case):
+    """wgrad_cbs_h2_k (weight gradient of out_tr.conv1, 32 -> ncls <= 4, vnet.py:165: fp16 two-piece operands, 32 voxels per
+    MFMA, dy as shifted {v, v+1} dword pairs in LDS) against the float64 oracle and against the fp32-MFMA kernel
+    (conv_impl 26), plain and accumulating; dy at gradient magnitude 1e-6, x at O(1)."""
+    ncls, cin, (N, D, H, W) = case
+    d = dev()
+    rng = np.random.default_rng(60 * ncls + D)
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    dy = (rng.standard_normal((N, ncls, D, H, W)) * 1e-6).astype(np.float32)
+    ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s_, p)[0]
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    M = N * D * H * W
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    out = {}
+    try:
+        for impl in (0, 26):
+            d.set_option("conv_impl", impl)
+            dwp, dbp = vec(np.full(ref.size, 0.5, np.float32)), vec(np.zeros(ncls))
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+            out[impl] = vec_back(dwp, ref.size).reshape(ref.shape)
+            d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
+            acc = vec_back(dwp, ref.size).reshape(ref.shape)
+            d.prof_enable(False)
+            rep = d.prof_report()
+            h2 = impl == 0 and ncls <= 3   # four classes = 32 row tiles = 256 accumulator registers: fp32 kernel
+            assert ("wgrad_cbs_h2" in rep) == h2 and ("wgrad_cbs_mfma" in rep) == (not h2), rep
+            assert rel_err(acc, 2 * ref) < _conv_tol(M) * 2
+    finally:
+        d.prof_enable(False)
+        d.set_option("conv_impl", 0)
+    e0, e26 = rel_err(out[0], ref), rel_err(out[26], ref)
+    print("cbs fp16x2 %.2e  fp32-MFMA %.2e" % (e0, e26))
+    assert e0 < _conv_tol(M) * 2 and e26 < _conv_tol(M) * 2
