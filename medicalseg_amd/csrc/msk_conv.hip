@@ -214,6 +214,51 @@ pointwise_small_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   }
 }
 
+// Weight gradient of the 1x1x1 convolution with few channels (out_tr.conv2, ncls -> ncls, vnet.py:169):
+// dW[cb][ca] = sum_v dy[v][cb] * x[v][ca] -- two streams of 12-16 B per voxel and CA x CB <= 16 running sums per thread
+// (the generic split-K MFMA kernel spent 0.20 ms on 100 MB; this is one pass at HBM speed).
+__global__ void __launch_bounds__(kThreads)
+wgrad_pw_small_k(WGrad g, long M, float* __restrict__ partial /*[grid][CA][CB]*/) {
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+    float xa[4], yb[4];
+    const float* xp = g.A + m * g.ald;
+    const float* yp = g.B + m * g.bld;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xa[a] = a < g.CA ? xp[a] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) yb[b] = b < g.CB ? yp[b] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(xa[a], yb[b], acc[a][b]);
+  }
+  __shared__ float sh[kThreads / 64][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float v = acc[a][b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);  // fixed tree: reproducible
+      if (lane == 0) sh[wave][a * 4 + b] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int a = threadIdx.x >> 2, b = threadIdx.x & 3;
+    if (a < g.CA && b < g.CB) {
+      float v = 0.f;
+      for (int w = 0; w < kThreads / 64; ++w) v += sh[w][threadIdx.x];
+      partial[((long)blockIdx.x * g.CA + a) * g.CB + b] = v;
+    }
+  }
+}
+
 inline int grid_for(long total, int num_cu) {
   long b = (total + kThreads - 1) / kThreads;
   long cap = (long)num_cu * 32;
@@ -360,6 +405,21 @@ fold_bn_k(const float* __restrict__ w, const float* __restrict__ b, const float*
 }
 
 int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
+  if (g.kd == 1 && g.kh == 1 && g.kw == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 0 && g.pw == 0 &&
+      g.CA <= 4 && g.CB <= 4 && ctx->conv_impl != 1 && ctx->conv_impl != 3) {
+    const long M = (long)g.N * g.BD * g.BH * g.BW;
+    long blocks = (M + kThreads * 16 - 1) / (kThreads * 16);
+    if (blocks > 4L * ctx->num_cu) blocks = 4L * ctx->num_cu;
+    if (blocks < 1) blocks = 1;
+    float* partial = (float*)msk_workspace(ctx, (size_t)blocks * g.CA * g.CB * sizeof(float));
+    if (!partial) return -1;
+    {
+      msk_launch_scope ls(ctx, "wgrad_pw_small");
+      hipLaunchKernelGGL(wgrad_pw_small_k, dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, g, M, partial);
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    return msk_wgrad_reduce(ctx, partial, (int)blocks, 1, g.CA, g.CB, g.dw, g.accumulate);
+  }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 18) {  // 18 = folded gather kernels for in_tr / out_tr (A/B)
     int r = msk_wgrad_c1(ctx, g);
     if (r < 0) return r;

@@ -1273,7 +1273,21 @@ namespace {
 __global__ void __launch_bounds__(kThreads)
 absmax_k(const float* __restrict__ x, int ld, int C, long voxels, unsigned* __restrict__ slot) {
   float m = 0.f;
-  if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
+  if (ld == C && (voxels * C) % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
+    // dense tensor: a flat float4 stream, eight loads in flight, no index arithmetic
+    const float4* p = reinterpret_cast<const float4*>(x);
+    const long total = voxels * C / 4, stride = (long)gridDim.x * blockDim.x;
+    auto fold = [&](const float4 q) { m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w))); };
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < total; i += 8 * stride) {
+      float4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = p[i + u * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fold(q[u]);
+    }
+    for (; i < total; i += stride) fold(p[i]);
+  } else if (C % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
     const int c4 = C >> 2;
     const long total = voxels * c4, stride = (long)gridDim.x * blockDim.x;
     auto at = [&](long i) {

@@ -238,7 +238,7 @@ adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
 
 inline int stat_blocks(long voxels, int VPB, int num_cu) {
   long want = (voxels + (long)VPB * 32 - 1) / ((long)VPB * 32);
-  long cap = (long)num_cu * 8;
+  long cap = (long)num_cu * 2;  // the single-wavefront final pass walks these partials: 512 of them, not 2048
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;

@@ -34,6 +34,7 @@ CONV_CASES = [
     (32, 2, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 9, 7, 40)),
     (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),      # out_tr.conv2
     (3, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),
+    (4, 2, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 19, 33, 47)),     # wgrad_pw_small_k: several blocks, CA != CB
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
