@@ -48,7 +48,7 @@ def main(tag):
                         "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 rocprofv3 reports half of a wide "
                         "coalesced read stream, MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)"}
         for k in fe:
-            if any(t in k for t in ("mfma", "valu", "wino", "tightk", "wbf_", "foldn", "gconv_ks")):
+            if any(t in k for t in ("mfma", "valu", "wino", "tightk", "wbf_", "foldn", "gconv_ks", "wgrad_cbs", "conv_tk")):
                 n = fe[k][1]
                 f_kb, w_kb = fe[k][0] / n, wr[k][0] / max(wr[k][1], 1)
                 name = k.split("(")[1].split("::")[-1] if "::" in k else k
@@ -69,7 +69,7 @@ def main(tag):
         res = {"_note": "mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), summed over "
                         "all launches of one training step, weight gradients on the main stream (--opt wgrad_async=0)"}
         for k, v in tot.items():
-            if any(t in k for t in ("mfma", "wino", "tightk", "wbf_", "foldn", "gconv_ks")) and v.get("GRBM_GUI_ACTIVE"):
+            if any(t in k for t in ("mfma", "wino", "tightk", "wbf_", "foldn", "gconv_ks", "wgrad_cbs", "conv_tk")) and v.get("GRBM_GUI_ACTIVE"):
                 res[k] = {"mfma_busy_frac": round((v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (v["GRBM_GUI_ACTIVE"] / 8), 4),
                           "gui_active_cycles_per_xcd": int(v["GRBM_GUI_ACTIVE"] / 8)}
         with open(os.path.join(out, f"{tag}_mfma_busy.json"), "w") as f:
