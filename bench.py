@@ -210,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    t_enq = time.perf_counter() - t0   # host time to ENQUEUE the steps (no synchronisation inside a step)
     dev.sync()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
@@ -318,7 +319,11 @@ def main():
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
                       "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn},
-           "final_loss": round(loss_val, 6), "roofline": roofline}
+           "final_loss": round(loss_val, 6),
+           # host time to enqueue one step (python + ctypes + HIP launches, no sync inside a step): the step is GPU-bound
+           # while this stays below ms_per_step
+           "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
+           "roofline": roofline}
     if dp_info is not None:
         out["dp"] = dp_info
     if args.profile_out:
