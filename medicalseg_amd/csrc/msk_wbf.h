@@ -120,6 +120,10 @@ inline void wbf_min_tile(int cout, int* td, int* th) {
   *td = cout == 32 ? 16 : 8;
   *th = cout <= 64 ? 16 : 8;
 }
+// Padding of the (d, h) position planes up to whole tiles that is still worth it: the 16-bit pipeline is 4-5x faster than the
+// fp32 Winograd kernels a declined layer falls back to, so up to 80 % padded matrix work wins (MRI level 256 x 256 x 9:
+// 9 -> 16 planes, 12.9 -> ~5 ms for its three kernels); 35 % was the round-1 break-even against the bf16x3 pipeline.
+constexpr double kWbfMaxPad = 1.8;
 inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* out) {
   static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
   const int dims[3] = {D, H, W};
@@ -128,7 +132,7 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
   for (int i = 0; i < 6; ++i) {
     const int ld = dims[kPerms[i][0]], lh = dims[kPerms[i][1]], lw = dims[kPerms[i][2]];
     if (lw % 4) continue;
-    if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > 1.35 * (double)ld * lh) continue;
+    if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > kWbfMaxPad * (double)ld * lh) continue;
     const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) / ((double)ld * lh);  // padding at the finest tile
     if (best < 0 || cost < best_cost - 1e-9) {
       best = i;
@@ -149,7 +153,7 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
 // a (TD x TH) position tiling fits the planes and wastes at most 35 % of the matrix work on padding
 inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
   const int td = (g.LD + TD - 1) / TD * TD, th = (g.LH + TH - 1) / TH * TH;
-  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= 1.35 * (double)g.LD * g.LH;
+  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= kWbfMaxPad * (double)g.LD * g.LH;
 }
 size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP);
 size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K);

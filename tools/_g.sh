@@ -1,2 +1,4 @@
-for b in 2 1; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-serialized --batch $b 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['host_enqueue_ms_per_step'], d['value'])"; done
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-serialized --size 64 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['host_enqueue_ms_per_step'], d['value'])"
+python tools/bench_workloads.py --model VNet --steps 5 2>&1 | tail -1
+python tools/bench_workloads.py --model VNet --steps 5 --profile-out gpurun_out/mri.tsv 2>&1 | tail -1
+sort -t$'\t' -k3 -g -r gpurun_out/mri.tsv | head -16
+python -m pytest tests/test_gpu_wbf.py tests/test_gpu_fullsize.py -q -x 2>&1 | tail -2
