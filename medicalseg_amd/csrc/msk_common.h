@@ -32,6 +32,9 @@ struct msk_ctx {
   size_t ws_bytes = 0;
   void* ws2 = nullptr;  // second independent scratch (packed weights)
   size_t ws2_bytes = 0;
+  void* ws3 = nullptr;  // third: channel-padded operands of the wbf pipeline (msk_conv.hip, gconv_wbf_padded)
+  size_t ws3_bytes = 0;
+  long wbf_pad_min_voxels = 1L << 18;  // option "wbf_pad_min_voxels"
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
   // profiling
@@ -96,6 +99,7 @@ extern thread_local std::string g_msk_global_err;
 int msk_fail(msk_ctx* ctx, const char* file, int line, const char* what, const char* detail);
 void* msk_workspace(msk_ctx* ctx, size_t bytes);   // returns nullptr on failure (error set)
 void* msk_workspace2(msk_ctx* ctx, size_t bytes);
+void* msk_workspace3(msk_ctx* ctx, size_t bytes);
 void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);

@@ -286,6 +286,110 @@ int check_conv_shapes(msk_ctx* ctx, const msk_conv_desc& cd, const msk_tensor& i
   return 0;
 }
 
+// ---- channel-padding wrapper of the 16-bit Winograd pipeline ---------------------------------------------------------
+// 'Same' 5^3 convolutions whose channel counts are not multiples of 32 (out_tr.conv1 of a 20-class model: 32 -> 20 and its
+// data gradient 20 -> 32, vnet.py:165 with the MRI config) ran on the fp32 Winograd kernels (2.97 + 5.3 ms at 512x512x12).
+// Here the deficient side is padded to 32 with ZEROS -- a zero-filled copy of the source tensor and/or a 32-channel
+// scratch destination, weights padded with zero rows/columns -- the pipeline runs on the padded problem, and a copy-out pass
+// adds the bias.  Exact: the padding contributes zero products.  (The weight gradient keeps its kernel: it runs on the
+// side stream, which has no third scratch.)
+__global__ void __launch_bounds__(kThreads)
+pad_weights_k(const float* __restrict__ w, int A, int B, int Ap, int Bp, int taps, float* __restrict__ out) {
+  const long total = (long)Ap * Bp * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const long r = i / taps;
+    const int b = (int)(r % Bp), a = (int)(r / Bp);
+    out[i] = (a < A && b < B) ? w[((long)a * B + b) * taps + t] : 0.f;
+  }
+}
+// dst[v][0..Cp) = src[v][0..C) then zeros (float4 granules: C % 4 == 0)
+__global__ void __launch_bounds__(kThreads)
+pad_channels_k(const float* __restrict__ src, int sld, int C, float* __restrict__ dst, int Cp, long voxels) {
+  const int q = Cp >> 2;
+  const long total = voxels * q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / q;
+    const int c = (int)(i - v * q) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) x = *reinterpret_cast<const float4*>(src + v * sld + c);
+    *reinterpret_cast<float4*>(dst + v * Cp + c) = x;
+  }
+}
+// dst[v][c] = (accumulate ? dst : 0) + tmp[v][c] + bias[c]   for c < C
+__global__ void __launch_bounds__(kThreads)
+unpad_channels_k(const float* __restrict__ tmp, int Cp, float* __restrict__ dst, int dld, int C, const float* __restrict__ bias,
+                 int accumulate, long voxels) {
+  const int q = C >> 2;
+  const long total = voxels * q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / q;
+    const int c = (int)(i - v * q) * 4;
+    float4 x = *reinterpret_cast<const float4*>(tmp + v * Cp + c);
+    if (bias) {
+      x.x += bias[c]; x.y += bias[c + 1]; x.z += bias[c + 2]; x.w += bias[c + 3];
+    }
+    float4* o = reinterpret_cast<float4*>(dst + v * dld + c);
+    if (accumulate) {
+      const float4 p = *o;
+      x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+    }
+    *o = x;
+  }
+}
+
+// returns 1 when handled, 0 when not eligible (nothing launched), < 0 on error
+int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B, int swap) {
+  if (ctx->conv_split != 2 || ctx->conv_impl != 0 || !ctx->wbf || ctx->no_winograd) return 0;
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
+  if (g.prelu || g.xform || g.fuse) return 0;  // (g.stats: not taken here -- msk_conv3d_fwd_ex then runs msk_bn_stats on y)
+  const int CKp = (g.CK + 31) / 32 * 32, CNp = (g.CN + 31) / 32 * 32;
+  if (CKp == g.CK && CNp == g.CN) return 0;
+  if (g.CK < 16 || g.CN < 16 || g.CK % 4 || g.CN % 4) return 0;  // at most half of a side is padding; float4 granules
+  if (g.sld % 4 || g.dld % 4 || (((uintptr_t)g.src) & 15) || (((uintptr_t)g.dst) & 15)) return 0;
+  const long voxels = (long)g.N * g.DD * g.DH * g.DW;
+  if (voxels < ctx->wbf_pad_min_voxels) return 0;  // small problems: the two extra passes cost more than the kernels differ
+  const int Ap = (A + 31) / 32 * 32, Bp = (B + 31) / 32 * 32;
+  const size_t wb = ((size_t)Ap * Bp * 125 * sizeof(float) + 255) & ~(size_t)255;
+  const size_t sb = CKp != g.CK ? (((size_t)voxels * CKp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  const size_t db = CNp != g.CN ? (((size_t)voxels * CNp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  // the eligibility test needs the final pointers (alignment): reserve first -- grow-only, kept for the next call
+  char* ws = (char*)msk_workspace3(ctx, wb + sb + db);
+  if (!ws) return -1;
+  float* wpad = (float*)ws;
+  float* tsrc = sb ? (float*)(ws + wb) : nullptr;
+  float* tdst = db ? (float*)(ws + wb + sb) : nullptr;
+  GConv gp = g;
+  if (tsrc) { gp.src = tsrc; gp.sld = CKp; }
+  if (tdst) { gp.dst = tdst; gp.dld = CNp; gp.accumulate = 0; gp.bias = nullptr; }
+  gp.CK = CKp; gp.CN = CNp;
+  gp.stats = nullptr;
+  if (!msk_gconv_wino_bf3_accepts(ctx, gp)) return 0;
+  {
+    msk_launch_scope ls(ctx, "pad_weights");
+    hipLaunchKernelGGL(pad_weights_k, dim3(grid_for((long)Ap * Bp * 125, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, A, B, Ap, Bp,
+                       125, wpad);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  if (tsrc) {
+    msk_launch_scope ls(ctx, "pad_channels");
+    hipLaunchKernelGGL(pad_channels_k, dim3(grid_for(voxels * (CKp / 4), ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g.src, g.sld, g.CK,
+                       tsrc, CKp, voxels);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  const int r = msk_gconv_wino_bf3(ctx, gp, wpad, Ap, Bp, swap);
+  if (r < 0) return r;
+  if (r == 0) return msk_fail(ctx, __FILE__, __LINE__, "gconv_wbf_padded", "the pipeline declined a problem it accepted");
+  if (tdst) {
+    msk_launch_scope ls(ctx, "unpad_channels");
+    hipLaunchKernelGGL(unpad_channels_k, dim3(grid_for(voxels * (g.CN / 4), ctx->num_cu)), dim3(kThreads), 0, ctx->stream, tdst, CNp, g.dst,
+                       g.dld, g.CN, g.bias, g.accumulate, voxels);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  return 1;
+}
+
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
 int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag, bool* act_fused) {
   const int taps = g.kd * g.kh * g.kw;
@@ -315,6 +419,9 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     if (r < 0) return r;
     if (r == 1) return 0;
     r = ctx->conv_impl == 9 ? 0 : msk_gconv_halo_valu2(ctx, g, w, A, B, swap);  // 9 = A/B: one-voxel VALU kernel
+    if (r < 0) return r;
+    if (r == 1) return 0;
+    r = gconv_wbf_padded(ctx, g, w, A, B, swap);  // channel counts that are not multiples of 32, padded with zeros
     if (r < 0) return r;
     if (r == 1) return 0;
     // 20 = fp32-MFMA Winograd kernels instead of the bf16x3 pipeline (A/B); option "wino_bf3" 0 does the same

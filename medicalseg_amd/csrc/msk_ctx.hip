@@ -34,6 +34,7 @@ static void* grow(msk_ctx* ctx, void** p, size_t* cur, size_t bytes) {
 }
 void* msk_workspace(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes); }
 void* msk_workspace2(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws2, &ctx->ws2_bytes, bytes); }
+void* msk_workspace3(msk_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->ws3, &ctx->ws3_bytes, bytes); }
 
 static hipEvent_t get_event(msk_ctx* ctx) {
   if (!ctx->event_pool.empty()) {
@@ -155,6 +156,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
+  if (ctx->ws3) hipFree(ctx->ws3);
   if (ctx->ws_side) hipFree(ctx->ws_side);
   if (ctx->scalar_ring) hipFree(ctx->scalar_ring);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
@@ -338,6 +340,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "direct_conv") == 0) {  // 1 = no Winograd kernels (same as env MSEGK_DIRECT_CONV=1)
     ctx->no_winograd = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "wbf_pad_min_voxels") == 0) {  // smallest problem the channel-padding wrapper of the wbf pipeline takes
+    ctx->wbf_pad_min_voxels = value > 0 ? value : 0;
     return 0;
   }
   if (strcmp(key, "wbf_tpb") == 0) {

@@ -476,3 +476,60 @@ def test_wbf_fp16_two_piece_split_scale_invariance(mag):
     errs = [rel_err(got[0], y_ref), rel_err(got[1], dx_ref), rel_err(got[2], dw_ref)]
     print("mag %g: fwd / dgrad / wgrad err %.2e %.2e %.2e" % ((mag,) + tuple(errs)))
     assert errs[0] < _conv_tol(c * K ** 3) and errs[1] < _conv_tol(c * K ** 3) and errs[2] < 2 * _conv_tol(N * D * H * W)
+
+
+@pytest.mark.parametrize("case", [(32, 20, (1, 12, 32, 24)), (20, 32, (1, 12, 32, 24)), (24, 40, (2, 8, 16, 16)), (48, 32, (1, 9, 16, 20))])
+def test_wbf_channel_padding_wrapper(case):
+    """Channel counts that are not multiples of 32 (out_tr.conv1 of the 20-class MRI model, vnet.py:165: 32 -> 20 and the data
+    gradient 20 -> 32) run through the fp16 two-piece pipeline on a zero-padded problem (gconv_wbf_padded, msk_conv.hip):
+    forward with bias, data gradient plain and accumulating, against the float64 oracle; the padding is exact, so the
+    tolerance is the pipeline's own."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", 2)
+    d.set_option("wbf_pad_min_voxels", 0)
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
+    dx_ref = O.conv3d_dgrad(dy.astype(np.float64), w.astype(np.float64), x.shape, s_, p)
+    xt, dyt, wp, bp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel()), vec(b)
+    d.set_option("prof_shapes", 0)
+    d.set_option("prof_only_halo", 0)
+    try:
+        yt = t_empty(N, cout, D, H, W, fill=9.0)
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.prof_enable(False)
+        rep = d.prof_report()
+        assert "wbf_gemm_h2_k" in rep and "pad_weights" in rep, rep
+        assert ("pad_channels" in rep) == (cin % 32 != 0) and ("unpad_channels" in rep) == (cout % 32 != 0), rep
+        e_f = rel_err(t_to_ncdhw(yt), y_ref)
+        dxt = t_empty(N, cin, D, H, W, fill=5.0)
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+        d.prof_enable(False)
+        rep = d.prof_report()
+        assert "wbf_gemm_h2_k" in rep, rep
+        assert ("pad_channels" in rep) == (cout % 32 != 0) and ("unpad_channels" in rep) == (cin % 32 != 0), rep
+        e_d = rel_err(t_to_ncdhw(dxt), dx_ref)
+        d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
+        e_a = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
+        # below the size threshold the wrapper steps aside
+        d.set_option("wbf_pad_min_voxels", 1 << 30)
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+        d.prof_enable(False)
+        assert "pad_weights" not in d.prof_report()
+        assert rel_err(t_to_ncdhw(yt), y_ref) < _conv_tol(cin * 125)
+    finally:
+        d.prof_enable(False)
+        d.set_option("wbf_pad_min_voxels", 1 << 18)
+    print("padded pipeline: fwd %.2e dgrad %.2e acc %.2e" % (e_f, e_d, e_a))
+    assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_a < _conv_tol(cout * 125)
