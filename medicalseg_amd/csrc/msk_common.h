@@ -71,6 +71,8 @@ struct msk_ctx {
   hipStream_t side = nullptr;
   void* ws_side = nullptr;
   size_t ws_side_bytes = 0;
+  void* ws3_side = nullptr;  // the side stream's third scratch (wgrad_wbf_padded)
+  size_t ws3_side_bytes = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool wgrad_async = false;
   bool side_dirty = false;
@@ -120,6 +122,8 @@ struct msk_side_scope {
     std::swap(ctx->stream, ctx->side);
     std::swap(ctx->ws, ctx->ws_side);
     std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+    std::swap(ctx->ws3, ctx->ws3_side);
+    std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
     ctx->side_dirty = true;
   }
   ~msk_side_scope() {
@@ -127,6 +131,8 @@ struct msk_side_scope {
     std::swap(ctx->stream, ctx->side);
     std::swap(ctx->ws, ctx->ws_side);
     std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
+    std::swap(ctx->ws3, ctx->ws3_side);
+    std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
   }
 };
 

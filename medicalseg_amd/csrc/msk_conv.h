@@ -81,6 +81,7 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
 bool msk_gconv_wino_bf3_accepts(msk_ctx* ctx, const GConv& g);  // the same eligibility tests, nothing launched
 // weight gradient of the same layers on the bf16 matrix pipe (msk_wgrad_wbf.hip)
 int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g);
+bool msk_wgrad_wbf_accepts(msk_ctx* ctx, const WGrad& g);  // its shape / alignment tests, nothing launched
 bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes);  // see msk_conv3d_bwd_bnact
 // kernel == stride transposed gather (up-convs, down-conv data gradients): taps folded into N (msk_conv_scatter.hip)
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);

@@ -390,6 +390,68 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   return 1;
 }
 
+// dw[cb][ca][t] (+)= tmp[cb][ca][t] out of the padded [CBp][CAp][taps] gradient
+__global__ void __launch_bounds__(kThreads)
+unpad_dw_k(const float* __restrict__ tmp, int CAp, float* __restrict__ dw, int CA, int CB, int taps, int accumulate) {
+  const long total = (long)CB * CA * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const long r = i / taps;
+    const int ca = (int)(r % CA), cb = (int)(r / CA);
+    const float v = tmp[((long)cb * CAp + ca) * taps + t];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
+// The weight-gradient side of gconv_wbf_padded: x and/or dy zero-padded to 32-channel multiples, the padded gradient
+// [CBp][CAp][125] in scratch, the valid block copied (or added) out.  Runs wherever the caller runs (the weight-gradient side
+// stream has its own third scratch).  1 = handled, 0 = not eligible, < 0 error.
+int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
+  if (ctx->conv_split != 2 || ctx->conv_impl != 0 || !ctx->wbf || ctx->no_winograd) return 0;
+  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
+  if (g.xform || g.yform || g.yfuse) return 0;
+  const int CAp = (g.CA + 31) / 32 * 32, CBp = (g.CB + 31) / 32 * 32;
+  if (CAp == g.CA && CBp == g.CB) return 0;
+  if (g.CA < 16 || g.CB < 16 || g.CA % 4 || g.CB % 4) return 0;
+  if (g.ald % 4 || g.bld % 4 || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15)) return 0;
+  const long voxels = (long)g.N * g.BD * g.BH * g.BW;
+  if (voxels < ctx->wbf_pad_min_voxels) return 0;
+  const size_t wb = ((size_t)CAp * CBp * 125 * sizeof(float) + 255) & ~(size_t)255;
+  const size_t ab = CAp != g.CA ? (((size_t)voxels * CAp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  const size_t bb = CBp != g.CB ? (((size_t)voxels * CBp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  char* ws = (char*)msk_workspace3(ctx, wb + ab + bb);
+  if (!ws) return -1;
+  float* dwp = (float*)ws;
+  float* ta = ab ? (float*)(ws + wb) : nullptr;
+  float* tb = bb ? (float*)(ws + wb + ab) : nullptr;
+  WGrad gp = g;
+  if (ta) { gp.A = ta; gp.ald = CAp; }
+  if (tb) { gp.B = tb; gp.bld = CBp; }
+  gp.CA = CAp; gp.CB = CBp; gp.dw = dwp; gp.accumulate = 0; gp.b_amax = nullptr;
+  if (!msk_wgrad_wbf_accepts(ctx, gp)) return 0;
+  if (ta) {
+    msk_launch_scope ls(ctx, "pad_channels");
+    hipLaunchKernelGGL(pad_channels_k, dim3(grid_for(voxels * (CAp / 4), ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g.A, g.ald, g.CA, ta,
+                       CAp, voxels);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  if (tb) {
+    msk_launch_scope ls(ctx, "pad_channels");
+    hipLaunchKernelGGL(pad_channels_k, dim3(grid_for(voxels * (CBp / 4), ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g.B, g.bld, g.CB, tb,
+                       CBp, voxels);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  const int r = msk_wgrad_wbf(ctx, gp);
+  if (r < 0) return r;
+  if (r == 0) return 0;  // (size limits inside the pipeline: the caller's other kernels take the original problem)
+  msk_launch_scope ls(ctx, "unpad_dw");
+  hipLaunchKernelGGL(unpad_dw_k, dim3(grid_for((long)g.CA * g.CB * 125, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, dwp, CAp, g.dw, g.CA,
+                     g.CB, 125, g.accumulate);
+  MSK_LAUNCH_CHECK(ctx);
+  return 1;
+}
+
 // Run a gather convolution.  w is canonical w[A][B][taps]; swap selects (k,n) = (b,a).
 int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, const char* tag, bool* act_fused) {
   const int taps = g.kd * g.kh * g.kw;
@@ -537,6 +599,11 @@ int run_wgrad_one(msk_ctx* ctx, const WGrad& g) {
   }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 3 && ctx->conv_impl != 16) {  // 16 = generic tap-row kernel (A/B)
     int r = msk_wgrad_ks(ctx, g);
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
+  {
+    const int r = wgrad_wbf_padded(ctx, g);  // channel counts that are not multiples of 32, padded with zeros
     if (r < 0) return r;
     if (r == 1) return 0;
   }

@@ -158,6 +158,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->ws3) hipFree(ctx->ws3);
   if (ctx->ws_side) hipFree(ctx->ws_side);
+  if (ctx->ws3_side) hipFree(ctx->ws3_side);
   if (ctx->scalar_ring) hipFree(ctx->scalar_ring);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
   for (int b = 0; b < 2; ++b) {

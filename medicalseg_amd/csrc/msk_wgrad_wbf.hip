@@ -378,6 +378,23 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
 }
 }  // namespace
 
+// the shape / alignment tests of msk_wgrad_wbf (nothing launched): msk_conv.hip's channel-padding wrapper asks before it pads
+bool msk_wgrad_wbf_accepts(msk_ctx* ctx, const WGrad& g) {
+  (void)ctx;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
+  if (!k5 && !k3) return false;
+  if (!(g.sd == 1 && g.sh == 1 && g.sw == 1)) return false;
+  if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return false;
+  if (g.CA < 32 || g.CA % 32 || g.CB < 32 || g.CB % 32) return false;
+  if (g.ald % 4 || g.bld % 4 || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15)) return false;
+  WbfGeom geo;
+  int mtd, mth;
+  wbf_min_tile(g.CB, &mtd, &mth);
+  if (!wbf_pick_geom(g.BD, g.BH, g.BW, mtd, mth, &geo) && !wbf_pick_geom(g.BD, g.BH, g.BW, 8, 8, &geo)) return false;
+  return wbf_tile_ok(geo, 8, 16) || wbf_tile_ok(geo, 8, 8);
+}
+
 // Returns 1 if handled, 0 if not eligible, < 0 on error.
 int msk_wgrad_wbf(msk_ctx* ctx, const WGrad& g) {
   const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;

@@ -520,6 +520,21 @@ def test_wbf_channel_padding_wrapper(case):
         e_d = rel_err(t_to_ncdhw(dxt), dx_ref)
         d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
         e_a = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
+        # weight gradient through the padded pipeline as well (on the side stream, with its own scratch)
+        dw_ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s_, p)[0]
+        dwp, dbp = vec(np.full(w.size, 0.25, np.float32)), vec(np.zeros(cout))
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+        d.prof_enable(False)
+        rep = d.prof_report()
+        assert "unpad_dw" in rep and "wbf_wgrad_h2_k" in rep, rep
+        from helpers import vec_back
+        e_w = rel_err(vec_back(dwp, w.size).reshape(w.shape), dw_ref)
+        d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
+        e_wa = rel_err(vec_back(dwp, w.size).reshape(w.shape), 2 * dw_ref)
+        M = N * D * H * W
+        assert e_w < 2 * _conv_tol(M) and e_wa < 2 * _conv_tol(M), (e_w, e_wa)
         # below the size threshold the wrapper steps aside
         d.set_option("wbf_pad_min_voxels", 1 << 30)
         d.prof_reset()
