@@ -104,21 +104,20 @@ __global__ void class_weights_final_k(const float* __restrict__ partial, int nb,
 
 __global__ void loss_final_k(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ out,
                              double* __restrict__ stats /*[3C+2]*/, const float* __restrict__ dice_weight) {
-  // one wavefront: the 64 lanes stride over the block partials of every (class, quantity) pair and are combined with a
-  // fixed-order shuffle tree (the first version let thread c walk all nb partials of class c alone: 0.4 ms at C = 3)
+  // 16 wavefronts: the (class, quantity) pairs are dealt out to the wavefronts, whose 64 lanes stride over the block
+  // partials and are combined with a fixed-order shuffle tree (one wavefront for everything took 0.075 ms at C = 3 with
+  // 2048 partials; thread c walking all partials of class c alone: 0.4 ms)
   __shared__ double q[64][5];
-  const int lane = threadIdx.x;
-  for (int c = 0; c < C; ++c) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      double s = 0.0;
-      for (int b = lane; b < nb; b += 64) s += partial[((long)b * 5 + k) * CB + c];
-      s = msk_wave_sum_d(s);
-      if (lane == 0) q[c][k] = s;
-    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int p = wave; p < C * 5; p += nwaves) {
+    const int c = p / 5, k = p - c * 5;
+    double s = 0.0;
+    for (int b = lane; b < nb; b += 64) s += partial[((long)b * 5 + k) * CB + c];
+    s = msk_wave_sum_d(s);
+    if (lane == 0) q[c][k] = s;
   }
   __syncthreads();
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     double sp = 0, sn = 0, sd = 0;
     for (int c = 0; c < C; ++c) {
       stats[c] = q[c][0];
@@ -238,7 +237,7 @@ adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
 
 inline int stat_blocks(long voxels, int VPB, int num_cu) {
   long want = (voxels + (long)VPB * 32 - 1) / ((long)VPB * 32);
-  long cap = (long)num_cu * 2;  // the single-wavefront final pass walks these partials: 512 of them, not 2048
+  long cap = (long)num_cu * 8;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;
@@ -288,7 +287,7 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   }
   {
     msk_launch_scope ls(ctx, "loss_fwd_final");
-    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(64), 0, ctx->stream, partial, nb, C, CB, out, stats, dice_weight);
+    hipLaunchKernelGGL(loss_final_k, dim3(1), dim3(1024), 0, ctx->stream, partial, nb, C, CB, out, stats, dice_weight);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 0;
