@@ -35,6 +35,7 @@ CONV_CASES = [
     (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),      # out_tr.conv2
     (3, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),
     (4, 2, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 19, 33, 47)),     # wgrad_pw_small_k: several blocks, CA != CB
+    (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 16, 64, 64)),   # MRI out_tr.conv2 (20 classes): MFMA gather kernel
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
