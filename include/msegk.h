@@ -346,6 +346,12 @@ int msk_add_act_join_bwd_ex(msk_ctx* ctx, msk_tensor y, const float* scale, cons
                             msk_tensor da, msk_tensor dres, int dres_accumulate, float* dalpha_outer, float* unit_sums,
                             float* maxes /*nullable*/);
 
+/* ELUCons(elu=True) (vnet.py:25-29): paddle.nn.ELU(alpha) as its own pass (the shipped configs use PReLU, which is fused
+ * into the BatchNorm kernels above).  out = x > 0 ? x : alpha*(exp(x)-1), in place allowed;
+ * dx (+)= dout * (out > 0 ? 1 : out + alpha) -- the derivative from the OUTPUT. */
+int msk_elu_fwd(msk_ctx* ctx, msk_tensor x, float alpha, msk_tensor out);
+int msk_elu_bwd(msk_ctx* ctx, msk_tensor out, msk_tensor dout, float alpha, msk_tensor dx, int accumulate);
+
 /* ---- deep supervision (models/vnet_deepsup.py:266-277) -------------- */
 /* F.interpolate(d, size=x.shape[2:], mode='trilinear') of a conv3^3 head: align_corners=
  * False, align_mode=0 [PADDLE]: per axis ratio = in/out, src = max(ratio*(o+0.5)-0.5, 0),

@@ -95,6 +95,8 @@ SIGNATURES = {
     "msk_class_weights": (_i, [_vp, _T, _vp]),
     "msk_loss_fwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _vp]),
     "msk_loss_bwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _f, _f, _T]),
+    "msk_elu_fwd": (_i, [_vp, _T, _f, _T]),
+    "msk_elu_bwd": (_i, [_vp, _T, _T, _f, _T, _i]),
     "msk_loss_fwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "msk_loss_bwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _T]),
     "msk_sgd_momentum": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f]),

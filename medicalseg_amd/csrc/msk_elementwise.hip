@@ -1388,3 +1388,63 @@ const float* msk_bn_bwd_bound(msk_ctx* ctx, int C, const float* scale, const flo
   return slot;
 }
 
+
+// ---------------------------------------------------------------------------
+// ELUCons(elu=True) (vnet.py:25-29): paddle.nn.ELU(alpha) as its own pass.  The shipped configs use PReLU (elu: False; the
+// reference notes NaN gradients with ELU, core/train.py:139), so ELU is not fused into the convolution / BatchNorm kernels:
+// the units run their PReLU-less forms and these two kernels follow / precede them.  The derivative is taken from the
+// OUTPUT (out > 0 ? 1 : out + alpha), so the pre-activation is not kept.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(kThreads)
+elu_fwd_k(const float* __restrict__ x, int xld, float* __restrict__ out, int old, int C, long voxels, float alpha) {
+  const long total = voxels * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / C;
+    const int c = (int)(i - v * C);
+    const float a = x[v * xld + c];
+    out[v * old + c] = a > 0.f ? a : alpha * expm1f(a);
+  }
+}
+__global__ void __launch_bounds__(kThreads)
+elu_bwd_k(const float* __restrict__ out, int old, const float* __restrict__ dout, int dld, float* __restrict__ dx, int xld,
+          int C, long voxels, float alpha, int accumulate) {
+  const long total = voxels * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / C;
+    const int c = (int)(i - v * C);
+    const float o = out[v * old + c];
+    const float g = dout[v * dld + c] * (o > 0.f ? 1.f : o + alpha);
+    float* d = dx + v * xld + c;
+    *d = accumulate ? *d + g : g;
+  }
+}
+}  // namespace
+
+extern "C" {
+int msk_elu_fwd(msk_ctx* ctx, msk_tensor x, float alpha, msk_tensor out) {
+  MSK_REQUIRE(ctx, x.c == out.c && msk_voxels(x) == msk_voxels(out), "shape mismatch");
+  const long voxels = msk_voxels(x);
+  long blocks = (voxels * x.c + kThreads - 1) / kThreads;
+  if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
+  if (blocks < 1) blocks = 1;
+  msk_launch_scope ls(ctx, "elu_fwd");
+  hipLaunchKernelGGL(elu_fwd_k, dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, (const float*)x.p, x.ld, (float*)out.p, out.ld,
+                     x.c, voxels, alpha);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+int msk_elu_bwd(msk_ctx* ctx, msk_tensor out, msk_tensor dout, float alpha, msk_tensor dx, int accumulate) {
+  MSK_REQUIRE(ctx, out.c == dout.c && out.c == dx.c && msk_voxels(out) == msk_voxels(dout) && msk_voxels(out) == msk_voxels(dx),
+              "shape mismatch");
+  const long voxels = msk_voxels(out);
+  long blocks = (voxels * out.c + kThreads - 1) / kThreads;
+  if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
+  if (blocks < 1) blocks = 1;
+  msk_launch_scope ls(ctx, "elu_bwd");
+  hipLaunchKernelGGL(elu_bwd_k, dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, (const float*)out.p, out.ld,
+                     (const float*)dout.p, dout.ld, (float*)dx.p, dx.ld, out.c, voxels, alpha, accumulate);
+  MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+}  // extern "C"

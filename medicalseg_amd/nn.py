@@ -378,11 +378,22 @@ class PReLU(Layer):
 
 
 class ELU(Layer):
+    """paddle.nn.ELU(alpha=1.0) -- ELUCons(elu=True) of the reference (vnet.py:25-29).  No parameter.  The units below run
+    their activation-less kernels and msk_elu_fwd / msk_elu_bwd as separate passes (the shipped configs use PReLU, which is
+    the fused path; the reference notes NaN gradients with ELU, core/train.py:139)."""
+
     def __init__(self, alpha=1.0):
         super().__init__()
-        raise NotImplementedError(
-            "elu=True is not built: every shipped config uses elu: False and the reference notes NaN "
-            "gradients with ELU (core/train.py:139)")
+        self.alpha = float(alpha)
+
+
+def _act_alpha(act):
+    """device pointer of a PReLU's slopes; None for no activation and for ELU (applied as its own pass)"""
+    return act._weight.ptr if isinstance(act, PReLU) else None
+
+
+def _act_alpha_grad(act):
+    return act._weight.grad_ptr if isinstance(act, PReLU) else None
 
 
 class Dropout3D(Layer):
@@ -482,7 +493,7 @@ class ConvBNAct:
         if out is None:
             od, oh, ow = conv.out_dims(x)
             out = Tensor.empty(dev, x.n, od, oh, ow, conv.cout)
-        alpha = self.act._weight.ptr if self.act is not None else None
+        alpha = _act_alpha(self.act)
         dev.call("msk_conv3d_fwd_act", conv.desc(), x.msk(), _fp(self._fold_w), _fp(self._fold_b), _fp(alpha), out.msk())
         self.x, self.res, self.y, self.out, self.bn_mode = x, None, None, out, 3   # 3: no backward through this
         return out
@@ -523,12 +534,14 @@ class ConvBNAct:
             self.bn_mode = 2
         if out is None:
             out = y.empty_like()
-        alpha = self.act._weight.ptr if self.act is not None else None
+        alpha = _act_alpha(self.act)
         if defer_act and res is None and alpha is not None:
             self.deferred = True
         else:
             dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
                      res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
+            if isinstance(self.act, ELU):
+                dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
         self.out = out
         return out
 
@@ -541,7 +554,11 @@ class ConvBNAct:
         bn, sc = self.bn, self.bn.scratch(dev)
         Cn = bn.num_features
         y, res = self.y, self.res
-        alpha = self.act._weight.ptr if self.act is not None else None
+        alpha = _act_alpha(self.act)
+        if isinstance(self.act, ELU):   # dout <- dout * elu'(u), taken from the unit's output; the rest is the BN-only backward
+            g = Tensor.empty(dev, dout.n, dout.d, dout.h, dout.w, dout.c)
+            dev.call("msk_elu_bwd", self.out.msk(), dout.msk(), C.c_float(self.act.alpha), g.msk(), 0)
+            dout = g
         resm = res.msk() if res is not None else NULL_TENSOR
         fuse = (FUSE_BN_BACKWARD and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and need_dx
                 and self.conv.cin == self.conv.cout)
@@ -562,7 +579,7 @@ class ConvBNAct:
             dev.call("msk_dp_allreduce_stats", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world
         dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
-                 _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
+                 _fp(_act_alpha_grad(self.act)), 1)
         dy = y.empty_like()
         if fuse:
             # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
@@ -616,6 +633,11 @@ class AddAct:
         self.a, self.b = a, b
         self.unit = unit if (unit is not None and getattr(unit, "deferred", False)) else None
         out = a.empty_like()
+        if isinstance(self.act, ELU):
+            a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), None, out.msk())   # a + b
+            a.dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
+            self.out = out
+            return out
         if self.unit is not None:
             u, sc = self.unit, self.unit.bn.scratch(a.dev)
             a.dev.call("msk_affine_act_join_fwd", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
@@ -630,10 +652,19 @@ class AddAct:
         Cn = a.c
         if self._sums is None:
             self._sums = dev.small(3 * Cn)
-        alpha = _fp(self.act._weight.ptr)
         ga, gb = a.ensure_grad(), b.ensure_grad()
         if a.grad_written:
             raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
+        if isinstance(self.act, ELU):
+            g = Tensor.empty(dev, dout.n, dout.d, dout.h, dout.w, dout.c)
+            dev.call("msk_elu_bwd", self.out.msk(), dout.msk(), C.c_float(self.act.alpha), g.msk(), 0)
+            # d(a + b): the gradient goes to both operands unchanged
+            dev.call("msk_affine_act_bwd_apply", a.msk(), None, None, b.msk(), None, None, None, None, g.msk(),
+                     None, C.c_double(1.0), 0, ga.msk(), gb.msk(), 1 if b.grad_written else 0)
+            a.grad_written = True
+            b.grad_written = True
+            return
+        alpha = _fp(self.act._weight.ptr)
         if getattr(self, "unit", None) is not None:
             # one pass: the join's data gradients and slope gradient AND the sums (and maxima) the unit's own backward starts
             # with -- its reduce pass is skipped (ConvBNAct.backward, presummed)

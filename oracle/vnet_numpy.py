@@ -363,6 +363,11 @@ class VNetOracle:
         return y
 
     def _prelu(self, name, x):
+        if getattr(self, "elu", False):  # ELUCons(elu=True) (vnet.py:25-29): nn.ELU(), alpha = 1, no parameter
+            y = Var(np.where(x.v > 0, x.v, np.expm1(np.minimum(x.v, 0))))
+            if self.tape is not None:
+                self.tape.record(lambda: x.acc(y.g * np.where(x.v > 0, 1.0, np.exp(np.minimum(x.v, 0)))))
+            return y
         a = self.p[name + "._weight"]
         y = Var(prelu(x.v, a))
         if self.tape is not None:

@@ -635,3 +635,53 @@ def test_reverse_transform_resizes_logits_back():
     # unchanged shape: no resize
     _, same = infer.inference(model, to_tensor(x), ori_shape=(16, 16, 16), transforms=[Resize3D((16, 16, 16))])
     assert np.array_equal(same.numpy(), small)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_vnet_elu_matches_oracle(train):
+    """VNet(elu=True) (ELUCons, vnet.py:25-29; nn.ELU as its own pass around the activation-less unit kernels): state dict
+    without PReLU tensors, logits, loss and every gradient against the float64 oracle's ELU branch, eval- and train-mode
+    BatchNorm (dropout off)."""
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation
+    shape, ncls, K, S, N = CFGS[0]
+    full = O.init_params(7, 1, ncls, K, S)
+    params = {k: v for k, v in full.items() if "relu" not in k}
+    model = VNet(elu=True, in_channels=1, num_classes=ncls, kernel_size=K, stride_size=S)
+    assert sorted(model.state_dict()) == sorted(params)             # ELU carries no parameter
+    missing, unexpected = model.set_state_dict(params)
+    assert not missing and not unexpected
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+    om = O.VNetOracle(params, 1, ncls, K, S)
+    om.elu = True
+    om.trainable = [n for n in om.trainable if "relu" not in n]
+    masks = {} if train else None
+    lg = om.forward(x, train=train, dropout_masks=masks)
+    ol = O.MixedLossOracle()
+    ll, per, dz = ol(lg, y)
+    g = om.backward(dz)
+    model.train() if train else model.eval()
+    model.set_dropout_masks(masks)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    logits = model(x)
+    scale = np.abs(lg).max()
+    assert np.abs(logits[0].numpy() - lg).max() < 2e-4 * scale
+    loss_list, per_d = loss_computation(logits, to_labels(y), losses)
+    loss = sum(loss_list)
+    loss.backward()
+    assert abs(float(loss) - sum(ll)) < 1e-4 * abs(sum(ll))
+    grads = {name: p_.grad_numpy() for name, p_ in model.named_parameters()}
+    assert sorted(grads) == sorted(om.trainable)
+    errs = []
+    for k in om.trainable:
+        ref = g[k]
+        if np.abs(ref).max() < 1e-9:   # conv bias ahead of a train-mode BatchNorm: exactly 0 in exact arithmetic
+            assert np.abs(grads[k]).max() < 1e-4
+            continue
+        errs.append(np.linalg.norm((grads[k] - ref).ravel()) / np.linalg.norm(ref.ravel()))
+    print("elu %s grad err: L2 worst %.2e median %.2e" % ("train" if train else "eval", max(errs), np.median(errs)))
+    # 16^3: the deep BatchNorm layers see 1-8 voxels per channel in train mode (same bounds as the PReLU net's test above)
+    assert max(errs) < (2e-2 if train else 1e-4)
+    model.clear_gradients()

@@ -932,3 +932,27 @@ def test_wgrad_cbs_h2_out_tr_class(case):
     e0, e26 = rel_err(out[0], ref), rel_err(out[26], ref)
     print("cbs fp16x2 %.2e  fp32-MFMA %.2e" % (e0, e26))
     assert e0 < _conv_tol(M) * 2 and e26 < _conv_tol(M) * 2
+
+
+def test_elu_fwd_bwd():
+    """msk_elu_fwd / msk_elu_bwd (paddle.nn.ELU, vnet.py:25-29): values, in-place forward, channel-slice views,
+    the derivative taken from the output, accumulate."""
+    d = dev()
+    rng = np.random.default_rng(12)
+    N, Cc, D, H, W = 2, 6, 3, 5, 7
+    x = (rng.standard_normal((N, Cc, D, H, W)) * 2).astype(np.float32)
+    x[0, 0, 0, 0, :3] = [0.0, -0.0, 1e-30]
+    dout = rng.standard_normal(x.shape).astype(np.float32)
+    for alpha in (1.0, 0.5):
+        ref = np.where(x > 0, x, alpha * np.expm1(np.minimum(x.astype(np.float64), 0)))
+        dref = dout * np.where(x > 0, 1.0, alpha * np.exp(np.minimum(x.astype(np.float64), 0)))
+        xt, ot = t_from_ncdhw(x), t_empty(N, Cc, D, H, W, fill=9.0)
+        d.call("msk_elu_fwd", xt.msk(), C.c_float(alpha), ot.msk())
+        assert rel_err(t_to_ncdhw(ot), ref) < 1e-6
+        d.call("msk_elu_fwd", xt.msk(), C.c_float(alpha), xt.msk())          # in place
+        assert np.array_equal(t_to_ncdhw(xt), t_to_ncdhw(ot))
+        dt, gt = t_from_ncdhw(dout), t_empty(N, Cc, D, H, W, fill=1.0)
+        d.call("msk_elu_bwd", ot.msk(), dt.msk(), C.c_float(alpha), gt.msk(), 0)
+        assert rel_err(t_to_ncdhw(gt), dref) < 2e-6
+        d.call("msk_elu_bwd", ot.msk(), dt.msk(), C.c_float(alpha), gt.msk(), 1)
+        assert rel_err(t_to_ncdhw(gt), 2 * dref) < 2e-6

@@ -96,6 +96,25 @@ def _labels():
     return to_tensor(np.zeros((1, 16, 16, 16), np.int32))
 
 
+def test_elu_control_flow(fake_pkg):
+    """VNet(elu=True) (vnet.py:25-29): ELU units drive a forward/backward through the real host stack; no PReLU tensors."""
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.utils import loss_computation
+    model = VNet(elu=True, num_classes=3)
+    assert not [k for k in model.state_dict() if "relu" in k]
+    assert len(model.parameters()) == 130 - 32          # 32 PReLU slope tensors fewer than the elu=False net
+    model.train()
+    logits = model(to_tensor(np.zeros((1, 1, 16, 16, 16), np.float32)))
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    ll, _ = loss_computation(logits, to_tensor(np.zeros((1, 16, 16, 16), np.int32)), losses)
+    sum(ll).backward()
+    model.eval()
+    from medicalseg_amd.core import infer
+    pred, _ = infer.inference(model, to_tensor(np.zeros((1, 1, 16, 16, 16), np.float32)))
+    assert tuple(pred.shape) == (1, 1, 16, 16, 16)
+
+
 def test_mri_config_shapes(fake_pkg):
     """Anisotropic MRI kernels: spatial chain 512x512x12 -> ... (vnet.py:258-265 comments),
     checked here at 1/8 scale in-plane."""

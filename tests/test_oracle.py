@@ -224,3 +224,39 @@ def test_dice_options_vs_torch_autograd(sigmoid_norm, weighted):
     l0, p0, d0 = O.dice(z, y)
     l1, p1, d1 = O._dice_general(z, y, 1e-6, True, None)
     assert abs(l0 - l1) < 1e-15 and np.abs(d0 - d1).max() < 1e-16
+
+
+def test_oracle_elu_branch_vs_torch_autograd():
+    """ELUCons(elu=True) (vnet.py:25-29): the oracle's ELU branch against the torch restatement with its PReLU modules
+    replaced by torch.nn.ELU -- logits and every gradient."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    S, ncls, N = (16, 16, 16), 3, 1
+    K = Sd = ((2, 2, 2),) * 4
+    rng = np.random.default_rng(3)
+    params = {k: v for k, v in O.init_params(2, 1, ncls, K, Sd).items() if "relu" not in k}
+    x = rng.standard_normal((N, 1) + S).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + S).astype(np.int32)
+    m = O.VNetOracle(params, 1, ncls, K, Sd)
+    m.elu = True
+    m.trainable = [n for n in m.trainable if "relu" not in n]
+    lg = m.forward(x, train=False)
+    L = O.MixedLossOracle()
+    ll, per, dz = L(lg, y)
+    g = m.backward(dz)
+    tm = TorchVNet(1, ncls, K, Sd).double()
+    full = O.init_params(2, 1, ncls, K, Sd)
+    tm.load_oracle_params({k: np.asarray(v, dtype=np.float64) for k, v in full.items()})
+    for parent in list(tm.modules()):
+        for name, child in list(parent.named_children()):
+            if isinstance(child, torch.nn.PReLU):
+                setattr(parent, name, torch.nn.ELU())
+    tm.train(False)
+    tl = tm(torch.tensor(x, dtype=torch.float64), None)
+    ce, dl, tper = torch_mixed_loss(tl, torch.tensor(y), torch.tensor(L.weight))
+    (ce + dl).backward()
+    assert np.abs(tl.detach().numpy() - lg).max() < 1e-10
+    gmax = max(np.abs(v).max() for v in g.values())
+    tg = tm.named_oracle_grads()
+    assert set(g) <= set(tg) | set(), sorted(set(g) - set(tg))[:3]
+    for k, v in g.items():
+        assert np.abs(tg[k] - v).max() < 1e-9 * gmax + 1e-12 * np.abs(v).max(), k
