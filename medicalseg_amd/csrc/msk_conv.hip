@@ -341,7 +341,10 @@ unpad_channels_k(const float* __restrict__ tmp, int Cp, float* __restrict__ dst,
 // returns 1 when handled, 0 when not eligible (nothing launched), < 0 on error
 int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B, int swap) {
   if (ctx->conv_split != 2 || ctx->conv_impl != 0 || !ctx->wbf || ctx->no_winograd) return 0;
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;  // the deep-supervision heads
+  if (!(k5 || k3) || !(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
+  const int taps = k5 ? 125 : 27;
   if (!(g.SD == g.DD && g.SH == g.DH && g.SW == g.DW)) return 0;
   if (g.prelu || g.xform || g.fuse) return 0;  // (g.stats: not taken here -- msk_conv3d_fwd_ex then runs msk_bn_stats on y)
   const int CKp = (g.CK + 31) / 32 * 32, CNp = (g.CN + 31) / 32 * 32;
@@ -351,7 +354,7 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   const long voxels = (long)g.N * g.DD * g.DH * g.DW;
   if (voxels < ctx->wbf_pad_min_voxels) return 0;  // small problems: the two extra passes cost more than the kernels differ
   const int Ap = (A + 31) / 32 * 32, Bp = (B + 31) / 32 * 32;
-  const size_t wb = ((size_t)Ap * Bp * 125 * sizeof(float) + 255) & ~(size_t)255;
+  const size_t wb = ((size_t)Ap * Bp * taps * sizeof(float) + 255) & ~(size_t)255;
   const size_t sb = CKp != g.CK ? (((size_t)voxels * CKp * sizeof(float) + 255) & ~(size_t)255) : 0;
   const size_t db = CNp != g.CN ? (((size_t)voxels * CNp * sizeof(float) + 255) & ~(size_t)255) : 0;
   // the eligibility test needs the final pointers (alignment): reserve first -- grow-only, kept for the next call
@@ -368,8 +371,8 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   if (!msk_gconv_wino_bf3_accepts(ctx, gp)) return 0;
   {
     msk_launch_scope ls(ctx, "pad_weights");
-    hipLaunchKernelGGL(pad_weights_k, dim3(grid_for((long)Ap * Bp * 125, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, A, B, Ap, Bp,
-                       125, wpad);
+    hipLaunchKernelGGL(pad_weights_k, dim3(grid_for((long)Ap * Bp * taps, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, A, B, Ap, Bp,
+                       taps, wpad);
     MSK_LAUNCH_CHECK(ctx);
   }
   if (tsrc) {
@@ -408,7 +411,10 @@ unpad_dw_k(const float* __restrict__ tmp, int CAp, float* __restrict__ dw, int C
 // stream has its own third scratch).  1 = handled, 0 = not eligible, < 0 error.
 int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   if (ctx->conv_split != 2 || ctx->conv_impl != 0 || !ctx->wbf || ctx->no_winograd) return 0;
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2)) return 0;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
+  if (!(k5 || k3) || !(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
+  const int taps = k5 ? 125 : 27;
   if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
   if (g.xform || g.yform || g.yfuse) return 0;
   const int CAp = (g.CA + 31) / 32 * 32, CBp = (g.CB + 31) / 32 * 32;
@@ -417,7 +423,7 @@ int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   if (g.ald % 4 || g.bld % 4 || (((uintptr_t)g.A) & 15) || (((uintptr_t)g.B) & 15)) return 0;
   const long voxels = (long)g.N * g.BD * g.BH * g.BW;
   if (voxels < ctx->wbf_pad_min_voxels) return 0;
-  const size_t wb = ((size_t)CAp * CBp * 125 * sizeof(float) + 255) & ~(size_t)255;
+  const size_t wb = ((size_t)CAp * CBp * taps * sizeof(float) + 255) & ~(size_t)255;
   const size_t ab = CAp != g.CA ? (((size_t)voxels * CAp * sizeof(float) + 255) & ~(size_t)255) : 0;
   const size_t bb = CBp != g.CB ? (((size_t)voxels * CBp * sizeof(float) + 255) & ~(size_t)255) : 0;
   char* ws = (char*)msk_workspace3(ctx, wb + ab + bb);
@@ -446,8 +452,8 @@ int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   if (r < 0) return r;
   if (r == 0) return 0;  // (size limits inside the pipeline: the caller's other kernels take the original problem)
   msk_launch_scope ls(ctx, "unpad_dw");
-  hipLaunchKernelGGL(unpad_dw_k, dim3(grid_for((long)g.CA * g.CB * 125, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, dwp, CAp, g.dw, g.CA,
-                     g.CB, 125, g.accumulate);
+  hipLaunchKernelGGL(unpad_dw_k, dim3(grid_for((long)g.CA * g.CB * taps, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, dwp, CAp, g.dw, g.CA,
+                     g.CB, taps, g.accumulate);
   MSK_LAUNCH_CHECK(ctx);
   return 1;
 }

@@ -478,20 +478,22 @@ def test_wbf_fp16_two_piece_split_scale_invariance(mag):
     assert errs[0] < _conv_tol(c * K ** 3) and errs[1] < _conv_tol(c * K ** 3) and errs[2] < 2 * _conv_tol(N * D * H * W)
 
 
-@pytest.mark.parametrize("case", [(32, 20, (1, 12, 32, 24)), (20, 32, (1, 12, 32, 24)), (24, 40, (2, 8, 16, 16)), (48, 32, (1, 9, 16, 20))])
+@pytest.mark.parametrize("case", [(32, 20, (1, 12, 32, 24)), (20, 32, (1, 12, 32, 24)), (24, 40, (2, 8, 16, 16)), (48, 32, (1, 9, 16, 20)),
+                                  (64, 20, (1, 9, 16, 20), 3), (20, 64, (2, 8, 16, 16), 3)])
 def test_wbf_channel_padding_wrapper(case):
     """Channel counts that are not multiples of 32 (out_tr.conv1 of the 20-class MRI model, vnet.py:165: 32 -> 20 and the data
     gradient 20 -> 32) run through the fp16 two-piece pipeline on a zero-padded problem (gconv_wbf_padded, msk_conv.hip):
     forward with bias, data gradient plain and accumulating, against the float64 oracle; the padding is exact, so the
     tolerance is the pipeline's own."""
-    cin, cout, (N, D, H, W) = case
-    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    cin, cout, (N, D, H, W) = case[:3]
+    ks = case[3] if len(case) > 3 else 5          # 3: the 3x3x3 deep-supervision heads (vnet_deepsup.py:247-256)
+    k, s_, p = (ks,) * 3, (1, 1, 1), (ks // 2,) * 3
     d = dev()
     d.set_option("conv_split", 2)
     d.set_option("wbf_pad_min_voxels", 0)
     rng = np.random.default_rng(cin * 7 + cout)
     x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
-    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * ks ** 3)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
     y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
