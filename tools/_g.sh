@@ -1,2 +1,3 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -2
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --skip-serialized 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+bash tools/pmc_kernel.sh conv_tk_h2 -- python tools/bench_conv.py --c 32 --cn 3 --size 128 --iters 3 2>&1 | grep "LDS\|MFMA_BUSY\|GRBM\|WAVE_CYC\|WAIT"
+echo ---
+bash tools/pmc_kernel.sh conv_foldn_h2 -- python tools/bench_conv.py --c 32 --cn 3 --size 128 --iters 3 2>&1 | grep "LDS\|MFMA_BUSY\|GRBM\|WAVE_CYC\|WAIT"
