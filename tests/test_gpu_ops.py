@@ -956,3 +956,47 @@ def test_elu_fwd_bwd():
         assert rel_err(t_to_ncdhw(gt), dref) < 2e-6
         d.call("msk_elu_bwd", ot.msk(), dt.msk(), C.c_float(alpha), gt.msk(), 1)
         assert rel_err(t_to_ncdhw(gt), 2 * dref) < 2e-6
+
+
+def test_out_tr_amax_travels_in_xform_header():
+    """out_tr.conv1 class (32 -> 3, vnet.py:165): msk_conv3d_xform_bytes is the 512-byte header, the forward kernel leaves max |x|
+    there, and the weight gradient that takes it (no absmax pass over x) equals the one that measures x itself -- bitwise,
+    both scale by the same power of two."""
+    d = dev()
+    rng = np.random.default_rng(77)
+    N, D, H, W = 2, 8, 16, 24
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    x = rng.standard_normal((N, 32, D, H, W)).astype(np.float32) * 3.7
+    w = (rng.standard_normal((3, 32) + k) / 60).astype(np.float32)
+    b = rng.standard_normal(3).astype(np.float32)
+    dy = (rng.standard_normal((N, 3, D, H, W)) * 1e-4).astype(np.float32)
+    xt, dyt, wp, bp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel()), vec(b)
+    nbytes = int(d.lib.msk_conv3d_xform_bytes(d.ctx, _desc(k, s_, p), xt.msk(), 3))
+    assert nbytes == 512
+    xf = d.malloc(nbytes)
+    yt = t_empty(N, 3, D, H, W)
+    d.call("msk_conv3d_fwd_ex", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk(), None, C.c_void_p(xf))
+    amax = d.d2h(xf, (64,), np.float32)
+    assert amax.max() == np.abs(x).max()
+    y_ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
+    assert rel_err(t_to_ncdhw(yt), y_ref) < _conv_tol(32 * 125)
+    d.set_option("prof_only_halo", 0)
+    outs = []
+    try:
+        for use in (True, False):
+            dwp, dbp = vec(np.zeros(w.size, np.float32)), vec(np.zeros(3))
+            d.prof_reset()
+            d.prof_enable(True)
+            if use:
+                d.call("msk_conv3d_wgrad_ex", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0, C.c_void_p(xf))
+            else:
+                d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+            d.prof_enable(False)
+            rep = d.prof_report()
+            assert "wgrad_cbs_h2" in rep and rep["absmax"][0] == (1 if use else 2), rep
+            outs.append(vec_back(dwp, w.size))
+    finally:
+        d.prof_enable(False)
+    assert np.array_equal(outs[0], outs[1])
+    ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s_, p)[0]
+    assert rel_err(outs[0].reshape(ref.shape), ref) < 2 * _conv_tol(N * D * H * W)
