@@ -60,6 +60,7 @@ struct msk_ctx {
   float* scalar_ring = nullptr;  // 1024 device floats handed out round-robin (msk_scalar_slots): amax scalars of the NP = 2 pipelines
   int scalar_next = 0;
   int wbf_tpb = 0;            // wbf_gemm_k: tiles per workgroup (0 = 1)
+  int wbf_fuse = 1;           // 1 = wbf_gemm_fused_k (matrix stage + output transform in one kernel) where eligible; 0 = three stages (A/B)
   int conv_split = 2;         // operand split of the Winograd pipelines: 2 = fp16 two-piece with per-tensor power-of-two scales (product), 3 = exact bf16x3
   int bwd_fuse = -1;          // msk_conv3d_bwd_bnact: -1 auto, 0 three calls, 1 one dual transform, 2 one transform per stream
   int foldn_wgs = 0;          // conv_foldn_k: workgroups per CU targeted by the D segmentation (0 = 2)

@@ -700,6 +700,279 @@ wbf_gemm_k(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// stages 2 + 3 in one kernel (round 3): a workgroup owns a (TD x TH) position tile of one (n, W-tile) plane and walks ALL
+// Winograd points; the per-point product M_xi lives in the accumulators only and is folded into the four output
+// accumulators  y_j += AT[j][xi] * M_xi  (exact power-of-two coefficients) as soon as its K loop ends.  M never reaches HBM
+// (it was 2x the output bytes written + read back by wbf_tout_k), the output transform, bias / accumulate / PReLU epilogue
+// and the BatchNorm statistics of y run on the registers.  Eligible when one workgroup covers all output channels
+// (ngrp == 1: CN <= 64 with the tile variants above), no split-K, and the packed weights of all points stay in an XCD's
+// L2 (<= 3.5 MB): the 32- and 64-channel levels = 88 % of the transform bytes of a VNet step.  The block -> tile map hands
+// every XCD a contiguous range of tiles (neighbouring halo tiles share their overlap in that XCD's L2).
+// 4 x MR x 16 output + MR x 16 product accumulators + fragments = ~230 VGPRs: two wavefronts per SIMD.
+// ---------------------------------------------------------------------------------------------------------
+struct FusedArgs {
+  GemmArgs g;  // M unused
+  float* dst;
+  int dld;
+  long dvn;
+  int dvd, dvh, dvw;
+  const float* bias;
+  const float* prelu;
+  int accumulate;
+  const float* in_amax;
+  const float* w_amax;
+  int scaled;
+  float* stat_partial;  // STATS: [tiles][CN][3] = (n, mean, M2) of the stored values
+  int per_xcd;          // tiles per XCD
+};
+
+struct WfRec {
+  float n, mean, m2;
+};
+__device__ __forceinline__ WfRec wfrec_merge(WfRec a, WfRec b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  WfRec r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean, f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+// AT[j][xi] of F(4,5) (points 0, +-1, +-2, +-1/2, inf) and F(4,3) (0, +-1, +-2, inf): column xi as (c0, c1, c2, c3)
+template <int K>
+__device__ __forceinline__ void at_column(int xi, float& c0, float& c1, float& c2, float& c3) {
+  const int last = K == 5 ? 7 : 5;
+  c0 = xi == last ? 0.f : 1.f;
+  if (xi == 0) { c1 = c2 = c3 = 0.f; return; }
+  if (xi == last) { c1 = c2 = 0.f; c3 = 1.f; return; }
+  const float sg = (xi & 1) ? 1.f : -1.f;
+  const int pr = (xi - 1) >> 1;                       // 0: +-1, 1: +-2, 2: +-1/2
+  const float p = pr == 0 ? 1.f : (pr == 1 ? 2.f : 0.5f);
+  c1 = sg * p;
+  c2 = p * p;
+  c3 = sg * p * p * p;
+}
+
+template <int MR, int WM, int WN, int TD, int TH, int K, int NP, bool STATS>
+__global__ void __launch_bounds__(WM * WN * 64, 2)
+wbf_gemm_fused_k(FusedArgs f) {
+  static_assert(WM * WN == 4 && WM * MR * 32 == TD * TH, "tile shape");
+  const GemmArgs& a = f.g;
+  constexpr int NT = WM * WN * 64;
+  constexpr int NXI = nxi_of(K), T2 = K * K, PADK = (K - 1) / 2;
+  constexpr int HDt = TD + K - 1, HPt = TH + K - 1, NSLOT = HDt * HPt, NPL = 2 * NP, NIT = NPL * NSLOT, ROUNDS = (NIT + NT - 1) / NT;
+  __shared__ uint4 lds[ROUNDS * NT];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // block -> tile: XCD x (= blockIdx % 8) walks the contiguous tile range [x * per_xcd, (x + 1) * per_xcd)
+  int b = (blockIdx.x & 7) * f.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= f.per_xcd || b >= a.nblk) return;
+  const int tile_id = b;
+  const int thi = b % a.tiles_h;
+  b /= a.tiles_h;
+  const int tdi = b % a.tiles_d;
+  b /= a.tiles_d;
+  const int t = b % a.T;
+  const int n = b / a.T;
+
+  unsigned voff[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    int it = r * NT + tid;
+    if (it >= NIT) it = 0;
+    const int pk = it / NSLOT, slot = it - pk * NSLOT;
+    const int row = slot / HPt, col = slot - row * HPt;
+    voff[r] = (unsigned)(pk * a.v_plane + ((long)row * a.HP + col) * 16);
+  }
+  const char* vtile0 = a.V + ((long)(n * a.T + t) * a.KC) * NPL * a.v_plane +
+                       ((long)(tdi * TD + 2 - PADK) * a.HP + thi * TH + 2 - PADK) * 16;
+  const unsigned ulane = (unsigned)(lh * a.CN + wn * 32 + li) * 16u;
+  const unsigned ustep = (unsigned)a.CN * 32u;
+  const unsigned uchunk = (unsigned)NP * ustep;
+  const unsigned utap = (unsigned)a.KC * uchunk;
+
+  int arow[MR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+    int fa, fb;
+    frag_pos<TH>(li, fa, fb);
+    arow[mr] = lh * NSLOT + ((wm * MR + mr) * (32 / TH) + fa) * HPt + fb;
+  }
+
+  f32x16 yo[4][MR];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) yo[i][mr][j] = 0.f;
+
+#pragma unroll 1
+  for (int xi = 0; xi < NXI; ++xi) {
+    const __amdgpu_buffer_rsrc_t vres =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(vtile0 + (long)xi * a.v_xi), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ures =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.U + (long)xi * a.u_xi), 0, 0xFFFFFFF0u, 0x00020000);
+    f32x16 acc[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
+
+#pragma unroll 1
+    for (int kc = 0; kc < a.KC; ++kc) {
+      __syncthreads();  // every wavefront is done reading the previous stage's tile
+      const unsigned vsoff = (unsigned)(kc * NPL * a.v_plane);
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * NT + wave * 64), 16,
+                                                 (int)voff[r], (int)vsoff, 0, 0);
+      const unsigned ukc = (unsigned)kc * uchunk;
+      uint4 bq[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bq[0][p] = buf_load16(ures, ulane, ukc + p * ustep);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+
+      uint4 aq[2][MR][NP];
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) {
+        const uint4* ap = lds + arow[mr];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) aq[0][mr][p] = ap[p * 2 * NSLOT];
+      }
+#pragma unroll
+      for (int tap = 0; tap < T2; ++tap) {
+        const int cur = tap & 1, nx = cur ^ 1;
+        if (tap + 1 < T2) {
+          const unsigned ub = (unsigned)(tap + 1) * utap + ukc;
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bq[nx][p] = buf_load16(ures, ulane, ub + p * ustep);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) {
+            const uint4* ap = lds + arow[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) aq[nx][mr][p] = ap[p * 2 * NSLOT];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (NP == 3) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][NP / 2]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][0]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP / 2]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        } else if (NP == 2) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        } else {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // output transform, one column of A^T: wave-uniform coefficients (scalar registers)
+    float c0, c1, c2, c3;
+    at_column<K>(xi, c0, c1, c2, c3);
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float m = acc[mr][j];
+        yo[0][mr][j] = fmaf(c0, m, yo[0][mr][j]);
+        yo[1][mr][j] = fmaf(c1, m, yo[1][mr][j]);
+        yo[2][mr][j] = fmaf(c2, m, yo[2][mr][j]);
+        yo[3][mr][j] = fmaf(c3, m, yo[3][mr][j]);
+      }
+  }
+
+  // epilogue: y = yo / (operand scales) + bias [+ dst] [PReLU]; a lane owns ONE output channel (column li of the MFMA
+  // result) and MR x 16 positions x 4 W outputs of it
+  const int co = wn * 32 + li;
+  const float osc = f.scaled ? 1.f / (wbf_scale_of(f.in_amax) * wbf_scale_of(f.w_amax)) : 1.f;
+  const float bv = f.bias ? f.bias[co] : 0.f;
+  const float sl = f.prelu ? f.prelu[co] : 1.f;
+  float* obase = f.dst + ((long)n * f.dvn + (long)(4 * t) * f.dvw) * f.dld + co;
+  const long wst = (long)f.dvw * f.dld;
+  float sk = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int fa, fb;
+      frag_pos<TH>((j & 3) + 8 * (j >> 2) + 4 * lh, fa, fb);
+      const int d = tdi * TD + (wm * MR + mr) * (32 / TH) + fa, h = thi * TH + fb;
+      if (d < a.LD && h < a.LH) {
+        float* o = obase + ((long)d * f.dvd + (long)h * f.dvh) * f.dld;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float r = fmaf(yo[i][mr][j], osc, bv);
+          if (f.accumulate) r += o[i * wst];
+          if (f.prelu) r = r > 0.f ? r : sl * r;
+          o[i * wst] = r;
+          if (STATS) {
+            if (cnt == 0.f) sk = r;
+            const float dlt = r - sk;
+            s1 += dlt;
+            s2 = fmaf(dlt, dlt, s2);
+            cnt += 1.f;
+          }
+        }
+      }
+    }
+  }
+  if (STATS) {
+    // (n, mean, M2) per lane -> the two lane halves -> the WM wavefronts that share this channel group -> one record
+    WfRec w = {0.f, 0.f, 0.f};
+    if (cnt > 0.f) {
+      w.n = cnt;
+      w.mean = sk + s1 / cnt;
+      w.m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+    }
+    WfRec o;
+    o.n = __shfl_xor(w.n, 32, 64);
+    o.mean = __shfl_xor(w.mean, 32, 64);
+    o.m2 = __shfl_xor(w.m2, 32, 64);
+    w = lh == 0 ? wfrec_merge(w, o) : wfrec_merge(o, w);  // both halves hold (lower, upper) merged in the same order
+    __syncthreads();  // the last stage's LDS reads are done
+    float* sh = reinterpret_cast<float*>(lds);
+    if (lh == 0) {
+      float* p_ = sh + (wave * 32 + li) * 3;
+      p_[0] = w.n; p_[1] = w.mean; p_[2] = w.m2;
+    }
+    __syncthreads();
+    if (wm == 0 && lh == 0) {
+      WfRec r = w;
+#pragma unroll
+      for (int q = 1; q < WM; ++q) {
+        const float* p_ = sh + ((q * WN + wn) * 32 + li) * 3;
+        WfRec e = {p_[0], p_[1], p_[2]};
+        r = wfrec_merge(r, e);
+      }
+      float* g_ = f.stat_partial + ((long)tile_id * a.CN + co) * 3;
+      g_[0] = r.n; g_[1] = r.mean; g_[2] = r.m2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // stage 3: output transform
 // ---------------------------------------------------------------------------------------------------------
 struct ToutArgs {
@@ -719,20 +992,6 @@ struct ToutArgs {
   int scaled;           // NP = 2
   float* stat_partial;  // STATS: per-block BatchNorm records [gridDim.x][CN][3] = (n, mean, M2) of the stored values
 };
-
-struct WfRec {
-  float n, mean, m2;
-};
-__device__ __forceinline__ WfRec wfrec_merge(WfRec a, WfRec b) {
-  if (b.n == 0.f) return a;
-  if (a.n == 0.f) return b;
-  WfRec r;
-  r.n = a.n + b.n;
-  const float d = b.mean - a.mean, f = b.n / r.n;
-  r.mean = a.mean + d * f;
-  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
-  return r;
-}
 
 // y_j = sum_xi AT[j][xi] m_xi for one scalar lane of the 8 (6) point values
 template <int K>
@@ -917,6 +1176,21 @@ void launch_gemm_variant(msk_ctx* ctx, int variant, const GemmArgs& ga, long nbl
   }
 }
 
+template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
+void launch_fused(msk_ctx* ctx, const FusedArgs& fa, bool stats) {
+  const dim3 grid((unsigned)(8 * fa.per_xcd));
+  if (stats) hipLaunchKernelGGL((wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true>), grid, dim3(WM * WN * 64), 0, ctx->stream, fa);
+  else hipLaunchKernelGGL((wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false>), grid, dim3(WM * WN * 64), 0, ctx->stream, fa);
+}
+template <int K, int NP>
+void launch_fused_variant(msk_ctx* ctx, int variant, const FusedArgs& fa, bool stats) {
+  switch (variant) {
+    case 3: launch_fused<2, 1, 4, 8, 8, K, NP>(ctx, fa, stats); break;
+    case 4: launch_fused<2, 4, 1, 16, 16, K, NP>(ctx, fa, stats); break;
+    default: launch_fused<2, 2, 2, 8, 16, K, NP>(ctx, fa, stats); break;
+  }
+}
+
 template <int K, int NP>
 int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, const WbfGeom& geo, const Var* bv, bool dry) {
   constexpr int NXI = nxi_of(K), NPL = 2 * NP;
@@ -950,12 +1224,17 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   const size_t u_xi = (size_t)K * K * KC * NPL * g.CN * 16;
   if (u_xi >= 0xFFFFFFF0ull) return 0;
   if (dry) return 1;  // every eligibility test passed; nothing launched
-  const size_t v_bytes = (NXI * v_xi + 255) & ~(size_t)255, m_bytes = ((size_t)ksplit * NXI * m_xi * sizeof(float) + 255) & ~(size_t)255;
+  // stages 2 + 3 in one kernel (wbf_gemm_fused_k): one workgroup per tile covers every output channel and every point
+  const bool fuse_out = ctx->wbf_fuse != 0 && ksplit == 1 && ngrp == 1 && (variant == 3 || variant == 4 || variant == 5) &&
+                        NXI * u_xi <= ((size_t)3584 << 10);
+  const size_t v_bytes = (NXI * v_xi + 255) & ~(size_t)255;
+  const size_t m_bytes = fuse_out ? 0 : (((size_t)ksplit * NXI * m_xi * sizeof(float) + 255) & ~(size_t)255);
   long tout_blocks = ((long)m_xi / 4 + 255) / 256;
   if (tout_blocks > 16L * ctx->num_cu) tout_blocks = 16L * ctx->num_cu;
   const int c4n = g.CN / 4;
-  const bool fuse_stats = g.stats != nullptr && !g.accumulate && !g.prelu && c4n <= 256 && (c4n & (c4n - 1)) == 0;
-  const size_t s_bytes = fuse_stats ? (size_t)tout_blocks * g.CN * 3 * sizeof(float) : 0;
+  const bool fuse_stats = g.stats != nullptr && !g.accumulate && !g.prelu && (fuse_out || (c4n <= 256 && (c4n & (c4n - 1)) == 0));
+  const long stat_rows = fuse_out ? base_blocks / NXI : tout_blocks;
+  const size_t s_bytes = fuse_stats ? (size_t)stat_rows * g.CN * 3 * sizeof(float) : 0;
   char* wsp = (char*)msk_workspace(ctx, (g.xform ? 0 : v_bytes) + m_bytes + s_bytes + 256);
   if (!wsp) return -1;
   char* V = g.xform ? (char*)g.xform + kWbfXformHeader : wsp;
@@ -1004,18 +1283,41 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       return -1;
     }
   }
-  {
-    GemmArgs ga{};
-    ga.V = V; ga.U = U; ga.M = M;
-    ga.N = g.N; ga.T = T; ga.KC = KC; ga.CN = g.CN; ga.LD = LD; ga.LH = LH; ga.DP = DP; ga.HP = HP;
-    ga.tiles_d = tiles_d; ga.tiles_h = tiles_h; ga.ngrp = ngrp; ga.ksplit = ksplit; ga.kc_per = kc_per;
-    ga.v_xi = (long)v_xi; ga.v_plane = (long)v_plane; ga.u_xi = (long)u_xi; ga.m_xi = (long)m_xi;
-    const char* tag = NP == 3 ? "wbf_gemm_k" : (NP == 2 ? "wbf_gemm_h2_k" : "wbf_gemm_f16_k");
-    if (ctx->prof && ctx->prof_shapes) {
-      char buf[200];
-      snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,k=%d,ks=%d]", tag, g.CK, g.CN, g.N, g.DD, g.DH, g.DW, K, ksplit);
-      tag = msk_intern_tag(ctx, buf);
+  GemmArgs ga{};
+  ga.V = V; ga.U = U; ga.M = M;
+  ga.N = g.N; ga.T = T; ga.KC = KC; ga.CN = g.CN; ga.LD = LD; ga.LH = LH; ga.DP = DP; ga.HP = HP;
+  ga.tiles_d = tiles_d; ga.tiles_h = tiles_h; ga.ngrp = ngrp; ga.ksplit = ksplit; ga.kc_per = kc_per;
+  ga.v_xi = (long)v_xi; ga.v_plane = (long)v_plane; ga.u_xi = (long)u_xi; ga.m_xi = (long)m_xi;
+  const char* tag = NP == 3 ? "wbf_gemm_k" : (NP == 2 ? "wbf_gemm_h2_k" : "wbf_gemm_f16_k");
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "%s[ck=%d,cn=%d,n=%d,dhw=%dx%dx%d,k=%d,ks=%d%s]", tag, g.CK, g.CN, g.N, g.DD, g.DH, g.DW, K, ksplit,
+             fuse_out ? ",fused" : "");
+    tag = msk_intern_tag(ctx, buf);
+  }
+  if (fuse_out) {
+    FusedArgs fa{};
+    fa.g = ga;
+    fa.g.nblk = (int)(base_blocks / NXI);
+    fa.dst = g.dst; fa.dld = g.dld;
+    fa.dvn = (long)g.DD * g.DH * g.DW; fa.dvd = vstr[pm[0]]; fa.dvh = vstr[pm[1]]; fa.dvw = vstr[pm[2]];
+    fa.bias = g.bias; fa.prelu = g.prelu; fa.accumulate = g.accumulate;
+    fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP == 2 ? 1 : 0;
+    fa.stat_partial = SP;
+    fa.per_xcd = (fa.g.nblk + 7) / 8;
+    {
+      msk_launch_scope ls(ctx, tag);
+      launch_fused_variant<K, NP>(ctx, variant, fa, fuse_stats);
+      MSK_LAUNCH_CHECK(ctx);
     }
+    if (fuse_stats) {
+      if (msk_bn_stats_merge(ctx, SP, fa.g.nblk, g.CN, g.stats) != 0) return -1;
+      ctx->stats_fused = true;
+    }
+    if (g.xform) ctx->xform_written = true;
+    return 1;
+  }
+  {
     msk_launch_scope ls(ctx, tag);
     launch_gemm_variant<K, NP>(ctx, variant, ga, nblk);
     MSK_LAUNCH_CHECK(ctx);

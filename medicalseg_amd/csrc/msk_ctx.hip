@@ -347,6 +347,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_pad_min_voxels = value > 0 ? value : 0;
     return 0;
   }
+  if (strcmp(key, "wbf_fuse") == 0) {
+    ctx->wbf_fuse = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_tpb") == 0) {
     ctx->wbf_tpb = value > 0 ? value : 0;
     return 0;
