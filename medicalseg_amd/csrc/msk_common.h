@@ -59,7 +59,12 @@ struct msk_ctx {
   long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
   float* scalar_ring = nullptr;  // 1024 device floats handed out round-robin (msk_scalar_slots): amax scalars of the NP = 2 pipelines
   int scalar_next = 0;
+  float* scalar_ring_side = nullptr;  // the weight-gradient stream's own ring (swapped with the stream)
+  int scalar_next_side = 0;
   int wbf_tpb = 0;            // wbf_gemm_k: tiles per workgroup (0 = 1)
+  void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
+  int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
+  int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
   int wbf_fuse = 1;           // 1 = wbf_gemm_fused_k (matrix stage + output transform in one kernel) where eligible; 0 = three stages (A/B)
   int conv_split = 2;         // operand split of the Winograd pipelines: 2 = fp16 two-piece with per-tensor power-of-two scales (product), 3 = exact bf16x3
   int bwd_fuse = -1;          // msk_conv3d_bwd_bnact: -1 auto, 0 three calls, 1 one dual transform, 2 one transform per stream
@@ -107,6 +112,11 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 int msk_join_side_impl(msk_ctx* ctx);
+// caller memory that may hold convolution weights was (or is about to be) written / freed: derived forms are stale
+void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes);
+void msk_weights_freed_impl(msk_ctx* ctx, const void* p);
+int msk_wbf_prepack_impl(msk_ctx* ctx);   // rebuild every stale packed-weight row in use (end of the optimizer kernels)
+void msk_wbf_pack_cache_free(msk_ctx* ctx);
 int msk_dp_wait_impl(msk_ctx* ctx);
 
 // Redirect launches of the enclosed scope to the side stream (with its own scratch) after making
@@ -125,6 +135,8 @@ struct msk_side_scope {
     std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
     std::swap(ctx->ws3, ctx->ws3_side);
     std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
+    std::swap(ctx->scalar_ring, ctx->scalar_ring_side);
+    std::swap(ctx->scalar_next, ctx->scalar_next_side);
     ctx->side_dirty = true;
   }
   ~msk_side_scope() {
@@ -134,6 +146,8 @@ struct msk_side_scope {
     std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
     std::swap(ctx->ws3, ctx->ws3_side);
     std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
+    std::swap(ctx->scalar_ring, ctx->scalar_ring_side);
+    std::swap(ctx->scalar_next, ctx->scalar_next_side);
   }
 };
 

@@ -368,6 +368,7 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   if (tdst) { gp.dst = tdst; gp.dld = CNp; gp.accumulate = 0; gp.bias = nullptr; }
   gp.CK = CKp; gp.CN = CNp;
   gp.stats = nullptr;
+  gp.w_persistent = false;  // wpad is scratch, rewritten per call
   if (!msk_gconv_wino_bf3_accepts(ctx, gp)) return 0;
   {
     msk_launch_scope ls(ctx, "pad_weights");
@@ -846,6 +847,7 @@ int conv3d_dgrad_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float
   g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
   g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
   g.transposed = 1; g.bias = nullptr; g.accumulate = accumulate; g.flip = 1;
+  g.w_persistent = true;
   g.in_amax = dy_amax;
   // w[Cout][Cin][tap]: k = Cout = a, n = Cin = b -> no swap
   return run_gconv(ctx, g, w, dy.c, dx.c, 0, "conv3d_dgrad_direct");
@@ -856,6 +858,7 @@ extern "C" {
 int msk_conv_fold_bn(msk_ctx* ctx, const float* w, const float* bias, const float* scale, const float* shift, int cout,
                      long inner, float* w_folded, float* b_folded) {
   MSK_REQUIRE(ctx, w && scale && shift && w_folded && b_folded && cout > 0 && inner > 0, "bad arguments");
+  msk_weights_changed_impl(ctx, w_folded, (size_t)cout * inner * sizeof(float));
   msk_launch_scope ls(ctx, "fold_bn");
   hipLaunchKernelGGL(fold_bn_k, dim3(grid_for((long)cout * inner, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, w, bias, scale,
                      shift, cout, inner, w_folded, b_folded);
@@ -873,6 +876,7 @@ int msk_conv3d_fwd_act(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float
   g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
   g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
   g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.w_persistent = true;
   g.prelu = prelu_slope;
   return run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct");
 }
@@ -886,6 +890,7 @@ int msk_conv3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
   g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
   g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
   g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.w_persistent = true;
   // w[Cout][Cin][tap]: k = Cin = b, n = Cout = a -> swap
   return run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct");
 }
@@ -914,6 +919,7 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
   g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
   g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
   g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.w_persistent = true;
   const size_t sper = (size_t)g.SD * g.SH * g.SW * g.sld * sizeof(float), dper = (size_t)g.DD * g.DH * g.DW * g.dld * sizeof(float);
   const size_t per = sper > dper ? sper : dper;
   const bool chunked = per > 0 && (size_t)g.N > kChunkBytes / per;
@@ -992,6 +998,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
     g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
     g.transposed = 1; g.bias = nullptr; g.accumulate = dx_accumulate; g.flip = 1;
+    g.w_persistent = true;
     WbfBnBwd bn{};
     bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
     bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;

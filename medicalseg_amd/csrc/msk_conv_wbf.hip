@@ -67,11 +67,32 @@ __device__ __forceinline__ double g_coef(int K, int xi, int kw) {
 // ---------------------------------------------------------------------------------------------------------
 // weights: U_xi[tap = kd*K+kh][k][n] = sum_kw G[xi][kw] w(kd, kh, kw; k, n), in double, then 3 bf16 pieces or one fp16
 // ---------------------------------------------------------------------------------------------------------
+// One packed-weight problem (device-visible descriptor; the table lives in the context's pack cache, see below)
+struct WbfPackDesc {
+  const float* w;
+  int A, B, swap, flip, CK, CN, KC, tsd, tsh, tsw;
+  unsigned short* out;
+  long xi_stride;  // elements
+  float* amax;     // amax array of the weights (kWbfAmaxWays floats): NP = 2 scale, also read by the output stage
+  long count;      // floats of the canonical weight tensor
+};
+// up to 250 table rows handled by one launch (blockIdx.y -> row), passed by value
+struct WbfPackList {
+  int n;
+  unsigned char row[252];
+};
+__global__ void wbf_pack_desc_store_k(WbfPackDesc* slot, WbfPackDesc d) { *slot = d; }
+
 template <int K, int NP>
 __global__ void __launch_bounds__(256)
-wbf_pack_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, int CN, int KC, int tsd, int tsh,
-                   int tsw, unsigned short* __restrict__ out, long xi_stride /*elements*/, const float* __restrict__ w_amax) {
-  const double wsc = NP == 2 ? (double)wbf_scale_of(w_amax) : 1.0;  // NP = 2: power-of-two scale into fp16 range
+wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfPackDesc single) {
+  const WbfPackDesc d = list.n < 0 ? single : table[list.row[blockIdx.y]];  // n < 0: one problem, descriptor by value
+  const float* __restrict__ w = d.w;
+  const int A = d.A, B = d.B, swap = d.swap, flip = d.flip, CK = d.CK, CN = d.CN, KC = d.KC, tsd = d.tsd, tsh = d.tsh, tsw = d.tsw;
+  (void)A;
+  unsigned short* __restrict__ out = d.out;
+  const long xi_stride = d.xi_stride;
+  const double wsc = NP == 2 ? (double)wbf_scale_of(d.amax) : 1.0;  // NP = 2: power-of-two scale into fp16 range
   constexpr int NXI = nxi_of(K), T2 = K * K, T3 = K * K * K;
   // one thread per (tap row, k, n): reads its K kw taps once, writes NXI x NP values
   const long total = (long)T2 * KC * 16 * CN;
@@ -121,6 +142,29 @@ wbf_pack_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip
         o[0] = __builtin_bit_cast(unsigned short, (_Float16)(float)s_);
       }
     }
+  }
+}
+
+// max |w| of the listed rows' weight tensors into their (zeroed) amax arrays: one atomic per block on the way blockIdx.x
+__global__ void __launch_bounds__(256)
+wbf_pack_absmax_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfPackDesc single) {
+  const WbfPackDesc d = list.n < 0 ? single : table[list.row[blockIdx.y]];
+  float m = 0.f;
+  const long n4 = d.count >> 2, stride = (long)gridDim.x * blockDim.x;
+  const float4* p = reinterpret_cast<const float4*>(d.w);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 q = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += stride) m = fmaxf(m, fabsf(d.w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    if (m > 0.f) (void)atomicMax(reinterpret_cast<unsigned*>(d.amax) + blockIdx.x % kWbfAmaxWays, __float_as_uint(m));
   }
 }
 
@@ -915,18 +959,35 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int fa, fb;
-      frag_pos<TH>((j & 3) + 8 * (j >> 2) + 4 * lh, fa, fb);
-      const int d = tdi * TD + (wm * MR + mr) * (32 / TH) + fa, h = thi * TH + fb;
-      if (d < a.LD && h < a.LH) {
-        float* o = obase + ((long)d * f.dvd + (long)h * f.dvh) * f.dld;
+    for (int jq = 0; jq < 4; ++jq) {
+      // four rows x four W outputs at a time; the accumulate path loads all 16 old values BEFORE the first store (a
+      // load -> add -> store chain per element serialises 128 memory round trips: the stores may alias the next load)
+      float* op[4];
+      bool ok[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        int fa, fb;
+        frag_pos<TH>(jj + 8 * jq + 4 * lh, fa, fb);
+        const int d = tdi * TD + (wm * MR + mr) * (32 / TH) + fa, h = thi * TH + fb;
+        ok[jj] = d < a.LD && h < a.LH;
+        op[jj] = obase + ((long)d * f.dvd + (long)h * f.dvh) * f.dld;
+      }
+      float old[4][4];
+      if (f.accumulate) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) old[jj][i] = ok[jj] ? __builtin_nontemporal_load(op[jj] + i * wst) : 0.f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if (!ok[jj]) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float r = fmaf(yo[i][mr][j], osc, bv);
-          if (f.accumulate) r += o[i * wst];
+          float r = fmaf(yo[i][mr][jq * 4 + jj], osc, bv);
+          if (f.accumulate) r += old[jj][i];
           if (f.prelu) r = r > 0.f ? r : sl * r;
-          o[i * wst] = r;
+          op[jj][i * wst] = r;
           if (STATS) {
             if (cnt == 0.f) sk = r;
             const float dlt = r - sk;
@@ -1176,6 +1237,139 @@ void launch_gemm_variant(msk_ctx* ctx, int variant, const GemmArgs& ga, long nbl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Packed-weight cache (round 3).  The transformed + split weights U of a layer depend on the weights only, and those
+// change once per optimizer step -- not per call: every (weights, direction, geometry) combination owns a table row with
+// a persistent U buffer and the amax array of its weights.  A row is rebuilt (absmax + pack)
+//   * for ALL rows in use at once, two launches, at the end of msk_sgd_momentum / msk_adam (msk_wbf_prepack): 28 pack
+//     launches + 14 absmax passes + their memsets per step became 2 + 1;
+//   * lazily at its next use otherwise.
+// Rows are invalidated by every entry point that writes caller memory which may hold weights (msk_weights_changed:
+// optimizer kernels, msk_h2d / msk_h2d_async / msk_memset / msk_d2d, msk_conv_fold_bn, msk_dp_broadcast, msk_free).
+// ---------------------------------------------------------------------------------------------------------
+struct WbfPackEntry {
+  WbfPackDesc d{};
+  int K = 0, NP = 0;
+  size_t u_bytes = 0;
+  bool live = false, valid = false;
+  long last_use = 0;
+};
+struct WbfPackCache {
+  static constexpr int kRows = 250;
+  WbfPackEntry e[kRows];
+  WbfPackDesc* table = nullptr;  // device copy of the descriptors
+  float* amax = nullptr;         // device [kRows][kWbfAmaxWays]
+  long epoch = 1;
+};
+
+WbfPackCache* pack_cache(msk_ctx* ctx) {
+  if (ctx->wpack) return (WbfPackCache*)ctx->wpack;
+  WbfPackCache* c = new WbfPackCache();
+  if (hipMalloc((void**)&c->table, sizeof(WbfPackDesc) * WbfPackCache::kRows) != hipSuccess ||
+      hipMalloc((void**)&c->amax, sizeof(float) * kWbfAmaxWays * WbfPackCache::kRows) != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "pack_cache", "hipMalloc failed");
+    delete c;
+    return nullptr;
+  }
+  ctx->wpack = c;
+  return c;
+}
+
+void pack_row_drop(msk_ctx* ctx, WbfPackEntry& e) {
+  if (!e.live) return;
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->side) hipStreamSynchronize(ctx->side);
+  if (e.d.out) hipFree(e.d.out);
+  e = WbfPackEntry();
+}
+
+// rebuild the listed rows: zero their amax arrays, one absmax launch, one pack launch per (K, NP) class.  A single row
+// travels by value (its table slot may not be written yet / is the scratch row).
+int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows) {
+  if (rows.empty()) return 0;
+  const bool one = rows.size() == 1;
+  const WbfPackDesc single = c->e[rows[0]].d;
+  bool need_amax = false;
+  for (int r : rows) need_amax |= c->e[r].NP == 2;
+  if (need_amax) {
+    // zero the amax arrays of runs of consecutive rows with one memset each (in steady state: one run)
+    size_t i = 0;
+    while (i < rows.size()) {
+      size_t j = i;
+      while (j + 1 < rows.size() && rows[j + 1] == rows[j] + 1) ++j;
+      MSK_CHECK_HIP(ctx, hipMemsetAsync(c->amax + (size_t)rows[i] * kWbfAmaxWays, 0, (j - i + 1) * kWbfAmaxWays * sizeof(float), ctx->stream));
+      i = j + 1;
+    }
+    WbfPackList l{};
+    for (int r : rows)
+      if (c->e[r].NP == 2) l.row[l.n++] = (unsigned char)r;
+    const unsigned ny = (unsigned)l.n;
+    if (one) l.n = -1;
+    msk_launch_scope ls(ctx, "wbf_pack_absmax");
+    hipLaunchKernelGGL(wbf_pack_absmax_k, dim3(64, ny), dim3(256), 0, ctx->stream, c->table, l, single);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  static const int kClasses[5][2] = {{5, 2}, {5, 3}, {3, 2}, {3, 3}, {3, 1}};
+  for (const auto& kc : kClasses) {
+    WbfPackList l{};
+    long most = 0;
+    for (int r : rows) {
+      const WbfPackEntry& e = c->e[r];
+      if (e.K != kc[0] || e.NP != kc[1]) continue;
+      l.row[l.n++] = (unsigned char)r;
+      const long blocks = ((long)e.K * e.K * e.d.KC * 16 * e.d.CN + 255) / 256;
+      if (blocks > most) most = blocks;
+    }
+    if (l.n == 0) continue;
+    if (most > 4L * ctx->num_cu) most = 4L * ctx->num_cu;
+    const dim3 grid((unsigned)most, (unsigned)l.n);
+    if (one) l.n = -1;
+    msk_launch_scope ls(ctx, "wbf_pack_weights");
+    if (kc[0] == 5 && kc[1] == 2) hipLaunchKernelGGL((wbf_pack_weights_k<5, 2>), grid, dim3(256), 0, ctx->stream, c->table, l, single);
+    else if (kc[0] == 5) hipLaunchKernelGGL((wbf_pack_weights_k<5, 3>), grid, dim3(256), 0, ctx->stream, c->table, l, single);
+    else if (kc[1] == 2) hipLaunchKernelGGL((wbf_pack_weights_k<3, 2>), grid, dim3(256), 0, ctx->stream, c->table, l, single);
+    else if (kc[1] == 3) hipLaunchKernelGGL((wbf_pack_weights_k<3, 3>), grid, dim3(256), 0, ctx->stream, c->table, l, single);
+    else hipLaunchKernelGGL((wbf_pack_weights_k<3, 1>), grid, dim3(256), 0, ctx->stream, c->table, l, single);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  for (int r : rows) c->e[r].valid = true;
+  return 0;
+}
+
+// the row of (weights, direction, geometry), created on first use; < 0 on error
+int pack_row_lookup(msk_ctx* ctx, WbfPackCache* c, const WbfPackDesc& key, int K, int NP, size_t u_bytes) {
+  int free_row = -1, lru = -1;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r) {  // (the last row is the scratch row of uncached calls)
+    WbfPackEntry& e = c->e[r];
+    if (!e.live) {
+      if (free_row < 0) free_row = r;
+      continue;
+    }
+    const WbfPackDesc& d = e.d;
+    if (d.w == key.w && e.K == K && e.NP == NP && d.A == key.A && d.B == key.B && d.swap == key.swap && d.flip == key.flip &&
+        d.CK == key.CK && d.CN == key.CN && d.KC == key.KC && d.tsd == key.tsd && d.tsh == key.tsh && d.tsw == key.tsw) {
+      e.last_use = c->epoch;
+      return r;
+    }
+    if (lru < 0 || e.last_use < c->e[lru].last_use) lru = r;
+  }
+  if (free_row < 0) {
+    pack_row_drop(ctx, c->e[lru]);
+    free_row = lru;
+  }
+  WbfPackEntry& e = c->e[free_row];
+  e.d = key;
+  e.K = K; e.NP = NP; e.u_bytes = u_bytes;
+  if (hipMalloc((void**)&e.d.out, u_bytes) != hipSuccess) {
+    msk_fail(ctx, __FILE__, __LINE__, "pack_row_lookup", "hipMalloc failed");
+    return -1;
+  }
+  e.d.amax = c->amax + (size_t)free_row * kWbfAmaxWays;
+  e.live = true; e.valid = false; e.last_use = c->epoch;
+  hipLaunchKernelGGL(wbf_pack_desc_store_k, dim3(1), dim3(1), 0, ctx->stream, c->table + free_row, e.d);  // no pageable-memory copy
+  return free_row;
+}
+
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
 void launch_fused(msk_ctx* ctx, const FusedArgs& fa, bool stats) {
   const dim3 grid((unsigned)(8 * fa.per_xcd));
@@ -1208,7 +1402,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   // split K (16-channel chunks) when the tiling alone cannot fill the chip
   const long base_blocks = (long)NXI * ngrp * tiles_h * tiles_d * T * g.N;
   int ksplit = 1, kc_per = KC;
-  if (base_blocks < 3L * ctx->num_cu) {
+  if (base_blocks < 3L * ctx->num_cu && ctx->wbf_fuse != 2) {  // ("wbf_fuse" 2: tests force the one-kernel form, which has no split-K)
     long want = (4L * ctx->num_cu + base_blocks - 1) / base_blocks;
     if (want > KC) want = KC;
     kc_per = (int)((KC + want - 1) / want);
@@ -1225,8 +1419,10 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   if (u_xi >= 0xFFFFFFF0ull) return 0;
   if (dry) return 1;  // every eligibility test passed; nothing launched
   // stages 2 + 3 in one kernel (wbf_gemm_fused_k): one workgroup per tile covers every output channel and every point
+  // (a workgroup does the work of NXI unfused ones: below two tiles per CU the chip is not filled -- 64ch@32^3, 128 tiles:
+  // 0.169 ms fused against 0.072 + 0.014 ms)
   const bool fuse_out = ctx->wbf_fuse != 0 && ksplit == 1 && ngrp == 1 && (variant == 3 || variant == 4 || variant == 5) &&
-                        NXI * u_xi <= ((size_t)3584 << 10);
+                        NXI * u_xi <= ((size_t)3584 << 10) && (base_blocks / NXI >= 2L * ctx->num_cu || ctx->wbf_fuse == 2);
   const size_t v_bytes = (NXI * v_xi + 255) & ~(size_t)255;
   const size_t m_bytes = fuse_out ? 0 : (((size_t)ksplit * NXI * m_xi * sizeof(float) + 255) & ~(size_t)255);
   long tout_blocks = ((long)m_xi / 4 + 255) / 256;
@@ -1240,30 +1436,49 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   char* V = g.xform ? (char*)g.xform + kWbfXformHeader : wsp;
   float* M = (float*)(g.xform ? wsp : wsp + v_bytes);
   float* SP = (float*)((char*)M + m_bytes);
-  char* U = (char*)msk_workspace2(ctx, NXI * u_xi);
-  if (!U) return -1;
-  // NP = 2: every operand is scaled into fp16 range by a power of two derived on the device from (a bound of) its maximum:
-  // the source tensor (kept in the xform header for the weight gradient), the weights
-  const float *in_amax = nullptr, *w_amax = nullptr;
+  // weights: the packed form U and the amax array the pack scaled by come from the cache row of (weights, direction,
+  // geometry) when the weights are the caller's own (g.w_persistent), else they are packed into scratch here
+  char* U = nullptr;
+  const float* w_amax = nullptr;
+  {
+    WbfPackDesc key{};
+    key.w = w_canon; key.A = A; key.B = B; key.swap = swap; key.flip = g.transposed ? 1 : 0; key.CK = g.CK; key.CN = g.CN; key.KC = KC;
+    key.tsd = tstr[pm[0]]; key.tsh = tstr[pm[1]]; key.tsw = tstr[pm[2]];
+    key.xi_stride = (long)(u_xi / 2);
+    key.count = (long)K * K * K * A * B;
+    WbfPackCache* c = pack_cache(ctx);
+    if (!c) return -1;
+    const bool cached = g.w_persistent && ctx->wbf_pack_cache != 0;
+    int row;
+    if (cached) {
+      row = pack_row_lookup(ctx, c, key, K, NP, NXI * u_xi);
+      if (row < 0) return -1;
+    } else {
+      // scratch row (the last one is reserved for it): rebuilt on every call, into the second workspace
+      row = WbfPackCache::kRows - 1;
+      WbfPackEntry& e = c->e[row];
+      key.out = (unsigned short*)msk_workspace2(ctx, NXI * u_xi);
+      if (!key.out) return -1;
+      key.amax = c->amax + (size_t)row * kWbfAmaxWays;
+      e.d = key; e.K = K; e.NP = NP; e.valid = false; e.live = false;
+    }
+    if (!c->e[row].valid) {
+      if (pack_rows_build(ctx, c, std::vector<int>{row}) != 0) return -1;
+      if (!cached) c->e[row].valid = false;
+    }
+    U = (char*)c->e[row].d.out;
+    w_amax = c->e[row].d.amax;
+  }
+  // NP = 2: the source tensor is scaled into fp16 range by a power of two derived on the device from (a bound of) its
+  // maximum (kept in the xform header for the weight gradient)
+  const float* in_amax = nullptr;
   if (NP == 2) {
     if (g.fuse) in_amax = g.fuse->amax;
     else if (g.in_amax) in_amax = g.in_amax;
     else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
-    w_amax = g.w_amax ? g.w_amax
-                      : msk_absmax(ctx, w_canon, 4, 4, ((long)K * K * K * g.CK * g.CN + 3) / 4,
-                                   g.xform ? (float*)g.xform + kWbfAmaxWays : nullptr);
-    if (!in_amax || !w_amax) return -1;
+    if (!in_amax) return -1;
   }
 
-  {
-    msk_launch_scope ls(ctx, "wbf_pack_weights");
-    long blocks = ((long)K * K * KC * 16 * g.CN + 255) / 256;
-    if (blocks > 16L * ctx->num_cu) blocks = 16L * ctx->num_cu;
-    hipLaunchKernelGGL((wbf_pack_weights_k<K, NP>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, swap,
-                       g.transposed ? 1 : 0, g.CK, g.CN, KC, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], (unsigned short*)U,
-                       (long)(u_xi / 2), w_amax);
-    MSK_LAUNCH_CHECK(ctx);
-  }
   {
     WbfTinArgs ta{};
     ta.src = g.src; ta.sld = g.sld;
@@ -1457,3 +1672,49 @@ int msk_gconv_wino_bf3(msk_ctx* ctx, const GConv& g, const float* w_canon, int A
 }
 // would msk_gconv_wino_bf3 run this problem?  (launches nothing)
 bool msk_gconv_wino_bf3_accepts(msk_ctx* ctx, const GConv& g) { return wino_bf3_impl(ctx, g, nullptr, 0, 0, 0, true) == 1; }
+
+// ---- packed-weight cache: invalidation and the batched rebuild (see WbfPackCache above)
+void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->wpack || !p) return;
+  WbfPackCache* c = (WbfPackCache*)ctx->wpack;
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r) {
+    WbfPackEntry& e = c->e[r];
+    if (!e.live) continue;
+    const char* b0 = (const char*)e.d.w;
+    const char* b1 = b0 + (size_t)e.d.count * sizeof(float);
+    if (a0 < b1 && b0 < a1) e.valid = false;
+  }
+}
+void msk_weights_freed_impl(msk_ctx* ctx, const void* p) {
+  // the allocation's size is not known here: rows whose weights START inside any freed block cannot be told apart from rows
+  // of a later allocation at the same address once it is reused, so every row keyed at or after p up to the next h2d is at
+  // risk -- drop the rows whose weights begin exactly at p, invalidate nothing else (a reused address is always (re)written
+  // through msk_h2d / an optimizer kernel before it is used as weights, which invalidates by range)
+  if (!ctx->wpack || !p) return;
+  WbfPackCache* c = (WbfPackCache*)ctx->wpack;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r)
+    if (c->e[r].live && (const void*)c->e[r].d.w == p) pack_row_drop(ctx, c->e[r]);
+}
+int msk_wbf_prepack_impl(msk_ctx* ctx) {
+  if (!ctx->wpack || !ctx->wbf_prepack) return 0;
+  WbfPackCache* c = (WbfPackCache*)ctx->wpack;
+  std::vector<int> rows;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r) {
+    const WbfPackEntry& e = c->e[r];
+    if (e.live && !e.valid && e.last_use >= c->epoch - 1) rows.push_back(r);  // rows used since the previous rebuild
+  }
+  c->epoch += 1;
+  return pack_rows_build(ctx, c, rows);
+}
+void msk_wbf_pack_cache_free(msk_ctx* ctx) {
+  if (!ctx->wpack) return;
+  WbfPackCache* c = (WbfPackCache*)ctx->wpack;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r)
+    if (c->e[r].live && c->e[r].d.out) hipFree(c->e[r].d.out);
+  if (c->table) hipFree(c->table);
+  if (c->amax) hipFree(c->amax);
+  delete c;
+  ctx->wpack = nullptr;
+}

@@ -154,12 +154,14 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   msk_dp_destroy(ctx);
   drain_prof(ctx);
   for (auto e : ctx->event_pool) hipEventDestroy(e);
+  msk_wbf_pack_cache_free(ctx);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->ws3) hipFree(ctx->ws3);
   if (ctx->ws_side) hipFree(ctx->ws_side);
   if (ctx->ws3_side) hipFree(ctx->ws3_side);
   if (ctx->scalar_ring) hipFree(ctx->scalar_ring);
+  if (ctx->scalar_ring_side) hipFree(ctx->scalar_ring_side);
   if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
   for (int b = 0; b < 2; ++b) {
     if (ctx->stage_ev[b]) hipEventDestroy(ctx->stage_ev[b]);
@@ -203,17 +205,26 @@ int msk_free(msk_ctx* ctx, void* p) {
   if (msk_join_side_impl(ctx) != 0) return -1;
   if (msk_dp_wait_impl(ctx) != 0) return -1;
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size > 0) msk_weights_changed_impl(ctx, base, size);
+    else (void)hipGetLastError();
+    msk_weights_freed_impl(ctx, p);
+  }
   MSK_CHECK_HIP(ctx, hipFree(p));
   return 0;
 }
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes) {
   if (bytes == 0) return 0;
   if (msk_join_side_impl(ctx) != 0) return -1;
+  msk_weights_changed_impl(ctx, p, bytes);
   MSK_CHECK_HIP(ctx, hipMemsetAsync(p, value, bytes, ctx->stream));
   return 0;
 }
 int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return 0;
+  msk_weights_changed_impl(ctx, dst, bytes);
   if (bytes >= (64u << 10) && bytes <= ((size_t)64 << 20)) {
     // batch-sized uploads (core/train.py:122-124 every iteration): through one of two pinned staging buffers, so the
     // call returns once src is copied out and the compute stream is NOT synchronised -- with the blocking path below
@@ -241,6 +252,7 @@ int msk_h2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 int msk_h2d_async(msk_ctx* ctx, void* dst, const void* pinned_src, size_t bytes) {
   if (bytes == 0) return 0;
+  msk_weights_changed_impl(ctx, dst, bytes);
   MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
@@ -253,6 +265,7 @@ int msk_d2h(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 int msk_d2d(msk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return 0;
+  msk_weights_changed_impl(ctx, dst, bytes);
   MSK_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
@@ -345,6 +358,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wbf_pad_min_voxels") == 0) {  // smallest problem the channel-padding wrapper of the wbf pipeline takes
     ctx->wbf_pad_min_voxels = value > 0 ? value : 0;
+    return 0;
+  }
+  if (strcmp(key, "wbf_pack_cache") == 0) {  // 0 = pack the weights of the Winograd pipelines on every call (A/B)
+    ctx->wbf_pack_cache = value;
+    return 0;
+  }
+  if (strcmp(key, "wbf_prepack") == 0) {  // 0 = stale packed weights are rebuilt lazily at their next use only
+    ctx->wbf_prepack = value;
     return 0;
   }
   if (strcmp(key, "wbf_fuse") == 0) {

@@ -203,6 +203,7 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
 }
 
 int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
+  msk_weights_changed_impl(ctx, buf, count * sizeof(float));
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (msk_join_side_impl(ctx) != 0) return -1;  // the gradient arena includes side-stream weight gradients
   msk_launch_scope ls(ctx, "rccl_allreduce");
@@ -254,6 +255,7 @@ int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_
 
 int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
+  msk_weights_changed_impl(ctx, buf, count * sizeof(float));  // parameters are broadcast once at wrap time
   if (ctx->host_transport) {
     if (ctx->world == 1) return 0;
     MSK_REQUIRE(ctx, root == 0, "host transport broadcasts from rank 0 only");

@@ -1332,23 +1332,36 @@ __global__ void bn_bwd_bound_k(int C, const float* __restrict__ scale, const flo
 }
 }  // namespace
 
+// Ring of amax arrays, one ring per stream (msk_side_scope swaps them with the streams): a slot is handed out ZEROED without
+// a memset of its own -- the ring is cleared half by half, on the stream that allocates from it, at the moment the
+// allocation cursor enters a half.  The slots of that half were handed out at least half a ring (512 arrays = many training
+// steps) ago and their consumers were enqueued before the streams last joined, so nothing still reads them.  (Round 2
+// issued one hipMemsetAsync per request: ~45 fill kernels per step.)
 float* msk_scalar_slots(msk_ctx* ctx, int n) {
-  constexpr int kRing = 1024 * kWbfAmaxWays;  // 1024 amax arrays
+  constexpr int kRing = 1024 * kWbfAmaxWays, kHalf = kRing / 2;
   n *= kWbfAmaxWays;
+  if (n > kHalf) {
+    msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "request larger than half the ring");
+    return nullptr;
+  }
   if (!ctx->scalar_ring) {
     if (hipMalloc((void**)&ctx->scalar_ring, kRing * sizeof(float)) != hipSuccess) {
       msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMalloc failed");
       return nullptr;
     }
+    ctx->scalar_next = 0;
   }
-  if (ctx->scalar_next + n > kRing) ctx->scalar_next = 0;
-  float* p = ctx->scalar_ring + ctx->scalar_next;
-  ctx->scalar_next += n;
-  if (hipMemsetAsync(p, 0, n * sizeof(float), ctx->stream) != hipSuccess) {
-    msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMemsetAsync failed");
-    return nullptr;
+  int start = ctx->scalar_next;
+  if (start % kHalf + n > kHalf) start = (start / kHalf + 1) * kHalf;  // a request never straddles the halves
+  if (start >= kRing) start = 0;
+  if (start % kHalf == 0) {
+    if (hipMemsetAsync(ctx->scalar_ring + start, 0, kHalf * sizeof(float), ctx->stream) != hipSuccess) {
+      msk_fail(ctx, __FILE__, __LINE__, "msk_scalar_slots", "hipMemsetAsync failed");
+      return nullptr;
+    }
   }
-  return p;
+  ctx->scalar_next = start + n;
+  return ctx->scalar_ring + start;
 }
 
 const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels, float* dst) {

@@ -544,11 +544,16 @@ int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* veloc
   long cap = (long)ctx->num_cu * 16;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  {
   msk_launch_scope ls(ctx, "sgd_momentum");
   hipLaunchKernelGGL(sgd_momentum_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, velocity, n4,
                      count, lr, momentum, weight_decay, grad_scale);
   MSK_LAUNCH_CHECK(ctx);
-  return 0;
+  }
+  // the packed / transformed forms of the convolution weights inside [param, param + count) are stale now: rebuild the ones
+  // in use in one go (two launches instead of one pack + one maximum per layer and direction inside the next step)
+  msk_weights_changed_impl(ctx, param, count * sizeof(float));
+  return msk_wbf_prepack_impl(ctx);
 }
 
 int msk_adam(msk_ctx* ctx, float* param, const float* grad, float* moment1, float* moment2, size_t count, float lr,
@@ -563,11 +568,14 @@ int msk_adam(msk_ctx* ctx, float* param, const float* grad, float* moment1, floa
   long blocks = (long)((count + kThreads - 1) / kThreads);
   const long cap = (long)ctx->num_cu * 16;
   if (blocks > cap) blocks = cap;
+  {
   msk_launch_scope ls(ctx, "adam");
   hipLaunchKernelGGL(adam_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, moment1, moment2, count, lr_t,
                      beta1, beta2, eps_t, weight_decay, grad_scale);
   MSK_LAUNCH_CHECK(ctx);
-  return 0;
+  }
+  msk_weights_changed_impl(ctx, param, count * sizeof(float));
+  return msk_wbf_prepack_impl(ctx);
 }
 
 }  // extern "C"

@@ -8,7 +8,9 @@ error no larger than 1.5x that of the exact-fp32 Winograd kernels it replaces on
 import numpy as np
 import pytest
 
-from helpers import dev, rel_err, t_empty, t_from_ncdhw, t_to_ncdhw, vec, vp
+import ctypes as C
+
+from helpers import dev, rel_err, t_empty, t_from_ncdhw, t_to_ncdhw, vec, vec_back, vp
 
 pytestmark = pytest.mark.gpu
 
@@ -550,3 +552,143 @@ def test_wbf_channel_padding_wrapper(case):
         d.set_option("wbf_pad_min_voxels", 1 << 18)
     print("padded pipeline: fwd %.2e dgrad %.2e acc %.2e" % (e_f, e_d, e_a))
     assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_a < _conv_tol(cout * 125)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: matrix stage + output transform in one kernel (wbf_gemm_fused_k), packed-weight cache
+# ---------------------------------------------------------------------------------------------------------
+FUSED_CASES = [
+    # (Cin, Cout, (N, D, H, W))  -- option "wbf_fuse" 2 forces the one-kernel form below its size threshold
+    (32, 32, (2, 16, 32, 16)),      # CN 32, 16 x 16 tiles, exact fit
+    (32, 32, (1, 30, 60, 8)),       # ragged d and h tiles: masked rows in the epilogue and in the statistics
+    (64, 64, (1, 20, 13, 16)),      # CN 64 (two column fragments per workgroup), transform along D
+    (64, 32, (1, 15, 30, 12)),      # 4 chunks
+]
+
+
+@pytest.mark.parametrize("split", [2, 3])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_wbf_fused_output_stage_matches_oracle_and_three_stage_form(case, split):
+    """Forward (bias, BatchNorm statistics of y), data gradient (plain and accumulating) and the PReLU epilogue of the
+    one-kernel form against the float64 oracle, and against the three-stage form (wbf_tout_k) on the same inputs."""
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", split)
+    rng = np.random.default_rng(cin * 7 + cout + H)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    alpha = rng.uniform(0.05, 0.5, cout).astype(np.float32)
+    f8 = lambda a: a.astype(np.float64)
+    y_ref = O.conv3d(f8(x), f8(w), f8(b), s_, p)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    wp, bp, ap = vec(w.ravel()), vec(b), vec(alpha)
+    cd = _desc(k, s_, p)
+    res = {}
+    try:
+        for mode in (2, 0):
+            d.set_option("wbf_fuse", mode)
+            yt, ya = t_empty(N, cout, D, H, W, fill=7.0), t_empty(N, cout, D, H, W, fill=7.0)
+            dxt = t_empty(N, cin, D, H, W, fill=3.0)
+            stats = vec(np.zeros(2 * cout, np.float32))
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_fwd_ex", cd, xt.msk(), vp(wp), vp(bp), yt.msk(), vp(stats), None)
+            d.prof_enable(False)
+            rep = d.prof_report()
+            # the one-kernel form has no output-transform launch; it needs the packed weights of all 8 points in an XCD's L2
+            # (<= 3.5 MB: 64 channels with the three-piece split are over it and keep the three stages)
+            one_kernel = mode == 2 and 8 * 25 * (cin // 16) * 2 * split * cout * 16 <= (3584 << 10)
+            assert ("wbf_tout_k" in rep) == (not one_kernel), rep
+            d.call("msk_conv3d_fwd_act", cd, xt.msk(), vp(wp), vp(bp), vp(ap), ya.msk())
+            d.call("msk_conv3d_dgrad", cd, dyt.msk(), vp(wp), dxt.msk(), 0)
+            dx1 = t_to_ncdhw(dxt)
+            d.call("msk_conv3d_dgrad", cd, dyt.msk(), vp(wp), dxt.msk(), 1)
+            res[mode] = (t_to_ncdhw(yt), vec_back(stats, 2 * cout), t_to_ncdhw(ya), dx1, t_to_ncdhw(dxt))
+    finally:
+        d.set_option("wbf_fuse", 1)
+    tol_f, tol_d = _conv_tol(cin * 125), _conv_tol(cout * 125)
+    act_ref = np.where(y_ref > 0, y_ref, alpha.reshape(1, -1, 1, 1, 1) * y_ref)
+    M = N * D * H * W
+    for mode, (y, st, ya, dx1, dx2) in res.items():
+        assert rel_err(y, y_ref) < tol_f, (mode, rel_err(y, y_ref))
+        assert rel_err(ya, act_ref) < tol_f
+        assert rel_err(dx1, dx_ref) < tol_d and rel_err(dx2, 2 * dx_ref) < tol_d
+        # statistics record: mean[C], M2[C] of the STORED values
+        yc = np.moveaxis(f8(y), 1, 0).reshape(cout, -1)
+        np.testing.assert_allclose(st[:cout], yc.mean(1), rtol=0, atol=2e-6 * np.abs(yc).max())
+        np.testing.assert_allclose(st[cout:], yc.var(1) * M, rtol=2e-5)
+    # the two forms differ in the summation order of the output transform (and in split-K on the small cases)
+    assert rel_err(res[2][0], res[0][0]) < 8e-6 and rel_err(res[2][3], res[0][3]) < 8e-6   # two fp32-class results (each 1-2.5e-6 from the oracle)
+    print(f"\nfused {case} split {split}: fwd {rel_err(res[2][0], y_ref):.2e} (three-stage {rel_err(res[0][0], y_ref):.2e})  "
+          f"dgrad {rel_err(res[2][3], dx_ref):.2e} ({rel_err(res[0][3], dx_ref):.2e})")
+
+
+def test_wbf_packed_weight_cache_follows_every_weight_write():
+    """The packed weights of a layer are cached per weight tensor; every entry point that can change the tensor must
+    invalidate them: h2d, d2d, memset, the optimizer kernels (which also rebuild them in one launch), free + reuse."""
+    cin = cout = 32
+    N, D, H, W = 1, 16, 16, 8
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", 2)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    xt, yt = t_from_ncdhw(x), t_empty(N, cout, D, H, W)
+    cd = _desc(k, s_, p)
+    f8 = lambda a: a.astype(np.float64)
+    mkw = lambda sc: (rng.standard_normal((cout, cin) + k) * sc / np.sqrt(cin * 125)).astype(np.float32)
+    b = np.zeros(cout, np.float32)
+    bp = vec(b)
+    count = cout * cin * 125
+
+    def check(wp, w, what):
+        d.call("msk_conv3d_fwd", cd, xt.msk(), vp(wp), vp(bp), yt.msk())
+        e = rel_err(t_to_ncdhw(yt), O.conv3d(f8(x), f8(w), f8(b), s_, p))
+        assert e < _conv_tol(cin * 125), (what, e)
+
+    w1 = mkw(1.0)
+    wp = vec(w1.ravel())
+    check(wp, w1, "first use")
+    check(wp, w1, "cached")
+    w2 = mkw(37.0)                      # a different maximum: a stale amax would show as well
+    d.h2d(wp, w2.ravel())
+    check(wp, w2, "after h2d")
+    w3 = mkw(1e-3)
+    src = vec(w3.ravel())
+    d.d2d(wp, src, count * 4)
+    check(wp, w3, "after d2d")
+    d.memset(wp, 0, count * 4)
+    check(wp, np.zeros_like(w1), "after memset")
+    # optimizer kernel: w <- w - lr * (g + wd * w), velocity 0, momentum 0
+    d.h2d(wp, w1.ravel())
+    g = mkw(1.0)
+    gp, vel = vec(g.ravel()), vec(np.zeros(count, np.float32))
+    check(wp, w1, "before sgd")
+    d.call("msk_sgd_momentum", vp(wp), vp(gp), vp(vel), C.c_size_t(count), C.c_float(0.5), C.c_float(0.0), C.c_float(0.0),
+           C.c_float(1.0))
+    d.prof_reset()
+    d.prof_enable(True)
+    check(wp, w1 - 0.5 * g, "after sgd")
+    d.prof_enable(False)
+    assert "wbf_pack_weights" not in d.prof_report(), d.prof_report()   # rebuilt by the optimizer kernel's epilogue, not here
+    m1, m2 = vec(np.zeros(count, np.float32)), vec(np.zeros(count, np.float32))
+    d.call("msk_adam", vp(wp), vp(gp), vp(m1), vp(m2), C.c_size_t(count), C.c_float(1e-2), C.c_float(0.9), C.c_float(0.999),
+           C.c_float(1e-8), C.c_double(0.9), C.c_double(0.999), C.c_float(0.0), C.c_float(1.0))
+    w_adam = d.d2h(wp, (cout, cin) + k, np.float32)
+    assert np.abs(w_adam - (w1 - 0.5 * g)).max() > 1e-3
+    check(wp, w_adam, "after adam")
+    # free + a new allocation (very likely at the same address) with other weights
+    d.free(wp)
+    w5 = mkw(5.0)
+    wp2 = vec(w5.ravel())
+    check(wp2, w5, "after free + malloc")
+    # cache off: same results
+    d.set_option("wbf_pack_cache", 0)
+    try:
+        check(wp2, w5, "cache off")
+    finally:
+        d.set_option("wbf_pack_cache", 1)
