@@ -65,6 +65,7 @@ struct msk_ctx {
   void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
   int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
+  int wgrad_fork = 1;         // fused LUConv backward: 1 = the weight gradient forks after the data-gradient GEMM is enqueued (it then overlaps the HBM-bound passes of the next layer instead of stretching that GEMM by 30 %: -0.25 ms per step), 0 = right after the dual transform
   int wbf_fuse = 1;           // 1 = wbf_gemm_fused_k (matrix stage + output transform in one kernel) where eligible; 0 = three stages (A/B)
   int conv_split = 2;         // operand split of the Winograd pipelines: 2 = fp16 two-piece with per-tensor power-of-two scales (product), 3 = exact bf16x3
   int bwd_fuse = -1;          // msk_conv3d_bwd_bnact: -1 auto, 0 three calls, 1 one dual transform, 2 one transform per stream

@@ -1490,7 +1490,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       if (msk_wbf_transform_dual(ctx, K, NP, ta, *g.fuse, true) != 0) return -1;
       // one-kernel form: the weight gradient (side stream) may start as soon as both transforms are written: fork here,
       // not after the GEMM
-      if (g.fuse->Y && ctx->wgrad_async && ctx->side != nullptr) {
+      if (g.fuse->Y && ctx->wgrad_async && ctx->side != nullptr && ctx->wgrad_fork == 0) {
         hipEventRecord(ctx->ev_fork, ctx->stream);
         ctx->fork_recorded = true;
       }

@@ -135,7 +135,23 @@ int msk_ctx_create(int device, msk_ctx** out) {
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
     const char* e = getenv("MSEGK_SIDE_PRIORITY");   // A/B: "0" = normal priority
     const int prio = (e && e[0] == '0') ? 0 : least;
-    MSK_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio));
+    const char* m = getenv("MSEGK_SIDE_CU_FRAC");    // A/B: confine the weight-gradient stream to 1/k of the CUs of every XCD
+    const int frac = m ? atoi(m) : 0;
+    if (frac > 1) {
+      // bit i of the mask is a CU; both plausible orders (XCD-major and XCD-interleaved) give every XCD the same share
+      // when whole groups of 8 consecutive bits are switched by (i / 8) % frac
+      uint32_t mask[8];
+      for (int wd = 0; wd < 8; ++wd) {
+        mask[wd] = 0;
+        for (int bit = 0; bit < 32; ++bit) {
+          const int i = wd * 32 + bit;
+          if ((i / 8) % frac == 0) mask[wd] |= 1u << bit;
+        }
+      }
+      MSK_CHECK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->side, 8, mask));
+    } else {
+      MSK_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio));
+    }
   }
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -366,6 +382,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wbf_prepack") == 0) {  // 0 = stale packed weights are rebuilt lazily at their next use only
     ctx->wbf_prepack = value;
+    return 0;
+  }
+  if (strcmp(key, "wgrad_fork") == 0) {
+    ctx->wgrad_fork = value;
     return 0;
   }
   if (strcmp(key, "wbf_fuse") == 0) {

@@ -73,9 +73,11 @@ class InputTransition(nn.Layer):
         self.relu1 = nn.ELU() if elu else nn.PReLU(self.num_features)
         self._unit = ConvBNAct(self.conv1, self.bn1, self.relu1)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: where the block's output goes (a channel slice of the concat buffer of the up-transition that takes it as
+        its skip connection: UpTransition.reserve_concat)"""
         # the tiled input is the residual: channel c of the sum reads x[..., c % in_channels]
-        return self._unit.forward(x, res=x)
+        return self._unit.forward(x, res=x, out=out)
 
     def backward(self, dout):
         self._unit.backward(dout, need_dx=False, res_needs_grad=False)
@@ -97,19 +99,20 @@ class DownTransition(nn.Layer):
         self._down = ConvBNAct(self.down_conv, self.bn1, self.relu1)
         self._join = AddAct(self.relu2)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: see InputTransition.forward"""
         down = self._down.forward(x)
         self._mask = self.dropout.make_mask(down) if self.if_dropout else None
         if self._mask is not None:
-            out = down.empty_like()
-            copy_scale(down, self._mask, out)
+            t = down.empty_like()
+            copy_scale(down, self._mask, t)
         else:
-            out = down
-        self._dropped = out
+            t = down
+        self._dropped = t
         self._t_down = down
-        out, unit = _run_ops(self.ops, out, down)
-        self._t_ops = out
-        return self._join.forward(out, down, unit=unit)
+        t, unit = _run_ops(self.ops, t, down)
+        self._t_ops = t
+        return self._join.forward(t, down, unit=unit, out=out)
 
     def backward(self, dout):
         down = self._t_down
@@ -141,6 +144,19 @@ class UpTransition(nn.Layer):
         self._up = ConvBNAct(self.up_conv, self.bn1, self.relu1)
         self._join = AddAct(self.relu2)
 
+    def reserve_concat(self, dev, n, dims):
+        """Zero-copy skip connection: allocate this block's concat buffer (vnet.py:152) AHEAD of the encoder block that
+        produces the skip tensor and return the channel slice that block should write its output into -- the skip half of
+        the concat is then never copied (forward) and its gradient never copied back (backward).  None when the skip path
+        has a dropout (the copy applies the mask) or MSEGK_ZERO_COPY_SKIP=0."""
+        self._reserved = None
+        if self.if_dropout2 or os.environ.get("MSEGK_ZERO_COPY_SKIP", "1") == "0":
+            return None
+        half = self.outChans // 2
+        xcat = Tensor.empty(dev, n, dims[0], dims[1], dims[2], self.outChans)
+        self._reserved = xcat
+        return xcat.channel_slice(half, self.outChans)
+
     def forward(self, x, skipx):
         dev = x.dev
         self._x, self._skip = x, skipx
@@ -156,10 +172,16 @@ class UpTransition(nn.Layer):
         if (od, oh, ow) != (skipx.d, skipx.h, skipx.w) or skipx.c != self.outChans - half:
             raise ValueError(f"skip connection shape {skipx.shape} does not match the up-sampled "
                              f"({x.n}, {half}, {od}, {oh}, {ow})")
-        # concat (vnet.py:152) is two channel-slice writes into one NDHWC buffer
-        xcat = Tensor.empty(dev, x.n, od, oh, ow, self.outChans)
+        # concat (vnet.py:152) is two channel-slice writes into one NDHWC buffer -- or one, when the skip tensor already
+        # lives in its half (reserve_concat)
+        res = getattr(self, "_reserved", None)
+        self._reserved = None
+        self._skip_in_place = (res is not None and self._m2 is None and skipx.ld == res.ld and
+                               skipx.ptr == res.ptr + 4 * half and res.gen == dev.arena.gen)
+        xcat = res if self._skip_in_place else Tensor.empty(dev, x.n, od, oh, ow, self.outChans)
         self._up.forward(xin, out=xcat.channel_slice(0, half))
-        copy_scale(skipx, self._m2, xcat.channel_slice(half, self.outChans))
+        if not self._skip_in_place:
+            copy_scale(skipx, self._m2, xcat.channel_slice(half, self.outChans))
         self._xcat = xcat
         out, unit = _run_ops(self.ops, xcat, xcat)
         return self._join.forward(out, xcat, unit=unit)
@@ -172,8 +194,12 @@ class UpTransition(nn.Layer):
         gcat = xcat.grad
         # skip branch
         skip = self._skip
-        sg = skip.ensure_grad()
-        copy_scale(gcat.channel_slice(half, self.outChans), self._m2, sg, accumulate=skip.grad_written)
+        if self._skip_in_place and skip.grad is None:
+            # the skip tensor IS the second half of the concat: so is its gradient (later writers accumulate into the slice)
+            skip.grad = gcat.channel_slice(half, self.outChans)
+        else:
+            sg = skip.ensure_grad()
+            copy_scale(gcat.channel_slice(half, self.outChans), self._m2, sg, accumulate=skip.grad_written)
         skip.grad_written = True
         # up-conv branch
         self._up.backward(gcat.channel_slice(0, half))
@@ -287,8 +313,9 @@ class VNet(nn.Layer):
         self.dev.arena.reset()
         if self.training:
             nn.Dropout3D.step += 1
-        out16 = self.in_tr(x)
-        out32 = self.down_tr32(out16)
+        # the two dropout-free skip connections are produced straight into the concat buffers of their up-transitions
+        out16 = self.in_tr(x, out=self.up_tr32.reserve_concat(self.dev, x.n, (x.d, x.h, x.w)))
+        out32 = self.down_tr32(out16, out=self.up_tr64.reserve_concat(self.dev, x.n, self.down_tr32.down_conv.out_dims(out16)))
         out64 = self.down_tr64(out32)
         out128 = self.down_tr128(out64)
         out256 = self.down_tr256(out128)

@@ -91,8 +91,9 @@ class VNetDeepSup(VNet):
         if self.training:
             nn.Dropout3D.step += 1
         size = (x.d, x.h, x.w)
-        out16 = self.in_tr(x)
-        out32 = self.down_tr32(out16)
+        # the two dropout-free skip connections are produced straight into the concat buffers of their up-transitions
+        out16 = self.in_tr(x, out=self.up_tr32.reserve_concat(self.dev, x.n, (x.d, x.h, x.w)))
+        out32 = self.down_tr32(out16, out=self.up_tr64.reserve_concat(self.dev, x.n, self.down_tr32.down_conv.out_dims(out16)))
         out64 = self.down_tr64(out32)
         out128 = self.down_tr128(out64)
         out256 = self.down_tr256(out128)

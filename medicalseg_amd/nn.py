@@ -627,12 +627,14 @@ class AddAct:
         self.act = act
         self._sums = None
 
-    def forward(self, a: Tensor, b: Tensor, unit: "ConvBNAct | None" = None) -> Tensor:
+    def forward(self, a: Tensor, b: Tensor, unit: "ConvBNAct | None" = None, out: Tensor | None = None) -> Tensor:
         """unit: the conv -> BN -> PReLU unit that produced `a` with defer_act=True: its BatchNorm apply + PReLU run inside
-        this join, on the convolution output (one pass instead of two, `a` is never written)."""
+        this join, on the convolution output (one pass instead of two, `a` is never written).  out: destination (may be a
+        channel slice of a wider buffer: zero-copy skip connections, UpTransition.reserve_concat)."""
         self.a, self.b = a, b
         self.unit = unit if (unit is not None and getattr(unit, "deferred", False)) else None
-        out = a.empty_like()
+        if out is None:
+            out = a.empty_like()
         if isinstance(self.act, ELU):
             a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), None, out.msk())   # a + b
             a.dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
