@@ -148,6 +148,23 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
                       msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/);
 int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
                         int accumulate, const void* xform /*nullable*/);
+/* "amax arrays" (round 3): the fp16 two-piece convolution pipeline scales every operand tensor by a power of two taken from
+ * its max |value|.  For a layer input that maximum can ride along in the pass that PRODUCES the tensor (bn1/relu1 of the
+ * previous LUConv, vnet.py:41; the residual joins :110-111,154; the Dropout3D copies :102,147-148) instead of costing a
+ * read of its own:
+ *   msk_amax_new            a zeroed device array of 64 floats whose maximum counts (from a ring: valid for the next
+ *                           ~500 requests, i.e. well beyond the training step that uses it);
+ *   msk_*_amax              as the entry point without the suffix, and max |written values| is folded into out_amax
+ *                           (nullable; several calls may fold into the same array: the two halves of a concat buffer);
+ *   msk_conv3d_fwd_ex2      as msk_conv3d_fwd_ex with x_amax (nullable) = such an array covering all of x.        */
+float* msk_amax_new(msk_ctx* ctx);
+int msk_conv3d_fwd_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias /*nullable*/,
+                       msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/, const float* x_amax /*nullable*/);
+int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                            const float* alpha, msk_tensor out, float* out_amax);
+int msk_affine_act_join_fwd_amax(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                                 msk_tensor res, const float* alpha_outer, msk_tensor out, float* out_amax);
+int msk_copy_scale_amax(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate, float* dst_amax);
 /* Backward of one conv -> BatchNorm(batch statistics) -> PReLU unit (LUConv, vnet.py:36-41; autograd of core/train.py:139)
  * in one call:   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1, no residual),
  *                dx (+)= conv^T(dy, w)   (dx.p NULL -> skipped),   dw (+)= sum dy * x.

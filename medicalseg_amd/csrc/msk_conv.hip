@@ -911,6 +911,11 @@ size_t msk_conv3d_xform_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int 
 
 int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
                       float* stats_local, void* xform) {
+  return msk_conv3d_fwd_ex2(ctx, cd, x, w, bias, y, stats_local, xform, nullptr);
+}
+
+int msk_conv3d_fwd_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                       float* stats_local, void* xform, const float* x_amax) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
   GConv g{};
   g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
@@ -929,6 +934,7 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
     g.stats = stats_local;
     g.xform = xform;
   }
+  g.in_amax = x_amax;  // max |x| from the pass that produced x (msk_amax_new): the fp16 two-piece pipeline skips its own read of x
   if (int rc = run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct")) return rc;
   if (xform && !ctx->xform_written)
     return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_fwd_ex",

@@ -459,7 +459,11 @@ int msk_gconv_halo_foldn(msk_ctx* ctx, const GConv& g, const float* w_canon, int
                                     : msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
     const float* w_amax = msk_absmax(ctx, w_canon, 4, 4, (125L * g.CK * g.CN + 3) / 4);
     if (!x_amax || !w_amax) return -1;
-    if (g.xform && !g.in_amax) ctx->xform_written = true;
+    if (g.xform) {
+      if (g.in_amax)  // the maximum came with the tensor (msk_conv3d_fwd_ex2): copy it into the header
+        MSK_CHECK_HIP(ctx, hipMemcpyAsync(g.xform, g.in_amax, kWbfAmaxWays * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->xform_written = true;
+    }
     {
       msk_launch_scope ls(ctx, "pack_weights_foldn");
       hipLaunchKernelGGL(pack_foldn_h2_weights_k, dim3(50), dim3(256), 0, ctx->stream, w_canon, A, B, swap, g.transposed ? 1 : 0, g.CN,

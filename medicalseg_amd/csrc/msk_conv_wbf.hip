@@ -1477,6 +1477,9 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     else if (g.in_amax) in_amax = g.in_amax;
     else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
     if (!in_amax) return -1;
+    // the kept transform's header carries the maximum it was scaled by (the weight gradient undoes it)
+    if (g.xform && !g.fuse && in_amax != (const float*)g.xform)
+      MSK_CHECK_HIP(ctx, hipMemcpyAsync(g.xform, in_amax, kWbfAmaxWays * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
 
   {

@@ -275,15 +275,31 @@ __device__ __forceinline__ void split_vc(long i, int cv, int cshift, long& v, in
   }
 }
 
+// max of a block folded into an amax array (msk_wbf.h: kWbfAmaxWays floats, bits of non-negative floats): ONE atomic per
+// block, on the way blockIdx % ways, nothing waits for it (per-wavefront atomics on a single address cost 0.2 ms per step)
+__device__ __forceinline__ void block_atomic_max(unsigned* amax, float m) {
+  __shared__ float shm_amax[kThreads / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __syncthreads();  // a second call reuses the array
+  if ((threadIdx.x & 63) == 0) shm_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, shm_amax[i]);
+    if (m > 0.f) (void)atomicMax(amax + (blockIdx.x + blockIdx.y * 7u) % kWbfAmaxWays, __float_as_uint(m));
+  }
+}
+
 template <int V>
 __global__ void __launch_bounds__(kThreads)
 affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                  const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                  const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C,
-                 const float* __restrict__ alpha_in) {
+                 const float* __restrict__ alpha_in, unsigned* __restrict__ out_amax) {
   const int cv = C / V;
   const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
+  float mx = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long v;
     int cg;
@@ -313,8 +329,11 @@ affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = o[j] > 0.f ? o[j] : alpha[c + j] * o[j];
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) mx = fmaxf(mx, fabsf(o[j]));
     stv<V>(out + v * ldo + c, o);
   }
+  if (out_amax) block_atomic_max(out_amax, mx);  // max |out| for the consumer that scales it into fp16 range (msk_amax_new)
 }
 
 // Channel-stationary float4 variants (C/4 a power of two, i.e. every VNet trunk layer): a thread keeps
@@ -325,7 +344,8 @@ __global__ void __launch_bounds__(kThreads)
 affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                     const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift,
-                    const float* __restrict__ alpha_in) {
+                    const float* __restrict__ alpha_in, unsigned* __restrict__ out_amax) {
+  float mx = 0.f;
   const long g = (long)blockIdx.x * kThreads + threadIdx.x;
   const int c = (int)(g & ((C >> 2) - 1)) * 4;
   const long vstride = ((long)gridDim.x * kThreads) >> cshift;
@@ -353,6 +373,7 @@ affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restric
       const float u = t + rv[j];
       o[j] = (alpha && !(u > 0.f)) ? al[j] * u : u;
     }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     *reinterpret_cast<float4*>(out + v * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
   };
   long v = g >> cshift;
@@ -364,6 +385,7 @@ affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restric
     body(v + vstride, xb, rb);
   }
   if (v < voxels) body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), load_res(v));
+  if (out_amax) block_atomic_max(out_amax, mx);
 }
 
 // ---------------------------------------------------------------------------
@@ -421,21 +443,6 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
     p[cl] = sh[0][t];
     p[CB + cl] = sh[1][t];
     p[2 * CB + cl] = sh[2][t];
-  }
-}
-
-// max of a block folded into an amax array (msk_wbf.h: kWbfAmaxWays floats, bits of non-negative floats): ONE atomic per
-// block, on the way blockIdx % ways, nothing waits for it (per-wavefront atomics on a single address cost 0.2 ms per step)
-__device__ __forceinline__ void block_atomic_max(unsigned* amax, float m) {
-  __shared__ float shm_amax[kThreads / 64];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  __syncthreads();  // a second call reuses the array
-  if ((threadIdx.x & 63) == 0) shm_amax[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, shm_amax[i]);
-    if (m > 0.f) (void)atomicMax(amax + (blockIdx.x + blockIdx.y * 7u) % kWbfAmaxWays, __float_as_uint(m));
   }
 }
 
@@ -759,10 +766,11 @@ __global__ void bias_grad_from_sums_k(int C, const float* sums, const float* sca
 template <int V>
 __global__ void __launch_bounds__(kThreads)
 copy_scale_k(const float* __restrict__ src, int lds_, const float* __restrict__ mask, float* __restrict__ dst,
-             int ldd, long voxels, long vox_per_n, int C, int acc) {
+             int ldd, long voxels, long vox_per_n, int C, int acc, unsigned* __restrict__ dst_amax) {
   const int cv = C / V;
   const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
+  float mx = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long v;
     int cg;
@@ -781,8 +789,11 @@ copy_scale_k(const float* __restrict__ src, int lds_, const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < V; ++j) s[j] += a[j];
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) mx = fmaxf(mx, fabsf(s[j]));
     stv<V>(dst + v * ldd + c, s);
   }
+  if (dst_amax) block_atomic_max(dst_amax, mx);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -988,7 +999,7 @@ int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* bet
 }
 
 static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
-                               const float* alpha, msk_tensor out, const float* alpha_in) {
+                               const float* alpha, msk_tensor out, const float* alpha_in, float* out_amax = nullptr) {
   MSK_REQUIRE(ctx, same_shape(x, out), "x/out shape mismatch");
   MSK_REQUIRE(ctx, (scale == nullptr) == (shift == nullptr), "scale and shift go together");
   if (res.p) MSK_REQUIRE(ctx, res.c > 0 && (res.c == x.c || x.c % res.c == 0), "residual channels must tile");
@@ -1001,18 +1012,32 @@ static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, c
     while ((1 << cshift) < cq) ++cshift;
     hipLaunchKernelGGL(affine_act_fwd_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
                        (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, (float*)out.p,
-                       out.ld, voxels, x.c, cshift, alpha_in);
+                       out.ld, voxels, x.c, cshift, alpha_in, (unsigned*)out_amax);
   } else if (v4) {
     hipLaunchKernelGGL(affine_act_fwd_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
-                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in);
+                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in, (unsigned*)out_amax);
   } else {
     hipLaunchKernelGGL(affine_act_fwd_k<1>, dim3(ew_blocks(voxels * x.c, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
-                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in);
+                       alpha, (float*)out.p, out.ld, voxels, x.c, alpha_in, (unsigned*)out_amax);
   }
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+float* msk_amax_new(msk_ctx* ctx) { return msk_scalar_slots(ctx, 1); }
+
+int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                            const float* alpha, msk_tensor out, float* out_amax) {
+  return affine_act_fwd_impl(ctx, x, scale, shift, res, alpha, out, nullptr, out_amax);
+}
+
+int msk_affine_act_join_fwd_amax(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                                 msk_tensor res, const float* alpha_outer, msk_tensor out, float* out_amax) {
+  MSK_REQUIRE(ctx, scale && shift && alpha_inner && alpha_outer && res.p, "join of a conv -> BN -> PReLU unit with a residual");
+  MSK_REQUIRE(ctx, res.c == y.c, "the residual has the unit's channel count");
+  return affine_act_fwd_impl(ctx, y, scale, shift, res, alpha_outer, out, alpha_inner, out_amax);
 }
 
 int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
@@ -1208,6 +1233,10 @@ int msk_bn_bias_grad(msk_ctx* ctx, int C, const float* sums, const float* scale,
 }
 
 int msk_copy_scale(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate) {
+  return msk_copy_scale_amax(ctx, src, mask, dst, accumulate, nullptr);
+}
+
+int msk_copy_scale_amax(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate, float* dst_amax) {
   MSK_REQUIRE(ctx, same_shape(src, dst), "src/dst shape mismatch");
   const long voxels = msk_voxels(src);
   const long vpn = (long)src.d * src.h * src.w;
@@ -1215,11 +1244,11 @@ int msk_copy_scale(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor d
   if (vec4_ok(src) && vec4_ok(dst)) {
     hipLaunchKernelGGL(copy_scale_k<4>, dim3(ew_blocks(voxels * src.c / 4, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)src.p, src.ld, mask, (float*)dst.p, dst.ld, voxels, vpn, src.c,
-                       accumulate);
+                       accumulate, (unsigned*)dst_amax);
   } else {
     hipLaunchKernelGGL(copy_scale_k<1>, dim3(ew_blocks(voxels * src.c, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)src.p, src.ld, mask, (float*)dst.p, dst.ld, voxels, vpn, src.c,
-                       accumulate);
+                       accumulate, (unsigned*)dst_amax);
   }
   MSK_LAUNCH_CHECK(ctx);
   return 0;

@@ -47,6 +47,13 @@ class Device:
         self.call("msk_malloc", C.c_size_t(max(int(nbytes), 16)), C.byref(p))
         return p.value
 
+    def amax_new(self) -> int:
+        """a zeroed device amax array (64 floats, from the context's ring: valid for the current training step)"""
+        p = self.lib.msk_amax_new(self.ctx)
+        if not p:
+            raise MskError(f"msk_amax_new failed: {_lib.last_error(self.ctx)}")
+        return p
+
     def free(self, ptr: int):
         self.call("msk_free", C.c_void_p(ptr))
 
@@ -173,7 +180,7 @@ class Tensor:
     ``shape`` reports the reference's logical NCDHW order so code written against the
     reference (``_, c, d, h, w = images.shape``; core/train.py:266) keeps working."""
 
-    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index")
+    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "amax")
 
     def __init__(self, dev, ptr, n, d, h, w, c, ld=None, gen=None):
         self.dev, self.ptr = dev, ptr
@@ -184,6 +191,10 @@ class Tensor:
         self.grad_written = False
         self.producer = None
         self.out_index = 0
+        # device "amax array" (msk_amax_new) that the passes WRITING this tensor fold max |value| into, or None.  A channel
+        # slice shares its parent's array (the parent's maximum is the maximum over its slices' writers); it is only handed
+        # to a consumer by code that knows every channel was written by such a pass (nn.ConvBNAct / AddAct / copy_scale).
+        self.amax = None
 
     # -- construction ------------------------------------------------------------------
     @staticmethod
@@ -207,6 +218,7 @@ class Tensor:
 
     def channel_slice(self, c0, c1):
         t = Tensor(self.dev, self.ptr + 4 * c0, self.n, self.d, self.h, self.w, c1 - c0, self.ld, self.gen)
+        t.amax = self.amax
         return t
 
     def check_live(self):

@@ -154,8 +154,11 @@ class UpTransition(nn.Layer):
             return None
         half = self.outChans // 2
         xcat = Tensor.empty(dev, n, dims[0], dims[1], dims[2], self.outChans)
+        if nn.PRODUCER_AMAX:
+            xcat.amax = dev.amax_new()     # shared by both halves' writers (Tensor.amax)
         self._reserved = xcat
-        return xcat.channel_slice(half, self.outChans)
+        self._reserved_skip = xcat.channel_slice(half, self.outChans)
+        return self._reserved_skip
 
     def forward(self, x, skipx):
         dev = x.dev
@@ -178,10 +181,21 @@ class UpTransition(nn.Layer):
         self._reserved = None
         self._skip_in_place = (res is not None and self._m2 is None and skipx.ld == res.ld and
                                skipx.ptr == res.ptr + 4 * half and res.gen == dev.arena.gen)
-        xcat = res if self._skip_in_place else Tensor.empty(dev, x.n, od, oh, ow, self.outChans)
-        self._up.forward(xin, out=xcat.channel_slice(0, half))
+        if self._skip_in_place:
+            xcat, s_skip = res, skipx
+        else:
+            xcat = Tensor.empty(dev, x.n, od, oh, ow, self.outChans)
+            if nn.PRODUCER_AMAX:
+                xcat.amax = dev.amax_new()
+            s_skip = xcat.channel_slice(half, self.outChans)
+        s_up = xcat.channel_slice(0, half)
+        self._up.forward(xin, out=s_up)
         if not self._skip_in_place:
-            copy_scale(skipx, self._m2, xcat.channel_slice(half, self.outChans))
+            copy_scale(skipx, self._m2, s_skip)
+        # max |xcat| is known iff BOTH halves were written by passes that folded into xcat's array (a writer that cannot --
+        # ELU, a folded inference conv -- clears its slice's reference)
+        if xcat.amax is None or s_up.amax != xcat.amax or s_skip.amax != xcat.amax:
+            xcat.amax = None
         self._xcat = xcat
         out, unit = _run_ops(self.ops, xcat, xcat)
         return self._join.forward(out, xcat, unit=unit)

@@ -254,8 +254,9 @@ class Conv3D(Layer):
             nbytes = int(dev.lib.msk_conv3d_xform_bytes(dev.ctx, self.desc(), x.msk(), self.cout))
             if nbytes > 0:
                 xf = dev.arena.alloc(nbytes)
-        dev.call("msk_conv3d_fwd_ex", self.desc(), x.msk(), C.c_void_p(self.weight.ptr), C.c_void_p(self.bias.ptr),
-                 y.msk(), C.c_void_p(stats_ptr) if stats_ptr else None, C.c_void_p(xf) if xf else None)
+        dev.call("msk_conv3d_fwd_ex2", self.desc(), x.msk(), C.c_void_p(self.weight.ptr), C.c_void_p(self.bias.ptr),
+                 y.msk(), C.c_void_p(stats_ptr) if stats_ptr else None, C.c_void_p(xf) if xf else None,
+                 C.c_void_p(x.amax) if (x.amax and PRODUCER_AMAX) else None)
         self._xform = (xf, x.ptr, dev.arena.gen) if xf else None
         return y
 
@@ -460,6 +461,21 @@ def _fp(ptr):
     return C.c_void_p(ptr) if ptr else None
 
 
+# A/B switch (env MSEGK_PRODUCER_AMAX=0): layer inputs are measured by an absmax pass of their own instead of in the pass
+# that writes them
+PRODUCER_AMAX = os.environ.get("MSEGK_PRODUCER_AMAX", "1") != "0"
+
+
+def _amax_for(out: Tensor):
+    """the amax array the pass writing `out` folds into: the tensor's own (a concat buffer's, shared by its slices), else a
+    fresh one"""
+    if not PRODUCER_AMAX:
+        return None
+    if out.amax is None:
+        out.amax = out.dev.amax_new()
+    return C.c_void_p(out.amax)
+
+
 # A/B switch (env MSEGK_BWD_FUSE=0): conv -> BN -> PReLU units run their backward as three calls (apply, dgrad, wgrad)
 FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
 
@@ -495,6 +511,7 @@ class ConvBNAct:
             out = Tensor.empty(dev, x.n, od, oh, ow, conv.cout)
         alpha = _act_alpha(self.act)
         dev.call("msk_conv3d_fwd_act", conv.desc(), x.msk(), _fp(self._fold_w), _fp(self._fold_b), _fp(alpha), out.msk())
+        out.amax = None     # written by a kernel that does not measure it
         self.x, self.res, self.y, self.out, self.bn_mode = x, None, None, out, 3   # 3: no backward through this
         return out
 
@@ -538,10 +555,14 @@ class ConvBNAct:
         if defer_act and res is None and alpha is not None:
             self.deferred = True
         else:
-            dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
-                     res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
             if isinstance(self.act, ELU):
+                dev.call("msk_affine_act_fwd", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                         res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
                 dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
+                out.amax = None
+            else:
+                dev.call("msk_affine_act_fwd_amax", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                         res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk(), _amax_for(out))
         self.out = out
         return out
 
@@ -638,14 +659,16 @@ class AddAct:
         if isinstance(self.act, ELU):
             a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), None, out.msk())   # a + b
             a.dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
+            out.amax = None
             self.out = out
             return out
         if self.unit is not None:
             u, sc = self.unit, self.unit.bn.scratch(a.dev)
-            a.dev.call("msk_affine_act_join_fwd", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
-                       b.msk(), _fp(self.act._weight.ptr), out.msk())
+            a.dev.call("msk_affine_act_join_fwd_amax", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
+                       b.msk(), _fp(self.act._weight.ptr), out.msk(), _amax_for(out))
         else:
-            a.dev.call("msk_affine_act_fwd", a.msk(), None, None, b.msk(), _fp(self.act._weight.ptr), out.msk())
+            a.dev.call("msk_affine_act_fwd_amax", a.msk(), None, None, b.msk(), _fp(self.act._weight.ptr), out.msk(),
+                       _amax_for(out))
         return out
 
     def backward(self, dout: Tensor):
@@ -690,4 +713,8 @@ class AddAct:
 
 
 def copy_scale(src: Tensor, mask_ptr, dst: Tensor, accumulate=False):
-    src.dev.call("msk_copy_scale", src.msk(), _fp(mask_ptr), dst.msk(), 1 if accumulate else 0)
+    if accumulate:      # the destination's old contents are not covered by any amax array
+        dst.amax = None
+        src.dev.call("msk_copy_scale", src.msk(), _fp(mask_ptr), dst.msk(), 1)
+    else:
+        src.dev.call("msk_copy_scale_amax", src.msk(), _fp(mask_ptr), dst.msk(), 0, _amax_for(dst))
