@@ -152,12 +152,12 @@ int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor
  * its max |value|.  For a layer input that maximum can ride along in the pass that PRODUCES the tensor (bn1/relu1 of the
  * previous LUConv, vnet.py:41; the residual joins :110-111,154; the Dropout3D copies :102,147-148) instead of costing a
  * read of its own:
- *   msk_amax_new            a zeroed device array of 64 floats whose maximum counts (from a ring: valid for the next
- *                           ~500 requests, i.e. well beyond the training step that uses it);
+ *   msk_amax_new            n consecutive zeroed device arrays of 64 floats whose maximum counts (from a ring: valid for
+ *                           the next ~500 requests, i.e. well beyond the training step that uses them);
  *   msk_*_amax              as the entry point without the suffix, and max |written values| is folded into out_amax
  *                           (nullable; several calls may fold into the same array: the two halves of a concat buffer);
  *   msk_conv3d_fwd_ex2      as msk_conv3d_fwd_ex with x_amax (nullable) = such an array covering all of x.        */
-float* msk_amax_new(msk_ctx* ctx);
+float* msk_amax_new(msk_ctx* ctx, int n /* consecutive arrays */);
 int msk_conv3d_fwd_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias /*nullable*/,
                        msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/, const float* x_amax /*nullable*/);
 int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
@@ -165,6 +165,39 @@ int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, cons
 int msk_affine_act_join_fwd_amax(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
                                  msk_tensor res, const float* alpha_outer, msk_tensor out, float* out_amax);
 int msk_copy_scale_amax(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate, float* dst_amax);
+/* Launch diet (round 3): the per-channel epilogues of a BatchNorm layer ride in the merge kernels that precede them.
+ *   msk_bn_fin              the arguments of msk_bn_finalize(world = 1, count) as a struct;
+ *   msk_conv3d_fwd_ex3      msk_conv3d_fwd_ex2, and with fin != NULL (stats_local required) the finalisation runs in the
+ *                           launch that merges the statistics: bitwise the results of msk_conv3d_fwd_ex2 + msk_bn_finalize.
+ *                           (SyncBatchNorm over several ranks keeps the separate calls: an all-gather sits between them.)
+ *   msk_bn_stats_fin        msk_bn_stats + msk_bn_finalize(world = 1) the same way (the up-convolutions, vnet.py:150);
+ *   msk_affine_act_bwd_reduce_pg / msk_add_act_join_bwd_pg
+ *                           as the _ex forms, and the parameter gradients msk_affine_act_param_grads would take from the
+ *                           sums are ADDED to dgamma / dbeta / dalpha (nullable) in the launch that merges the sums;
+ *                           clear_maxes = 0: `maxes` arrives zeroed (msk_amax_new(ctx, 2)), no memset is enqueued.        */
+typedef struct msk_bn_fin {
+  const float* gamma; /* nullable */
+  const float* beta;  /* nullable */
+  float eps, momentum;
+  double count;       /* values per channel (N*D*H*W) */
+  float* running_mean; /* nullable */
+  float* running_var;  /* nullable */
+  float* save_mean;
+  float* save_invstd;
+  float* scale;        /* NULL = no finalisation */
+  float* shift;
+} msk_bn_fin;
+int msk_conv3d_fwd_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias /*nullable*/,
+                       msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/, const float* x_amax /*nullable*/,
+                       const msk_bn_fin* fin /*nullable*/);
+int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_bn_fin* fin /*nullable*/);
+int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                                 const float* alpha, const float* mean, const float* invstd, msk_tensor dout, float* sums,
+                                 float* maxes /*nullable*/, int clear_maxes, float* dgamma, float* dbeta, float* dalpha);
+int msk_add_act_join_bwd_pg(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, const float* mean, const float* invstd, msk_tensor dout,
+                            msk_tensor da, msk_tensor dres, int dres_accumulate, float* dalpha_outer, float* unit_sums,
+                            float* maxes /*nullable*/, int clear_maxes, float* unit_dgamma, float* unit_dbeta, float* unit_dalpha);
 /* Backward of one conv -> BatchNorm(batch statistics) -> PReLU unit (LUConv, vnet.py:36-41; autograd of core/train.py:139)
  * in one call:   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1, no residual),
  *                dx (+)= conv^T(dy, w)   (dx.p NULL -> skipped),   dw (+)= sum dy * x.

@@ -28,6 +28,13 @@ class MskConvDesc(C.Structure):
                 ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32)]
 
 
+class MskBnFin(C.Structure):
+    """msk_bn_fin (include/msegk.h): the arguments of msk_bn_finalize(world = 1) as a struct"""
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("count", C.c_double), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p)]
+
+
 NULL_TENSOR = MskTensor(None, 0, 0, 0, 0, 0, 0)
 
 _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -68,7 +75,11 @@ SIGNATURES = {
     "msk_conv3d_xform_bytes": (_sz, [_vp, _CD, _T, _i]),
     "msk_conv3d_fwd_ex": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp]),
     "msk_conv3d_wgrad_ex": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp]),
-    "msk_amax_new": (_vp, [_vp]),
+    "msk_amax_new": (_vp, [_vp, _i]),
+    "msk_conv3d_fwd_ex3": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp, _vp, _vp]),
+    "msk_bn_stats_fin": (_i, [_vp, _T, _vp, _vp]),
+    "msk_affine_act_bwd_reduce_pg": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _T, _vp, _vp, _i, _vp, _vp, _vp]),
+    "msk_add_act_join_bwd_pg": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _vp, _vp, _T, _T, _T, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "msk_conv3d_fwd_ex2": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp, _vp]),
     "msk_affine_act_fwd_amax": (_i, [_vp, _T, _vp, _vp, _T, _vp, _T, _vp]),
     "msk_affine_act_join_fwd_amax": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _T, _vp]),

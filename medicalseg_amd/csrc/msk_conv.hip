@@ -916,7 +916,14 @@ int msk_conv3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float*
 
 int msk_conv3d_fwd_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
                        float* stats_local, void* xform, const float* x_amax) {
+  return msk_conv3d_fwd_ex3(ctx, cd, x, w, bias, y, stats_local, xform, x_amax, nullptr);
+}
+
+int msk_conv3d_fwd_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                       float* stats_local, void* xform, const float* x_amax, const msk_bn_fin* fin) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  if (fin && !fin->scale) fin = nullptr;
+  MSK_REQUIRE(ctx, !fin || stats_local, "msk_conv3d_fwd_ex3: fin needs stats_local");
   GConv g{};
   g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
   g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
@@ -933,13 +940,14 @@ int msk_conv3d_fwd_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float
   if (!chunked) {
     g.stats = stats_local;
     g.xform = xform;
+    g.fin = fin;
   }
   g.in_amax = x_amax;  // max |x| from the pass that produced x (msk_amax_new): the fp16 two-piece pipeline skips its own read of x
   if (int rc = run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct")) return rc;
   if (xform && !ctx->xform_written)
     return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_fwd_ex",
                     "xform buffer given but the transform pipeline did not run (size it with msk_conv3d_xform_bytes: 0 = pass NULL)");
-  if (stats_local && !ctx->stats_fused) return msk_bn_stats(ctx, y, stats_local);
+  if (stats_local && !ctx->stats_fused) return msk_bn_stats_fin(ctx, y, stats_local, fin);
   return 0;
 }
 
@@ -1012,10 +1020,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     bn.Y = (char*)ybuf;
     bn.y_xi = (long)(y_bytes / ((cd.kd == 5) ? 8 : 6));
     if (split2) g.w_amax = (const float*)xform + kWbfAmaxWays;  // max |w| of this layer, left there by the forward pass
-    if (split2) {  // fp16 pieces: dy is scaled by a power of two from a device-side bound of its maximum
-      bn.amax = msk_bn_bwd_bound(ctx, y.c, scale, sums_total, M_total, maxes);
-      if (!bn.amax) return -1;
-    }
+
     // form 1 (one kernel writes both transforms; least traffic: best without a side stream) or form 2 (each stream's
     // transform evaluates dy itself: the main stream -- the critical path -- moves 20 instead of 28 B per element, the
     // weight-gradient stream 20 instead of 16).  Option "bwd_fuse": 0 = three calls, 1 / 2 = force a form, -1 = auto.
@@ -1024,6 +1029,18 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     // auto: with the two-piece fp16 operands the one-kernel form wins even with the side stream on (24.1 vs 24.7 ms per
     // step: its transforms are a third cheaper); with the exact bf16 x 3 split form 2 does (30.1-30.2 vs 30.3-30.4)
     const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : ((side_on && !split2) ? 2 : 1);
+    if (split2) {  // fp16 pieces: dy is scaled by a power of two from a device-side bound of its maximum
+      if (form == 1) {
+        // the dual transform evaluates the bound itself and leaves it in a (zeroed) ring array for the kernels behind it
+        float* slot = msk_scalar_slots(ctx, 1);
+        if (!slot) return -1;
+        bn.amax = slot;
+        bn.maxes = maxes;
+      } else {
+        bn.amax = msk_bn_bwd_bound(ctx, y.c, scale, sums_total, M_total, maxes);
+        if (!bn.amax) return -1;
+      }
+    }
     if (form == 2) {
       // nothing is launched unless both pipelines accept: the weight gradient was planned above, ask the data gradient
       bn.Y = nullptr;

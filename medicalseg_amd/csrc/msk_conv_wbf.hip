@@ -360,6 +360,7 @@ struct DualArgs {
   char* Y;
   long y_xi;
   const float* amax;
+  const float* maxes;  // see WbfBnBwd
 };
 
 template <int K, int NP>
@@ -415,6 +416,36 @@ wbf_tin_dual_k(DualArgs b) {
     s1[j] = b.sums[c] * b.invM;
     s2[j] = b.sums[b.C + c] * b.invM;
   }
+  // NP = 2: power-of-two scale of dy from (a bound of) its maximum: given (b.amax), or evaluated here (b.maxes)
+  float sc2 = 1.f;
+  if (NP == 2) {
+    if (b.maxes) {
+      __shared__ float shb[3][4];
+      float ma = 0.f, mb = 0.f, mc = 0.f;
+      for (int c = threadIdx.x; c < b.C; c += 256) {
+        ma = fmaxf(ma, fabsf(b.scale[c]));
+        mb = fmaxf(mb, fabsf(b.sums[c] * b.invM));
+        mc = fmaxf(mc, fabsf(b.sums[b.C + c] * b.invM));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+        mc = fmaxf(mc, __shfl_xor(mc, o, 64));
+      }
+      if (pl == 0) { shb[0][cgl] = ma; shb[1][cgl] = mb; shb[2][cgl] = mc; }
+      __syncthreads();
+      ma = fmaxf(fmaxf(shb[0][0], shb[0][1]), fmaxf(shb[0][2], shb[0][3]));
+      mb = fmaxf(fmaxf(shb[1][0], shb[1][1]), fmaxf(shb[1][2], shb[1][3]));
+      mc = fmaxf(fmaxf(shb[2][0], shb[2][1]), fmaxf(shb[2][2], shb[2][3]));
+      const float bound = ma * (wbf_amax_of(b.maxes) + mb + wbf_amax_of(b.maxes + kWbfAmaxWays) * mc);
+      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) const_cast<float*>(b.amax)[0] = bound;  // zeroed ring array
+      sc2 = wbf_scale_from(bound);
+    } else {
+      sc2 = wbf_scale_of(b.amax);
+    }
+  }
+  (void)sc2;
   if (pos >= a.DP * a.HP) return;
   const int dp = pos / a.HP, hp = pos - dp * a.HP;
   const int d = dp - 2, h = hp - 2;
@@ -429,8 +460,6 @@ wbf_tin_dual_k(DualArgs b) {
   const float* gb = b.dout + vox0 * b.dld + cg * 8;
   const long xstep = (long)a.svw * b.yld, gstep = (long)a.svw * b.dld;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float sc2 = NP == 2 ? wbf_scale_of(b.amax) : 1.f;
-  (void)sc2;
 
   // dy of 8 channels at logical position w (zero outside the volume)
   auto dy_at = [&](int w, float4& o0, float4& o1) {
@@ -1529,7 +1558,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       MSK_LAUNCH_CHECK(ctx);
     }
     if (fuse_stats) {
-      if (msk_bn_stats_merge(ctx, SP, fa.g.nblk, g.CN, g.stats) != 0) return -1;
+      if (msk_bn_stats_merge(ctx, SP, fa.g.nblk, g.CN, g.stats, g.fin) != 0) return -1;
       ctx->stats_fused = true;
     }
     if (g.xform) ctx->xform_written = true;
@@ -1558,7 +1587,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       MSK_LAUNCH_CHECK(ctx);
     }
     if (fuse_stats) {
-      if (msk_bn_stats_merge(ctx, SP, (int)tout_blocks, g.CN, g.stats) != 0) return -1;
+      if (msk_bn_stats_merge(ctx, SP, (int)tout_blocks, g.CN, g.stats, g.fin) != 0) return -1;
       ctx->stats_fused = true;
     }
   }
@@ -1602,7 +1631,7 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   da.t.lane_map = 1;
   da.y = bn.y; da.yld = bn.yld; da.dout = bn.dout; da.dld = bn.dld;
   da.scale = bn.scale; da.shift = bn.shift; da.alpha = bn.alpha; da.mean = bn.mean; da.invstd = bn.invstd; da.sums = bn.sums;
-  da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax;
+  da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax; da.maxes = bn.maxes;
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;

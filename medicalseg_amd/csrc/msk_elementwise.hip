@@ -164,8 +164,11 @@ bn_stats_partial_v4(const float* __restrict__ x, long voxels, int C, int ld, int
 
 // One block per channel: 64 lanes stride over the nb block partials (Chan merge in double),
 // then a fixed-order tree over the 64 lane results -> deterministic and ~nb/64 serial steps.
+// fin.scale != NULL: the per-channel finalisation of msk_bn_finalize(world = 1) runs here as well (one launch less per
+// BatchNorm layer): the same arithmetic on the same float-rounded (mean, M2) record, so the results are bitwise those of
+// the two-kernel form.
 __global__ void __launch_bounds__(64)
-bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ stats /*[2C]*/) {
+bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ stats /*[2C]*/, msk_bn_fin fin) {
   __shared__ double sn[64], sm[64], s2[64];
   const int c = blockIdx.x, t = threadIdx.x;
   const int cb = c / CB, cl = c % CB;
@@ -191,8 +194,20 @@ bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* 
     __syncthreads();
   }
   if (t == 0) {
-    stats[c] = (float)sm[0];
-    stats[C + c] = (float)s2[0];
+    const float fm = (float)sm[0], fm2 = (float)s2[0];
+    stats[c] = fm;
+    stats[C + c] = fm2;
+    if (fin.scale) {
+      const double mu = (double)fm, var = (double)fm2 / fin.count;  // biased (paddle BatchNorm training)
+      const double invstd = 1.0 / sqrt(var + (double)fin.eps);
+      const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
+      fin.save_mean[c] = (float)mu;
+      fin.save_invstd[c] = (float)invstd;
+      fin.scale[c] = (float)(g * invstd);
+      fin.shift[c] = (float)(b - mu * g * invstd);
+      if (fin.running_mean) fin.running_mean[c] = fin.momentum * fin.running_mean[c] + (1.f - fin.momentum) * (float)mu;
+      if (fin.running_var) fin.running_var[c] = fin.momentum * fin.running_var[c] + (1.f - fin.momentum) * (float)var;
+    }
   }
 }
 
@@ -591,7 +606,10 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
 // tree over the lanes (deterministic).
 __global__ void __launch_bounds__(64)
 sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq, float* __restrict__ sums /*[nq][C]*/,
-             int accumulate) {
+             int accumulate, float* __restrict__ g0 = nullptr, float* __restrict__ g1 = nullptr, float* __restrict__ g2 = nullptr,
+             float* __restrict__ g3 = nullptr) {
+  // g0..g3 (nullable): quantity q of channel c is also ADDED to gq[c] -- the parameter gradients that
+  // msk_affine_act_param_grads would take from sums afterwards (d beta, d gamma, d alpha; the join's d alpha)
   __shared__ double sh[64];
   const int i = blockIdx.x, t = threadIdx.x;
   const int q = i / C, c = i % C;
@@ -604,7 +622,12 @@ sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq, f
     if (t < k) sh[t] += sh[t + k];
     __syncthreads();
   }
-  if (t == 0) sums[i] = accumulate ? sums[i] + (float)sh[0] : (float)sh[0];
+  if (t == 0) {
+    const float v = (float)sh[0];
+    sums[i] = accumulate ? sums[i] + v : v;
+    float* g = q == 0 ? g0 : (q == 1 ? g1 : (q == 2 ? g2 : g3));
+    if (g) g[c] += v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -929,16 +952,18 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
 
 }  // extern "C"
 
-int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats) {
+int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats, const msk_bn_fin* fin) {
   msk_launch_scope ls(ctx, "bn_stats_merge");
-  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(64), 0, ctx->stream, partial, nb, C, C, stats);
+  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(64), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }
 
 extern "C" {
 
-int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
+int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) { return msk_bn_stats_fin(ctx, x, stats_local, nullptr); }
+
+int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_bn_fin* fin) {
   const long voxels = msk_voxels(x);
   MSK_REQUIRE(ctx, voxels > 0 && x.c > 0, "empty tensor");
   if (x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x)) {
@@ -953,7 +978,8 @@ int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local);
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
+                       fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
@@ -970,7 +996,8 @@ int msk_bn_stats(msk_ctx* ctx, msk_tensor x, float* stats_local) {
   }
   {
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local);
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
+                       fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
   }
   return 0;
@@ -1026,7 +1053,7 @@ static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, c
   return 0;
 }
 
-float* msk_amax_new(msk_ctx* ctx) { return msk_scalar_slots(ctx, 1); }
+float* msk_amax_new(msk_ctx* ctx, int n) { return msk_scalar_slots(ctx, n > 0 ? n : 1); }
 
 int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
                             const float* alpha, msk_tensor out, float* out_amax) {
@@ -1061,13 +1088,19 @@ int msk_affine_act_bwd_reduce(msk_ctx* ctx, msk_tensor x, const float* scale, co
 int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
                                  const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
                                  float* sums, float* maxes) {
+  return msk_affine_act_bwd_reduce_pg(ctx, x, scale, shift, res, alpha, mean, invstd, dout, sums, maxes, 1, nullptr, nullptr, nullptr);
+}
+
+int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                                 const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
+                                 float* sums, float* maxes, int clear_maxes, float* dgamma, float* dbeta, float* dalpha) {
   MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
   const long voxels = msk_voxels(x);
   const bool v4 = x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x) && vec4_ok(dout) &&
                   (res.p == nullptr || res.c != x.c || vec4_ok(res));
   if (maxes) {
     MSK_REQUIRE(ctx, v4, "maxes are produced by the float4 kernel only: channel count and strides multiples of 4, 16-byte aligned tensors");
-    MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
+    if (clear_maxes) MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
   }
   if (v4) {
     const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
@@ -1083,7 +1116,8 @@ int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale,
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0);
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0, dbeta, dgamma,
+                       dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
@@ -1102,7 +1136,7 @@ int msk_affine_act_bwd_reduce_ex(msk_ctx* ctx, msk_tensor x, const float* scale,
   {
     msk_launch_scope ls(ctx, "sums_merge");
     hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c,
-                       g.CB, 3, sums, 0);
+                       g.CB, 3, sums, 0, dbeta, dgamma, dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 0;
@@ -1149,7 +1183,8 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
 static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, const float* shift, const float* alpha_in,
                            msk_tensor b, const float* alpha, msk_tensor dout, msk_tensor da, msk_tensor db, int db_accumulate,
                            float* dalpha, const float* mean = nullptr, const float* invstd = nullptr, float* unit_sums = nullptr,
-                           float* maxes = nullptr) {
+                           float* maxes = nullptr, int clear_maxes = 1, float* u_dgamma = nullptr, float* u_dbeta = nullptr,
+                           float* u_dalpha = nullptr) {
   MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && same_shape(a, db), "shape mismatch");
   MSK_REQUIRE(ctx, alpha != nullptr && dalpha != nullptr, "join needs alpha and its gradient");
   MSK_REQUIRE(ctx, a.c % 4 == 0 && a.c / 4 <= kThreads && vec4_ok(a) && vec4_ok(b) && vec4_ok(dout) && vec4_ok(da) &&
@@ -1160,7 +1195,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
   if (unit_sums) {  // the unit's BatchNorm/PReLU sums in the same pass
     float* partial4 = (float*)msk_workspace(ctx, (size_t)nb * 4 * 4 * QCB * sizeof(float));
     if (!partial4) return -1;
-    if (maxes) MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
+    if (maxes && clear_maxes) MSK_CHECK_HIP(ctx, hipMemsetAsync(maxes, 0, 2 * kWbfAmaxWays * sizeof(float), ctx->stream));
     {
       msk_launch_scope ls(ctx, "add_act_bwd_unit");
       hipLaunchKernelGGL(affine_act_bwd_reduce_v4_k<2>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)a.p, a.ld, scale,
@@ -1170,10 +1205,9 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
     }
     msk_launch_scope ls(ctx, "sums_merge");
     // quantities 0..2 -> unit_sums[3C] (overwritten), quantity 3 -> dalpha of the join (accumulated)
-    hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0);
-    MSK_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(param_grads_k, dim3(msk_cdiv(a.c, 64)), dim3(64), 0, ctx->stream, a.c, (const float*)(unit_sums + a.c),
-                       (float*)nullptr, (float*)nullptr, dalpha, 1);
+    // ... and the parameter gradients ride along: the unit's (d beta, d gamma, d alpha_inner; nullable) and the join's d alpha
+    hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0, u_dbeta,
+                       u_dgamma, u_dalpha, dalpha);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
@@ -1212,6 +1246,15 @@ int msk_add_act_join_bwd_ex(msk_ctx* ctx, msk_tensor y, const float* scale, cons
   MSK_REQUIRE(ctx, scale && shift && alpha_inner && mean && invstd && unit_sums, "the unit's BatchNorm coefficients, statistics and sums buffer");
   return add_act_bwd_impl(ctx, y, scale, shift, alpha_inner, res, alpha_outer, dout, da, dres, dres_accumulate, dalpha_outer, mean,
                           invstd, unit_sums, maxes);
+}
+
+int msk_add_act_join_bwd_pg(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
+                            msk_tensor res, const float* alpha_outer, const float* mean, const float* invstd, msk_tensor dout,
+                            msk_tensor da, msk_tensor dres, int dres_accumulate, float* dalpha_outer, float* unit_sums,
+                            float* maxes, int clear_maxes, float* unit_dgamma, float* unit_dbeta, float* unit_dalpha) {
+  MSK_REQUIRE(ctx, scale && shift && alpha_inner && mean && invstd && unit_sums, "the unit's BatchNorm coefficients, statistics and sums buffer");
+  return add_act_bwd_impl(ctx, y, scale, shift, alpha_inner, res, alpha_outer, dout, da, dres, dres_accumulate, dalpha_outer, mean,
+                          invstd, unit_sums, maxes, clear_maxes, unit_dgamma, unit_dbeta, unit_dalpha);
 }
 
 int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma, float* dbeta, float* dalpha,

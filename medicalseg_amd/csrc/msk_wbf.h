@@ -55,13 +55,15 @@ __device__ __forceinline__ float wbf_amax_of(const float* amax) {
   }
   return m;
 }
-__device__ __forceinline__ float wbf_scale_of(const float* amax) {
-  if (!amax) return 1.f;
-  const float a = wbf_amax_of(amax);
+__device__ __forceinline__ float wbf_scale_from(float a) {
   if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
   int e;
   (void)frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)
   return ldexpf(1.f, 10 - e);
+}
+__device__ __forceinline__ float wbf_scale_of(const float* amax) {
+  if (!amax) return 1.f;
+  return wbf_scale_from(wbf_amax_of(amax));
 }
 
 // Stage 1 (wbf_tin_k<MODE>): MODE 0  V = B^T x  (8 transformed values per 4 inputs, sliding 8-wide window along w)
@@ -96,8 +98,12 @@ struct WbfBnBwd {
   const float *scale, *shift, *alpha, *mean, *invstd, *sums;  // [C] each, sums [2C]
   float invM;
   char* Y;            // second output: the A dy transform in the layout of the first (null: not written)
-  const float* amax;  // NP = 2: device scalar bounding max |dy| (msk_bn_bwd_bound), else NULL
+  const float* amax;  // NP = 2: amax array bounding max |dy| (msk_bn_bwd_bound, or written by the dual kernel: below), else NULL
   long y_xi;
+  // NP = 2, one-kernel form: the bound  max|scale| * (max|du| + max|sums[c]/M| + max|xhat| * max|sums[C+c]/M|)  is evaluated
+  // by the dual transform itself from the two amax arrays the reduce pass left (every block the same arithmetic on the same
+  // inputs; block 0 stores it to `amax` for the kernels behind it) -- no separate bound kernel on the critical path
+  const float* maxes;
 };
 // writes B^T dy to a.V when write_v and A dy to bn.Y when that is non-null
 int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& a, const WbfBnBwd& bn, bool write_v);
@@ -158,5 +164,5 @@ inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
 size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP);
 size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K);
 // merge of per-block BatchNorm partial records [nb][C][3] = (n, mean, M2) into stats[2C] (msk_elementwise.hip)
-int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats);
+int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats, const msk_bn_fin* fin = nullptr);  // fin: + msk_bn_finalize(world 1) in the same launch
 

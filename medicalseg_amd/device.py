@@ -47,9 +47,9 @@ class Device:
         self.call("msk_malloc", C.c_size_t(max(int(nbytes), 16)), C.byref(p))
         return p.value
 
-    def amax_new(self) -> int:
-        """a zeroed device amax array (64 floats, from the context's ring: valid for the current training step)"""
-        p = self.lib.msk_amax_new(self.ctx)
+    def amax_new(self, n=1) -> int:
+        """n consecutive zeroed device amax arrays (64 floats each, from the context's ring: valid for the current step)"""
+        p = self.lib.msk_amax_new(self.ctx, n)
         if not p:
             raise MskError(f"msk_amax_new failed: {_lib.last_error(self.ctx)}")
         return p

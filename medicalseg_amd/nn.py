@@ -18,7 +18,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from ._lib import NULL_TENSOR, MskConvDesc, MskError
+from ._lib import NULL_TENSOR, MskBnFin, MskConvDesc, MskError
 from .device import Tensor, get_device
 
 BN_EPS = 1e-5
@@ -234,10 +234,11 @@ class Conv3D(Layer):
     def out_dims(self, x: Tensor):
         return tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip((x.d, x.h, x.w), self.p, self.k, self.s))
 
-    def run_forward(self, x: Tensor, y: Tensor | None = None, stats_ptr=None, keep_xform=False) -> Tensor:
+    def run_forward(self, x: Tensor, y: Tensor | None = None, stats_ptr=None, keep_xform=False, fin=None) -> Tensor:
         """stats_ptr: device buffer [2*Cout] that receives the BatchNorm statistics record of y (taken in the
         convolution's output stage when the kernel can, msk_conv3d_fwd_ex).  keep_xform: keep the transformed input the
-        convolution computes anyway in the activation arena for this layer's weight gradient."""
+        convolution computes anyway in the activation arena for this layer's weight gradient.  fin: MskBnFin -- the
+        BatchNorm finalisation runs in the launch that merges the statistics (msk_conv3d_fwd_ex3)."""
         if x.c != self.cin:
             raise ValueError(f"Conv3D expects {self.cin} input channels, got {x.c}")
         od, oh, ow = self.out_dims(x)
@@ -254,9 +255,9 @@ class Conv3D(Layer):
             nbytes = int(dev.lib.msk_conv3d_xform_bytes(dev.ctx, self.desc(), x.msk(), self.cout))
             if nbytes > 0:
                 xf = dev.arena.alloc(nbytes)
-        dev.call("msk_conv3d_fwd_ex2", self.desc(), x.msk(), C.c_void_p(self.weight.ptr), C.c_void_p(self.bias.ptr),
+        dev.call("msk_conv3d_fwd_ex3", self.desc(), x.msk(), C.c_void_p(self.weight.ptr), C.c_void_p(self.bias.ptr),
                  y.msk(), C.c_void_p(stats_ptr) if stats_ptr else None, C.c_void_p(xf) if xf else None,
-                 C.c_void_p(x.amax) if (x.amax and PRODUCER_AMAX) else None)
+                 C.c_void_p(x.amax) if (x.amax and PRODUCER_AMAX) else None, C.byref(fin) if fin is not None else None)
         self._xform = (xf, x.ptr, dev.arena.gen) if xf else None
         return y
 
@@ -476,6 +477,11 @@ def _amax_for(out: Tensor):
     return C.c_void_p(out.amax)
 
 
+# A/B switch (env MSEGK_FUSE_SMALL=0): the per-channel kernels of a BatchNorm layer (finalize, parameter gradients) as
+# launches of their own instead of inside the merge kernels (msk_conv3d_fwd_ex3, msk_*_pg)
+FUSE_SMALL = os.environ.get("MSEGK_FUSE_SMALL", "1") != "0"
+
+
 # A/B switch (env MSEGK_BWD_FUSE=0): conv -> BN -> PReLU units run their backward as three calls (apply, dgrad, wgrad)
 FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
 
@@ -527,22 +533,32 @@ class ConvBNAct:
         self.x, self.res = x, res
         bn, sc = self.bn, self.bn.scratch(dev)
         Cn = bn.num_features
+        # one rank (or rank-local statistics): the finalisation rides in the launch that merges the statistics
+        fin = None
+        if bn.training and FUSE_SMALL and not (dev.world > 1 and BatchNorm3D.sync):
+            od, oh, ow = self.conv.out_dims(x)
+            fin = MskBnFin(bn.weight.ptr, bn.bias.ptr, bn.epsilon, bn.momentum, float(x.n * od * oh * ow), bn._mean.ptr,
+                           bn._variance.ptr, sc["mean"], sc["invstd"], sc["scale"], sc["shift"])
         if bn.training and type(self.conv) is Conv3D:
             # statistics from the convolution's output stage, transformed input kept for the weight gradient
-            y = self.conv.run_forward(x, stats_ptr=sc["stats"], keep_xform=True)
+            y = self.conv.run_forward(x, stats_ptr=sc["stats"], keep_xform=True, fin=fin)
         else:
             y = self.conv.run_forward(x)
             if bn.training:
-                dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
+                if fin is not None:
+                    dev.call("msk_bn_stats_fin", y.msk(), _fp(sc["stats"]), C.byref(fin))
+                else:
+                    dev.call("msk_bn_stats", y.msk(), _fp(sc["stats"]))
         self.y = y
         if bn.training:
-            gathered, nstat = sc["stats"], 1
-            if dev.world > 1 and BatchNorm3D.sync:
-                dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))
-                gathered, nstat = sc["gathered"], dev.world
-            dev.call("msk_bn_finalize", _fp(gathered), nstat, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
-                     _fp(bn.bias.ptr), C.c_float(bn.epsilon), C.c_float(bn.momentum), _fp(bn._mean.ptr),
-                     _fp(bn._variance.ptr), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(sc["scale"]), _fp(sc["shift"]))
+            if fin is None:
+                gathered, nstat = sc["stats"], 1
+                if dev.world > 1 and BatchNorm3D.sync:
+                    dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))
+                    gathered, nstat = sc["gathered"], dev.world
+                dev.call("msk_bn_finalize", _fp(gathered), nstat, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
+                         _fp(bn.bias.ptr), C.c_float(bn.epsilon), C.c_float(bn.momentum), _fp(bn._mean.ptr),
+                         _fp(bn._variance.ptr), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(sc["scale"]), _fp(sc["shift"]))
             self.bn_mode = 1
         else:
             dev.call("msk_bn_eval_coeffs", Cn, _fp(bn.weight.ptr), _fp(bn.bias.ptr), _fp(bn._mean.ptr),
@@ -585,12 +601,27 @@ class ConvBNAct:
                 and self.conv.cin == self.conv.cout)
         # the maxima of |du| and |xhat| ride along when the fused backward may need to scale dy into fp16 range
         want_maxes = fuse and Cn % 4 == 0 and y.ld % 4 == 0 and dout.ld % 4 == 0 and y.ptr % 16 == 0 and dout.ptr % 16 == 0
-        if getattr(self, "presummed", False):     # the join behind this unit already reduced (msk_add_act_join_bwd_ex)
+        pg_done = False
+        maxes = sc["maxes"]
+        if getattr(self, "presummed", False):     # the join behind this unit already reduced (msk_add_act_join_bwd_ex / _pg)
             self.presummed = False
             want_maxes = fuse
+            pg_done = getattr(self, "presummed_pg", False)
+            maxes = getattr(self, "presummed_maxes", None) or sc["maxes"]
+        elif want_maxes and FUSE_SMALL:
+            maxes = dev.amax_new(2)               # zeroed ring arrays: no memset
+            dev.call("msk_affine_act_bwd_reduce_pg", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                     _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]), _fp(maxes), 0,
+                     _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr), _fp(_act_alpha_grad(self.act)))
+            pg_done = True
         elif want_maxes:
             dev.call("msk_affine_act_bwd_reduce_ex", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                      _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]), _fp(sc["maxes"]))
+        elif FUSE_SMALL:
+            dev.call("msk_affine_act_bwd_reduce_pg", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+                     _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]), None, 0,
+                     _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr), _fp(_act_alpha_grad(self.act)))
+            pg_done = True
         else:
             dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                      _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
@@ -599,8 +630,9 @@ class ConvBNAct:
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
             dev.call("msk_dp_allreduce_stats", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world
-        dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
-                 _fp(_act_alpha_grad(self.act)), 1)
+        if not pg_done:
+            dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
+                     _fp(_act_alpha_grad(self.act)), 1)
         dy = y.empty_like()
         if fuse:
             # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
@@ -617,7 +649,7 @@ class ConvBNAct:
             dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
                      _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
                      _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,
-                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(sc["maxes"]) if want_maxes else None)
+                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(maxes) if want_maxes else None)
             x.grad_written = True
             conv._xform = None
             self.dy = dy if ybuf is None else None
@@ -694,9 +726,18 @@ class AddAct:
             # one pass: the join's data gradients and slope gradient AND the sums (and maxima) the unit's own backward starts
             # with -- its reduce pass is skipped (ConvBNAct.backward, presummed)
             u, sc = self.unit, self.unit.bn.scratch(dev)
-            dev.call("msk_add_act_join_bwd_ex", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr), b.msk(),
-                     alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(), 1 if b.grad_written else 0,
-                     _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(sc["maxes"]))
+            if FUSE_SMALL:
+                mx = dev.amax_new(2)
+                dev.call("msk_add_act_join_bwd_pg", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
+                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(),
+                         1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(mx), 0,
+                         _fp(u.bn.weight.grad_ptr), _fp(u.bn.bias.grad_ptr), _fp(u.act._weight.grad_ptr))
+                u.presummed_pg, u.presummed_maxes = True, mx
+            else:
+                dev.call("msk_add_act_join_bwd_ex", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
+                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(),
+                         1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(sc["maxes"]))
+                u.presummed_pg, u.presummed_maxes = False, None
             u.presummed = True
         elif Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
             # one pass: both data gradients and the alpha-gradient sum (a join has no BatchNorm)
