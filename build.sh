@@ -21,4 +21,12 @@ for o in $OBJS; do
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsegk.so $OBJS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/libmsegk.so"
+# test build: the same objects, msk_dp.hip recompiled with the host transport (two ranks as two processes on ONE GPU,
+# tests/test_gpu_dp2.py) -- the release library does not contain it
+T=build/msk_dp_test.o
+if [ ! -f $T ] || [ medicalseg_amd/csrc/msk_dp.hip -nt $T ] || [ medicalseg_amd/csrc/msk_common.h -nt $T ] || [ include/msegk.h -nt $T ]; then
+  hipcc $FLAGS $EXTRA -DMSK_TEST_TRANSPORT -c medicalseg_amd/csrc/msk_dp.hip -o $T
+fi
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsegk_test.so ${OBJS/build\/msk_dp.o/$T} -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo "built $OUT/libmsegk_test.so"
 if [ -f oracle/c/Makefile ]; then make -s -C oracle/c; fi

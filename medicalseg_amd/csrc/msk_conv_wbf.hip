@@ -706,22 +706,14 @@ wbf_gemm_k(GemmArgs a) {
         const unsigned ub = (unsigned)(tap + 1) * utap + ukc;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-#ifdef WBF_EXP_NOB
-          bq[nx][p] = bq[cur][p]; (void)ub;
-#else
           bq[nx][p] = buf_load16(ures, ulane, ub + p * ustep);
-#endif
         }
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
           const uint4* ap = lds + arow[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
 #pragma unroll
           for (int p = 0; p < NP; ++p) {
-#ifdef WBF_EXP_NOA
-            aq[nx][mr][p] = aq[cur][mr][p]; (void)ap;
-#else
             aq[nx][mr][p] = ap[p * 2 * NSLOT];
-#endif
           }
         }
       }

@@ -1,7 +1,19 @@
 // Data-parallel collectives: RCCL over xGMI, one process per GPU.
 // Replaces paddle.distributed.fleet DataParallel / SyncBatchNorm communication
-// (core/train.py:81-85, cvlibs/config.py:322).  All collectives are enqueued on the
-// context's compute stream so they order with the kernels that produce/consume them.
+// (core/train.py:81-85, cvlibs/config.py:322).
+//
+// Three stream / communicator arrangements (ctx->dp_mode, option "dp_mode" / DataParallel):
+//   1 (default)  ONE communicator on ONE communication stream carries everything in program order: the SyncBatchNorm
+//                exchanges (the compute stream waits for their result through an event), the gradient buckets (nobody
+//                waits until msk_dp_wait) and broadcast / barrier.  Every rank enqueues the same sequence on the same
+//                single stream, so the device-side order of the collectives is total and identical on all ranks -- no
+//                pair of communicators that could wait for each other -- while the buckets still overlap the rest of
+//                backward.  A statistics exchange can queue behind at most the bucket in flight (<= 16 MB: ~0.1 ms over
+//                xGMI at 8 GPUs).
+//   0            everything on the compute stream (one all-reduce of the whole arena after backward; no overlap).
+//   2            round-2 form, opt-in: buckets on a second communicator (ncclCommSplit) and stream, statistics on the
+//                compute stream's communicator.  Two communicators executing concurrently are only deadlock-free while
+//                their kernels can be co-resident.
 #include <rccl/rccl.h>
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -39,6 +51,7 @@ struct StdoutToStderr {
     }
   }
 };
+#ifdef MSK_TEST_TRANSPORT   // compiled into libmsegk_test.so only (build.sh); the release library has no such path
 // ---------------------------------------------------------------------------------------------------------
 // Host transport (env MSEGK_DP_TRANSPORT=host): the same collectives through pinned-less host staging and TCP sockets
 // in a star around rank 0, which reduces in rank order (deterministic).  It exists so that the N-rank code paths --
@@ -148,6 +161,56 @@ int host_collective(msk_ctx* ctx, const float* dsend, float* drecv, size_t count
   MSK_CHECK_HIP(ctx, hipMemcpy(drecv, out.data(), out_bytes, hipMemcpyHostToDevice));
   return 0;
 }
+int host_broadcast(msk_ctx* ctx, float* buf, size_t count, int root) {
+  if (ctx->world == 1) return 0;
+  MSK_REQUIRE(ctx, root == 0, "host transport broadcasts from rank 0 only");
+  std::vector<float> h(count);
+  MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->rank == 0) {
+    MSK_CHECK_HIP(ctx, hipMemcpy(h.data(), buf, count * sizeof(float), hipMemcpyDeviceToHost));
+    for (int r = 1; r < ctx->world; ++r)
+      if (!send_all(ctx->host_fds[r], h.data(), count * sizeof(float)))
+        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during broadcast");
+  } else {
+    if (!recv_all(ctx->host_fds[0], h.data(), count * sizeof(float)))
+      return msk_fail(ctx, __FILE__, __LINE__, "host transport", "rank 0 closed during broadcast");
+    MSK_CHECK_HIP(ctx, hipMemcpy(buf, h.data(), count * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+#else
+int host_broadcast(msk_ctx* ctx, float*, size_t, int) {
+  return msk_fail(ctx, __FILE__, __LINE__, "host transport", "not compiled into this library");
+}
+int host_connect(msk_ctx* ctx, int, int) {
+  return msk_fail(ctx, __FILE__, __LINE__, "MSEGK_DP_TRANSPORT=host", "the host transport is a test facility: it is compiled into libmsegk_test.so only");
+}
+int host_collective(msk_ctx* ctx, const float*, float*, size_t, int, hipStream_t) {
+  return msk_fail(ctx, __FILE__, __LINE__, "host transport", "not compiled into this library");
+}
+#endif
+
+// Mode 1: a collective that the compute stream needs the result of.  The communication stream picks up the current tail
+// of the compute stream, runs the collective, and the compute stream waits for it.
+struct CommBridge {
+  msk_ctx* ctx;
+  hipStream_t run;   // the stream the collective is enqueued on
+  bool bridged;
+  explicit CommBridge(msk_ctx* c) : ctx(c), run(c->stream), bridged(false) {
+    if (c->dp_mode == 1 && c->comm_stream != nullptr && !c->host_transport) {
+      hipEventRecord(c->ev_comm_main, c->stream);
+      hipStreamWaitEvent(c->comm_stream, c->ev_comm_main, 0);
+      run = c->comm_stream;
+      bridged = true;
+    }
+  }
+  ~CommBridge() {
+    if (bridged) {
+      hipEventRecord(ctx->ev_comm_back, ctx->comm_stream);
+      hipStreamWaitEvent(ctx->stream, ctx->ev_comm_back, 0);
+    }
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -186,18 +249,24 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   ctx->comm = (void*)comm;
   ctx->rank = rank;
   ctx->world = world;
-  // second communicator + stream for the gradient buckets (collective: every rank is inside msk_dp_init)
+  // mode 2 only: second communicator for the gradient buckets (collective: every rank is inside msk_dp_init)
+  {
+    const char* me = getenv("MSEGK_DP_MODE");
+    if (me && me[0] >= '0' && me[0] <= '2') ctx->dp_mode = me[0] - '0';
+  }
   ncclComm_t comm_grad = nullptr;
-  if (ncclCommSplit(comm, 0, rank, &comm_grad, nullptr) != ncclSuccess || comm_grad == nullptr) {
-    // no second communicator: the buckets then go through the first one ON THE COMPUTE STREAM (correct, not
-    // overlapped) -- see msk_dp_allreduce_async
-    comm_grad = nullptr;
+  if (ctx->dp_mode == 2) {
+    if (ncclCommSplit(comm, 0, rank, &comm_grad, nullptr) != ncclSuccess || comm_grad == nullptr) {
+      comm_grad = nullptr;
+      ctx->dp_mode = 1;   // no second communicator: the single-communicator arrangement
+    }
   }
   ctx->comm_grad = (void*)comm_grad;
   MSK_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_main, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_side, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_back, hipEventDisableTiming));
   ctx->comm_pending = false;
   return 0;
 }
@@ -208,14 +277,17 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count) {
   if (msk_join_side_impl(ctx) != 0) return -1;  // the gradient arena includes side-stream weight gradients
   msk_launch_scope ls(ctx, "rccl_allreduce");
   if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
-  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  CommBridge br(ctx);
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, br.run));
   return 0;
 }
 
 int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (count == 0) return 0;
-  if (ctx->host_transport || ctx->comm_grad == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);  // no second communicator
+  if (ctx->host_transport || ctx->dp_mode == 0 || ctx->comm_stream == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);
+  // mode 1: the single communicator on the communication stream; mode 2: the second communicator
+  ncclComm_t bucket_comm = (ncclComm_t)(ctx->dp_mode == 2 ? ctx->comm_grad : ctx->comm);
   // the bucket's gradients come from the compute stream (data-gradient chain, bias/BN/PReLU gradients) and from the
   // weight-gradient side stream: wait for the current tail of both, block neither
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_main, ctx->stream));
@@ -224,7 +296,8 @@ int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
     MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_comm_side, ctx->side));
     MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_side, 0));
   }
-  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm_grad, ctx->comm_stream));
+  msk_weights_changed_impl(ctx, buf, count * sizeof(float));
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, bucket_comm, ctx->comm_stream));
   ctx->comm_pending = true;
   return 0;
 }
@@ -237,7 +310,8 @@ int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   msk_launch_scope ls(ctx, "rccl_allreduce_stats");
   if (ctx->host_transport) return ctx->world > 1 ? host_collective(ctx, buf, buf, count, 0, ctx->stream) : 0;
-  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  CommBridge br(ctx);
+  MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, br.run));
   return 0;
 }
 
@@ -249,33 +323,18 @@ int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_
     MSK_CHECK_HIP(ctx, hipMemcpyAsync(recv, send, count_per_rank * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
   }
-  MSK_CHECK_NCCL(ctx, ncclAllGather(send, recv, count_per_rank, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+  CommBridge br(ctx);
+  MSK_CHECK_NCCL(ctx, ncclAllGather(send, recv, count_per_rank, ncclFloat, (ncclComm_t)ctx->comm, br.run));
   return 0;
 }
 
 int msk_dp_broadcast(msk_ctx* ctx, float* buf, size_t count, int root) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   msk_weights_changed_impl(ctx, buf, count * sizeof(float));  // parameters are broadcast once at wrap time
-  if (ctx->host_transport) {
-    if (ctx->world == 1) return 0;
-    MSK_REQUIRE(ctx, root == 0, "host transport broadcasts from rank 0 only");
-    // all-gather semantics reduced to "keep rank 0's copy": everybody contributes, rank 0's slice is what survives
-    std::vector<float> h(count);
-    MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->rank == 0) {
-      MSK_CHECK_HIP(ctx, hipMemcpy(h.data(), buf, count * sizeof(float), hipMemcpyDeviceToHost));
-      for (int r = 1; r < ctx->world; ++r)
-        if (!send_all(ctx->host_fds[r], h.data(), count * sizeof(float)))
-          return msk_fail(ctx, __FILE__, __LINE__, "host transport", "peer closed during broadcast");
-    } else {
-      if (!recv_all(ctx->host_fds[0], h.data(), count * sizeof(float)))
-        return msk_fail(ctx, __FILE__, __LINE__, "host transport", "rank 0 closed during broadcast");
-      MSK_CHECK_HIP(ctx, hipMemcpy(buf, h.data(), count * sizeof(float), hipMemcpyHostToDevice));
-    }
-    return 0;
-  }
+  if (ctx->host_transport) return host_broadcast(ctx, buf, count, root);
   msk_launch_scope ls(ctx, "rccl_broadcast");
-  MSK_CHECK_NCCL(ctx, ncclBroadcast(buf, buf, count, ncclFloat, root, (ncclComm_t)ctx->comm, ctx->stream));
+  CommBridge br(ctx);
+  MSK_CHECK_NCCL(ctx, ncclBroadcast(buf, buf, count, ncclFloat, root, (ncclComm_t)ctx->comm, br.run));
   return 0;
 }
 
@@ -288,7 +347,10 @@ int msk_dp_barrier(msk_ctx* ctx) {
     MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
   }
-  MSK_CHECK_NCCL(ctx, ncclAllReduce(tok, tok, 1, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  {
+    CommBridge br(ctx);
+    MSK_CHECK_NCCL(ctx, ncclAllReduce(tok, tok, 1, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, br.run));
+  }
   MSK_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -312,6 +374,7 @@ int msk_dp_destroy(msk_ctx* ctx) {
     hipEventDestroy(ctx->ev_comm_main);
     hipEventDestroy(ctx->ev_comm_side);
     hipEventDestroy(ctx->ev_comm_done);
+    hipEventDestroy(ctx->ev_comm_back);
     ctx->comm_stream = nullptr;
     ctx->comm_pending = false;
   }

@@ -159,16 +159,16 @@ class DataParallel:
       waits for all buckets (`msk_dp_wait`) before the optimizer, which applies 1/nranks;
     * BatchNorm statistics are exchanged inside the layers (SyncBatchNorm semantics).
 
-    `overlap=False` keeps the single all-reduce after backward on the compute stream.
+    `overlap=False` keeps the single all-reduce after backward.
 
-    Default (`overlap=None`): buckets overlap with backward only when BatchNorm statistics are rank-local
-    (`--no_sync_bn`).  With SyncBatchNorm (the reference's behaviour and this package's default) the 48 statistics
-    exchanges per step run on the compute stream's communicator while buckets would be in flight on a second
-    communicator and stream; every rank enqueues both in the same order, but the DEVICE-side execution order of two
-    streams is not defined, and concurrently executing communicators are only deadlock-free when their kernels can be
-    co-resident.  That combination has never run on two real GPUs (1-GPU boxes only), so it is opt-in:
-    `DataParallel(overlap=True)` / env MSEGK_DP_OVERLAP=1.  Cost of the safe default: the 182 MB all-reduce
-    (~1-2 ms over xGMI at 8 GPUs) is exposed after backward."""
+    Default (`overlap=None`, round 3): buckets overlap with backward ALSO under SyncBatchNorm (the reference's behaviour and
+    this package's default).  The statistics exchanges and the buckets share ONE communicator on ONE communication stream
+    (`msk_dp.hip`, dp_mode 1): every rank enqueues the same sequence of collectives on that single stream, so their
+    device-side order is total and identical everywhere -- nothing can wait for a collective another rank has queued behind
+    a different one -- and a statistics exchange queues behind at most the one bucket in flight.  The round-2 form (buckets
+    on a second communicator and stream, statistics on the compute stream's communicator) is the opt-in
+    `MSEGK_DP_MODE=2`: two communicators executing concurrently are only deadlock-free while their kernels can be
+    co-resident.  `MSEGK_DP_OVERLAP=0` forces the single all-reduce when `overlap` is not given explicitly."""
 
     def __init__(self, model, overlap=None, bucket_bytes=16 << 20, force=False):
         self._layers = model
@@ -185,12 +185,8 @@ class DataParallel:
             if fa is not None and fa.count:
                 dev.call("msk_dp_broadcast", C.c_void_p(fa.value_ptr), C.c_size_t(fa.count), 0)
             model.arena.grad_scale = 1.0 / dev.world
-            ov_env = os.environ.get("MSEGK_DP_OVERLAP")
-            if ov_env is not None:
-                overlap = ov_env != "0"
-            elif overlap is None:
-                from .nn import BatchNorm3D
-                overlap = not BatchNorm3D.sync
+            if overlap is None:      # an explicit argument wins over the environment (advisor finding, round 2)
+                overlap = os.environ.get("MSEGK_DP_OVERLAP", "1") != "0"
             if overlap and hasattr(model, "_grad_ready_hooks"):
                 params = model.arena.params
                 self._index = {id(p): i for i, p in enumerate(params)}

@@ -19,6 +19,10 @@ def make_data(N=4, S=16, ncls=3):
 
 def main():
     out, overlap, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    # the host transport lives in the TEST build of the library only (build.sh: libmsegk_test.so)
+    from medicalseg_amd import _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmsegk_test.so")
+    _lib._lib = None            # (importing the package loaded the release library; no context exists yet)
     from medicalseg_amd import optimizer as optim
     from medicalseg_amd import parallel
     from medicalseg_amd.device import to_tensor

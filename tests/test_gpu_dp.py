@@ -70,11 +70,14 @@ def test_dataparallel_wrapper_step_world1():
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("dp_mode", [1, 2])
 @pytest.mark.parametrize("model_name", ["VNet", "VNetDeepSup"])
-def test_overlapped_gradient_buckets_world1(model_name):
-    """The bucketed, overlapped gradient exchange (communication stream + second communicator + weight-gradient side
-    stream) on a 1-rank communicator: a sum over one rank is the identity, so the updated parameters must be
-    bit-identical to the unwrapped step -- any missing stream dependency shows up as a difference."""
+def test_overlapped_gradient_buckets_world1(model_name, dp_mode):
+    """The bucketed, overlapped gradient exchange (communication stream + weight-gradient side stream; dp_mode 1: the one
+    communicator that also carries the SyncBatchNorm exchanges -- the default --, dp_mode 2: a second communicator) on a
+    1-rank communicator: a sum over one rank is the identity, so the updated parameters must be bit-identical to the
+    unwrapped step -- any missing stream dependency shows up as a difference.  Statistics-type collectives are issued
+    between the buckets (a 1-rank model does not exchange statistics by itself) and must return their input."""
     from medicalseg_amd import _lib, models
     from medicalseg_amd import optimizer as optim
     from medicalseg_amd import parallel
@@ -85,7 +88,14 @@ def test_overlapped_gradient_buckets_world1(model_name):
     lib = _lib.load()
     buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
     assert lib.msk_dp_unique_id(buf) == 0, _lib.last_error(None)
+    d.set_option("dp_mode", dp_mode)
     d.call("msk_dp_init", buf.raw, 0, 1)
+    probe = np.arange(64, dtype=np.float32)
+    pa, pb = vec(probe), vec(np.zeros(64, np.float32))
+
+    def stats_probe(model, block):        # runs between the gradient buckets of backward
+        d.call("msk_dp_allreduce_stats", C.c_void_p(pa), C.c_size_t(64))
+        d.call("msk_dp_allgather", C.c_void_p(pa), C.c_void_p(pb), C.c_size_t(64))
     try:
         nout = 4 if model_name == "VNetDeepSup" else 1
         rng = np.random.default_rng(0)
@@ -100,6 +110,8 @@ def test_overlapped_gradient_buckets_world1(model_name):
             model.eval()
             net = model if mode == "plain" else parallel.DataParallel(model, force=True, overlap=mode == "buckets",
                                                                       bucket_bytes=4 << 20)
+            if mode == "buckets":
+                model._grad_ready_hooks.append(stats_probe)
             opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
             losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])] * nout,
                       "coef": [1.0 / nout] * nout}
@@ -114,8 +126,10 @@ def test_overlapped_gradient_buckets_world1(model_name):
         for k in outs[0]:
             assert np.array_equal(outs[0][k], outs[1][k]), k
             assert np.array_equal(outs[0][k], outs[2][k]), k
+        assert np.array_equal(d.d2h(pa, (64,), np.float32), probe) and np.array_equal(d.d2h(pb, (64,), np.float32), probe)
     finally:
         d.call("msk_dp_destroy")
+        d.set_option("dp_mode", 1)
 
 
 @pytest.mark.parametrize("C_,shape", [(32, (2, 8, 12, 12)), (256, (2, 4, 4, 4)), (3, (4, 5, 6, 7))])

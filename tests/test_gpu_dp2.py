@@ -118,7 +118,8 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    MSEGK_DP_TRANSPORT="host")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2",
+        # (tests/run_bench_testlib.py: bench.py on the test build of the library -- the release build has no host transport)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "run_bench_testlib.py"), "--gpus", "2",
                                        "--steps", "2", "--warmup", "1", "--size", "32", "--batch", "1", "--no-cpu-baseline",
                                        "--skip-serialized"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = []
@@ -132,4 +133,4 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and len(j["dp"]["per_rank_step_ms"]) == 2
     assert j["dp"]["calls_per_step"]["rccl_allgather"] == 24 and j["dp"]["calls_per_step"]["rccl_allreduce_stats"] == 24
-    assert j["dp"]["calls_per_step"]["rccl_allreduce"] == 1                                  # safe default: one all-reduce
+    assert j["dp"]["calls_per_step"]["rccl_allreduce"] >= 3        # default: gradient buckets enqueued while backward runs
