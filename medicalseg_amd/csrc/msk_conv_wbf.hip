@@ -316,10 +316,10 @@ wbf_tin_k(WbfTinArgs a) {
         *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
       } else if (NP == 2) {
         uint4 hi, lo;
-        wbf_split2h_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
-        wbf_split2h_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
-        wbf_split2h_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
-        wbf_split2h_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
+        wbf_split2hs_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
+        wbf_split2hs_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
+        wbf_split2hs_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
+        wbf_split2hs_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
         *reinterpret_cast<uint4*>(o) = hi;
         *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
       } else {
@@ -376,10 +376,10 @@ __device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8
     *reinterpret_cast<uint4*>(o + 4 * plane) = lo;
   } else if (NP == 2) {
     uint4 hi, lo;
-    wbf_split2h_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
-    wbf_split2h_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
-    wbf_split2h_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
-    wbf_split2h_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
+    wbf_split2hs_pair(v[0][xi] * sc2, v[1][xi] * sc2, hi.x, lo.x);
+    wbf_split2hs_pair(v[2][xi] * sc2, v[3][xi] * sc2, hi.y, lo.y);
+    wbf_split2hs_pair(v[4][xi] * sc2, v[5][xi] * sc2, hi.z, lo.z);
+    wbf_split2hs_pair(v[6][xi] * sc2, v[7][xi] * sc2, hi.w, lo.w);
     *reinterpret_cast<uint4*>(o) = hi;
     *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
   } else {
@@ -733,9 +733,11 @@ wbf_gemm_k(GemmArgs a) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
       } else if (NP == 2) {
-        // small terms first: lo*hi, hi*lo, hi*hi
+        // small terms first: lo*hi, hi*lo, hi*hi.  The activation's low piece is stored times 2^11 (msk_wbf.h): its partner
+        // is the weight's high piece times 2^-11, made here
+        const uint4 bdown = wbf_hi_down(bq[cur][0]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
 #pragma unroll
@@ -940,8 +942,9 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
         } else if (NP == 2) {
+          const uint4 bdown = wbf_hi_down(bq[cur][0]);  // partner of the scaled low piece (msk_wbf.h)
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
 #pragma unroll

@@ -35,6 +35,28 @@ __device__ __forceinline__ void wbf_split2h_pair(float x0, float x1, unsigned& h
   f32x2 r = {x0 - hf.x, x1 - hf.y};
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wbf_f16x2));
 }
+// Round 3: the format of the TRANSFORMED ACTIVATION / GRADIENT planes (V, Y) keeps the low piece SCALED by 2^11:
+//     x*s = h + l,   h = fp16(x*s),   l' = fp16((x*s - h) * 2^11)
+// |x*s - h| <= 2^-11 |h|, so l' has the magnitude of h and is a NORMAL fp16 number whenever h is (down to 2^-14 in scaled
+// units = 2^-24 of the tensor's maximum) -- the plain low piece went subnormal 2^12 below the maximum, which left elements
+// 2^17 / 2^20 below it with 17 / 14 significant bits (tests/test_gpu_wbf.py::test_wbf_fp16_split_sparse_outliers_keep_the_bulk:
+// bulk error 1.2e-5 / 1.0e-4; now fp32 class).  The matrix stage multiplies l' by the partner's high piece times 2^-11, made in
+// registers (v_pk_mul_f16, exact for partners >= 2^-3 in scaled units): still three MFMAs into one accumulator.
+constexpr float kWbfLoScale = 2048.f;
+__device__ __forceinline__ void wbf_split2hs_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  f32x2 x = {x0, x1};
+  const wbf_f16x2 h = __builtin_convertvector(x, wbf_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  f32x2 r = {(x0 - hf.x) * kWbfLoScale, (x1 - hf.y) * kWbfLoScale};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wbf_f16x2));
+}
+typedef _Float16 wbf_f16x8 __attribute__((ext_vector_type(8)));
+// high piece of the partner operand times 2^-11 (for the product with a scaled low piece)
+__device__ __forceinline__ uint4 wbf_hi_down(uint4 h) {
+  const wbf_f16x8 v = __builtin_bit_cast(wbf_f16x8, h) * (_Float16)(1.0f / kWbfLoScale);
+  return __builtin_bit_cast(uint4, v);
+}
 // A caller-owned transformed-input buffer (msk_conv3d_fwd_ex's xform) starts with a header of kWbfXformHeader bytes whose
 // two amax arrays hold the max |x| the transform was scaled by and the max |w| of the layer's weights (NP = 2; unused
 // otherwise): the weight gradient that consumes the buffer later undoes the first, the data gradient of the same step reuses

@@ -158,6 +158,11 @@ wbf_wgrad_k(WgArgs a) {
           const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
           bq[c][p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         }
+      s16x8 bdown[2] = {bq[0][0], bq[1][0]};
+      if (NP == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bdown[c] = __builtin_bit_cast(s16x8, wbf_hi_down(__builtin_bit_cast(uint4, bq[c][0])));
+      }
 #pragma unroll
       for (int j = 0; j < NT0; ++j) {
         if (j < ntap) {   // wave-uniform
@@ -169,6 +174,8 @@ wbf_wgrad_k(WgArgs a) {
             const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
             aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           }
+          s16x8 adown = aq[0];
+          if (NP == 2) adown = __builtin_bit_cast(s16x8, wbf_hi_down(__builtin_bit_cast(uint4, aq[0])));
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             if (NP == 3) {
@@ -179,8 +186,13 @@ wbf_wgrad_k(WgArgs a) {
               WGW_MFMA(acc[j][c], aq[0], bq[c][NP / 2]);
               WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
             } else if (NP == 2) {
-              WGW_MFMA_H(acc[j][c], aq[NP - 1], bq[c][0]);  // small terms first
-              WGW_MFMA_H(acc[j][c], aq[0], bq[c][NP - 1]);
+              // both operands carry their low piece times 2^11 (msk_wbf.h): each meets the OTHER operand's high piece
+              // times 2^-11, made in registers.  (Exact while that high piece is >= 2^-3 in scaled units, i.e. within 2^13
+              // of its tensor's maximum; for quieter CHANNELS the cross terms fade out gradually -- measured in
+              // tests/test_gpu_wbf.py::test_wbf_fp16_split_quiet_channels_in_the_weight_gradient.  A second accumulator
+              // for the cross terms, scaled in fp32, removes the limit but costs 112 registers: 3 -> 1 wavefronts per SIMD.)
+              WGW_MFMA_H(acc[j][c], aq[NP - 1], bdown[c]);  // small terms first
+              WGW_MFMA_H(acc[j][c], adown, bq[c][NP - 1]);
               WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
             } else {
               WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);

@@ -692,3 +692,165 @@ def test_wbf_packed_weight_cache_follows_every_weight_write():
         check(wp2, w5, "cache off")
     finally:
         d.set_option("wbf_pack_cache", 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: the fp16 two-piece operand format under ADVERSARIAL intra-tensor dynamic range
+# ---------------------------------------------------------------------------------------------------------
+def _bulk_err(got, ref, region):
+    """max |got - ref| over `region` relative to max |ref| over the same region"""
+    g, r = got[region].astype(np.float64), ref[region]
+    return float(np.abs(g - r).max() / (np.abs(r).max() + 1e-300))
+
+
+def _three_kernel_sets(d, fn):
+    """fn() -> result, under the product format (conv_split 2), the exact bf16 x 3 split and the exact-fp32 Winograd kernels"""
+    out = {}
+    try:
+        for name, split, bf3 in (("fp16x2", 2, 1), ("bf16x3", 3, 1), ("fp32", 2, 0)):
+            d.set_option("conv_split", split)
+            d.set_option("wino_bf3", bf3)
+            out[name] = fn()
+    finally:
+        d.set_option("conv_split", 2)
+        d.set_option("wino_bf3", 1)
+    return out
+
+
+@pytest.mark.parametrize("log2_range", [10, 14, 17, 20])
+def test_wbf_fp16_split_sparse_outliers_keep_the_bulk(log2_range):
+    """x (and dy) = a unit-scale bulk plus a slab of outliers 2^r above it.  The tensor-wide power-of-two scale is set by
+    the outliers; the claim under test is that the BULK -- outputs whose receptive field holds no outlier -- is still
+    computed at fp32 class: error of the bulk relative to the bulk's own maximum, against the float64 oracle, next to the
+    exact bf16 x 3 split and the exact-fp32 Winograd kernels on the same data."""
+    c, K, (N, D, H, W) = 32, 5, (1, 24, 16, 16)
+    k, s_, p = (K,) * 3, (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(100 + log2_range)
+    f8 = lambda a: a.astype(np.float64)
+    big = float(2.0 ** log2_range)
+    x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    x = np.where(x > 0, x, 0.25 * x).astype(np.float32)
+    dy = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    # outliers: 1 % of the voxels of the planes d < 4 (all channels of a hit voxel)
+    hit = rng.random((N, 1, 4, H, W)) < 0.01
+    x[:, :, :4] = np.where(hit, x[:, :, :4] * big, x[:, :, :4])
+    dy[:, :, :4] = np.where(hit, dy[:, :, :4] * big, dy[:, :, :4])
+    w = (rng.standard_normal((c, c) + k) * np.sqrt(2.0 / (c * K ** 3))).astype(np.float32)
+    y_ref = O.conv3d(f8(x), f8(w), None, s_, p)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    bulk = (slice(None), slice(None), slice(8, None))        # d >= 8: no outlier within the 5^3 support
+    xt, dyt, wp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel())
+    desc = _desc(k, s_, p)
+
+    def run():
+        yt, dxt = t_empty(N, c, D, H, W, fill=7.0), t_empty(N, c, D, H, W, fill=3.0)
+        d.call("msk_conv3d_fwd", desc, xt.msk(), vp(wp), None, yt.msk())
+        d.call("msk_conv3d_dgrad", desc, dyt.msk(), vp(wp), dxt.msk(), 0)
+        y, dx = t_to_ncdhw(yt), t_to_ncdhw(dxt)
+        return (_bulk_err(y, y_ref, bulk), _bulk_err(dx, dx_ref, bulk), rel_err(y, y_ref), rel_err(dx, dx_ref))
+
+    e = _three_kernel_sets(d, run)
+    print("\noutliers 2^%d above the bulk: BULK error fwd / dgrad   fp16x2 %.2e %.2e | bf16x3 %.2e %.2e | fp32 Winograd %.2e %.2e"
+          "   (whole tensor: %.2e %.2e | %.2e %.2e | %.2e %.2e)" % (
+              (log2_range,) + e["fp16x2"][:2] + e["bf16x3"][:2] + e["fp32"][:2] + e["fp16x2"][2:] + e["bf16x3"][2:] + e["fp32"][2:]))
+    tol = _conv_tol(c * K ** 3)
+    # whole tensor (dominated by the outliers): the usual bound
+    assert e["fp16x2"][2] < tol and e["fp16x2"][3] < tol
+    # the bulk: fp32 class -- the tolerance of every convolution kernel, and no worse than 4x the exact-fp32 kernels' bulk error
+    for i in (0, 1):
+        assert e["fp16x2"][i] < tol, (i, e)
+        assert e["fp16x2"][i] < 4 * max(e["fp32"][i], 5e-7), (i, e)
+
+
+def test_wbf_fp16_split_real_loss_gradient_with_sparse_classes():
+    """dy shaped like what backward really feeds the LUConv layers: the CE + Dice logit gradient of a label map with a class
+    of 0.05 % of the voxels (large gradients there, ~1e-6 elsewhere), spread over 32 channels, plus an x with a dead channel
+    (exact zeros) and a near-constant one.  Data gradient and weight gradient against the float64 oracle; the quiet region
+    (no rare-class voxel in the support) is reported separately."""
+    c, K, (N, D, H, W) = 32, 5, (1, 16, 32, 32)
+    k, s_, p = (K,) * 3, (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(7)
+    f8 = lambda a: a.astype(np.float64)
+    logits = rng.standard_normal((N, 3, D, H, W)) * 2.0
+    labels = (rng.random((N, D, H, W)) < 0.3).astype(np.int32)           # classes 0 / 1 everywhere ...
+    rare = np.zeros((N, D, H, W), bool)
+    rare[:, :3, :6, :6] = rng.random((N, 3, 6, 6)) < 0.08                 # ... class 2 on a few voxels of one corner
+    labels[rare] = 2
+    logits[:, 2][~rare] -= 12.0                                           # confidently not class 2 elsewhere: tiny gradients
+    _, _, dz = O.MixedLossOracle()(logits, labels)
+    mix = rng.standard_normal((3, c)) / np.sqrt(3.0)
+    dy = np.einsum("nkdhw,kc->ncdhw", dz, mix).astype(np.float32)
+    x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    x = np.where(x > 0, x, 0.25 * x).astype(np.float32)
+    x[:, 3] = 0.0                                                         # a dead channel
+    x[:, 5] = 1e-3 + 1e-7 * x[:, 5]                                       # a nearly constant one
+    w = (rng.standard_normal((c, c) + k) * np.sqrt(2.0 / (c * K ** 3))).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(f8(dy), f8(w), x.shape, s_, p)
+    dw_ref, _ = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    quiet = (slice(None), slice(None), slice(8, None))                    # d >= 8: the rare class is >= 5 planes away
+    print("\n|dy|: max %.3e, median %.3e, quiet-region max %.3e" % (np.abs(dy).max(), np.median(np.abs(dy)), np.abs(dy[quiet]).max()))
+    xt, dyt, wp = t_from_ncdhw(x), t_from_ncdhw(dy), vec(w.ravel())
+    desc = _desc(k, s_, p)
+
+    def run():
+        dxt = t_empty(N, c, D, H, W, fill=3.0)
+        dw = vec(np.zeros(w.size, np.float32))
+        d.call("msk_conv3d_dgrad", desc, dyt.msk(), vp(wp), dxt.msk(), 0)
+        d.call("msk_conv3d_wgrad", desc, xt.msk(), dyt.msk(), vp(dw), None, 0)
+        d.sync()
+        dx = t_to_ncdhw(dxt)
+        dwv = d.d2h(dw, (w.size,), np.float32).reshape(w.shape)
+        return (rel_err(dx, dx_ref), _bulk_err(dx, dx_ref, quiet), rel_err(dwv, dw_ref),
+                float(np.abs(dwv[:, 3]).max()))                           # the dead channel's weight gradient: exactly 0
+
+    e = _three_kernel_sets(d, run)
+    for name, v in e.items():
+        print("%-7s dgrad %.2e (quiet region %.2e)  wgrad %.2e  dead-channel |dw| %.1e" % ((name,) + v))
+    tol = _conv_tol(c * K ** 3)
+    v = e["fp16x2"]
+    assert v[0] < tol and v[2] < 2 * _conv_tol(N * D * H * W) and v[3] == 0.0
+    assert v[1] < tol and v[1] < 4 * max(e["fp32"][1], 5e-7), e
+
+
+@pytest.mark.parametrize("log2_range", [10, 13, 17, 20])
+def test_wbf_fp16_split_quiet_channels_in_the_weight_gradient(log2_range):
+    """Per-CHANNEL dynamic range: half of the channels of x and of dy are 2^r below the other half (a nearly dead feature
+    next to a loud one).  The weight gradient sums over all positions, so there is no quiet REGION -- but dw[co, ci] of a
+    quiet (co, ci) pair is built from quiet operands only; its error is taken relative to the quiet block's own maximum."""
+    c, K, (N, D, H, W) = 32, 5, (1, 16, 16, 16)
+    k, s_, p = (K,) * 3, (1, 1, 1), (2, 2, 2)
+    d = dev()
+    rng = np.random.default_rng(200 + log2_range)
+    f8 = lambda a: a.astype(np.float64)
+    small = float(2.0 ** -log2_range)
+    x = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, c, D, H, W)).astype(np.float32)
+    x[:, 16:] *= small
+    dy[:, 16:] *= small
+    dw_ref, _ = O.conv3d_wgrad(f8(dy), f8(x), k, s_, p)
+    xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+    desc = _desc(k, s_, p)
+    blocks = {"loud x loud": (slice(0, 16), slice(0, 16)), "quiet x loud": (slice(16, 32), slice(0, 16)),
+              "quiet x quiet": (slice(16, 32), slice(16, 32))}
+
+    def run():
+        dw = vec(np.zeros(dw_ref.size, np.float32))
+        d.call("msk_conv3d_wgrad", desc, xt.msk(), dyt.msk(), vp(dw), None, 0)
+        d.sync()
+        g = d.d2h(dw, (dw_ref.size,), np.float32).reshape(dw_ref.shape)
+        return tuple(_bulk_err(g, dw_ref, b) for b in blocks.values())
+
+    e = _three_kernel_sets(d, run)
+    print("\nchannels 2^-%d: weight-gradient error per block (%s)   fp16x2 %.2e %.2e %.2e | bf16x3 %.2e %.2e %.2e | fp32 Winograd "
+          "%.2e %.2e %.2e" % ((log2_range, ", ".join(blocks)) + e["fp16x2"] + e["bf16x3"] + e["fp32"]))
+    # The weight-gradient kernel keeps ONE accumulator: a low piece meets the other operand's high piece times 2^-11 made in
+    # fp16 registers, which is exact while that high piece sits within 2^13 of its tensor's maximum.  Claimed envelope:
+    # fp32 class up to 2^13 between channels, then one bit per factor of two (asserted with a margin of 16).
+    tol = 2 * _conv_tol(N * D * H * W)
+    for i in range(3):
+        bound = max(4 * max(e["fp32"][i], 5e-7), 16 * 2.0 ** (log2_range - 13) * 2.0 ** -22)
+        assert e["fp16x2"][i] < bound, (i, e, bound)
+        if log2_range <= 13:
+            assert e["fp16x2"][i] < tol
