@@ -989,7 +989,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
   MSK_REQUIRE(ctx, dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
                        dy_scratch.c == y.c, "dy_scratch must match y");
   // ---- fused form: conditions under which BOTH gradient pipelines take pre-written transforms
-  const bool split2 = wbf_pieces(ctx, cd.kd) == 2;
+  const bool split2 = wbf_pieces(ctx, cd.kd) != 3;   // fp16 operands (two pieces, or one: conv_fp16): power-of-two tensor scales
   bool fused = ctx->bwd_fuse != 0 && (!split2 || maxes != nullptr) && ybuf != nullptr && xform != nullptr && dx.p != nullptr && ctx->wbf && !ctx->no_winograd && ctx->conv_impl == 0 &&
                x.c == y.c && y.ld % 4 == 0 && dout.ld % 4 == 0 && (((uintptr_t)y.p) & 15) == 0 && (((uintptr_t)dout.p) & 15) == 0;
   const size_t per = (size_t)x.d * x.h * x.w * (x.ld > y.ld ? x.ld : y.ld) * sizeof(float);

@@ -92,7 +92,7 @@ wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfP
   (void)A;
   unsigned short* __restrict__ out = d.out;
   const long xi_stride = d.xi_stride;
-  const double wsc = NP == 2 ? (double)wbf_scale_of(d.amax) : 1.0;  // NP = 2: power-of-two scale into fp16 range
+  const double wsc = NP != 3 ? (double)wbf_scale_of(d.amax) : 1.0;  // fp16 operands (NP = 2, 1): power-of-two scale into fp16 range
   constexpr int NXI = nxi_of(K), T2 = K * K, T3 = K * K * K;
   // one thread per (tap row, k, n): reads its K kw taps once, writes NXI x NP values
   const long total = (long)T2 * KC * 16 * CN;
@@ -139,7 +139,7 @@ wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfP
         o[0] = __builtin_bit_cast(unsigned short, h);
         o[pstep] = __builtin_bit_cast(unsigned short, (_Float16)(v - (double)(float)h));
       } else {
-        o[0] = __builtin_bit_cast(unsigned short, (_Float16)(float)s_);
+        o[0] = __builtin_bit_cast(unsigned short, (_Float16)(float)(s_ * wsc));
       }
     }
   }
@@ -259,7 +259,7 @@ wbf_tin_k(WbfTinArgs a) {
   const float* xb = a.src + ((long)n * a.svn + (long)d * a.svd + (long)h * a.svh) * a.sld + cg * 8;
   const long wstep = (long)a.svw * a.sld;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float sc2 = NP == 2 ? wbf_scale_of(a.amax) : 1.f;
+  const float sc2 = NP != 3 ? wbf_scale_of(a.amax) : 1.f;  // fp16 operands: the tensor's power-of-two scale (round 3: also the single-fp16 form -- gradients of ~1e-7 sit inside fp16's subnormal range)
   (void)sc2;
 
   float4 win[WIN][2];
@@ -324,10 +324,10 @@ wbf_tin_k(WbfTinArgs a) {
         *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
       } else {
         uint4 hv;
-        hv.x = pack_f16_pair(v[0][xi], v[1][xi]);
-        hv.y = pack_f16_pair(v[2][xi], v[3][xi]);
-        hv.z = pack_f16_pair(v[4][xi], v[5][xi]);
-        hv.w = pack_f16_pair(v[6][xi], v[7][xi]);
+        hv.x = pack_f16_pair(v[0][xi] * sc2, v[1][xi] * sc2);
+        hv.y = pack_f16_pair(v[2][xi] * sc2, v[3][xi] * sc2);
+        hv.z = pack_f16_pair(v[4][xi] * sc2, v[5][xi] * sc2);
+        hv.w = pack_f16_pair(v[6][xi] * sc2, v[7][xi] * sc2);
         *reinterpret_cast<uint4*>(o) = hv;
       }
     }
@@ -384,10 +384,10 @@ __device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8
     *reinterpret_cast<uint4*>(o + 2 * plane) = lo;
   } else {
     uint4 hv;
-    hv.x = pack_f16_pair(v[0][xi], v[1][xi]);
-    hv.y = pack_f16_pair(v[2][xi], v[3][xi]);
-    hv.z = pack_f16_pair(v[4][xi], v[5][xi]);
-    hv.w = pack_f16_pair(v[6][xi], v[7][xi]);
+    hv.x = pack_f16_pair(v[0][xi] * sc2, v[1][xi] * sc2);
+    hv.y = pack_f16_pair(v[2][xi] * sc2, v[3][xi] * sc2);
+    hv.z = pack_f16_pair(v[4][xi] * sc2, v[5][xi] * sc2);
+    hv.w = pack_f16_pair(v[6][xi] * sc2, v[7][xi] * sc2);
     *reinterpret_cast<uint4*>(o) = hv;
   }
 }
@@ -418,7 +418,7 @@ wbf_tin_dual_k(DualArgs b) {
   }
   // NP = 2: power-of-two scale of dy from (a bound of) its maximum: given (b.amax), or evaluated here (b.maxes)
   float sc2 = 1.f;
-  if (NP == 2) {
+  if (NP != 3) {
     if (b.maxes) {
       __shared__ float shb[3][4];
       float ma = 0.f, mb = 0.f, mc = 0.f;
@@ -1314,7 +1314,7 @@ int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows)
   const bool one = rows.size() == 1;
   const WbfPackDesc single = c->e[rows[0]].d;
   bool need_amax = false;
-  for (int r : rows) need_amax |= c->e[r].NP == 2;
+  for (int r : rows) need_amax |= c->e[r].NP != 3;
   if (need_amax) {
     // zero the amax arrays of runs of consecutive rows with one memset each (in steady state: one run)
     size_t i = 0;
@@ -1326,7 +1326,7 @@ int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows)
     }
     WbfPackList l{};
     for (int r : rows)
-      if (c->e[r].NP == 2) l.row[l.n++] = (unsigned char)r;
+      if (c->e[r].NP != 3) l.row[l.n++] = (unsigned char)r;
     const unsigned ny = (unsigned)l.n;
     if (one) l.n = -1;
     msk_launch_scope ls(ctx, "wbf_pack_absmax");
@@ -1496,7 +1496,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   // NP = 2: the source tensor is scaled into fp16 range by a power of two derived on the device from (a bound of) its
   // maximum (kept in the xform header for the weight gradient)
   const float* in_amax = nullptr;
-  if (NP == 2) {
+  if (NP != 3) {
     if (g.fuse) in_amax = g.fuse->amax;
     else if (g.in_amax) in_amax = g.in_amax;
     else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
@@ -1544,7 +1544,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.dst = g.dst; fa.dld = g.dld;
     fa.dvn = (long)g.DD * g.DH * g.DW; fa.dvd = vstr[pm[0]]; fa.dvh = vstr[pm[1]]; fa.dvw = vstr[pm[2]];
     fa.bias = g.bias; fa.prelu = g.prelu; fa.accumulate = g.accumulate;
-    fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP == 2 ? 1 : 0;
+    fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP != 3 ? 1 : 0;
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
     {
@@ -1574,7 +1574,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     oa.stat_partial = SP;
     oa.in_amax = in_amax;
     oa.w_amax = w_amax;
-    oa.scaled = NP == 2 ? 1 : 0;
+    oa.scaled = NP != 3 ? 1 : 0;
     {
       msk_launch_scope ls(ctx, "wbf_tout_k");
       if (fuse_stats) hipLaunchKernelGGL((wbf_tout_k<true, K>), dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);

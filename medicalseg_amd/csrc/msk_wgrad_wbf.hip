@@ -323,7 +323,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   if (!wsp) return -1;
   char* V = have_v ? (char*)const_cast<void*>(g.xform) + kWbfXformHeader : wsp;
   const float* v_amax = nullptr;  // NP = 2: the scale of the A operand (from the xform header, or computed here)
-  if (NP == 2 && have_v) v_amax = (const float*)g.xform;
+  if (NP != 3 && have_v) v_amax = (const float*)g.xform;
   char* Y = have_y ? (char*)const_cast<void*>(g.yform) : (have_v ? wsp : wsp + vb);
   float* P = (float*)(have_y ? (have_v ? wsp : wsp + vb) : Y + yb);
 
@@ -333,7 +333,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
   ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
   if (!have_v) {  // else: V written by msk_conv3d_fwd_ex for this tensor
-    if (NP == 2) {
+    if (NP != 3) {
       v_amax = msk_absmax(ctx, g.A, g.ald, g.CA, (long)g.N * g.AD * g.AH * g.AW);
       if (!v_amax) return -1;
       ta.amax = v_amax;
@@ -351,7 +351,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   } else if (have_y) {
     y_amax = g.y_amax;
   } else {
-    if (NP == 2) {
+    if (NP != 3) {
       y_amax = msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);
       if (!y_amax) return -1;
     }
@@ -383,7 +383,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
     long blocks = ((long)T2 * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;
     hipLaunchKernelGGL((wbf_wgrad_reduce_k<K>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit, NS,
-                       KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate, y_amax, v_amax, NP == 2 ? 1 : 0);
+                       KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate, y_amax, v_amax, NP != 3 ? 1 : 0);
     MSK_LAUNCH_CHECK(ctx);
   }
   return 1;
