@@ -294,6 +294,8 @@ int msk_dropout_mask(msk_ctx* ctx, uint64_t seed, uint64_t step, uint32_t site, 
 int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate);
 /* paddle.argmax(logit, axis=1) (core/infer.py:92) */
 int msk_argmax_c(msk_ctx* ctx, msk_tensor x, int32_t* out);
+/* out[v][c] = softmax over c of x[v][:]  -- F.softmax(logits, axis=1) of the AUC path of evaluate (core/val.py:121-123)  */
+int msk_softmax_c(msk_ctx* ctx, msk_tensor x, msk_tensor out);
 
 /* ---- loss ------------------------------------------------------------------ */
 /* losses/loss_utils.py:31-40 class_weights: w_c = sum(1-softmax_c)/sum(softmax_c) */

@@ -108,6 +108,7 @@ SIGNATURES = {
     "msk_dropout_mask": (_i, [_vp, _u64, _u64, _u32, _i, _f, _vp]),
     "msk_channel_sum": (_i, [_vp, _T, _vp, _i]),
     "msk_argmax_c": (_i, [_vp, _T, _vp]),
+    "msk_softmax_c": (_i, [_vp, _T, _T]),
     "msk_class_weights": (_i, [_vp, _T, _vp]),
     "msk_loss_fwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _vp]),
     "msk_loss_bwd": (_i, [_vp, _T, _vp, _vp, _i, _vp, _f, _f, _T]),

@@ -9,7 +9,8 @@ import numpy as np
 from .. import nn
 from ..datasets import DataLoader
 from ..device import to_tensor
-from ..utils import TimeAverager, logger, loss_computation, save_array
+from ..device import Tensor
+from ..utils import TimeAverager, logger, loss_computation, metric, save_array
 from . import infer
 
 np.set_printoptions(suppress=True)
@@ -18,9 +19,6 @@ np.set_printoptions(suppress=True)
 def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_roc=False, writer=None,
              save_dir=None):
     new_loss = {'types': [losses['types'][0]], 'coef': [losses['coef'][0]]}
-    if auc_roc:
-        logger.warning("evaluate(auc_roc=True): the AUC/ROC path of the reference (core/val.py:121-131, sklearn on host "
-                       "logits) is not built; mDice only.")
     if writer is not None:
         logger.warning("evaluate(writer=...): VisualDL logging is not built; the writer is ignored.")
     model.eval()
@@ -37,6 +35,7 @@ def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_
     mdice = 0.0
     channel_dice_array = np.array([])
     loss_all = 0.0
+    logits_all, label_all = [], []   # auc_roc: softmax scores and labels of the whole set on the host (core/val.py:121-131)
     with nn.fused_inference():       # one scope for the whole set: BN is folded into the conv weights once
         for it, (im, label, idx) in enumerate(loader):
             reader_cost_averager.record(time.time() - batch_start)
@@ -45,6 +44,12 @@ def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_
                                            transforms=eval_dataset.transforms.transforms)
             loss, per_channel_dice = loss_computation(logits, label_t, new_loss)
             loss = sum(loss)
+            if auc_roc:
+                lg = logits[0] if isinstance(logits, (list, tuple)) else logits
+                probs = Tensor.empty(lg.dev, lg.n, lg.d, lg.h, lg.w, lg.c)
+                lg.dev.call("msk_softmax_c", lg.msk(), probs.msk())       # F.softmax(logits, axis=1) on the device
+                logits_all.append(probs.numpy())
+                label_all.append(np.asarray(label))
             loss_all += loss.numpy()
             pcd = np.asarray(per_channel_dice)
             mdice += np.mean(pcd)
@@ -61,8 +66,13 @@ def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_
     channel_dice_array = channel_dice_array / total_iters
     loss_all = loss_all / total_iters
     result_dict = {"mdice": float(mdice)}
+    auc_infor = ""
+    if auc_roc:
+        auc = metric.auc_roc(np.concatenate(logits_all), np.concatenate(label_all), num_classes=eval_dataset.num_classes)
+        auc_infor = ' Auc_roc: {:.4f}'.format(auc)
+        result_dict['auc_roc'] = auc
     if print_detail and local_rank == 0:
         logger.info("[EVAL] #Images: {}, Dice: {:.4f}, Loss: {:6f}".format(len(eval_dataset), mdice,
-                                                                           float(np.ravel(loss_all)[0])))
+                                                                           float(np.ravel(loss_all)[0])) + auc_infor)
         logger.info("[EVAL] Class dice: \n" + str(np.round(channel_dice_array, 4)))
     return result_dict

@@ -875,6 +875,20 @@ __global__ void argmax_k(const float* __restrict__ x, int ld, long voxels, int C
   }
 }
 
+// softmax over the channel axis of every voxel (F.softmax(logits, axis=1) of the reference's AUC path, core/val.py:121-123)
+__global__ void softmax_c_k(const float* __restrict__ x, int ld, long voxels, int C, float* __restrict__ out, int old) {
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (long)gridDim.x * blockDim.x) {
+    const float* p = x + v * ld;
+    float m = p[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[c] - m);
+    const float inv = 1.f / s;
+    float* o = out + v * old;
+    for (int c = 0; c < C; ++c) o[c] = expf(p[c] - m) * inv;
+  }
+}
+
 // NCDHW <-> NDHWC through a 32x32 LDS tile (voxel x channel)
 __global__ void __launch_bounds__(256)
 ncdhw_to_ndhwc_k(const float* __restrict__ src, float* __restrict__ dst, int ld, long V, int C) {
@@ -1324,6 +1338,16 @@ int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
                        out, accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
+  return 0;
+}
+
+int msk_softmax_c(msk_ctx* ctx, msk_tensor x, msk_tensor out) {
+  MSK_REQUIRE(ctx, same_shape(x, out), "x/out shape mismatch");
+  const long voxels = msk_voxels(x);
+  msk_launch_scope ls(ctx, "softmax_c");
+  hipLaunchKernelGGL(softmax_c_k, dim3(ew_blocks(voxels, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, (const float*)x.p, x.ld,
+                     voxels, x.c, (float*)out.p, out.ld);
+  MSK_LAUNCH_CHECK(ctx);
   return 0;
 }
 

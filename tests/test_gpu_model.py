@@ -203,6 +203,31 @@ def test_eval_mdice_matches_oracle():
     assert abs(res["mdice"] - md / 3) < 1e-4
 
 
+def test_eval_auc_roc_matches_numpy_restatement():
+    """evaluate(auc_roc=True) (core/val.py:121-131,174): device softmax of the logits of every validation volume, collected
+    on the host, one-vs-rest macro AUC -- against the float64 oracle's logits -> numpy softmax -> sklearn's roc_auc_score
+    (what the reference's utils/metric.py:102-105 calls; its 4-D shape check is the only thing not reproduced)."""
+    skm = pytest.importorskip("sklearn.metrics")
+    from medicalseg_amd.core import evaluate
+    from medicalseg_amd.datasets import SyntheticCT
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    shape, ncls, K, S, _ = CFGS[0]
+    model, params = _build(ncls, K, S, seed=2)
+    ds = SyntheticCT(num_samples=3, shape=shape, num_classes=ncls, mode="val")
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    res = evaluate(model, ds, losses, print_detail=False, auc_roc=True)
+    om = O.VNetOracle(params, 1, ncls, K, S)
+    scores, labs = [], []
+    for i in range(3):
+        im, lab, _ = ds[i]
+        lg = om.forward(im[None], train=False, record=False)
+        scores.append(np.moveaxis(O.softmax(lg, axis=1), 1, -1).reshape(-1, ncls))
+        labs.append(np.asarray(lab).reshape(-1))
+    ref = skm.roc_auc_score(np.concatenate(labs), np.concatenate(scores), multi_class="ovr")
+    print("auc_roc %.6f (oracle + sklearn %.6f), mdice %.4f" % (res["auc_roc"], ref, res["mdice"]))
+    assert abs(res["auc_roc"] - ref) < 1e-4 and 0.0 <= res["auc_roc"] <= 1.0
+
+
 def test_preprocess_matches_reference_goldens():
     from medicalseg_amd import preprocess as pp
     g = np.load(os.path.join(HERE, "golden", "preprocess_golden.npz"))

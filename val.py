@@ -14,6 +14,7 @@ def parse_args():
     p.add_argument('--save_dir', dest='save_dir', help='The path to save result', type=str, default="saved_model/val")
     p.add_argument('--num_workers', dest='num_workers', help='Num workers for data loader', type=int, default=0)
     p.add_argument('--print_detail', dest='print_detail', type=bool, default=True)
+    p.add_argument('--auc_roc', dest='auc_roc', help='Whether to use auc_roc metric', type=bool, default=False)
     return p.parse_args()
 
 
@@ -32,7 +33,7 @@ def main(args):
         load_entire_model(model, args.model_path)
         logger.info('Loaded trained params of model successfully')
     print(evaluate(model, val_dataset, cfg.loss, num_workers=args.num_workers, print_detail=args.print_detail,
-                   save_dir=args.save_dir))
+                   auc_roc=args.auc_roc, save_dir=args.save_dir))
 
 
 if __name__ == '__main__':
