@@ -70,6 +70,25 @@ def lu_conv_work(n, d, h, w, products=6):
     return work
 
 
+# HIP-event tag (msk_launch_scope) -> bucket of tools/summarize_rocprof.py
+TAG_BUCKETS = (("lu_gemm", ("wbf_gemm_",)), ("lu_wgrad", ("wbf_wgrad_",)),
+               ("lu_transforms", ("wbf_tin_", "wbf_ty_", "wbf_tout_k", "wbf_pack_", "absmax")),
+               ("ks_convs", ("gconv_ks_fwd", "convT_scatter_mfma", "gconv_gather_mfma", "wgrad_ks_mfma", "wgrad_mfma")),
+               ("tiny_channel", ("conv_foldn", "conv_tk_", "conv_halo_tightk", "wgrad_cbs", "conv_c1_", "wgrad_c1_", "wgrad_pw_small",
+                                 "pointwise_small", "pack_weights_foldn", "pack_weights_tightk")),
+               ("loss_optim", ("loss_", "sgd_momentum", "adam", "class_weights")),
+               ("bn_prelu_join", ("affine_act", "add_act", "bn_", "sums_merge", "copy_scale", "dropout_mask", "channel_sum")),
+               ("weight_packs_reduces", ("pack_weights", "wgrad_reduce")))
+
+
+def bucket_times(prof, steps):
+    out = {}
+    for tag, (calls, ms) in prof.items():
+        b = next((name for name, keys in TAG_BUCKETS if any(tag.startswith(k) for k in keys)), "other")
+        out[b] = out.get(b, 0.0) + ms / steps
+    return out
+
+
 def _kernel_line(prof, name, flops_step, exec_step, steps, note=None):
     ms = sum(v[1] for k, v in prof.items() if k.startswith(name))
     calls = sum(v[0] for k, v in prof.items() if k.startswith(name))
@@ -207,14 +226,26 @@ def main():
     full_profile = bool(args.profile_out or args.shapes)
     dev.set_option("prof_only_halo", 0 if full_profile else 1)
     dev.prof_enable(True)
+    use_marks = args.steps < 1000
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if use_marks:
+        dev.call("msk_mark", 0)
+    for i in range(args.steps):
         last = step()
+        if use_marks:
+            dev.call("msk_mark", i + 1)     # an event on the stream: no host synchronisation inside the timed region
     t_enq = time.perf_counter() - t0   # host time to ENQUEUE the steps (no synchronisation inside a step)
     dev.sync()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     dev.prof_enable(False)
+    step_ms = []
+    if use_marks:
+        import ctypes as _C
+        for i in range(args.steps):
+            ms = _C.c_float()
+            dev.call("msk_mark_elapsed", i, i + 1, _C.byref(ms))
+            step_ms.append(float(ms.value))
     prof = dev.prof_report()
     loss_val = float(last)
     # untimed extra pass with the weight gradients on the MAIN stream: inside the timed region the data-gradient
@@ -272,19 +303,37 @@ def main():
                                                                           "avg_launch_ms": 0.0}
     kms = line["avg_launch_ms"] * line["launches"]
     total_kernel_ms = sum(v[1] for v in prof.values())
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if os.path.exists(tpath) and S == 128 and B == 2:   # PMC pass of this exact workload (tools/summarize_rocprof.py)
+    traffic, traffic_src, hbm = None, None, None
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
+                                  os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) if os.path.exists(pth)), None)
+    if tpath and S == 128 and B == 2:   # PMC passes of this exact workload (tools/profile_gpu.sh, tools/summarize_rocprof.py)
         try:
             tj = json.load(open(tpath))
-            # all tile variants of the kernel template with this operand split (its last template argument)
-            ent = [v for k, v in tj.items() if k.startswith("wbf_gemm_k<") and k.rstrip(">").endswith(", %d" % split) and isinstance(v, dict)]
+            rel = os.path.relpath(tpath, ROOT)
+            # all tile variants of the matrix-stage templates with this operand split
+            ent = [v for k, v in tj.items() if (k.startswith("wbf_gemm_k<") or k.startswith("wbf_gemm_fused_k<")) and isinstance(v, dict)
+                   and (", %d>" % split in k or ", %d, true>" % split in k or ", %d, false>" % split in k)]
             nl = sum(v["launches"] for v in ent)
             traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent) / nl) if nl else None
-            traffic_src = "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                          "captured %s, NOT measured in this run" % tj.get("_captured", "in round 2")
+            traffic_src = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, captured %s, NOT measured in " \
+                          "this run" % (rel, tj.get("_captured", "earlier"))
+            ws = tj.get("_whole_step")
+            if ws:
+                # 15.62 GB per sample of which the 0.91 GB optimizer term is per step
+                alg = (15.62 - 0.91) * B * (S / 128.0) ** 3 + 0.91
+                hbm = {"algorithmic_GB_per_step": round(alg, 2), "counter_GB_per_step": round(ws["hbm_bytes_per_step"] / 1e9, 2),
+                       "ratio": round(ws["hbm_bytes_per_step"] / 1e9 / alg, 2), "source": traffic_src,
+                       "buckets_counter_GB_per_step": {k: round(v / 1e9, 2) for k, v in ws["buckets_bytes_per_step"].items()}}
         except Exception:
             traffic = None
+    if hbm is not None and prof_serial:
+        # achieved HBM rate per bucket: counter bytes of the PMC passes / HIP-event time of the bucket's kernels in the untimed
+        # serialized pass of THIS run (kernels do not overlap there)
+        bt = bucket_times(prof_serial, 2)
+        hbm["buckets"] = {b: {"counter_GB": g, "ms": round(bt.get(b, 0.0), 3),
+                              "TB_per_s": round(g / bt[b], 2) if bt.get(b, 0.0) > 0 else None}
+                          for b, g in hbm.pop("buckets_counter_GB_per_step").items()}
+        hbm["serialized_kernel_ms_per_step"] = round(sum(bt.values()), 3)
     lu_flops = sum(v[0] for v in work.values())            # algorithmic FLOPs of the LUConv layers, fwd + dgrad + wgrad
     lu_exec = sum(v[3] for v in work.values())
     total_flops = step_flops_per_sample() * B * (S / 128.0) ** 3
@@ -306,6 +355,7 @@ def main():
                                              WGRAD_TAGS[split] + " in the same untimed pass (it runs on the side stream in the timed region)"),
                 # fraction of the step the EXECUTED work would take at the hardware peaks (bf16 pipe for the LUConv
                 # layers, fp32 MFMA peak for the remaining convolutions); <= 1
+                "hbm": hbm,
                 "step_executed_frac": round(t_floor / (ms_per_step * 1e-3), 4),
                 "step_algorithmic_speedup_vs_fp32_roofline": round(total_flops / (ms_per_step * 1e-3) / 1e12
                                                                    / PEAK_FP32_MFMA_TFLOPS, 4)}
@@ -319,6 +369,11 @@ def main():
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
                       "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn},
+           # per-step times from stream marks (no synchronisation inside the timed region): SURVEY 8 d1 asks for the median;
+           # `value` stays the contract's K-steps-between-two-synchronisations figure
+           "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
+           "value_median": round(voxels_per_step / (float(np.median(step_ms)) * 1e-3), 1) if step_ms else None,
+           "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)] if step_ms else None,
            "final_loss": round(loss_val, 6),
            # host time to enqueue one step (python + ctypes + HIP launches, no sync inside a step): the step is GPU-bound
            # while this stays below ms_per_step

@@ -63,6 +63,8 @@ SIGNATURES = {
     "msk_mem_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "msk_timer_start": (_i, [_vp]),
     "msk_timer_stop": (_i, [_vp, C.POINTER(_f)]),
+    "msk_mark": (_i, [_vp, _i]),
+    "msk_mark_elapsed": (_i, [_vp, _i, _i, C.POINTER(_f)]),
     "msk_prof_enable": (_i, [_vp, _i]),
     "msk_prof_reset": (_i, [_vp]),
     "msk_prof_report": (_i, [_vp, C.c_char_p, _i, C.POINTER(_i)]),

@@ -42,6 +42,7 @@ struct msk_ctx {
   std::map<std::string, msk_prof_entry> prof_map;
   std::vector<msk_pending_event> prof_pending;
   std::vector<hipEvent_t> event_pool;
+  std::vector<hipEvent_t> marks;   // msk_mark / msk_mark_elapsed
   std::set<std::string> tag_pool;  // interned dynamic tags (pointers stay valid)
   bool prof_shapes = false;        // append problem shapes to conv tags
   // options

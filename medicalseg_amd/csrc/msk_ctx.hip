@@ -170,6 +170,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   msk_dp_destroy(ctx);
   drain_prof(ctx);
   for (auto e : ctx->event_pool) hipEventDestroy(e);
+  for (auto e : ctx->marks) if (e) hipEventDestroy(e);
   msk_wbf_pack_cache_free(ctx);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
@@ -306,6 +307,25 @@ int msk_timer_stop(msk_ctx* ctx, float* ms) {
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
   MSK_CHECK_HIP(ctx, hipEventSynchronize(ctx->t1));
   MSK_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return 0;
+}
+
+// Marks on the compute stream for per-step timing without host synchronisation inside the timed region (bench.py: the
+// median of the timed steps): msk_mark(i) records event i (0..1023), msk_mark_elapsed(a, b) waits for b.
+int msk_mark(msk_ctx* ctx, int idx) {
+  MSK_REQUIRE(ctx, idx >= 0 && idx < 1024, "mark index out of range");
+  if (msk_join_side_impl(ctx) != 0) return -1;   // a step ends when both streams are done
+  if (msk_dp_wait_impl(ctx) != 0) return -1;
+  if ((int)ctx->marks.size() <= idx) ctx->marks.resize(idx + 1, nullptr);
+  if (!ctx->marks[idx]) MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->marks[idx]));
+  MSK_CHECK_HIP(ctx, hipEventRecord(ctx->marks[idx], ctx->stream));
+  return 0;
+}
+int msk_mark_elapsed(msk_ctx* ctx, int a, int b, float* ms) {
+  MSK_REQUIRE(ctx, a >= 0 && b >= 0 && a < (int)ctx->marks.size() && b < (int)ctx->marks.size() && ctx->marks[a] && ctx->marks[b],
+              "mark not recorded");
+  MSK_CHECK_HIP(ctx, hipEventSynchronize(ctx->marks[b]));
+  MSK_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->marks[a], ctx->marks[b]));
   return 0;
 }
 

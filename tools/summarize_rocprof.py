@@ -26,6 +26,25 @@ def agg(path, counter):
     return d
 
 
+BUCKETS = (("lu_gemm", ("wbf_gemm_k", "wbf_gemm_fused_k")),
+           ("lu_wgrad", ("wbf_wgrad_k", "wbf_wgrad_reduce_k")),
+           ("lu_transforms", ("wbf_tin_k", "wbf_tin_dual_k", "wbf_tout_k", "wbf_pack_", "absmax_k")),
+           ("ks_convs", ("gconv_ks_fwd_k", "convT_scatter_mfma_k", "gconv_gather_mfma_k", "wgrad_ks_mfma_k", "wgrad_mfma_k")),
+           ("tiny_channel", ("conv_foldn", "conv_tk_", "conv_halo_tightk", "wgrad_cbs", "conv_c1_", "wgrad_c1_", "wgrad_pw_small",
+                             "pointwise_small", "conv_halo_valu", "pack_foldn", "pack_tk")),
+           ("loss_optim", ("loss_", "sgd_momentum_k", "adam_k", "class_weights")),
+           ("bn_prelu_join", ("affine_act", "bn_", "sums_merge_k", "param_grads_k", "copy_scale_k", "dropout_mask_k",
+                              "channel_sum", "bias_grad")),
+           ("weight_packs_reduces", ("pack_weights_k", "wgrad_reduce", "wgrad_prereduce")))
+
+
+def bucket_of(name):
+    for b, keys in BUCKETS:
+        if any(name.startswith(k) or ("<" in name and name.split("<")[0].startswith(k)) for k in keys):
+            return b
+    return "other"
+
+
 def main(tag):
     go = os.path.join(ROOT, "gpurun_out")
     out = os.path.join(ROOT, "profiles")
@@ -47,14 +66,22 @@ def main(tag):
                "_note": "per-launch averages over one training step; FETCH_SIZE/WRITE_SIZE are in KiB; "
                         "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 rocprofv3 reports half of a wide "
                         "coalesced read stream, MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)"}
-        for k in fe:
-            if any(t in k for t in ("mfma", "valu", "wino", "tightk", "wbf_", "foldn", "gconv_ks", "wgrad_cbs", "conv_tk")):
-                n = fe[k][1]
-                f_kb, w_kb = fe[k][0] / n, wr[k][0] / max(wr[k][1], 1)
-                name = k.split("(")[1].split("::")[-1] if "::" in k else k
-                short = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
-                res[short] = {"launches": n, "FETCH_SIZE_KiB": round(f_kb, 1), "WRITE_SIZE_KiB": round(w_kb, 1),
-                              "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024)}
+        steps = int(os.environ.get("PROFILE_STEPS", "1"))      # training steps inside the PMC passes (profile_gpu.sh: 1)
+        total = 0.0
+        buckets = collections.defaultdict(float)
+        for k in sorted(set(fe) | set(wr)):     # EVERY kernel of the step (round 2 listed the convolution families only)
+            n = max(fe[k][1], wr[k][1], 1)
+            f_kb, w_kb = fe[k][0] / max(fe[k][1], 1), wr[k][0] / max(wr[k][1], 1)
+            short = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+            per_launch = (2 * f_kb + w_kb) * 1024
+            res[short] = {"launches": n, "FETCH_SIZE_KiB": round(f_kb, 1), "WRITE_SIZE_KiB": round(w_kb, 1),
+                          "hbm_bytes_per_launch": int(per_launch), "bucket": bucket_of(short)}
+            total += per_launch * n / steps
+            buckets[bucket_of(short)] += per_launch * n / steps
+        res["_whole_step"] = {"hbm_bytes_per_step": int(total), "steps_profiled": steps,
+                              "buckets_bytes_per_step": {b: int(v) for b, v in sorted(buckets.items())},
+                              "note": "sum over ALL kernel launches of one training step (VNet 128^3, batch 2); memset / copy "
+                                      "commands of the runtime are not kernels and are not counted"}
         with open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
     sq_p = os.path.join(go, "prof_sq", "r01_counter_collection.csv")
