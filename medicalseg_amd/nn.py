@@ -35,6 +35,20 @@ def _triple(v):
 
 _init_rng = np.random.default_rng(0)
 
+# Host-side accounting of ALGORITHMIC convolution FLOPs (2 k^3 Cin Cout per output voxel and pass) for the
+# workload benchmarks: {"on": True} makes every convolution call add its count under its kernel class.
+FLOPS = {"on": False, "same_k5": 0.0, "same_k3": 0.0, "other": 0.0}
+
+
+def _count_flops(conv, n, out_voxels, passes):
+    if not FLOPS["on"]:
+        return
+    k = conv.k[0] * conv.k[1] * conv.k[2]
+    f = 2.0 * k * conv.cin * conv.cout * n * out_voxels * passes
+    same = conv.s == (1, 1, 1) and not conv.transposed and conv.cin >= 16 and conv.cout >= 16
+    key = "same_k5" if (same and conv.k == (5, 5, 5)) else ("same_k3" if (same and conv.k == (3, 3, 3)) else "other")
+    FLOPS[key] += f
+
 
 def seed(s: int):
     """Seed parameter initialisation (paddle.seed, train.py:120-123)."""
@@ -244,6 +258,7 @@ class Conv3D(Layer):
         od, oh, ow = self.out_dims(x)
         if y is None:
             y = Tensor.empty(x.dev, x.n, od, oh, ow, self.cout)
+        _count_flops(self, x.n, od * oh * ow, 1)
         dev = x.dev
         self._xform = None
         if stats_ptr is None and not keep_xform:
@@ -263,6 +278,7 @@ class Conv3D(Layer):
 
     def run_backward(self, x: Tensor, dy: Tensor, need_dx=True, bias_grad=True):
         dev = x.dev
+        _count_flops(self, x.n, dy.d * dy.h * dy.w, 2 if need_dx else 1)
         xf = getattr(self, "_xform", None)
         if xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen:   # same tensor, same arena generation
             dev.call("msk_conv3d_wgrad_ex", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
@@ -307,12 +323,14 @@ class Conv3DTranspose(Layer):
         od, oh, ow = self.out_dims(x)
         if y is None:
             y = Tensor.empty(x.dev, x.n, od, oh, ow, self.cout)
+        _count_flops(self, x.n, x.d * x.h * x.w, 1)      # transposed conv: per INPUT voxel
         x.dev.call("msk_convT3d_fwd", self.desc(), x.msk(), C.c_void_p(self.weight.ptr),
                    C.c_void_p(self.bias.ptr), y.msk())
         return y
 
     def run_backward(self, x: Tensor, dy: Tensor, need_dx=True, bias_grad=True):
         dev = x.dev
+        _count_flops(self, x.n, x.d * x.h * x.w, 2 if need_dx else 1)
         dev.call("msk_convT3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
                  C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
         if need_dx:
@@ -646,6 +664,7 @@ class ConvBNAct:
                 if nbytes > 0:
                     ybuf = dev.arena.alloc(nbytes)
             dx = x.ensure_grad()
+            _count_flops(conv, x.n, y.d * y.h * y.w, 2)
             dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
                      _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
                      _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,

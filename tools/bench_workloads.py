@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--iso", action="store_true", help="isotropic 2x2x2 kernels/strides (lung) instead of the MRI ones")
     ap.add_argument("--profile-out", default=None)
+    ap.add_argument("--json-out", default=None, help="write ms/step, algorithmic FLOP rates and the roofline fraction here")
     a = ap.parse_args()
     from medicalseg_amd import models, optimizer as optim
     from medicalseg_amd.device import get_device, to_tensor
@@ -55,6 +56,11 @@ def main():
     for _ in range(a.warmup):
         step()
     dev.sync()
+    from medicalseg_amd import nn as _nn
+    _nn.FLOPS.update(on=True, same_k5=0.0, same_k3=0.0, other=0.0)
+    step()                                   # one (untimed) step with the host-side FLOP accounting on
+    _nn.FLOPS["on"] = False
+    dev.sync()
     if a.profile_out:
         dev.set_option("prof_shapes", 1)
         dev.prof_enable(True)
@@ -66,6 +72,28 @@ def main():
     vox = a.batch * shape[0] * shape[1] * shape[2]
     print(f"{a.model} {shape} ncls={a.num_classes} batch={a.batch}: {ms:.2f} ms/step, {vox / ms / 1e3:.2f} M voxels/s"
           + (" (per-kernel profiling on: serialised)" if a.profile_out else ""))
+    if a.json_out:
+        import json
+        F = _nn.FLOPS
+        alg = F["same_k5"] + F["same_k3"] + F["other"]
+        # time the EXECUTED matrix work needs at the peaks: 'same' 5^3 / 3^3 convolutions on the 16-bit pipe (Winograd F(4,5):
+        # 0.4 of the MACs, F(4,3): 0.5; x3 products per fp32 product with two-piece operands, x1 with fp16 operands), everything
+        # else at the fp32 MFMA peak
+        prod3 = 1.0 if (a.model == "UNet3D" and a.precision == "fp16") else 3.0
+        floor_s = (F["same_k5"] * 0.4 * 3.0 + F["same_k3"] * 0.5 * prod3) / 2500e12 + F["other"] / 157.3e12
+        res = {"workload": f"{a.model} {shape} ncls={a.num_classes} batch={a.batch} precision={a.precision}",
+               "ms_per_step": round(ms, 3), "voxels_per_s": round(vox / ms * 1e3, 1),
+               "algorithmic_flop_per_step": alg, "algorithmic_tflops": round(alg / ms / 1e9, 1),
+               "algorithmic_speedup_vs_fp32_mfma_peak": round(alg / ms / 1e9 / 157.3, 3),
+               "roofline": {"bound": "mfma", "frac": round(floor_s / (ms * 1e-3), 4),
+                            "definition": "time the executed matrix work of the step needs at the hardware peaks (16-bit pipe 2500 "
+                                          "TFLOP/s for the Winograd-pipeline convolutions, fp32 MFMA 157.3 TFLOP/s for the rest) / "
+                                          "measured step time -- the step_executed_frac of bench.py",
+                            "flop_same_k5": F["same_k5"], "flop_same_k3": F["same_k3"], "flop_other": F["other"]}}
+        os.makedirs(os.path.dirname(os.path.abspath(a.json_out)) or ".", exist_ok=True)
+        with open(a.json_out, "w") as f:
+            json.dump(res, f, indent=1)
+        print(json.dumps(res))
     if a.profile_out:
         prof = dev.prof_report()
         total = sum(ms_ for _, ms_ in prof.values())
