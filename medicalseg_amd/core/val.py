@@ -16,12 +16,33 @@ from . import infer
 np.set_printoptions(suppress=True)
 
 
+def _load_dataset_json(eval_dataset):
+    path = getattr(eval_dataset, "dataset_json_path", "")
+    if path and os.path.exists(path):
+        import json
+        with open(path, encoding="utf-8") as f:
+            return json.load(f)
+    return None
+
+
+def _image_info(dataset_json, idx):
+    """spacing / direction / origin of one validation volume (reference core/val.py:96-97,149-154); identity geometry when
+    the dataset has no json (synthetic data)"""
+    try:
+        name = str(idx[0]).split("/")[-1].split(".")[0]
+        j = dataset_json["training"][name]
+        return {"spacing": j["spacing_resample"], "direction": j["direction"], "origin": j["origin"], "format": "xyz"}
+    except Exception:
+        return {"spacing": (1.0, 1.0, 1.0), "direction": (1, 0, 0, 0, 1, 0, 0, 0, 1), "origin": (0.0, 0.0, 0.0), "format": "xyz"}
+
+
 def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_roc=False, writer=None,
              save_dir=None):
     new_loss = {'types': [losses['types'][0]], 'coef': [losses['coef'][0]]}
     if writer is not None:
         logger.warning("evaluate(writer=...): VisualDL logging is not built; the writer is ignored.")
     model.eval()
+    dataset_json = _load_dataset_json(eval_dataset)
     from ..parallel import ParallelEnv
     env = ParallelEnv()
     local_rank = env.local_rank
@@ -55,8 +76,11 @@ def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_
             mdice += np.mean(pcd)
             channel_dice_array = pcd.copy() if channel_dice_array.size == 0 else channel_dice_array + pcd
             if it < 5 and save_dir is not None:
+                # reference core/val.py:137-153: npy + nii.gz with the volume's geometry from the dataset json
+                info = _image_info(dataset_json, idx)
                 save_array(save_path=os.path.join(save_dir, str(it)),
-                           save_content={'pred': pred.numpy(), 'label': label, 'img': im}, form=('npy', ))
+                           save_content={'pred': pred.numpy(), 'label': label, 'img': im},
+                           form=('npy', 'nii.gz'), image_infor=info)
             batch_cost_averager.record(time.time() - batch_start, num_samples=len(label))
             reader_cost_averager.reset()
             batch_cost_averager.reset()

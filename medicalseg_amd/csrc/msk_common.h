@@ -51,6 +51,7 @@ struct msk_ctx {
   bool wbf = true;  // env MSEGK_WBF=0 / option "wino_bf3" 0: keep the fp32-MFMA Winograd kernels (exact-fp32 products)
   bool stats_fused = false;  // set by a conv kernel that wrote GConv::stats itself
   bool xform_written = false;  // set when GConv::xform was filled
+  std::set<const void*> xform_ok;  // xform buffers msk_conv3d_fwd_ex* really filled: a buffer the pipeline declined (alignment, size limits) is ignored by the weight gradient instead of failing the forward pass (advisor, round 2)
   bool conv_fp16 = false;  // option "conv_fp16": 3x3x3 convolutions with fp16 matrix operands (UNet3D precision='fp16')
   int wbf_tin_map = 1;  // lane mapping of wbf_tin_k (1: one channel group per wavefront, 1 KiB store runs; measured 3-10 % faster)
   int wbf_variant = -1;  // tuning: force a tile variant of wbf_gemm_k (-1 = least padding)
@@ -115,6 +116,7 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 int msk_join_side_impl(msk_ctx* ctx);
+void msk_set_ew_caps(int ew, int red);   // msk_elementwise.hip tuning knobs
 // caller memory that may hold convolution weights was (or is about to be) written / freed: derived forms are stale
 void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes);
 void msk_weights_freed_impl(msk_ctx* ctx, const void* p);

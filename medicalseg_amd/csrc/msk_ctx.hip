@@ -410,6 +410,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->dp_mode = value;
     return 0;
   }
+  if (strcmp(key, "ew_cap") == 0) {      // tuning: blocks per CU of the elementwise kernels (default 32)
+    msk_set_ew_caps(value, 0);
+    return 0;
+  }
+  if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 8)
+    msk_set_ew_caps(0, value);
+    return 0;
+  }
   if (strcmp(key, "wgrad_fork") == 0) {
     ctx->wgrad_fork = value;
     return 0;

@@ -208,7 +208,7 @@ class Config(object):
             cls = optim.Momentum
         elif kind == 'adam':  # config.py:214-216
             cls = optim.Adam
-        elif kind in optim.__all__:
+        elif kind in optim.OPTIMIZERS:      # (not optim.__all__: 'lr' is the scheduler namespace, not an optimizer)
             cls = getattr(optim, kind)
         else:
             raise RuntimeError('Unknown optimizer type {}.'.format(kind))

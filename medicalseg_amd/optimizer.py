@@ -6,6 +6,17 @@ import math
 import numpy as np
 
 __all__ = ["Momentum", "SGD", "Adam", "lr"]
+OPTIMIZERS = ("Momentum", "SGD", "Adam")     # names accepted as an optimizer `type` (cvlibs/config.py); `lr` is the scheduler namespace
+
+
+def _warn_unused(cls_name, kw):
+    """paddle.optimizer.* options this package does not implement (grad_clip, lazy_mode, multi_precision, use_nesterov ...):
+    the reference passes them through to Paddle (cvlibs/config.py:217-224); dropping one silently would train differently
+    without a trace."""
+    if kw:
+        import warnings
+        warnings.warn("%s: option(s) %s are not implemented by medicalseg_amd and are IGNORED" % (cls_name, sorted(kw)))
+
 
 
 class _LR:
@@ -82,6 +93,7 @@ class Momentum:
     kernel over 45.6 M floats (K10)."""
 
     def __init__(self, learning_rate=0.001, momentum=0.9, parameters=None, weight_decay=None, **kw):
+        _warn_unused(type(self).__name__, kw)
         if not parameters:
             raise ValueError("parameters must be a non-empty list")
         # tensors no forward path reaches get no gradient and are skipped by paddle's optimizer
@@ -164,7 +176,7 @@ class Momentum:
 
 class SGD(Momentum):
     def __init__(self, learning_rate=0.001, parameters=None, weight_decay=None, **kw):
-        super().__init__(learning_rate, 0.0, parameters, weight_decay)
+        super().__init__(learning_rate, 0.0, parameters, weight_decay, **kw)
 
 
 class Adam:
@@ -175,6 +187,7 @@ class Adam:
 
     def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, parameters=None, weight_decay=None,
                  **kw):
+        _warn_unused("Adam", kw)
         if not parameters:
             raise ValueError("parameters must be a non-empty list")
         parameters = [p for p in parameters if not getattr(p, "frozen", False)]

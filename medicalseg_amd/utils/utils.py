@@ -86,9 +86,101 @@ def worker_init_fn(worker_id):
     np.random.seed(np.random.get_state()[1][0] + worker_id)
 
 
+_NIFTI_DTYPES = {"uint8": (2, 8), "int16": (4, 16), "int32": (8, 32), "float32": (16, 32), "float64": (64, 64),
+                 "int8": (256, 8), "uint16": (512, 16), "uint32": (768, 32), "int64": (1024, 64), "uint64": (1280, 64)}
+
+
+def write_nifti(path, arr_zyx, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1, 0, 0, 0, 1, 0, 0, 0, 1)):
+    """Minimal single-file NIfTI-1 writer (.nii / .nii.gz) for what the reference hands to SimpleITK
+    (utils/utils.py:237-249: GetImageFromArray(val) + SetSpacing / SetOrigin / SetDirection + WriteImage): `arr_zyx` is
+    indexed [z, y, x] like a SimpleITK array, spacing / origin / direction are ITK's (x, y, z order, LPS frame).  The sform /
+    qform hold the same affine in NIfTI's RAS frame (x and y rows negated), as ITK's NIfTI writer stores it."""
+    import gzip
+    import struct
+    a = np.ascontiguousarray(arr_zyx)
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8)
+    if a.dtype.name not in _NIFTI_DTYPES:
+        a = a.astype(np.float32)
+    if a.ndim != 3:
+        raise ValueError("write_nifti expects a 3-D array, got shape {}".format(a.shape))
+    code, bits = _NIFTI_DTYPES[a.dtype.name]
+    nz, ny, nx = a.shape
+    sp = [float(v) for v in spacing][:3]
+    D = np.asarray(direction, dtype=np.float64).reshape(3, 3)
+    A = D * np.asarray(sp)[None, :]                       # LPS voxel -> world
+    flip = np.diag([-1.0, -1.0, 1.0])
+    R = flip @ A                                          # RAS
+    t = flip @ np.asarray([float(v) for v in origin][:3])
+    # quaternion of the rotation part (qfac = -1 when the matrix is a reflection)
+    Rn = R / np.maximum(np.linalg.norm(R, axis=0, keepdims=True), 1e-30)
+    qfac = 1.0
+    if np.linalg.det(Rn) < 0:
+        Rn[:, 2] = -Rn[:, 2]
+        qfac = -1.0
+    tr = Rn[0, 0] + Rn[1, 1] + Rn[2, 2]
+    if tr > 0:
+        qa = 0.5 * np.sqrt(1.0 + tr)
+        qb, qc, qd = (Rn[2, 1] - Rn[1, 2]) / (4 * qa), (Rn[0, 2] - Rn[2, 0]) / (4 * qa), (Rn[1, 0] - Rn[0, 1]) / (4 * qa)
+    else:
+        i = int(np.argmax([Rn[0, 0], Rn[1, 1], Rn[2, 2]]))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        q = np.zeros(4)
+        q[i + 1] = 0.5 * np.sqrt(max(1.0 + Rn[i, i] - Rn[j, j] - Rn[k, k], 0.0))
+        q[0] = (Rn[k, j] - Rn[j, k]) / (4 * q[i + 1])
+        q[j + 1] = (Rn[j, i] + Rn[i, j]) / (4 * q[i + 1])
+        q[k + 1] = (Rn[k, i] + Rn[i, k]) / (4 * q[i + 1])
+        if q[0] < 0:
+            q = -q
+        qa, qb, qc, qd = q
+    hdr = bytearray(348)
+    struct.pack_into("<i", hdr, 0, 348)
+    struct.pack_into("<8h", hdr, 40, 3, nx, ny, nz, 1, 1, 1, 1)                 # dim
+    struct.pack_into("<hh", hdr, 70, code, bits)                               # datatype, bitpix
+    struct.pack_into("<8f", hdr, 76, qfac, sp[0], sp[1], sp[2], 0.0, 0.0, 0.0, 0.0)   # pixdim
+    struct.pack_into("<f", hdr, 108, 352.0)                                    # vox_offset
+    struct.pack_into("<f", hdr, 112, 1.0)                                      # scl_slope
+    hdr[123] = 2                                                               # xyzt_units: mm
+    struct.pack_into("<hh", hdr, 252, 1, 1)                                    # qform_code, sform_code (scanner)
+    struct.pack_into("<6f", hdr, 256, qb, qc, qd, t[0], t[1], t[2])
+    for r in range(3):
+        struct.pack_into("<4f", hdr, 280 + 16 * r, R[r, 0], R[r, 1], R[r, 2], t[r])
+    hdr[344:348] = b"n+1\0"
+    payload = bytes(hdr) + b"\0\0\0\0" + a.astype(a.dtype.newbyteorder("<")).tobytes()   # x fastest = [z][y][x] C order
+    if path.endswith(".gz"):
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            f.write(payload)
+    else:
+        with open(path, "wb") as f:
+            f.write(payload)
+
+
 def save_array(save_path, save_content, form=('npy', ), image_infor=None):
-    """Save the first predictions of an evaluation run (reference utils.py:205-256); only
-    the .npy form is built (NIfTI needs SimpleITK, absent here)."""
-    os.makedirs(os.path.dirname(os.path.abspath(save_path)) or ".", exist_ok=True)
+    """Save the first predictions of an evaluation run (reference utils.py:205-256): 'npy', and 'nii' / 'nii.gz' through a
+    built-in NIfTI-1 writer (the reference uses SimpleITK, absent here) with the reference's axis convention
+    (image_infor['format'] 'xyz' arrays are transposed to zyx; spacing / origin / direction as in the dataset json)."""
+    if not isinstance(save_content, dict):
+        raise TypeError('The save_content need to be dict which the key is the save name and the value is the numpy array '
+                        'to be saved, but recieved {}'.format(type(save_content)))
+    content = {}
     for key, val in save_content.items():
-        np.save('{}_{}.npy'.format(save_path, key), np.asarray(val))
+        val = np.asarray(val)
+        content[key] = np.squeeze(val) if val.ndim > 3 else val
+    if save_path is None:
+        return
+    os.makedirs(os.path.dirname(os.path.abspath(save_path)) or ".", exist_ok=True)
+    for suffix in form:
+        if suffix == 'npy':
+            for key, val in content.items():
+                np.save('{}_{}.npy'.format(save_path, key), val)
+        elif suffix in ('nii', 'nii.gz'):
+            info = image_infor or {"format": "zyx"}
+            for key, val in content.items():
+                if info.get("format", "zyx") == "xyz":
+                    val = np.transpose(val, [2, 1, 0])
+                elif info.get("format", "zyx") != "zyx":
+                    raise RuntimeError("the image format {} is not supported".format(info["format"]))
+                write_nifti('{}_{}.{}'.format(save_path, key, suffix), val, info.get("spacing", (1.0, 1.0, 1.0)),
+                            info.get("origin", (0.0, 0.0, 0.0)), info.get("direction", (1, 0, 0, 0, 1, 0, 0, 0, 1)))
+        else:
+            raise RuntimeError('Save format other than npy or nii/nii.gz is not supported yet.')
