@@ -14,8 +14,11 @@ def main():
     from medicalseg_amd._lib import NULL_TENSOR
     from medicalseg_amd.device import Tensor, get_device
     dev = get_device()
+    for kv in sys.argv[1:]:                      # KEY=INT msk_set_option knobs (ew_cap, reduce_cap)
+        k, v = kv.split("=")
+        dev.set_option(k, int(v))
     vp = lambda p: C.c_void_p(p) if p else None
-    for (n, s, c) in [(2, 128, 32), (2, 128, 16), (2, 64, 64), (2, 32, 128)]:
+    for (n, s, c) in [(2, 128, 32), (2, 128, 16), (2, 64, 64)]:
         vox = n * s ** 3
         mk = lambda: Tensor(dev, dev.malloc(vox * c * 4), n, s, s, s, c, c, None)
         x, dout, dx, res, dres = mk(), mk(), mk(), mk(), mk()
