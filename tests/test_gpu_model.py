@@ -471,12 +471,14 @@ def test_vnet_32cube_batch2_gradients_calibrated():
     projections; the surviving signal is small) -- the float64 oracle re-run in FLOAT32 is itself 7.7e-4 (median
     per-tensor rel-L2) away from float64, and the exact-fp32 direct kernels 4.9e-4 / 5.7e-3 (median / worst tensor).  A
     per-tensor bound of 1e-3 is therefore not attainable by any fp32 implementation; what is asserted:
-      * every tensor rel-L2 <= 1.2e-2, median <= 5e-3 for the product kernels (measured: the product pipeline 3.0e-3 median /
-        4.1e-3 ... 6.5e-3 worst), median <= 7e-3 for the two A/B kernel sets;
+      * every tensor rel-L2 <= 8e-3, median <= 4e-3 for the product kernels (round 3, scaled low pieces: 1.2e-3 median / 1.6e-3 worst; round 2: 3.0e-3 median /
+        4.1e-3 ... 6.5e-3 worst), median <= 5e-3 for the two A/B kernel sets;
       * NO ranking between the kernel sets: the medians are noise realisations -- the exact-fp32 Winograd set measured
         6.1e-3 / 8.8e-3 and later 1.6e-3 when only the summation order of the FIRST layer's kernel changed
         (conv_c1_mfma_k), with its own kernels untouched;
-    a structural error (missing term, wrong scale) is O(1) and a 1 % systematic error doubles the worst tensor."""
+    a structural error (missing term, wrong scale) is O(1) and a 1 % systematic error doubles the worst tensor;
+      * (round 3) the SYSTEMATIC part separately: the least-squares scale of every weight tensor's gradient against the
+        oracle's is within 1e-3 of one (measured <= 2e-4) -- rounding noise projects out, a wrong factor does not."""
     from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
     from medicalseg_amd.utils import loss_computation
     shape, ncls, N = (32, 32, 32), 3, 2
@@ -515,22 +517,31 @@ def test_vnet_32cube_batch2_gradients_calibrated():
             assert abs(float(loss_list[0]) - ll_ref[0]) < 2e-5 * abs(ll_ref[0])
             assert abs(float(loss_list[1]) - ll_ref[1]) < 2e-5
             assert np.abs(np.asarray(per) - per_ref).max() < 1e-5
-            l2s = {}
+            l2s, bias = {}, {}
             for name, p in model.named_parameters():
                 ref = g_ref[name]
                 if np.abs(ref).max() < 1e-9:   # conv bias ahead of a train-mode BN: exactly 0 in exact arithmetic
                     assert np.abs(p.grad_numpy()).max() < 1e-4
                     continue
-                l2s[name] = _l2(p.grad_numpy(), ref)
+                g = p.grad_numpy().astype(np.float64)
+                l2s[name] = _l2(g, ref)
+                # SYSTEMATIC part of the error: the least-squares scale of g against the oracle, minus one.  Rounding noise
+                # is (nearly) orthogonal to the reference and averages out in this projection -- for a tensor of n values it
+                # is ~ rel-L2 / sqrt(n) --, a wrong factor in some kernel (a 1 % error in one layer's weight gradient, which
+                # the rel-L2 bound alone would let pass) shows at full size.
+                if ref.size >= 1000:
+                    bias[name] = float(np.vdot(g, ref) / np.vdot(ref, ref) - 1.0)
             worst = max(l2s, key=l2s.get)
-            stats[tag] = (float(np.median(list(l2s.values()))), l2s[worst])
-            print("32^3 N=2 %-11s logits %.2e | gradient rel-L2 median %.2e worst %.2e (%s)" %
-                  (tag, e_lg, stats[tag][0], l2s[worst], worst))
-            assert l2s[worst] < 1.2e-2 and stats[tag][0] < 7e-3, (tag, worst, l2s[worst])
+            wb = max(bias, key=lambda k_: abs(bias[k_]))
+            stats[tag] = (float(np.median(list(l2s.values()))), l2s[worst], abs(bias[wb]))
+            print("32^3 N=2 %-11s logits %.2e | gradient rel-L2 median %.2e worst %.2e (%s) | worst scale bias of a weight tensor %.2e (%s)" %
+                  (tag, e_lg, stats[tag][0], l2s[worst], worst, bias[wb], wb))
+            assert l2s[worst] < 8e-3 and stats[tag][0] < 5e-3, (tag, worst, l2s[worst])
+            assert abs(bias[wb]) < 1e-3, (tag, wb, bias[wb])
         finally:
             for k_ in opts:
                 d.set_option(k_, 1 if k_ == "wino_bf3" else 0)
-    assert stats["product"][0] < 5e-3
+    assert stats["product"][0] < 4e-3
 
 
 def test_training_trajectory_product_pipeline_vs_exact_fp32_kernels():
