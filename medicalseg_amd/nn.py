@@ -352,6 +352,9 @@ class BatchNorm3D(Layer):
     collectives per step and leaves the single gradient all-reduce."""
 
     sync = True
+    # tests: run the SyncBatchNorm collectives (all-gather of the statistics, all-reduce of the backward sums) also on a
+    # 1-rank communicator, where they are identities -- exercises the communication-stream hand-over inside a real step
+    force_collectives = False
 
     def __init__(self, num_features, momentum=BN_MOMENTUM, epsilon=BN_EPS):
         super().__init__()
@@ -553,7 +556,8 @@ class ConvBNAct:
         Cn = bn.num_features
         # one rank (or rank-local statistics): the finalisation rides in the launch that merges the statistics
         fin = None
-        if bn.training and FUSE_SMALL and not (dev.world > 1 and BatchNorm3D.sync):
+        multi = (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync
+        if bn.training and FUSE_SMALL and not multi:
             od, oh, ow = self.conv.out_dims(x)
             fin = MskBnFin(bn.weight.ptr, bn.bias.ptr, bn.epsilon, bn.momentum, float(x.n * od * oh * ow), bn._mean.ptr,
                            bn._variance.ptr, sc["mean"], sc["invstd"], sc["scale"], sc["shift"])
@@ -571,7 +575,7 @@ class ConvBNAct:
         if bn.training:
             if fin is None:
                 gathered, nstat = sc["stats"], 1
-                if dev.world > 1 and BatchNorm3D.sync:
+                if multi:
                     dev.call("msk_dp_allgather", _fp(sc["stats"]), _fp(sc["gathered"]), C.c_size_t(2 * Cn))
                     gathered, nstat = sc["gathered"], dev.world
                 dev.call("msk_bn_finalize", _fp(gathered), nstat, C.c_double(y.voxels), Cn, _fp(bn.weight.ptr),
@@ -644,7 +648,7 @@ class ConvBNAct:
             dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                      _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
         sums_total, m_total = sc["sums"], float(y.voxels)
-        if self.bn_mode == 1 and dev.world > 1 and BatchNorm3D.sync:
+        if self.bn_mode == 1 and (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync:
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
             dev.call("msk_dp_allreduce_stats", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world

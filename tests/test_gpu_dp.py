@@ -70,6 +70,64 @@ def test_dataparallel_wrapper_step_world1():
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("dp_mode", [0, 1, 2])
+def test_syncbn_collectives_inside_a_real_step_world1(dp_mode):
+    """TRAIN-mode steps on a 1-rank RCCL communicator with the SyncBatchNorm collectives forced on (24 all-gathers + 24
+    all-reduces per step, identities on one rank) next to the overlapped gradient buckets: every stream hand-over of the
+    multi-GPU step (compute <-> communication stream, weight-gradient side stream -> buckets) is exercised inside the real
+    training flow, and the parameters after two steps must equal the plain single-GPU step BIT FOR BIT -- a missing
+    dependency or a collective on the wrong stream shows as a difference (or a hang, caught by the test timeout)."""
+    from medicalseg_amd import _lib, models, nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd import parallel
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    d = dev()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 1, 32, 32, 32)).astype(np.float32)
+    y = rng.integers(0, 3, (2, 32, 32, 32)).astype(np.int32)
+    outs, init = [], None
+    for mode in ("plain", "dp"):
+        if mode == "dp":
+            buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+            assert _lib.load().msk_dp_unique_id(buf) == 0, _lib.last_error(None)
+            d.set_option("dp_mode", dp_mode)
+            d.call("msk_dp_init", buf.raw, 0, 1)
+            nn.BatchNorm3D.force_collectives = True
+        try:
+            model = models.VNet(num_classes=3)
+            if init is None:
+                init = model.state_dict()
+            model.set_state_dict(init)
+            model.train()
+            model.set_dropout_masks({})     # (the mask stream is keyed by the step counter and the site ids: not comparable across models)
+            net = model if mode == "plain" else parallel.DataParallel(model, force=True, overlap=dp_mode != 0, bucket_bytes=4 << 20)
+            opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+            losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+            if mode == "dp":
+                d.prof_reset()
+                d.prof_enable(True)
+            for _ in range(2):
+                ll, _ = loss_computation(net(x), to_tensor(y), losses)
+                sum(ll).backward()
+                opt.step()
+                model.clear_gradients()
+            outs.append(model.state_dict())
+            if mode == "dp":
+                d.sync()
+                d.prof_enable(False)
+                rep = d.prof_report()
+                assert rep["rccl_allgather"][0] == 48 and rep["rccl_allreduce_stats"][0] == 48, rep
+        finally:
+            if mode == "dp":
+                nn.BatchNorm3D.force_collectives = False
+                d.call("msk_dp_destroy")
+                d.set_option("dp_mode", 1)
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("dp_mode", [1, 2])
 @pytest.mark.parametrize("model_name", ["VNet", "VNetDeepSup"])
 def test_overlapped_gradient_buckets_world1(model_name, dp_mode):
