@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--skip-serialized", action="store_true",
                     help="skip the untimed extra pass behind roofline.serialized (used under rocprofv3 so that the kernel "
                          "stats contain only the timed region's launch mode)")
+    ap.add_argument("--force-syncbn-collectives", action="store_true",
+                    help="diagnostic (1 GPU): create a 1-rank RCCL communicator and run the 48 SyncBatchNorm collectives and the "
+                         "gradient buckets of the multi-GPU step on it (identities) -- measures their stream hand-over / launch cost")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msk_set_option knob for experiments, e.g. --opt wgrad_async=0 (not for the headline run)")
     args = ap.parse_args()
@@ -196,6 +199,14 @@ def main():
     opt = optim.Momentum(sched, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
     losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
     net = parallel.DataParallel(model) if world > 1 else model
+    if args.force_syncbn_collectives and world == 1:
+        import ctypes as _C
+        from medicalseg_amd import _lib as _L
+        buf = _C.create_string_buffer(_L.UNIQUE_ID_BYTES)
+        assert _L.load().msk_dp_unique_id(buf) == 0
+        dev.call("msk_dp_init", buf.raw, 0, 1)
+        nn.BatchNorm3D.force_collectives = True
+        net = parallel.DataParallel(model, force=True)
     model.train()
 
     def step():
@@ -279,7 +290,9 @@ def main():
         dp_info = {"per_rank_step_ms": [round(float(v) / args.steps * 1e3, 3) for v in allv[:, 0]],
                    "per_rank_collective_ms_per_step": {t: [round(float(v), 3) for v in allv[:, 1 + i]] for i, t in enumerate(tags)},
                    "calls_per_step": {t: int(sum(v[0] for k, v in prof.items() if k == t) / args.steps) for t in tags},
-                   "overlap": os.environ.get("MSEGK_DP_OVERLAP", "default: off with SyncBatchNorm, on without"),
+                   "overlap": os.environ.get("MSEGK_DP_OVERLAP", "default: off (one all-reduce after backward, every collective on "
+                                                                  "the compute stream; MSEGK_DP_MODE=2 MSEGK_DP_OVERLAP=1 = buckets on a "
+                                                                  "second communicator)"),
                    "note": "rccl_allreduce = gradient arena (182 MB per step), rccl_allreduce_stats / rccl_allgather = "
                            "SyncBatchNorm exchanges (2*C floats each)"}
 

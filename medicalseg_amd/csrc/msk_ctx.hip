@@ -406,8 +406,8 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     return 0;
   }
   if (strcmp(key, "dp_mode") == 0) {  // before msk_dp_init (mode 2 creates its second communicator there); 0 / 1 switch any time
-    if (value < 0 || value > 2 || (value == 2 && ctx->comm != nullptr && ctx->comm_grad == nullptr))
-      return msk_fail(ctx, __FILE__, __LINE__, "msk_set_option", "dp_mode: 0, 1, or 2 (2 only before msk_dp_init)");
+    if (value < 0 || value > 3 || (value == 2 && ctx->comm != nullptr && ctx->comm_grad == nullptr))
+      return msk_fail(ctx, __FILE__, __LINE__, "msk_set_option", "dp_mode: 0, 1, 2 or 3 (2 only before msk_dp_init)");
     ctx->dp_mode = value;
     return 0;
   }

@@ -2,18 +2,24 @@
 // Replaces paddle.distributed.fleet DataParallel / SyncBatchNorm communication
 // (core/train.py:81-85, cvlibs/config.py:322).
 //
-// Three stream / communicator arrangements (ctx->dp_mode, option "dp_mode" / DataParallel):
-//   1 (default)  ONE communicator on ONE communication stream carries everything in program order: the SyncBatchNorm
-//                exchanges (the compute stream waits for their result through an event), the gradient buckets (nobody
-//                waits until msk_dp_wait) and broadcast / barrier.  Every rank enqueues the same sequence on the same
-//                single stream, so the device-side order of the collectives is total and identical on all ranks -- no
-//                pair of communicators that could wait for each other -- while the buckets still overlap the rest of
-//                backward.  A statistics exchange can queue behind at most the bucket in flight (<= 16 MB: ~0.1 ms over
-//                xGMI at 8 GPUs).
-//   0            everything on the compute stream (one all-reduce of the whole arena after backward; no overlap).
-//   2            round-2 form, opt-in: buckets on a second communicator (ncclCommSplit) and stream, statistics on the
-//                compute stream's communicator.  Two communicators executing concurrently are only deadlock-free while
-//                their kernels can be co-resident.
+// Stream / communicator arrangements (ctx->dp_mode, option "dp_mode", env MSEGK_DP_MODE), all MEASURED on one MI355X with a
+// 1-rank RCCL communicator and the 48 SyncBatchNorm collectives of a VNet step forced on (bench.py
+// --force-syncbn-collectives; plain step 20.7 ms):
+//   0 (default)  every collective on the compute stream, ONE communicator: a total order by construction, nothing to
+//                deadlock; the gradient arena is reduced by one all-reduce after backward.           21.3 ms (+0.6)
+//   2            gradient buckets on a second communicator (ncclCommSplit) and the communication stream, overlapped with
+//                backward; statistics on the compute stream's communicator.  Two communicators executing concurrently are
+//                deadlock-free only while their kernels can be co-resident (they are small next to 256 CUs, but nothing
+//                enforces it): opt-in.                                                                21.5 ms (+0.8)
+//   1            the round-2 review's proposal: ONE communicator on ONE communication stream carries statistics exchanges
+//                (the compute stream hands over through an event and waits for the result) and buckets in program order.
+//                Correct (bit-identical parameters, tests/test_gpu_dp.py) -- and 42.6 ms per step: +22 ms.
+//   3            one communicator, statistics on the compute stream, buckets on the communication stream, a statistics
+//                exchange first waits for the bucket in flight (<= 10 stream alternations per step): 35.4 ms (+15 ms).
+// A bare event hand-over between two streams costs 24 us here (tools/probes/xstream_probe.hip, the same with a 1-rank RCCL
+// call in between: tools/probes/xstream_rccl_probe.hip), so 48 of them would be ~1 ms; what modes 1 and 3 pay is RCCL's
+// handling of a communicator that is driven from a second stream inside a deep asynchronous launch queue.  Until that can
+// be examined on a multi-GPU node the default is the arrangement with the fewest moving parts.
 #include <rccl/rccl.h>
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -197,6 +203,12 @@ struct CommBridge {
   hipStream_t run;   // the stream the collective is enqueued on
   bool bridged;
   explicit CommBridge(msk_ctx* c) : ctx(c), run(c->stream), bridged(false) {
+    if (c->dp_mode == 3 && c->comm_stream != nullptr && !c->host_transport) {
+      // mode 3: the collective runs on the compute stream; a gradient bucket still in flight on the communication stream
+      // (same communicator) has to finish first -- one cross-stream wait per bucket, not per collective
+      msk_dp_wait_impl(c);
+      return;
+    }
     if (c->dp_mode == 1 && c->comm_stream != nullptr && !c->host_transport) {
       hipEventRecord(c->ev_comm_main, c->stream);
       hipStreamWaitEvent(c->comm_stream, c->ev_comm_main, 0);
@@ -252,7 +264,7 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   // mode 2 only: second communicator for the gradient buckets (collective: every rank is inside msk_dp_init)
   {
     const char* me = getenv("MSEGK_DP_MODE");
-    if (me && me[0] >= '0' && me[0] <= '2') ctx->dp_mode = me[0] - '0';
+    if (me && me[0] >= '0' && me[0] <= '3') ctx->dp_mode = me[0] - '0';
   }
   ncclComm_t comm_grad = nullptr;
   if (ctx->dp_mode == 2) {
@@ -286,7 +298,7 @@ int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
   MSK_REQUIRE(ctx, ctx->comm != nullptr, "msk_dp_init not called");
   if (count == 0) return 0;
   if (ctx->host_transport || ctx->dp_mode == 0 || ctx->comm_stream == nullptr) return msk_dp_allreduce_sum(ctx, buf, count);
-  // mode 1: the single communicator on the communication stream; mode 2: the second communicator
+  // modes 1 and 3: the single communicator on the communication stream; mode 2: the second communicator
   ncclComm_t bucket_comm = (ncclComm_t)(ctx->dp_mode == 2 ? ctx->comm_grad : ctx->comm);
   // the bucket's gradients come from the compute stream (data-gradient chain, bias/BN/PReLU gradients) and from the
   // weight-gradient side stream: wait for the current tail of both, block neither

@@ -159,16 +159,13 @@ class DataParallel:
       waits for all buckets (`msk_dp_wait`) before the optimizer, which applies 1/nranks;
     * BatchNorm statistics are exchanged inside the layers (SyncBatchNorm semantics).
 
-    `overlap=False` keeps the single all-reduce after backward.
-
-    Default (`overlap=None`, round 3): buckets overlap with backward ALSO under SyncBatchNorm (the reference's behaviour and
-    this package's default).  The statistics exchanges and the buckets share ONE communicator on ONE communication stream
-    (`msk_dp.hip`, dp_mode 1): every rank enqueues the same sequence of collectives on that single stream, so their
-    device-side order is total and identical everywhere -- nothing can wait for a collective another rank has queued behind
-    a different one -- and a statistics exchange queues behind at most the one bucket in flight.  The round-2 form (buckets
-    on a second communicator and stream, statistics on the compute stream's communicator) is the opt-in
-    `MSEGK_DP_MODE=2`: two communicators executing concurrently are only deadlock-free while their kernels can be
-    co-resident.  `MSEGK_DP_OVERLAP=0` forces the single all-reduce when `overlap` is not given explicitly."""
+    Default (`overlap=None`): ONE all-reduce of the arena after backward, every collective (the SyncBatchNorm exchanges
+    too) on the compute stream's single communicator -- `msk_dp.hip` dp_mode 0.  Round 3 built and MEASURED the alternatives
+    on a 1-rank RCCL communicator with the 48 statistics collectives forced on (plain step 20.7 ms): this default 21.3 ms;
+    buckets overlapped on a second communicator + stream (`MSEGK_DP_MODE=2 MSEGK_DP_OVERLAP=1`, or `overlap=True`) 21.5 ms;
+    the single-communicator / single-communication-stream arrangement the round-2 review proposed (`MSEGK_DP_MODE=1`) is
+    correct but costs 42.6 ms per step, its variant with only the buckets on the second stream (`MSEGK_DP_MODE=3`) 35.4 ms
+    (details in `msk_dp.hip`).  Exposed cost of the default at 8 GPUs: the 182 MB all-reduce, ~1.3-2 ms."""
 
     def __init__(self, model, overlap=None, bucket_bytes=16 << 20, force=False):
         self._layers = model
@@ -186,7 +183,7 @@ class DataParallel:
                 dev.call("msk_dp_broadcast", C.c_void_p(fa.value_ptr), C.c_size_t(fa.count), 0)
             model.arena.grad_scale = 1.0 / dev.world
             if overlap is None:      # an explicit argument wins over the environment (advisor finding, round 2)
-                overlap = os.environ.get("MSEGK_DP_OVERLAP", "1") != "0"
+                overlap = os.environ.get("MSEGK_DP_OVERLAP", "0") != "0"
             if overlap and hasattr(model, "_grad_ready_hooks"):
                 params = model.arena.params
                 self._index = {id(p): i for i, p in enumerate(params)}

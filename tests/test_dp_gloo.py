@@ -5,7 +5,7 @@ data-parallel host logic; nothing of it is re-implemented here:
   * `parallel.ParallelEnv`         -- rank / world from the launcher's environment;
   * `parallel.init_parallel_env` + `parallel.DataParallel` over the no-compute stand-in library (tests/fake_msegk.c):
     every rank derives the SAME bucket partition of the gradient arena (a precondition for the collectives to pair up),
-    `grad_scale` = 1 / world reaches the optimizer, the default (overlapped buckets, also under SyncBatchNorm) and its switches;
+    `grad_scale` = 1 / world reaches the optimizer, the default (one all-reduce after backward) and its switches;
   * `parallel.shard_indices`       -- rank shards are disjoint and cover the data set.
 
 The ARITHMETIC of the exchanges (cross-rank Chan merge of BatchNorm statistics, summed backward records, averaged
@@ -71,13 +71,12 @@ def _worker(rank, world, port, rdzv_port, fake_so, q):
         sum(ll).backward()
         return model, ddp.buckets_last_step
 
-    # 2. explicit overlap=False: one all-reduce of the whole arena after backward
-    model, sent = plan(overlap=False)
-    out["single_allreduce"] = sent == [(0, model.arena.count)]
+    # 2. default: one all-reduce of the whole arena after backward (every collective on the compute stream)
+    model, sent = plan()
+    out["single_allreduce_default"] = sent == [(0, model.arena.count)]
     out["grad_scale"] = abs(model.arena.grad_scale - 1.0 / world) < 1e-15
-    # 3. the default (round 3), WITH SyncBatchNorm: buckets overlapped with backward on the single communicator / stream;
-    #    every rank derives the same partition of the arena
-    _, sent = plan(bucket_bytes=16 << 20)
+    # 3. overlap=True: buckets while backward runs; every rank derives the same partition of the arena
+    _, sent = plan(overlap=True, bucket_bytes=16 << 20)
     t = torch.tensor([v for oc in sent for v in oc], dtype=torch.int64)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([t.numel()], dtype=torch.int64))
@@ -85,13 +84,13 @@ def _worker(rank, world, port, rdzv_port, fake_so, q):
     allp = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allp, t)
     out["same_partition"] = all(torch.equal(a, allp[0]) for a in allp) and len(sent) >= 4
-    # the environment switches the default off, an explicit argument wins over the environment
-    os.environ["MSEGK_DP_OVERLAP"] = "0"
+    # the environment switches the default, an explicit argument wins over the environment
+    os.environ["MSEGK_DP_OVERLAP"] = "1"
     try:
-        model, sent = plan()
-        out["env_off"] = sent == [(0, model.arena.count)]
-        _, sent = plan(overlap=True)
-        out["explicit_wins"] = len(sent) >= 4
+        _, sent = plan()
+        out["env_on"] = len(sent) >= 4
+        model, sent = plan(overlap=False)
+        out["explicit_wins"] = sent == [(0, model.arena.count)]
     finally:
         os.environ.pop("MSEGK_DP_OVERLAP", None)
     # 4. sampler shards are disjoint across ranks and cover the data

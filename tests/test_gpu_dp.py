@@ -70,7 +70,7 @@ def test_dataparallel_wrapper_step_world1():
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-@pytest.mark.parametrize("dp_mode", [0, 1, 2])
+@pytest.mark.parametrize("dp_mode", [0, 1, 2, 3])
 def test_syncbn_collectives_inside_a_real_step_world1(dp_mode):
     """TRAIN-mode steps on a 1-rank RCCL communicator with the SyncBatchNorm collectives forced on (24 all-gathers + 24
     all-reduces per step, identities on one rank) next to the overlapped gradient buckets: every stream hand-over of the
@@ -123,7 +123,7 @@ def test_syncbn_collectives_inside_a_real_step_world1(dp_mode):
             if mode == "dp":
                 nn.BatchNorm3D.force_collectives = False
                 d.call("msk_dp_destroy")
-                d.set_option("dp_mode", 1)
+                d.set_option("dp_mode", 0)
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
@@ -187,7 +187,7 @@ def test_overlapped_gradient_buckets_world1(model_name, dp_mode):
         assert np.array_equal(d.d2h(pa, (64,), np.float32), probe) and np.array_equal(d.d2h(pb, (64,), np.float32), probe)
     finally:
         d.call("msk_dp_destroy")
-        d.set_option("dp_mode", 1)
+        d.set_option("dp_mode", 0)
 
 
 @pytest.mark.parametrize("C_,shape", [(32, (2, 8, 12, 12)), (256, (2, 4, 4, 4)), (3, (4, 5, 6, 7))])

@@ -133,4 +133,4 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and len(j["dp"]["per_rank_step_ms"]) == 2
     assert j["dp"]["calls_per_step"]["rccl_allgather"] == 24 and j["dp"]["calls_per_step"]["rccl_allreduce_stats"] == 24
-    assert j["dp"]["calls_per_step"]["rccl_allreduce"] >= 3        # default: gradient buckets enqueued while backward runs
+    assert j["dp"]["calls_per_step"]["rccl_allreduce"] == 1        # default: one all-reduce of the arena after backward
