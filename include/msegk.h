@@ -428,11 +428,14 @@ int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);   /* joins the
 /* SyncBatchNorm backward sums (2*C floats, produced on the main stream): same reduction WITHOUT the join,
  * so the 24 per-step statistics exchanges do not serialise the side stream */
 int msk_dp_allreduce_stats(msk_ctx* ctx, float* buf, size_t count);
-/* Gradient buckets, overlapped with the rest of backward (the Paddle reducer's role behind core/train.py:82-85):
- * the sum is enqueued on the context's COMMUNICATION stream with its own communicator (ncclCommSplit of the first,
- * so it never queues behind the SyncBatchNorm exchanges of the compute stream); it starts after everything enqueued so
- * far on the compute and weight-gradient streams and does not block either.  msk_dp_wait makes the compute stream
- * wait for all outstanding buckets (call it before the optimizer); msk_sync implies it. */
+/* Gradient buckets (the Paddle reducer's role behind core/train.py:82-85).  Where the sum runs depends on the arrangement
+ * chosen with msk_set_option(ctx, "dp_mode", m) / env MSEGK_DP_MODE before msk_dp_init (measurements: msk_dp.hip):
+ *   0 (default) on the compute stream, like msk_dp_allreduce_sum -- callers then send the whole buffer once after backward;
+ *   2           on the context's COMMUNICATION stream with its own communicator (ncclCommSplit of the first): it starts after
+ *               everything enqueued so far on the compute and weight-gradient streams, blocks neither, and never queues
+ *               behind the SyncBatchNorm exchanges of the compute stream;
+ *   1 / 3       on the communication stream with the one communicator (1: the statistics exchanges run there too).
+ * msk_dp_wait makes the compute stream wait for all outstanding buckets (call it before the optimizer); msk_sync implies it. */
 int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count);
 int msk_dp_wait(msk_ctx* ctx);
 int msk_dp_allgather(msk_ctx* ctx, const float* send, float* recv, size_t count_per_rank);
