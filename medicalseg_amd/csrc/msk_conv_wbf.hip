@@ -243,6 +243,7 @@ wbf_tin_k(WbfTinArgs a) {
   // lane mapping (A/B, option "wbf_tin_map"): 0 = 4 channel groups fastest (reads: full 128-byte lines per 4 lanes;
   // stores: 4 runs of 256 B per wavefront), 1 = one channel group per wavefront (stores: one 1 KiB run; reads: 32 of
   // every 128 bytes per lane, the rest of the line goes to the block's other wavefronts through L1/L2)
+  if (a.amax_copy && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kWbfAmaxWays) a.amax_copy[threadIdx.x] = a.amax[threadIdx.x];
   const int cgl = a.lane_map ? (threadIdx.x >> 6) : (threadIdx.x & 3), pl = a.lane_map ? (threadIdx.x & 63) : (threadIdx.x >> 2);
   const int ncgb = a.CK >> 5;
   const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
@@ -1501,10 +1502,10 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     else if (g.in_amax) in_amax = g.in_amax;
     else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
     if (!in_amax) return -1;
-    // the kept transform's header carries the maximum it was scaled by (the weight gradient undoes it)
-    if (g.xform && !g.fuse && in_amax != (const float*)g.xform)
-      MSK_CHECK_HIP(ctx, hipMemcpyAsync(g.xform, in_amax, kWbfAmaxWays * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
+  // the kept transform's header carries the maximum it was scaled by (the weight gradient undoes it): copied by the input
+  // transform kernel when it arrived in another array
+  float* hdr_copy = (NP != 3 && g.xform && !g.fuse && in_amax != (const float*)g.xform) ? (float*)g.xform : nullptr;
 
   {
     WbfTinArgs ta{};
@@ -1513,6 +1514,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CK; ta.KC = KC;
     ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
     ta.amax = in_amax;
+    ta.amax_copy = hdr_copy;
     if (g.fuse) {
       if (msk_wbf_transform_dual(ctx, K, NP, ta, *g.fuse, true) != 0) return -1;
       // one-kernel form: the weight gradient (side stream) may start as soon as both transforms are written: fork here,

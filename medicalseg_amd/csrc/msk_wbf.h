@@ -103,6 +103,7 @@ struct WbfTinArgs {
   long v_xi;  // bytes between xi planes
   int lane_map;
   const float* amax;  // NP = 2: device scalar, (bound of) max |value| of the source tensor -> wbf_scale_of; NULL = unscaled
+  float* amax_copy;   // non-null: block 0 copies the amax array there (the header of a kept transform) -- no memcpy command
 };
 // K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
 int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& a);
