@@ -153,6 +153,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode fails on hosts whose
+    # driver only supports dmabuf ("hipIpcGetMemHandle: invalid argument").  Must be in the environment before the HIP
+    # runtime initialises, i.e. before the library is loaded; an explicit setting wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not os.path.exists(LIB_PATH):
         raise MskError(
             f"{LIB_PATH} is missing: build it with ./build.sh (or __graft_entry__.build()). "
