@@ -10,6 +10,7 @@
 //   * a lane ends up with 4 consecutive output channels of one voxel: a wavefront's store covers 16 voxels x 64 B = 1 KiB
 //     of contiguous output.
 #include "msk_conv.h"
+#include "msk_wbf.h"   // msk_bn_stats_merge
 
 namespace {
 
@@ -27,7 +28,22 @@ struct C1Args {
   int flip;
   int tiles_d, tiles_h, tiles_w, ntiles;
   unsigned src_bytes;
+  float* stat_partial;  // non-null: BatchNorm records [gridDim.x][CN][3] = (n, mean, M2) of the stored values (msk_conv3d_fwd_ex)
 };
+
+struct C1Rec {
+  float n, mean, m2;
+};
+__device__ __forceinline__ C1Rec c1rec_merge(C1Rec a, C1Rec b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  C1Rec r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean, f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
 
 __global__ void __launch_bounds__(256)
 conv_c1_mfma_k(C1Args a) {
@@ -57,6 +73,10 @@ conv_c1_mfma_k(C1Args a) {
   float bq[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bq[j] = (a.bias && cq + j < a.CN) ? a.bias[cq + j] : 0.f;
+
+  // BatchNorm statistics of the stored values (in_tr: conv -> BatchNorm, vnet.py:70,74): shifted sums per lane over ALL the
+  // voxels it stores (the workgroup is persistent), merged once at the end -- saves a 268 MB read of y per step
+  float sk[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, cnt = 0.f;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int t_ = tile;
@@ -106,6 +126,19 @@ conv_c1_mfma_k(C1Args a) {
             if (gw < a.W) {
               float* o = a.dst + (rowv + gw) * a.dld + cq;
               const f32x4 v = c == 0 ? acc0 : acc1;
+              if (a.stat_partial) {
+                if (cnt == 0.f) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) sk[j] = v[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float dl = v[j] - sk[j];
+                  s1[j] += dl;
+                  s2[j] = fmaf(dl, dl, s2[j]);
+                }
+                cnt += 1.f;
+              }
               if (cq + 3 < a.CN) {
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
               } else {
@@ -117,6 +150,43 @@ conv_c1_mfma_k(C1Args a) {
           }
         }
       }
+    }
+  }
+  if (a.stat_partial) {
+    __shared__ float shr[4][16][3];
+    C1Rec r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = C1Rec{0.f, 0.f, 0.f};
+      if (cnt > 0.f) {
+        r[j].n = cnt;
+        r[j].mean = sk[j] + s1[j] / cnt;
+        r[j].m2 = fmaxf(s2[j] - s1[j] * s1[j] / cnt, 0.f);
+      }
+      // the 16 lanes li of a quad group hold the same four channels: fixed butterfly order
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        C1Rec q;
+        q.n = __shfl_xor(r[j].n, o, 64);
+        q.mean = __shfl_xor(r[j].mean, o, 64);
+        q.m2 = __shfl_xor(r[j].m2, o, 64);
+        r[j] = (li & o) ? c1rec_merge(q, r[j]) : c1rec_merge(r[j], q);   // both partners merge (lower, upper)
+      }
+    }
+    __syncthreads();
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        shr[wave][cq + j][0] = r[j].n; shr[wave][cq + j][1] = r[j].mean; shr[wave][cq + j][2] = r[j].m2;
+      }
+    }
+    __syncthreads();
+    if (tid < a.CN) {
+      C1Rec t = {shr[0][tid][0], shr[0][tid][1], shr[0][tid][2]};
+#pragma unroll
+      for (int w = 1; w < 4; ++w) t = c1rec_merge(t, C1Rec{shr[w][tid][0], shr[w][tid][1], shr[w][tid][2]});
+      float* o = a.stat_partial + ((long)blockIdx.x * a.CN + tid) * 3;
+      o[0] = t.n; o[1] = t.mean; o[2] = t.m2;
     }
   }
 }
@@ -151,8 +221,19 @@ int msk_gconv_c1_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A,
     snprintf(buf, sizeof(buf), "conv_c1_mfma[cn=%d,n=%d,dhw=%dx%dx%d]", g.CN, g.N, g.DD, g.DH, g.DW);
     tag = msk_intern_tag(ctx, buf);
   }
-  msk_launch_scope ls(ctx, tag);
-  hipLaunchKernelGGL(conv_c1_mfma_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-  MSK_LAUNCH_CHECK(ctx);
+  const bool want_stats = g.stats != nullptr && !g.prelu && g.CN == 16;   // (all four channel quads live: the LDS record table is full)
+  if (want_stats) {
+    a.stat_partial = (float*)msk_workspace(ctx, (size_t)blocks * g.CN * 3 * sizeof(float));
+    if (!a.stat_partial) return -1;
+  }
+  {
+    msk_launch_scope ls(ctx, tag);
+    hipLaunchKernelGGL(conv_c1_mfma_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+    MSK_LAUNCH_CHECK(ctx);
+  }
+  if (want_stats) {
+    if (msk_bn_stats_merge(ctx, a.stat_partial, (int)blocks, g.CN, g.stats, g.fin) != 0) return -1;
+    ctx->stats_fused = true;
+  }
   return 1;
 }

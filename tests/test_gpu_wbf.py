@@ -178,7 +178,7 @@ def test_wbf_wgrad_matches_oracle(case):
 
 
 @pytest.mark.parametrize("case", [(32, 32, (2, 16, 32, 16)), (64, 128, (1, 8, 16, 8)), (32, 64, (1, 14, 30, 8)),
-                                  (16, 16, (1, 8, 8, 8))])
+                                  (16, 16, (1, 8, 8, 8)), (1, 16, (2, 9, 20, 40))])   # last: in_tr.conv1, statistics in conv_c1_mfma_k's epilogue (ragged tiles)
 def test_conv3d_fwd_ex_stats_and_kept_transform(case):
     """msk_conv3d_fwd_ex: (a) the BatchNorm statistics record taken in the output transform equals msk_bn_stats of the
     stored y (float64 oracle: mean / M2 of y_ref); (b) the transformed input it leaves in the caller's buffer gives the
