@@ -34,6 +34,8 @@ def main():
             "bn_stats (1 read)": (1, lambda: dev.call("msk_bn_stats", x.msk(), vp(stats))),
             "affine_act_fwd (1r+1w)": (2, lambda: dev.call("msk_affine_act_fwd", x.msk(), vp(scale), vp(shift), NULL_TENSOR,
                                                           vp(alpha), dx.msk())),
+            "affine_act_fwd + amax": (2, lambda: dev.call("msk_affine_act_fwd_amax", x.msk(), vp(scale), vp(shift), NULL_TENSOR,
+                                                         vp(alpha), dx.msk(), vp(stats))),
             "bwd_reduce (2r)": (2, lambda: dev.call("msk_affine_act_bwd_reduce", x.msk(), vp(scale), vp(shift), NULL_TENSOR,
                                                    vp(alpha), vp(mean), vp(invstd), dout.msk(), vp(sums))),
             "bwd_apply (2r+1w)": (3, lambda: dev.call("msk_affine_act_bwd_apply", x.msk(), vp(scale), vp(shift), NULL_TENSOR,
