@@ -858,3 +858,74 @@ def test_wbf_fp16_split_quiet_channels_in_the_weight_gradient(log2_range):
         assert e["fp16x2"][i] < bound, (i, e, bound)
         if log2_range <= 13:
             assert e["fp16x2"][i] < tol
+
+
+@pytest.mark.parametrize("case", [(32, 32, (2, 16, 32, 16)), (1, 16, (1, 12, 16, 32)), (16, 32, (1, 8, 8, 8))])
+def test_fwd_ex3_finalisation_in_the_merge_is_bitwise_the_two_call_form(case):
+    """msk_conv3d_fwd_ex3(fin) == msk_conv3d_fwd_ex2 + msk_bn_finalize(world 1): same statistics record, and bit-identical
+    mean / invstd / scale / shift / running statistics (the claim of include/msegk.h); the third case takes its statistics
+    from msk_bn_stats_fin (no epilogue statistics for that kernel)."""
+    import ctypes as C
+    from medicalseg_amd._lib import MskBnFin
+    cin, cout, (N, D, H, W) = case
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", 2)
+    rng = np.random.default_rng(cin + 3 * cout)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 2.0, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    xt, wp, bp, gp, bep = t_from_ncdhw(x), vec(w.ravel()), vec(b), vec(gamma), vec(beta)
+    cd = _desc(k, s_, p)
+    M = float(N * D * H * W)
+    res = []
+    for fused in (0, 1):
+        yt = t_empty(N, cout, D, H, W, fill=7.0)
+        bufs = {n_: vec(np.full(cout, 3.0 if n_ in ("rm", "rv") else 9.0, np.float32)) for n_ in ("rm", "rv", "mean", "invstd", "scale", "shift")}
+        stats = vec(np.zeros(2 * cout, np.float32))
+        if fused:
+            fin = MskBnFin(gp, bep, 1e-5, 0.9, M, bufs["rm"], bufs["rv"], bufs["mean"], bufs["invstd"], bufs["scale"], bufs["shift"])
+            d.call("msk_conv3d_fwd_ex3", cd, xt.msk(), vp(wp), vp(bp), yt.msk(), vp(stats), None, None, C.byref(fin))
+        else:
+            d.call("msk_conv3d_fwd_ex2", cd, xt.msk(), vp(wp), vp(bp), yt.msk(), vp(stats), None, None)
+            d.call("msk_bn_finalize", vp(stats), 1, C.c_double(M), cout, vp(gp), vp(bep), C.c_float(1e-5), C.c_float(0.9),
+                   vp(bufs["rm"]), vp(bufs["rv"]), vp(bufs["mean"]), vp(bufs["invstd"]), vp(bufs["scale"]), vp(bufs["shift"]))
+        res.append({n_: vec_back(p_, cout) for n_, p_ in bufs.items()} | {"stats": vec_back(stats, 2 * cout), "y": t_to_ncdhw(yt)})
+    for n_ in res[0]:
+        assert np.array_equal(res[0][n_], res[1][n_]), n_
+    yc = np.moveaxis(res[1]["y"].astype(np.float64), 1, 0).reshape(cout, -1)
+    np.testing.assert_allclose(res[1]["mean"], yc.mean(1), rtol=0, atol=3e-6 * np.abs(yc).max())
+    np.testing.assert_allclose(res[1]["rv"], 0.9 * 3.0 + 0.1 * yc.var(1), rtol=2e-5)
+
+
+def test_bwd_reduce_pg_is_bitwise_reduce_plus_param_grads():
+    """msk_affine_act_bwd_reduce_pg == msk_affine_act_bwd_reduce_ex + msk_affine_act_param_grads (accumulating), maxes from the
+    zeroed ring arrays instead of a memset."""
+    import ctypes as C
+    from medicalseg_amd._lib import NULL_TENSOR
+    c, (N, D, H, W) = 32, (2, 8, 16, 16)
+    d = dev()
+    rng = np.random.default_rng(9)
+    mk = lambda: t_from_ncdhw(rng.standard_normal((N, c, D, H, W)).astype(np.float32))
+    x, dout = mk(), mk()
+    v = lambda lo=0.5, hi=1.5: vec(rng.uniform(lo, hi, c).astype(np.float32))
+    scale, shift, alpha, mean, invstd = v(), v(-0.5, 0.5), v(0.1, 0.4), v(-0.2, 0.2), v()
+    outs = []
+    for pg in (0, 1):
+        sums = vec(np.zeros(4 * c, np.float32))
+        grads = [vec(np.full(c, 2.0, np.float32)) for _ in range(3)]        # dgamma, dbeta, dalpha start at 2: accumulate
+        if pg:
+            maxes = d.amax_new(2)
+            d.call("msk_affine_act_bwd_reduce_pg", x.msk(), vp(scale), vp(shift), NULL_TENSOR, vp(alpha), vp(mean), vp(invstd),
+                   dout.msk(), vp(sums), vp(maxes), 0, vp(grads[0]), vp(grads[1]), vp(grads[2]))
+        else:
+            maxes = vec(np.full(128, 5.0, np.float32))                       # stale contents: the _ex form clears them
+            d.call("msk_affine_act_bwd_reduce_ex", x.msk(), vp(scale), vp(shift), NULL_TENSOR, vp(alpha), vp(mean), vp(invstd),
+                   dout.msk(), vp(sums), vp(maxes))
+            d.call("msk_affine_act_param_grads", c, vp(sums), vp(grads[0]), vp(grads[1]), vp(grads[2]), 1)
+        mx = vec_back(maxes, 128)
+        outs.append([vec_back(sums, 3 * c)] + [vec_back(g, c) for g in grads] + [np.array([mx[:64].max(), mx[64:].max()])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[1][4][0] > 0 and np.abs(outs[1][1] - 2.0).max() > 1e-3
