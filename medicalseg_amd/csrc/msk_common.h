@@ -50,6 +50,7 @@ struct msk_ctx {
   bool no_winograd = false;  // env MSEGK_DIRECT_CONV=1 / option "direct_conv": direct kernels only (bit-exact fp32 fmaf chains)
   bool wbf = true;  // env MSEGK_WBF=0 / option "wino_bf3" 0: keep the fp32-MFMA Winograd kernels (exact-fp32 products)
   bool stats_fused = false;  // set by a conv kernel that wrote GConv::stats itself
+  bool wgrad_db_done = false;  // set by a weight-gradient kernel that produced WGrad::db itself
   bool xform_written = false;  // set when GConv::xform was filled
   std::set<const void*> xform_ok;  // xform buffers msk_conv3d_fwd_ex* really filled: a buffer the pipeline declined (alignment, size limits) is ignored by the weight gradient instead of failing the forward pass (advisor, round 2)
   bool conv_fp16 = false;  // option "conv_fp16": 3x3x3 convolutions with fp16 matrix operands (UNet3D precision='fp16')

@@ -48,6 +48,8 @@ struct WGrad {
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;
+  float* db;   // bias gradient a kernel that reads the tensor anyway may produce (sets ctx->wgrad_db_done), or null
+  int db_src;  // 1: column sums of B (convolution), 2: sums of A over every tap (transposed convolution)
   // Winograd kernels only (filled by msk_wgrad_wino): BD/BH/BW are then LOGICAL dims, a permutation of the tensor's
   // axes, and a voxel's index is n*vsn + d*vsd + h*vsh + w*vsw
   long vsn;
@@ -105,5 +107,8 @@ const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels
 // n zeroed device scalars from the same ring (valid until ~1000 later requests)
 float* msk_scalar_slots(msk_ctx* ctx, int n);
 const float* msk_bn_bwd_bound(msk_ctx* ctx, int C, const float* scale, const float* sums, double M_total, const float* maxes);
+// slabs of `pitch` floats: taps*CA*CB sums in (tap, ca, cb) order followed by nbias bias sums (-> db[0..nbias))
+int msk_wgrad_reduce_ex(msk_ctx* ctx, const float* partial, int splits, long pitch, int taps, int CA, int CB, float* dw,
+                        int accumulate, int nbias, float* db, int db_accumulate);
 int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
                      int accumulate);

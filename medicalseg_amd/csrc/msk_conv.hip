@@ -665,12 +665,12 @@ int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int s
 // float4 variant (CB % 4 == 0): a lane owns 4 consecutive cb of one (tap, ca) row -> 1 KiB per wavefront load,
 // two slabs in flight per slice (the scalar version moved 256 B per load and reached ~1.6 TB/s)
 __global__ void __launch_bounds__(kThreads)
-wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int stride, int taps, int CA, int CB,
-                  float* __restrict__ dw, int accumulate) {
+wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int stride, long pitch, int taps, int CA, int CB,
+                  float* __restrict__ dw, int accumulate, int nbias, float* __restrict__ db, int db_accumulate) {
   __shared__ double sh[4][64][4];
-  const long per = (long)taps * CA * CB, per4 = (per >> 2) * stride;  // slab pitch in float4 (slab k at k*stride)
+  const long per = (long)taps * CA * CB, per4 = (pitch >> 2) * stride;  // slab pitch in float4 (slab k at k*stride)
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const long n4 = per >> 2;
+  const long n4 = pitch >> 2;   // the slab's tail (pitch - per floats) holds bias sums
   for (long base = (long)blockIdx.x * 64; base < n4; base += (long)gridDim.x * 64) {
     const long i4 = base + lane;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
@@ -695,15 +695,26 @@ wgrad_reduce_v4_k(const float* __restrict__ partial, int splits, int stride, int
     __syncthreads();
     if (slice == 0 && i4 < n4) {
       const long idx = i4 << 2;  // = (tap*CA + ca)*CB + cb
-      const int cb = (int)(idx % CB);
-      const long r = idx / CB;
-      const int ca = (int)(r % CA);
-      const int tap = (int)(r / CA);
+      if (idx >= per) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double sum = (sh[0][lane][j] + sh[1][lane][j]) + (sh[2][lane][j] + sh[3][lane][j]);
-        float* o = dw + ((long)(cb + j) * CA + ca) * taps + tap;
-        *o = accumulate ? *o + (float)sum : (float)sum;
+        for (int j = 0; j < 4; ++j) {
+          const long b = idx - per + j;
+          if (b < nbias) {
+            const double sum = (sh[0][lane][j] + sh[1][lane][j]) + (sh[2][lane][j] + sh[3][lane][j]);
+            db[b] = db_accumulate ? db[b] + (float)sum : (float)sum;
+          }
+        }
+      } else {
+        const int cb = (int)(idx % CB);
+        const long r = idx / CB;
+        const int ca = (int)(r % CA);
+        const int tap = (int)(r / CA);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double sum = (sh[0][lane][j] + sh[1][lane][j]) + (sh[2][lane][j] + sh[3][lane][j]);
+          float* o = dw + ((long)(cb + j) * CA + ca) * taps + tap;
+          *o = accumulate ? *o + (float)sum : (float)sum;
+        }
       }
     }
     __syncthreads();
@@ -742,7 +753,14 @@ wgrad_prereduce_k(float* __restrict__ partial, int splits, int chunk, long per) 
 
 int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, int CA, int CB, float* dw,
                      int accumulate) {
-  const long per = (long)taps * CA * CB;
+  return msk_wgrad_reduce_ex(ctx, partial, splits, (long)taps * CA * CB, taps, CA, CB, dw, accumulate, 0, nullptr, 0);
+}
+
+int msk_wgrad_reduce_ex(msk_ctx* ctx, const float* partial, int splits, long pitch, int taps, int CA, int CB, float* dw,
+                        int accumulate, int nbias, float* db, int db_accumulate) {
+  const long per = pitch;   // floats every stage walks per slab (the bias tail included)
+  MSK_REQUIRE(ctx, pitch == (long)taps * CA * CB || (CB % 4 == 0 && pitch % 4 == 0 && (((uintptr_t)partial) & 15) == 0),
+              "msk_wgrad_reduce_ex: a bias tail needs the float4 reduction");
   msk_launch_scope ls(ctx, "wgrad_reduce");
   int stride = 1;
   {
@@ -762,8 +780,8 @@ int msk_wgrad_reduce(msk_ctx* ctx, const float* partial, int splits, int taps, i
   if (CB % 4 == 0 && (((uintptr_t)partial) & 15) == 0) {
     long rb = (per / 4 + 63) / 64;
     if (rb > (long)ctx->num_cu * 32) rb = (long)ctx->num_cu * 32;
-    hipLaunchKernelGGL(wgrad_reduce_v4_k, dim3((unsigned)rb), dim3(kThreads), 0, ctx->stream, partial, splits, stride, taps,
-                       CA, CB, dw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_v4_k, dim3((unsigned)rb), dim3(kThreads), 0, ctx->stream, partial, splits, stride, pitch, taps,
+                       CA, CB, dw, accumulate, nbias, db, db_accumulate);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
@@ -799,14 +817,26 @@ int run_gconv(msk_ctx* ctx, GConv g, const float* w, int A, int B, int swap, con
 }
 
 int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* db, int accumulate) {
-  if (db) {
-    if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
-  }
   const size_t aper = (size_t)g.AD * g.AH * g.AW * g.ald * sizeof(float), bper = (size_t)g.BD * g.BH * g.BW * g.bld * sizeof(float);
   const size_t per = aper > bper ? aper : bper;
   long nmax = per > 0 ? (long)(kChunkBytes / per) : g.N;
   if (nmax < 1) nmax = 1;
-  if (g.N <= nmax) return run_wgrad_one(ctx, g);
+  if (g.N <= nmax) {
+    // the bias gradient is a column sum of a tensor the weight-gradient kernel reads anyway: a kernel that can fold it in
+    // does (wgrad_db_done), otherwise the separate pass follows
+    WGrad gb = g;
+    if (db && (bias_src.p == g.A || bias_src.p == g.B)) {
+      gb.db = db;
+      gb.db_src = bias_src.p == g.B ? 1 : 2;
+    }
+    ctx->wgrad_db_done = false;
+    if (int rc = run_wgrad_one(ctx, gb)) return rc;
+    if (db && !ctx->wgrad_db_done) return msk_channel_sum(ctx, bias_src, db, accumulate) != 0 ? -1 : 0;
+    return 0;
+  }
+  if (db) {
+    if (msk_channel_sum(ctx, bias_src, db, accumulate) != 0) return -1;
+  }
   const int total = g.N;
   for (int n0 = 0; n0 < total; n0 += (int)nmax) {
     WGrad c = g;

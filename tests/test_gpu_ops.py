@@ -144,6 +144,66 @@ def test_convT3d_fwd_dgrad_wgrad(case, impl):
         d.set_option("conv_impl", 0)
 
 
+KS2_CASES = [
+    # (transposed, fine channels, coarse channels, k (= s), (N, coarse D, H, W), fine ld, coarse ld, bias folded into the kernel)
+    (0, 16, 32, (2, 2, 2), (2, 16, 16, 17), 16, 32, True),     # down conv 16 -> 32: one row group, bias = column sums of dy
+    (1, 16, 64, (2, 2, 2), (2, 16, 16, 17), 32, 64, True),     # up conv 64 -> 16 into a concat slice (ld 32): bias = sums of dy over the taps
+    (0, 32, 64, (2, 2, 2), (1, 16, 16, 16), 32, 64, True),     # two row groups share dy; the first one carries the bias
+    (1, 32, 128, (2, 2, 2), (1, 16, 16, 17), 64, 128, False),  # four row groups: a transposed conv's bias takes the separate pass
+    (0, 12, 40, (2, 2, 2), (1, 15, 17, 19), 12, 48, True),     # 96 rows (a dead row tile), ragged column tiles, odd dims
+    (1, 8, 20, (2, 2, 1), (2, 16, 16, 9), 8, 20, True),        # four taps, one 32-row tile, anisotropic
+    (0, 16, 32, (2, 2, 2), (1, 4, 16, 16), 16, 32, True),      # M = 1024 < 4096: the one-tap-per-tile kernel + channel sums
+]
+
+
+@pytest.mark.parametrize("case", KS2_CASES)
+def test_wgrad_ks2_fine_levels(case):
+    """Kernel == stride weight gradient with (tap, channel) rows (msk_wgrad_ks.hip, wgrad_ks2_k) and the bias gradient folded
+    into the same pass: against the float64 oracle, accumulate semantics, channel-slice strides, and which kernels ran."""
+    tr, cf, cc, k, (N, D, H, W), ldf, ldc, folded = case
+    d = dev()
+    rng = np.random.default_rng(cf * 1000 + cc + tr)
+    fD, fH, fW = D * k[0], H * k[1], W * k[2]
+    fine = rng.standard_normal((N, cf, fD, fH, fW)).astype(np.float32)
+    coarse = rng.standard_normal((N, cc, D, H, W)).astype(np.float32)
+    ft, ct = t_from_ncdhw(fine, ld=ldf), t_from_ncdhw(coarse, ld=ldc)
+    cd = _desc(k, k, (0, 0, 0))
+    taps = int(np.prod(k))
+    if tr:   # up conv: x = coarse (cc channels), dy = fine (cf channels); w [cc][cf][k]
+        dw_ref, db_ref = O.conv_transpose3d_wgrad(fine.astype(np.float64), coarse.astype(np.float64), k, k)
+        nw, nb, fn, args = cc * cf * taps, cf, "msk_convT3d_wgrad", (ct.msk(), ft.msk())
+    else:    # down conv: x = fine, dy = coarse; w [cc][cf][k]
+        dw_ref, db_ref = O.conv3d_wgrad(coarse.astype(np.float64), fine.astype(np.float64), k, k, (0, 0, 0))
+        nw, nb, fn, args = cc * cf * taps, cc, "msk_conv3d_wgrad", (ft.msk(), ct.msk())
+    M = N * D * H * W
+    d.set_option("wgrad_async", 0)
+    try:
+        dwp, dbp = vec(np.full(nw, 0.5, np.float32)), vec(np.full(nb, 0.25, np.float32))
+        d.prof_reset()
+        d.prof_enable(True)
+        d.call(fn, cd, *args, vp(dwp), vp(dbp), 0)
+        d.sync()
+        d.prof_enable(False)
+        tags = set(d.prof_report())
+        big = M >= 4096
+        assert ("wgrad_ks2_mfma" in tags) == big and ("wgrad_ks_mfma" in tags) == (not big), tags
+        assert ("channel_sum_partial" in tags) == (not (big and folded)), tags
+        tol = _conv_tol(M) * 2
+        assert rel_err(vec_back(dwp, nw).reshape(dw_ref.shape), dw_ref) < tol
+        assert rel_err(vec_back(dbp, nb), db_ref) < 1e-5 * np.sqrt(M * (taps if tr else 1) / 1000 + 1)
+        d.call(fn, cd, *args, vp(dwp), vp(dbp), 1)
+        assert rel_err(vec_back(dwp, nw).reshape(dw_ref.shape), 2 * dw_ref) < tol
+        assert rel_err(vec_back(dbp, nb), 2 * db_ref) < 1e-5 * np.sqrt(M * (taps if tr else 1) / 1000 + 1)
+        # the kernel it replaces gives the same sums up to fp32 summation order
+        d.set_option("conv_impl", 19)
+        dw2, db2 = vec(np.zeros(nw, np.float32)), vec(np.zeros(nb, np.float32))
+        d.call(fn, cd, *args, vp(dw2), vp(db2), 0)
+        assert rel_err(vec_back(dw2, nw).reshape(dw_ref.shape), dw_ref) < tol
+    finally:
+        d.set_option("conv_impl", 0)
+        d.set_option("wgrad_async", 1)
+
+
 def test_conv_strided_channel_slice():
     """Tensors that are channel slices of wider buffers (zero-copy concat) work for convs."""
     d = dev()
