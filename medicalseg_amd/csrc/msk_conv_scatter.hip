@@ -127,6 +127,122 @@ convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
   }
 }
 
+
+// ---- LDS-staged form ------------------------------------------------------------------------------------------------------
+// The kernel above reads and writes in MFMA-fragment shape: a lane owns a voxel, so a wavefront's 16-byte accesses land as
+// 32-byte runs on 32 different lines (x loads at a voxel stride, stores at two fine voxels' stride), and a wavefront's load,
+// MFMA and store phases follow each other.  Measured at 32 -> 16 @ 64^3 -> 128^3: 0.051 ms without the stores, 0.091 ms
+// without the loads, 0.116 ms together (335 MB: 2.9 TB/s).  Here a workgroup stages its 64 source voxels through LDS with
+// whole-line loads (16 B per lane, consecutive lanes consecutive addresses), takes the MFMA operand from LDS as
+// ds_read_b128 (voxel pitch = an odd number of 16-byte slots: conflict-free), and every wavefront owns whole 32-row tiles
+// (for 16 output channels: the two W-adjacent fine voxels of one (kd, kh)) whose results go through a private LDS patch and
+// leave as 1 KB contiguous stores -- the accumulate reads and the bias ride on the same coalesced pass.
+template <int TPW>  // 32-row tiles of (tap, cn) per wavefront
+__global__ void __launch_bounds__(256, TPW == 1 ? 4 : 3)
+convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
+  extern __shared__ float4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int XP = KC * 8 + 4;                       // floats per staged voxel: (XP / 4) odd
+  constexpr int OP = 36;                           // floats per voxel of a wavefront's output patch
+  float* Xs = smem;                                // [64][XP]
+  float* Os = smem + 64 * XP + wave * (32 * OP);   // [32][OP] per wavefront
+  unsigned* vbase = reinterpret_cast<unsigned*>(smem + 64 * XP + 4 * 32 * OP);  // [64] destination element offset of a source voxel
+  const long M = (long)g.N * g.SD * g.SH * g.SW;
+  const long m0 = (long)blockIdx.x * 64;
+
+  // stage x: 64 voxels x KC*8 channels (zero padded), 16 B per thread per pass
+  {
+    const int P4 = KC * 2;
+    const float* src = g.src + m0 * g.sld;
+    for (int idx = tid; idx < 64 * P4; idx += 256) {
+      const int v = idx / P4, p = idx - v * P4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + v < M && p * 4 < g.CK) val = *reinterpret_cast<const float4*>(src + (long)v * g.sld + p * 4);
+      *reinterpret_cast<float4*>(Xs + v * XP + p * 4) = val;
+    }
+    if (tid < 64) {
+      const long m = m0 + tid;
+      unsigned b = 0xFFFFFFFFu;
+      if (m < M) {
+        const unsigned r = (unsigned)m;
+        const unsigned t1 = r / (unsigned)g.SW, t2 = t1 / (unsigned)g.SH;
+        const unsigned w_ = r - t1 * (unsigned)g.SW, h_ = t1 - t2 * (unsigned)g.SH;
+        const unsigned n_ = t2 / (unsigned)g.SD, d_ = t2 - n_ * (unsigned)g.SD;
+        b = (((n_ * g.DD + d_ * g.sd) * g.DH + h_ * g.sh) * g.DW + w_ * g.sw) * g.dld;
+      }
+      vbase[tid] = b;
+    }
+  }
+  __syncthreads();
+
+  const int ntiles = jpad >> 5;
+  const int khw = g.kh * g.kw, rows = g.kd * khw * g.CN;
+#pragma unroll 1
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave * TPW + t;
+    if (tile >= ntiles) break;   // wave-uniform; no barrier below
+    f32x16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[h][j] = 0.f;
+    const float4* wl = bf + (long)lh * jpad + tile * 32 + li;
+    const float* x0 = Xs + li * XP + lh * 4;
+    for (int kc0 = 0; kc0 < KC; kc0 += 4) {
+      float4 w4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4[i] = kc0 + i < KC ? wl[(long)(kc0 + i) * 2 * jpad] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kc0 + i < KC) {  // wave-uniform
+          const float4 xa = *reinterpret_cast<const float4*>(x0 + (kc0 + i) * 8);
+          const float4 xb = *reinterpret_cast<const float4*>(x0 + 32 * XP + (kc0 + i) * 8);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].x, xa.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].x, xb.x, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].y, xa.y, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].y, xb.y, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].z, xa.z, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].z, xb.z, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].w, xa.w, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[i].w, xb.w, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    // this lane's quad of the tile in the store pass: rows tile*32 + 4*rq .. +3 = one tap, 4 consecutive output channels
+    const int rq = lane & 7, row = tile * 32 + rq * 4;
+    const bool rok = row < rows;
+    const int tap = rok ? row / g.CN : 0, cn = rok ? row - tap * g.CN : 0;
+    const int ta = tap / khw, tb = (tap - ta * khw) / g.kw, tc = tap - ta * khw - tb * g.kw;
+    const unsigned toff = ((unsigned)(ta * g.DH + tb) * g.DW + tc) * g.dld + cn;
+    const float4 bv = (g.bias && rok) ? *reinterpret_cast<const float4*>(g.bias + cn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // D[row][col = voxel li]: lane holds rows 8q + 4lh + {0..3}
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(Os + li * OP + 8 * q + 4 * lh) = make_float4(acc[h][4 * q], acc[h][4 * q + 1], acc[h][4 * q + 2], acc[h][4 * q + 3]);
+      // the patch is private to the wavefront: LDS operations of one wavefront complete in order
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = i * 8 + (lane >> 3);
+        const unsigned vb = vbase[h * 32 + v];
+        float4 o = *reinterpret_cast<const float4*>(Os + v * OP + rq * 4);
+        if (rok && vb != 0xFFFFFFFFu) {
+          float* dp = g.dst + (size_t)vb + toff;
+          o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+          if (g.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(dp);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+          }
+          *reinterpret_cast<float4*>(dp) = o;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap) {
@@ -144,7 +260,7 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   if (M >= (1L << 31) || dst_elems >= (1UL << 32)) return 0;  // 32-bit row arithmetic in the epilogue
   // deep levels (<= 16^3 sources) have too few 128-voxel tiles to fill 256 CUs: the parity-class kernel, which
   // also parallelises over the classes, measured faster there (0.08 vs 0.14 ms at 256->128 @ 8^3)
-  if (M < 16384 && ctx->conv_impl != 7) return 0;
+  if (M < 16384 && ctx->conv_impl != 7 && ctx->conv_impl != 22) return 0;
   const int KC = (g.CK + 7) / 8;
   const int jpad = ((taps * g.CN + 31) / 32) * 32;
   float4* bf = (float4*)msk_workspace2(ctx, (size_t)KC * 2 * jpad * sizeof(float4));
@@ -166,6 +282,17 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   }
   msk_launch_scope ls(ctx, tag);
   const int ntiles = jpad / 32;
+  // LDS-staged form: up to 16 row tiles (4 per wavefront), the staged voxels + patches within 64 KB; 22 = fragment-shaped kernel (A/B)
+  const size_t lds = ((size_t)64 * (KC * 8 + 4) + 4 * 32 * 36 + 64) * sizeof(float);
+  if (ntiles <= 16 && lds <= 65536 && (!g.bias || ((uintptr_t)g.bias) % 16 == 0) && ctx->conv_impl != 22) {
+    const dim3 grid((unsigned)((M + 63) / 64));
+    const int tpw = (ntiles + 3) / 4;
+    if (tpw <= 1) hipLaunchKernelGGL((convT_scatter_lds_k<1>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
+    else if (tpw == 2) hipLaunchKernelGGL((convT_scatter_lds_k<2>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
+    else hipLaunchKernelGGL((convT_scatter_lds_k<4>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
+    MSK_LAUNCH_CHECK(ctx);
+    return 1;
+  }
   const int ntg = ntiles % 4 == 0 ? 4 : (ntiles % 2 == 0 ? 2 : 1);
   dim3 grid((unsigned)((M + 127) / 128), ntiles / ntg);
   switch (ntg) {

@@ -112,7 +112,7 @@ CONVT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", [0, 1, 7])
+@pytest.mark.parametrize("impl", [0, 1, 7, 22])   # 7: taps-folded scatter kernels at any size; 22: their fragment-shaped form
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_convT3d_fwd_dgrad_wgrad(case, impl):
     cin, cout, k, s, (N, D, H, W) = case
@@ -202,6 +202,37 @@ def test_wgrad_ks2_fine_levels(case):
     finally:
         d.set_option("conv_impl", 0)
         d.set_option("wgrad_async", 1)
+
+
+@pytest.mark.parametrize("impl", [0, 22])
+def test_convT_scatter_into_concat_slice(impl):
+    """Up-convolution forward into the first 16 channels of a 32-channel concat buffer (vnet.py:133-150: the zero-copy skip
+    connection) at a size the LDS-staged scatter kernel takes by default, and the data gradient of a down-convolution
+    accumulating into a tensor that already holds the skip gradient."""
+    d = dev()
+    d.set_option("conv_impl", impl)
+    try:
+        rng = np.random.default_rng(31)
+        N, D, H, W = 1, 16, 32, 33
+        x = rng.standard_normal((N, 64, D, H, W)).astype(np.float32)
+        w = (rng.standard_normal((64, 16, 2, 2, 2)) / 16).astype(np.float32)
+        b = rng.standard_normal(16).astype(np.float32)
+        y_ref = O.conv_transpose3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), (2, 2, 2))
+        xt, yt = t_from_ncdhw(x), t_empty(N, 16, 2 * D, 2 * H, 2 * W, ld=32, fill=-3.0)
+        d.call("msk_convT3d_fwd", _desc((2,) * 3, (2,) * 3, (0,) * 3), xt.msk(), vp(vec(w.ravel())), vp(vec(b)), yt.msk())
+        assert rel_err(t_to_ncdhw(yt), y_ref) < 3e-5
+        raw = vec_back(yt.ptr, N * 8 * D * H * W * 32).reshape(-1, 32)
+        assert np.all(raw[:, 16:] == -3.0)      # the skip half of the buffer is untouched
+        # down conv 16 -> 32 data gradient, accumulating
+        dy = rng.standard_normal((N, 32, D, H, W)).astype(np.float32)
+        wd = (rng.standard_normal((32, 16, 2, 2, 2)) / 11).astype(np.float32)
+        g0 = rng.standard_normal((N, 16, 2 * D, 2 * H, 2 * W)).astype(np.float32)
+        dx_ref = O.conv3d_dgrad(dy.astype(np.float64), wd.astype(np.float64), g0.shape, (2,) * 3, (0,) * 3) + g0
+        dxt = t_from_ncdhw(g0)
+        d.call("msk_conv3d_dgrad", _desc((2,) * 3, (2,) * 3, (0,) * 3), t_from_ncdhw(dy).msk(), vp(vec(wd.ravel())), dxt.msk(), 1)
+        assert rel_err(t_to_ncdhw(dxt), dx_ref) < _conv_tol(32 * 8)
+    finally:
+        d.set_option("conv_impl", 0)
 
 
 def test_conv_strided_channel_slice():
