@@ -68,6 +68,7 @@ struct msk_ctx {
   void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
   int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
+  int ks_legacy = 0;          // option "ks_legacy" (A/B): bit 0 = one-tap-per-tile k == s weight gradient, bit 1 = fragment-shaped k == s scatter kernel
   int wgrad_fork = 1;         // fused LUConv backward: 1 = the weight gradient forks after the data-gradient GEMM is enqueued (it then overlaps the HBM-bound passes of the next layer instead of stretching that GEMM by 30 %: -0.25 ms per step), 0 = right after the dual transform
   int wbf_fuse = 1;           // 1 = wbf_gemm_fused_k (matrix stage + output transform in one kernel) where eligible; 0 = three stages (A/B)
   int conv_split = 2;         // operand split of the Winograd pipelines: 2 = fp16 two-piece with per-tensor power-of-two scales (product), 3 = exact bf16x3

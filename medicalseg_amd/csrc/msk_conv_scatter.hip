@@ -260,7 +260,7 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   if (M >= (1L << 31) || dst_elems >= (1UL << 32)) return 0;  // 32-bit row arithmetic in the epilogue
   // deep levels (<= 16^3 sources) have too few 128-voxel tiles to fill 256 CUs: the parity-class kernel, which
   // also parallelises over the classes, measured faster there (0.08 vs 0.14 ms at 256->128 @ 8^3)
-  if (M < 16384 && ctx->conv_impl != 7 && ctx->conv_impl != 22) return 0;
+  if (M < 16384 && ctx->conv_impl != 7) return 0;
   const int KC = (g.CK + 7) / 8;
   const int jpad = ((taps * g.CN + 31) / 32) * 32;
   float4* bf = (float4*)msk_workspace2(ctx, (size_t)KC * 2 * jpad * sizeof(float4));
@@ -282,9 +282,9 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   }
   msk_launch_scope ls(ctx, tag);
   const int ntiles = jpad / 32;
-  // LDS-staged form: up to 16 row tiles (4 per wavefront), the staged voxels + patches within 64 KB; 22 = fragment-shaped kernel (A/B)
+  // LDS-staged form: up to 16 row tiles (4 per wavefront), the staged voxels + patches within 64 KB; option ks_legacy bit 1 = fragment-shaped kernel (A/B)
   const size_t lds = ((size_t)64 * (KC * 8 + 4) + 4 * 32 * 36 + 64) * sizeof(float);
-  if (ntiles <= 16 && lds <= 65536 && (!g.bias || ((uintptr_t)g.bias) % 16 == 0) && ctx->conv_impl != 22) {
+  if (ntiles <= 16 && lds <= 65536 && (!g.bias || ((uintptr_t)g.bias) % 16 == 0) && !(ctx->ks_legacy & 2)) {
     const dim3 grid((unsigned)((M + 63) / 64));
     const int tpw = (ntiles + 3) / 4;
     if (tpw <= 1) hipLaunchKernelGGL((convT_scatter_lds_k<1>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);

@@ -335,7 +335,7 @@ wgrad_ks2_k(WGrad g, Ks2Args a) {
 
 // fine levels: rows = (tap, ca); 1 handled, 0 not eligible, < 0 error
 int wgrad_ks2(msk_ctx* ctx, const WGrad& g, int taps, long M, size_t abytes, size_t bbytes) {
-  if (ctx->conv_impl == 19) return 0;                       // 19 = the one-tap-per-tile kernel everywhere (A/B)
+  if (ctx->ks_legacy & 1) return 0;                         // the one-tap-per-tile kernel everywhere (A/B)
   if (g.CA > 32 || g.CB > 128 || g.CB % 4 || M < 4096) return 0;
   const int rtiles = (taps * g.CA + 31) / 32, cbt = (g.CB + 31) / 32;
   const int CT = cbt <= 1 ? 1 : (cbt == 2 ? 2 : 4);

@@ -112,12 +112,13 @@ CONVT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", [0, 1, 7, 22])   # 7: taps-folded scatter kernels at any size; 22: their fragment-shaped form
+@pytest.mark.parametrize("impl", [0, 1, 7, 22])   # 7: taps-folded scatter kernels at any size; 22: 7 with their fragment-shaped form
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_convT3d_fwd_dgrad_wgrad(case, impl):
     cin, cout, k, s, (N, D, H, W) = case
     d = dev()
-    d.set_option("conv_impl", impl)
+    d.set_option("conv_impl", 7 if impl == 22 else impl)
+    d.set_option("ks_legacy", 2 if impl == 22 else 0)
     try:
         rng = np.random.default_rng(cin * 131 + cout)
         x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
@@ -142,6 +143,7 @@ def test_convT3d_fwd_dgrad_wgrad(case, impl):
         assert rel_err(vec_back(dbp, cout), db_ref) < 2e-5
     finally:
         d.set_option("conv_impl", 0)
+        d.set_option("ks_legacy", 0)
 
 
 KS2_CASES = [
@@ -195,12 +197,12 @@ def test_wgrad_ks2_fine_levels(case):
         assert rel_err(vec_back(dwp, nw).reshape(dw_ref.shape), 2 * dw_ref) < tol
         assert rel_err(vec_back(dbp, nb), 2 * db_ref) < 1e-5 * np.sqrt(M * (taps if tr else 1) / 1000 + 1)
         # the kernel it replaces gives the same sums up to fp32 summation order
-        d.set_option("conv_impl", 19)
+        d.set_option("ks_legacy", 1)
         dw2, db2 = vec(np.zeros(nw, np.float32)), vec(np.zeros(nb, np.float32))
         d.call(fn, cd, *args, vp(dw2), vp(db2), 0)
         assert rel_err(vec_back(dw2, nw).reshape(dw_ref.shape), dw_ref) < tol
     finally:
-        d.set_option("conv_impl", 0)
+        d.set_option("ks_legacy", 0)
         d.set_option("wgrad_async", 1)
 
 
@@ -210,7 +212,7 @@ def test_convT_scatter_into_concat_slice(impl):
     connection) at a size the LDS-staged scatter kernel takes by default, and the data gradient of a down-convolution
     accumulating into a tensor that already holds the skip gradient."""
     d = dev()
-    d.set_option("conv_impl", impl)
+    d.set_option("ks_legacy", 2 if impl == 22 else 0)
     try:
         rng = np.random.default_rng(31)
         N, D, H, W = 1, 16, 32, 33
@@ -232,7 +234,7 @@ def test_convT_scatter_into_concat_slice(impl):
         d.call("msk_conv3d_dgrad", _desc((2,) * 3, (2,) * 3, (0,) * 3), t_from_ncdhw(dy).msk(), vp(vec(wd.ravel())), dxt.msk(), 1)
         assert rel_err(t_to_ncdhw(dxt), dx_ref) < _conv_tol(32 * 8)
     finally:
-        d.set_option("conv_impl", 0)
+        d.set_option("ks_legacy", 0)
 
 
 def test_conv_strided_channel_slice():
