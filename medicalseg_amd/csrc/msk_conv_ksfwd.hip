@@ -18,7 +18,7 @@ namespace {
 constexpr unsigned kOOBk = 0xFFFFFFF0u;
 
 template <int NR, int KB>  // NR N tiles (32 output channels each) per workgroup, KB K steps per operand batch
-__global__ void __launch_bounds__(256, NR == 1 ? 4 : 2)
+__global__ void __launch_bounds__(256, NR == 1 ? 4 : (NR == 2 ? 4 : 2))
 gconv_ks_fwd_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned src_bytes) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -153,7 +153,7 @@ int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, 
   const float4* w4 = reinterpret_cast<const float4*>(wm);
   switch (NR) {
     case 4: hipLaunchKernelGGL((gconv_ks_fwd_k<4, 2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes); break;
-    case 2: hipLaunchKernelGGL((gconv_ks_fwd_k<2, 4>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes); break;
+    case 2: hipLaunchKernelGGL((gconv_ks_fwd_k<2, 2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes); break;
     default: hipLaunchKernelGGL((gconv_ks_fwd_k<1, 4>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes); break;
   }
   MSK_LAUNCH_CHECK(ctx);
