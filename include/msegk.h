@@ -169,6 +169,12 @@ int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, cons
 int msk_affine_act_join_fwd_amax(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,
                                  msk_tensor res, const float* alpha_outer, msk_tensor out, float* out_amax);
 int msk_copy_scale_amax(msk_ctx* ctx, msk_tensor src, const float* mask, msk_tensor dst, int accumulate, float* dst_amax);
+/* the gradient side of the same idea: dy_amax (nullable) = the amax array the pass that wrote dy folded max |dy| into
+ * (msk_affine_act_bwd_apply_amax); msk_conv3d_wgrad_ex2 otherwise as msk_conv3d_wgrad_ex.                        */
+int msk_conv3d_dgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate,
+                        const float* dy_amax /*nullable*/);
+int msk_conv3d_wgrad_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
+                         int accumulate, const void* xform /*nullable*/, const float* dy_amax /*nullable*/);
 /* Launch diet (round 3): the per-channel epilogues of a BatchNorm layer ride in the merge kernels that precede them.
  *   msk_bn_fin              the arguments of msk_bn_finalize(world = 1, count) as a struct;
  *   msk_conv3d_fwd_ex3      msk_conv3d_fwd_ex2, and with fin != NULL (stats_local required) the finalisation runs in the
@@ -281,6 +287,14 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
                              const float* invstd, const float* gamma, msk_tensor dout,
                              const float* sums_total, double M_total, int bn_mode,
                              msk_tensor dx, msk_tensor dres, int dres_acc);
+/* the same; dx_amax (nullable, an amax array of msk_amax_new) additionally receives max |dx| -- the gradient kernels of the
+ * convolution in front (msk_conv3d_dgrad_ex / msk_conv3d_wgrad_ex2) then skip their own pass over dx.  One array may collect
+ * several calls (per-sample InstanceNorm units): the maximum is associative.                                    */
+int msk_affine_act_bwd_apply_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
+                                  msk_tensor res, const float* alpha, const float* mean,
+                                  const float* invstd, const float* gamma, msk_tensor dout,
+                                  const float* sums_total, double M_total, int bn_mode,
+                                  msk_tensor dx, msk_tensor dres, int dres_acc, float* dx_amax /*nullable*/);
 /* parameter gradients of the above from the (all-reduced) sums:
  *   dgamma (+)= sums[C..2C), dbeta (+)= sums[0..C), dalpha (+)= sums[2C..3C)     */
 int msk_affine_act_param_grads(msk_ctx* ctx, int C, const float* sums, float* dgamma,

@@ -89,6 +89,8 @@ SIGNATURES = {
     "msk_conv3d_bwd_bnact_bytes": (_sz, [_vp, _CD, _T, _T]),
     "msk_conv3d_bwd_bnact": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i, _vp, _vp, _vp]),
     "msk_conv3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
+    "msk_conv3d_dgrad_ex": (_i, [_vp, _CD, _T, _vp, _T, _i, _vp]),
+    "msk_conv3d_wgrad_ex2": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp, _vp]),
     "msk_conv3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_convT3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),
     "msk_convT3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
@@ -100,6 +102,7 @@ SIGNATURES = {
     "msk_affine_act_bwd_reduce": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _T, _vp]),
     "msk_affine_act_bwd_reduce_ex": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _T, _vp, _vp]),
     "msk_affine_act_bwd_apply": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _vp, _T, _vp, _d, _i, _T, _T, _i]),
+    "msk_affine_act_bwd_apply_amax": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _vp, _T, _vp, _d, _i, _T, _T, _i, _vp]),
     "msk_affine_act_param_grads": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
     "msk_add_act_bwd": (_i, [_vp, _T, _T, _vp, _T, _T, _T, _i, _vp]),
     "msk_affine_act_join_fwd": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _T]),

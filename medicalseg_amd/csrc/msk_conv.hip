@@ -995,6 +995,16 @@ int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float*
   return conv3d_dgrad_impl(ctx, cd, dy, w, dx, accumulate, nullptr);
 }
 
+int msk_conv3d_dgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate,
+                        const float* dy_amax) {
+  return conv3d_dgrad_impl(ctx, cd, dy, w, dx, accumulate, dy_amax);
+}
+
+int msk_conv3d_wgrad_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
+                         const void* xform, const float* dy_amax) {
+  return conv3d_wgrad_impl(ctx, cd, x, dy, dw, db, accumulate, xform, dy_amax);
+}
+
 int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
   msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);

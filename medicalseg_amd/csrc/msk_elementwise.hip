@@ -641,10 +641,12 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
                        int cres, const float* __restrict__ alpha, const float* __restrict__ mean,
                        const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
                        const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx,
-                       int lddx, float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C) {
+                       int lddx, float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C,
+                       unsigned* __restrict__ dx_amax) {
   const int cv = C / V;
   const int cshift = (cv & (cv - 1)) == 0 ? __ffs(cv) - 1 : -1;  // wave-uniform
   const long total = voxels * cv;
+  float mx = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long v;
     int cg;
@@ -684,6 +686,8 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
       }
     }
     if (dx) stv<V>(dx + v * lddx + c, o);
+#pragma unroll
+    for (int j = 0; j < V; ++j) mx = fmaxf(mx, fabsf(o[j]));
     if (dres) {
       if (dres_acc) {
         float a[V];
@@ -694,6 +698,7 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
       stv<V>(dres + v * lddr + c, du);
     }
   }
+  if (dx_amax) block_atomic_max(dx_amax, mx);   // max |dx| for the gradient kernels that scale it into fp16 range (msk_amax_new)
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -702,7 +707,8 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
                           const float* __restrict__ alpha, const float* __restrict__ mean,
                           const float* __restrict__ invstd, const float* __restrict__ dout, int ldd,
                           const float* __restrict__ sums, float invM, int bn_mode, float* __restrict__ dx, int lddx,
-                          float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C, int cshift) {
+                          float* __restrict__ dres, int lddr, int dres_acc, long voxels, int C, int cshift,
+                          unsigned* __restrict__ dx_amax) {
   __builtin_amdgcn_s_setprio(3);  // HBM-bound pass on the critical path: issue ahead of the co-resident weight-gradient waves
   const long g = (long)blockIdx.x * kThreads + threadIdx.x;
   const int c = (int)(g & ((C >> 2) - 1)) * 4;
@@ -719,6 +725,7 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
     s2[j] = bn_mode == 1 ? sums[C + c + j] * invM : 0.f;
   }
   const bool need_res = res && alpha;
+  float mx = 0.f;
   auto load_res = [&](long v) {
     if (!need_res) return make_float4(0.f, 0.f, 0.f, 0.f);
     if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
@@ -746,6 +753,7 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
       }
     }
     if (dx) *reinterpret_cast<float4*>(dx + v * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     if (dres) {
       float4* rp = reinterpret_cast<float4*>(dres + v * lddr + c);
       float4 w = make_float4(du[0], du[1], du[2], du[3]);
@@ -769,6 +777,7 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
   if (v < voxels)
     body(v, *reinterpret_cast<const float4*>(x + v * ldx + c), *reinterpret_cast<const float4*>(dout + v * ldd + c),
          load_res(v));
+  if (dx_amax) block_atomic_max(dx_amax, mx);
 }
 
 __global__ void param_grads_k(int C, const float* sums, float* dgamma, float* dbeta, float* dalpha, int acc) {
@@ -1161,6 +1170,14 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
                              const float* alpha, const float* mean, const float* invstd, const float* gamma,
                              msk_tensor dout, const float* sums_total, double M_total, int bn_mode,
                              msk_tensor dx, msk_tensor dres, int dres_acc) {
+  return msk_affine_act_bwd_apply_amax(ctx, x, scale, shift, res, alpha, mean, invstd, gamma, dout, sums_total, M_total, bn_mode, dx,
+                                       dres, dres_acc, nullptr);
+}
+
+int msk_affine_act_bwd_apply_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                                  const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                                  msk_tensor dout, const float* sums_total, double M_total, int bn_mode,
+                                  msk_tensor dx, msk_tensor dres, int dres_acc, float* dx_amax) {
   (void)gamma;
   MSK_REQUIRE(ctx, same_shape(x, dout), "x/dout shape mismatch");
   if (dx.p) MSK_REQUIRE(ctx, same_shape(x, dx), "x/dx shape mismatch");
@@ -1179,17 +1196,17 @@ int msk_affine_act_bwd_apply(msk_ctx* ctx, msk_tensor x, const float* scale, con
     hipLaunchKernelGGL(affine_act_bwd_apply_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, mean,
                        invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode, (float*)dx.p, dx.ld,
-                       (float*)dres.p, dres.ld, dres_acc, voxels, x.c, cshift);
+                       (float*)dres.p, dres.ld, dres_acc, voxels, x.c, cshift, (unsigned*)dx_amax);
   } else if (v4) {
     hipLaunchKernelGGL(affine_act_bwd_apply_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads),
                        0, ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
                        alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
-                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c);
+                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c, (unsigned*)dx_amax);
   } else {
     hipLaunchKernelGGL(affine_act_bwd_apply_k<1>, dim3(ew_blocks(voxels * x.c, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
                        alpha, mean, invstd, (const float*)dout.p, dout.ld, sums_total, invM, bn_mode,
-                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c);
+                       (float*)dx.p, dx.ld, (float*)dres.p, dres.ld, dres_acc, voxels, x.c, (unsigned*)dx_amax);
   }
   MSK_LAUNCH_CHECK(ctx);
   return 0;

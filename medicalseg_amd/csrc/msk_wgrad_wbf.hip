@@ -352,7 +352,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
     y_amax = g.y_amax;
   } else {
     if (NP != 3) {
-      y_amax = msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);
+      y_amax = g.b_amax ? g.b_amax : msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);   // the caller may hold it (amax array)
       if (!y_amax) return -1;
     }
     ta.amax = y_amax;

@@ -19,7 +19,7 @@ import numpy as np
 from .. import nn
 from ..cvlibs import manager
 from ..device import Tensor, to_tensor
-from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _fp, copy_scale
+from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _amax_for, _fp, copy_scale
 from .vnet import VNet
 
 
@@ -77,14 +77,15 @@ class ConvINAct(ConvBNAct):
         sc, Cn = norm.scratch(dev, y.n), norm.num_features
         alpha = self.act._weight.ptr if self.act is not None else None
         vox = float(y.d * y.h * y.w)
+        am = _amax_for(out)   # max |out| over all samples rides in the normalise passes (the next 3^3 conv scales by it)
         for i in range(y.n):
             yv, co = _sample(y, i), norm.sample_coeffs(sc, i)
             dev.call("msk_bn_stats", yv.msk(), _fp(sc["stats"]))
             dev.call("msk_bn_finalize", _fp(sc["stats"]), 1, C.c_double(vox), Cn, _fp(norm.scale.ptr), _fp(norm.bias.ptr),
                      C.c_float(norm.epsilon), C.c_float(1.0), _fp(sc["rmean"]), _fp(sc["rvar"]), _fp(co["mean"]),
                      _fp(co["invstd"]), _fp(co["scale"]), _fp(co["shift"]))
-            dev.call("msk_affine_act_fwd", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
-                     _sample(out, i).msk())
+            dev.call("msk_affine_act_fwd_amax", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                     _sample(out, i).msk(), am)
         self.out, self.bn_mode = out, 1
         return out
 
@@ -94,15 +95,16 @@ class ConvINAct(ConvBNAct):
         alpha = self.act._weight.ptr if self.act is not None else None
         vox = float(y.d * y.h * y.w)
         dy = y.empty_like()
+        dya = _amax_for(dy) if type(self.conv) is nn.Conv3D and self.conv.s == (1, 1, 1) else None
         for i in range(y.n):
             yv, dv, co = _sample(y, i), _sample(dout, i), norm.sample_coeffs(sc, i)
             dev.call("msk_affine_act_bwd_reduce", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
                      _fp(co["mean"]), _fp(co["invstd"]), dv.msk(), _fp(sc["sums"]))
             dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(norm.scale.grad_ptr), _fp(norm.bias.grad_ptr),
                      _fp(self.act._weight.grad_ptr) if self.act is not None else None, 1)
-            dev.call("msk_affine_act_bwd_apply", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+            dev.call("msk_affine_act_bwd_apply_amax", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
                      _fp(co["mean"]), _fp(co["invstd"]), _fp(norm.scale.ptr), dv.msk(), _fp(sc["sums"]),
-                     C.c_double(vox), 1, _sample(dy, i).msk(), NULL_TENSOR, 0)
+                     C.c_double(vox), 1, _sample(dy, i).msk(), NULL_TENSOR, 0, dya)
         self.dy = dy
         # the conv bias gradient is identically zero behind per-sample statistics (the backward removes the mean)
         self.conv.run_backward(self.x, dy, need_dx=need_dx, bias_grad=False)
@@ -166,6 +168,7 @@ class Up(nn.Layer):
                              f"({x.n}, {self.c_lo}, {od}, {oh}, {ow}): every input side must be a multiple of 2^(depth-1)")
         self._x, self._skip = x, skip
         xcat = Tensor.empty(x.dev, x.n, od, oh, ow, 2 * self.c_lo)
+        _amax_for(xcat)   # one amax array for the buffer: both producers below fold into it through their slices
         self._up.forward(x, out=xcat.channel_slice(0, self.c_lo))
         copy_scale(skip, None, xcat.channel_slice(self.c_lo, 2 * self.c_lo))
         self._xcat = xcat

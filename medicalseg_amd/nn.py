@@ -280,17 +280,20 @@ class Conv3D(Layer):
         dev = x.dev
         _count_flops(self, x.n, dy.d * dy.h * dy.w, 2 if need_dx else 1)
         xf = getattr(self, "_xform", None)
-        if xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen:   # same tensor, same arena generation
-            dev.call("msk_conv3d_wgrad_ex", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
-                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1, C.c_void_p(xf[0]))
+        xfp = C.c_void_p(xf[0]) if (xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen) else None   # same tensor, same arena generation
+        # max |dy| folded in by the pass that wrote dy (msk_affine_act_bwd_apply_amax): no absmax pass of their own below
+        dya = C.c_void_p(dy.amax) if (dy.amax and PRODUCER_AMAX) else None
+        if xfp is not None or dya is not None:
+            dev.call("msk_conv3d_wgrad_ex2", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1, xfp, dya)
         else:
             dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
                      C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
         self._xform = None
         if need_dx:
             dx = x.ensure_grad()
-            dev.call("msk_conv3d_dgrad", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
-                     1 if x.grad_written else 0)
+            dev.call("msk_conv3d_dgrad_ex", self.desc(), dy.msk(), C.c_void_p(self.weight.ptr), dx.msk(),
+                     1 if x.grad_written else 0, dya)
             x.grad_written = True
 
     forward = run_forward
@@ -683,9 +686,11 @@ class ConvBNAct:
             g = res.ensure_grad()
             dres, dres_acc = g.msk(), 1 if res.grad_written else 0
             res.grad_written = True
-        dev.call("msk_affine_act_bwd_apply", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
+        # max |dy| rides in this pass when a 'same' convolution (the 16-bit pipeline scales its operands) consumes dy
+        dya = _amax_for(dy) if type(self.conv) is Conv3D and self.conv.s == (1, 1, 1) else None
+        dev.call("msk_affine_act_bwd_apply_amax", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                  _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(), _fp(sums_total),
-                 C.c_double(m_total), self.bn_mode, dy.msk(), dres, dres_acc)
+                 C.c_double(m_total), self.bn_mode, dy.msk(), dres, dres_acc, dya)
         self.dy = dy  # kept for introspection (tests); freed with the arena
         # conv bias gradient = sum_v dy[v][c]: identically zero behind a batch-statistics BN (its backward
         # removes the mean), scale * sum(dout * prelu') behind a running-statistics BN -- either way no

@@ -929,3 +929,56 @@ def test_bwd_reduce_pg_is_bitwise_reduce_plus_param_grads():
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
     assert outs[1][4][0] > 0 and np.abs(outs[1][1] - 2.0).max() > 1e-3
+
+
+@pytest.mark.parametrize("split", [2, 1])   # fp16 two-piece / single fp16 (conv_fp16): both scale dy by its maximum
+def test_gradient_maximum_from_the_pass_that_writes_dy(split):
+    """msk_affine_act_bwd_apply_amax writes the same dy as msk_affine_act_bwd_apply and folds max |dy| into an amax array; the
+    gradient entry points given that array (msk_conv3d_dgrad_ex / msk_conv3d_wgrad_ex2) return bit-identical results to the
+    plain calls, which measure dy with a pass of their own."""
+    import ctypes as C
+    from medicalseg_amd._lib import NULL_TENSOR
+    c, (N, D, H, W) = 32, (2, 8, 16, 16)
+    d = dev()
+    d.set_option("conv_split", 2)
+    d.set_option("conv_fp16", 1 if split == 1 else 0)
+    d.set_option("wgrad_async", 0)
+    try:
+        rng = np.random.default_rng(17 + split)
+        mk = lambda s=1.0: t_from_ncdhw((s * rng.standard_normal((N, c, D, H, W))).astype(np.float32))
+        y, dout, x = mk(), mk(3e-4), mk()
+        v = lambda lo, hi: vec(rng.uniform(lo, hi, c).astype(np.float32))
+        scale, shift, alpha, mean, invstd, gamma = v(0.5, 1.5), v(-0.5, 0.5), v(0.1, 0.4), v(-0.2, 0.2), v(0.5, 1.5), v(0.5, 1.5)
+        sums = vec((rng.standard_normal(3 * c) * 10).astype(np.float32))
+        M = float(N * D * H * W)
+        outs = []
+        for with_amax in (0, 1):
+            dy = t_empty(N, c, D, H, W, fill=0.0)
+            am = d.amax_new(1) if with_amax else None
+            args = (y.msk(), vp(scale), vp(shift), NULL_TENSOR, vp(alpha), vp(mean), vp(invstd), vp(gamma), dout.msk(), vp(sums),
+                    C.c_double(M), 1, dy.msk(), NULL_TENSOR, 0)
+            if with_amax:
+                d.call("msk_affine_act_bwd_apply_amax", *args, vp(am))
+            else:
+                d.call("msk_affine_act_bwd_apply", *args)
+            dyh = t_to_ncdhw(dy)
+            if with_amax:
+                assert vec_back(am, 64).max() == np.abs(dyh).max()
+            w = (rng.standard_normal((c, c, 5, 5, 5)) / 60).astype(np.float32) if not outs else w
+            wp = vec(w.ravel()) if not outs else wp
+            dx = t_empty(N, c, D, H, W, fill=1.0)
+            dw, db = vec(np.zeros(w.size, np.float32)), vec(np.zeros(c, np.float32))
+            cd = _desc((5,) * 3, (1,) * 3, (2,) * 3)
+            if with_amax:
+                d.call("msk_conv3d_dgrad_ex", cd, dy.msk(), vp(wp), dx.msk(), 1, vp(am))
+                d.call("msk_conv3d_wgrad_ex2", cd, x.msk(), dy.msk(), vp(dw), vp(db), 0, None, vp(am))
+            else:
+                d.call("msk_conv3d_dgrad", cd, dy.msk(), vp(wp), dx.msk(), 1)
+                d.call("msk_conv3d_wgrad", cd, x.msk(), dy.msk(), vp(dw), vp(db), 0)
+            outs.append((dyh, t_to_ncdhw(dx), vec_back(dw, w.size), vec_back(db, c)))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        assert np.abs(outs[0][2]).max() > 0
+    finally:
+        d.set_option("conv_fp16", 0)
+        d.set_option("wgrad_async", 1)
