@@ -19,6 +19,10 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--levels", type=int, default=2, help="how many of the four VNet levels (finest first)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")
+    ap.add_argument("--fine-ld", type=int, default=0, help="voxel stride (floats) of the 16- / 32-channel fine tensors: 2x their channels = "
+                    "the zero-copy concat slices of the real step")
+    ap.add_argument("--sets", type=int, default=1, help="rotate over this many copies of every tensor (cold LLC: 4 sets of the 128^3 level "
+                    "exceed the 256 MB MALL)")
     a = ap.parse_args()
     from medicalseg_amd._lib import MskConvDesc
     from medicalseg_amd.device import Tensor, get_device
@@ -32,11 +36,26 @@ def main():
     cd = MskConvDesc(2, 2, 2, 2, 2, 2, 0, 0, 0)
     n = a.n
 
-    def mk(s, ch, fill=True):
-        t = Tensor(dev, dev.malloc(n * s ** 3 * ch * 4), n, s, s, s, ch, ch, None)
-        if fill:
-            dev.h2d(t.ptr, rng.standard_normal(n * s ** 3 * ch, dtype=np.float32))
-        return t
+    class Rot:
+        """a.sets copies of one tensor; .msk() hands out the next one"""
+
+        def __init__(self, ts):
+            self.ts, self.i = ts, 0
+            self.ptr = ts[0].ptr
+
+        def msk(self):
+            self.i = (self.i + 1) % len(self.ts)
+            return self.ts[self.i].msk()
+
+    def mk(s, ch, fill=True, fine=False):
+        ld = a.fine_ld * ch // 16 if (fine and a.fine_ld) else ch
+        ts = []
+        for _ in range(a.sets):
+            t = Tensor(dev, dev.malloc(n * s ** 3 * ld * 4), n, s, s, s, ch, ld, None)
+            if fill:
+                dev.h2d(t.ptr, rng.standard_normal(n * s ** 3 * ld, dtype=np.float32))
+            ts.append(t)
+        return Rot(ts)
 
     def run(name, fn, nbytes):
         fn()
@@ -60,7 +79,7 @@ def main():
     for s, dci, dco, uci, uco in levels:
         vf, vc = n * s ** 3, n * (s // 2) ** 3
         # down conv: x[s, dci] -> y[s/2, dco]
-        x, y, dx = mk(s, dci), mk(s // 2, dco), mk(s, dci)
+        x, y, dx = mk(s, dci, fine=True), mk(s // 2, dco), mk(s, dci, fine=True)
         w = dev.malloc(dci * dco * 8 * 4)
         dev.h2d(w, (rng.standard_normal(dci * dco * 8) * 0.05).astype(np.float32))
         dw, b, db = dev.malloc(dci * dco * 8 * 4), dev.small(dco), dev.small(dco)
@@ -73,7 +92,7 @@ def main():
         run(f"down wgrad {dci}x{dco}", lambda: dev.call("msk_conv3d_wgrad", cd, x.msk(), y.msk(), vp(dw), vp(db), 0),
             4 * (vf * dci + vc * dco))
         # up conv (transposed): u[s/2, uci] -> v[s, uco]
-        u, v, du = mk(s // 2, uci), mk(s, uco), mk(s // 2, uci)
+        u, v, du = mk(s // 2, uci), mk(s, uco, fine=True), mk(s // 2, uci)
         wt = dev.malloc(uci * uco * 8 * 4)
         dev.h2d(wt, (rng.standard_normal(uci * uco * 8) * 0.05).astype(np.float32))
         dwt, bt, dbt = dev.malloc(uci * uco * 8 * 4), dev.small(uco), dev.small(uco)
@@ -83,8 +102,9 @@ def main():
             4 * (vf * uco + vc * uci))
         run(f"up   wgrad {uci}x{uco}", lambda: dev.call("msk_convT3d_wgrad", cd, u.msk(), v.msk(), vp(dwt), vp(dbt), 0),
             4 * (vc * uci + vf * uco))
-        for t in (x, y, dx, u, v, du):
-            dev.free(t.ptr)
+        for r in (x, y, dx, u, v, du):
+            for t in r.ts:
+                dev.free(t.ptr)
 
 
 if __name__ == "__main__":

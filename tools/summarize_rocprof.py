@@ -29,7 +29,7 @@ def agg(path, counter):
 BUCKETS = (("lu_gemm", ("wbf_gemm_k", "wbf_gemm_fused_k")),
            ("lu_wgrad", ("wbf_wgrad_k", "wbf_wgrad_reduce_k")),
            ("lu_transforms", ("wbf_tin_k", "wbf_tin_dual_k", "wbf_tout_k", "wbf_pack_", "absmax_k")),
-           ("ks_convs", ("gconv_ks_fwd_k", "convT_scatter_mfma_k", "gconv_gather_mfma_k", "wgrad_ks_mfma_k", "wgrad_mfma_k")),
+           ("ks_convs", ("gconv_ks_fwd_k", "convT_scatter_mfma_k", "convT_scatter_lds_k", "gconv_gather_mfma_k", "wgrad_ks_mfma_k", "wgrad_ks2_k", "wgrad_mfma_k")),
            ("tiny_channel", ("conv_foldn", "conv_tk_", "conv_halo_tightk", "wgrad_cbs", "conv_c1_", "wgrad_c1_", "wgrad_pw_small",
                              "pointwise_small", "conv_halo_valu", "pack_foldn", "pack_tk")),
            ("loss_optim", ("loss_", "sgd_momentum_k", "adam_k", "class_weights")),
@@ -66,7 +66,7 @@ def main(tag):
                "_note": "per-launch averages over one training step; FETCH_SIZE/WRITE_SIZE are in KiB; "
                         "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 rocprofv3 reports half of a wide "
                         "coalesced read stream, MI355X_MICROARCH.md section HBM; WRITE_SIZE uncalibrated)"}
-        steps = int(os.environ.get("PROFILE_STEPS", "1"))      # training steps inside the PMC passes (profile_gpu.sh: 1)
+        steps = int(os.environ.get("PROFILE_STEPS", "4"))      # training steps inside the PMC passes (profile_gpu.sh: 3 warm-up + 1)
         total = 0.0
         buckets = collections.defaultdict(float)
         for k in sorted(set(fe) | set(wr)):     # EVERY kernel of the step (round 2 listed the convolution families only)
