@@ -134,12 +134,22 @@ wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfP
         o[pstep] = mid;
         o[2 * pstep] = lo;
       } else if (NP == 2) {
+        // through fp32: a double -> fp16 conversion has no instruction (the compiler expands it to ~40 integer operations: this
+        // kernel was VALU-bound on 16 of them per element, 0.43 ms per step); the low piece takes whatever the high piece's
+        // rounding left, so the pair represents v exactly as well
+        // (the empty asm keeps the compiler from folding float -> half of double -> float back into the one conversion)
         const double v = s_ * wsc;
-        const _Float16 h = (_Float16)v;
+        float vf = (float)v;
+        asm volatile("" : "+v"(vf));
+        const _Float16 h = (_Float16)vf;
+        float rf = (float)(v - (double)(float)h);
+        asm volatile("" : "+v"(rf));
         o[0] = __builtin_bit_cast(unsigned short, h);
-        o[pstep] = __builtin_bit_cast(unsigned short, (_Float16)(v - (double)(float)h));
+        o[pstep] = __builtin_bit_cast(unsigned short, (_Float16)rf);
       } else {
-        o[0] = __builtin_bit_cast(unsigned short, (_Float16)(float)(s_ * wsc));
+        float vf = (float)(s_ * wsc);
+        asm volatile("" : "+v"(vf));
+        o[0] = __builtin_bit_cast(unsigned short, (_Float16)vf);
       }
     }
   }
