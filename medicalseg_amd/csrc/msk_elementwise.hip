@@ -168,13 +168,16 @@ bn_stats_partial_v4(const float* __restrict__ x, long voxels, int C, int ld, int
 // fin.scale != NULL: the per-channel finalisation of msk_bn_finalize(world = 1) runs here as well (one launch less per
 // BatchNorm layer): the same arithmetic on the same float-rounded (mean, M2) record, so the results are bitwise those of
 // the two-kernel form.
-__global__ void __launch_bounds__(64)
+constexpr int kMergeThreads = 256;
+__global__ void __launch_bounds__(kMergeThreads)
 bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ stats /*[2C]*/, msk_bn_fin fin) {
-  __shared__ double sn[64], sm[64], s2[64];
+  // 256 threads per channel: a thread's chain of dependent (load, divide, update) steps is nb / 256 long -- with 64 threads the
+  // 2 K - 8 K records of a 128^3 layer made this 12 us launch (24 per step) a latency chain of 128 steps
+  __shared__ double sn[kMergeThreads], sm[kMergeThreads], s2[kMergeThreads];
   const int c = blockIdx.x, t = threadIdx.x;
   const int cb = c / CB, cl = c % CB;
   double n = 0, mean = 0, m2 = 0;
-  for (int b = t; b < nb; b += 64) {
+  for (int b = t; b < nb; b += kMergeThreads) {
     const float* p = partial + (((long)cb * nb + b) * CB + cl) * 3;
     const double bn = p[0];
     if (bn == 0) continue;
@@ -185,7 +188,7 @@ bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* 
   }
   sn[t] = n; sm[t] = mean; s2[t] = m2;
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
+  for (int s = kMergeThreads / 2; s > 0; s >>= 1) {
     if (t < s && sn[t + s] > 0) {
       const double bn = sn[t + s], d = sm[t + s] - sm[t], tot = sn[t] + bn, f = bn / tot;
       s2[t] = s2[t] + s2[t + s] + d * d * sn[t] * f;
@@ -978,7 +981,7 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
 
 int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats, const msk_bn_fin* fin) {
   msk_launch_scope ls(ctx, "bn_stats_merge");
-  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(64), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
+  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(kMergeThreads), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -1002,7 +1005,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
     return 0;
@@ -1020,7 +1023,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
   }
   {
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
   }
