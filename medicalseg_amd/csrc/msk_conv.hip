@@ -1048,6 +1048,22 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
   gw.pd = cd.pd; gw.ph = cd.ph; gw.pw = cd.pw;
   gw.dw = dw; gw.accumulate = dw_accumulate;
   gw.xform = xform;
+  // ---- one input channel, no data gradient (in_tr.conv1, vnet.py:67): dy is evaluated inside the weight-gradient kernel.  It is
+  // the LAST weight gradient of a backward pass -- it runs on the calling stream: the side stream may still be busy with the
+  // gradients queued before it, and nothing is left here for it to overlap with
+  if (x.c == 1 && !dx.p && ctx->bwd_fuse != 0 && ctx->conv_impl == 0 && !(per > 0 && (size_t)x.n > kChunkBytes / per)) {
+    WbfBnBwd bn{};
+    bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
+    bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
+    bn.invM = (float)(1.0 / M_total);
+    WGrad gc = gw;
+    gc.B = nullptr;
+    gc.xform = nullptr;
+    gc.yfuse = &bn;
+    const int r = msk_wgrad_c1(ctx, gc);   // 0: not its shape class, nothing launched
+    if (r < 0) return r;
+    if (r == 1) return 0;
+  }
   size_t y_bytes = 0;
   if (fused && !msk_wgrad_wbf_fusable(ctx, gw, &y_bytes)) fused = false;
   if (fused) {

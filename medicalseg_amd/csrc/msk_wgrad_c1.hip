@@ -8,6 +8,7 @@
 // one ds_read_b32 at (voxel + tap offset from an LDS table), the B operand one coalesced dword of dy (16 channels of 4
 // consecutive voxels = 256 B per load).  A workgroup walks tiles round-robin and writes ONE partial slab.
 #include "msk_conv.h"
+#include "msk_wbf.h"   // WbfBnBwd
 
 namespace {
 
@@ -18,10 +19,13 @@ __device__ __forceinline__ float c1_load(__amdgpu_buffer_rsrc_t r, unsigned voff
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
 }
 
-template <int KS>
+// FUSE: dy is not read -- it is evaluated from (y, dout) and the per-channel BatchNorm-backward coefficients, the arithmetic of
+// affine_act_bwd_apply (msk_conv3d_bwd_bnact for the one-input-channel class): the in_tr unit's backward loses a pass that read
+// two and wrote one full-resolution tensor, and the step's last weight gradient starts one kernel earlier.
+template <int KS, bool FUSE>
 __global__ void __launch_bounds__(256)
 wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, float* __restrict__ partial, unsigned a_bytes,
-                unsigned b_bytes) {
+                unsigned b_bytes, WbfBnBwd yf, unsigned d_bytes) {
   constexpr int TD = 4, TH = 8, TW = 32, P = KS / 2;
   constexpr int HD = TD + 2 * P, HH = TH + 2 * P, HW = TW + 2 * P;
   constexpr int NV = HD * HH * HW;
@@ -34,7 +38,15 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
   const int wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
   const int D = g.BD, H = g.BH, W = g.BW;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? yf.y : g.B), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? yf.dout : g.B), 0, FUSE ? d_bytes : b_bytes, 0x00020000);
+  // this lane's output channel r: coefficients of dy = scale * (du - sums[c]/M - xhat * sums[C + c]/M)
+  float c_sc = 0.f, c_sf = 0.f, c_al = 1.f, c_mu = 0.f, c_is = 0.f, c_s1 = 0.f, c_s2 = 0.f;
+  if (FUSE && r < g.CB) {
+    c_sc = yf.scale[r]; c_sf = yf.shift[r]; c_al = yf.alpha ? yf.alpha[r] : 1.f; c_mu = yf.mean[r]; c_is = yf.invstd[r];
+    c_s1 = yf.sums[r] * yf.invM; c_s2 = yf.sums[g.CB + r] * yf.invM;
+  }
+  const bool has_alpha = FUSE && yf.alpha != nullptr;
 
   for (int i = tid; i < RT * 16; i += 256)
     toff[i] = i < TAPS ? ((i / (KS * KS)) * HH + (i / KS) % KS) * HW + i % KS : NV;
@@ -83,7 +95,20 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
           const bool vok = gh < H && gw < W;
           // x of a voxel outside the volume only ever meets dy = 0 (vok false -> b = 0): its halo index needs no guard
           bs[u] = (wave * HH + h) * HW + w;
-          bv[u] = c1_load(rb, (vok && r < g.CB) ? (unsigned)(((((n * D + gd) * H + gh) * W + gw) * g.bld) + r) * 4u : kOOB1);
+          if (!FUSE) {
+            bv[u] = c1_load(rb, (vok && r < g.CB) ? (unsigned)(((((n * D + gd) * H + gh) * W + gw) * g.bld) + r) * 4u : kOOB1);
+          } else {
+            const bool live = vok && r < g.CB;
+            const unsigned vx = (unsigned)(((n * D + gd) * H + gh) * W + gw);
+            const float yv = c1_load(rb, live ? (vx * (unsigned)yf.yld + r) * 4u : kOOB1);
+            float d = c1_load(rd, live ? (vx * (unsigned)yf.dld + r) * 4u : kOOB1);
+            if (has_alpha) {
+              const float uu = fmaf(yv, c_sc, c_sf);
+              if (!(uu > 0.f)) d *= c_al;
+            }
+            const float xh = (yv - c_mu) * c_is;
+            bv[u] = live ? c_sc * (d - c_s1 - xh * c_s2) : 0.f;
+          }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u)
@@ -116,8 +141,10 @@ int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
     return 0;
   if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
   const long M = (long)g.N * g.BD * g.BH * g.BW;
-  const size_t abytes = (size_t)M * g.ald * sizeof(float), bbytes = (size_t)M * g.bld * sizeof(float);
-  if (M >= (1L << 30) || abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull) return 0;
+  const WbfBnBwd* yf = g.yfuse;   // msk_conv3d_bwd_bnact: dy evaluated in the kernel (B is not read)
+  const size_t abytes = (size_t)M * g.ald * sizeof(float), bbytes = (size_t)M * (yf ? yf->yld : g.bld) * sizeof(float);
+  const size_t dbytes = yf ? (size_t)M * yf->dld * sizeof(float) : 0;
+  if (M >= (1L << 30) || abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull || dbytes >= 0xFFFFFFF0ull) return 0;
   const int tiles_d = (g.BD + 3) / 4, tiles_h = (g.BH + 7) / 8, tiles_w = (g.BW + 31) / 32;
   const long ntiles = (long)g.N * tiles_d * tiles_h * tiles_w;
   if (ntiles > 0x7fffffff) return 0;
@@ -131,12 +158,16 @@ int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
     const char* tag = "wgrad_c1_mfma";
     if (ctx->prof && ctx->prof_shapes) {
       char buf[160];
-      snprintf(buf, sizeof(buf), "wgrad_c1_mfma[cb=%d,M=%ld,splits=%ld]", g.CB, M, splits);
+      snprintf(buf, sizeof(buf), "wgrad_c1_mfma[cb=%d,M=%ld,splits=%ld%s]", g.CB, M, splits, yf ? ",bn-fused" : "");
       tag = msk_intern_tag(ctx, buf);
     }
     msk_launch_scope ls(ctx, tag);
-    hipLaunchKernelGGL((wgrad_c1_mfma_k<5>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
-                       tiles_w, partial, (unsigned)abytes, (unsigned)bbytes);
+    if (yf)
+      hipLaunchKernelGGL((wgrad_c1_mfma_k<5, true>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
+                         tiles_w, partial, (unsigned)abytes, (unsigned)bbytes, *yf, (unsigned)dbytes);
+    else
+      hipLaunchKernelGGL((wgrad_c1_mfma_k<5, false>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
+                         tiles_w, partial, (unsigned)abytes, (unsigned)bbytes, WbfBnBwd{}, 0u);
     MSK_LAUNCH_CHECK(ctx);
   }
   const int rc = msk_wgrad_reduce(ctx, partial, (int)splits, taps, 1, g.CB, g.dw, g.accumulate);

@@ -508,6 +508,8 @@ FUSE_SMALL = os.environ.get("MSEGK_FUSE_SMALL", "1") != "0"
 
 # A/B switch (env MSEGK_BWD_FUSE=0): conv -> BN -> PReLU units run their backward as three calls (apply, dgrad, wgrad)
 FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
+# A/B switch (env MSEGK_BWD_FUSE_C1=0): in_tr.conv1's BatchNorm backward as a pass of its own in front of its weight gradient
+FUSE_BN_BACKWARD_C1 = os.environ.get("MSEGK_BWD_FUSE_C1", "1") != "0"
 
 
 class ConvBNAct:
@@ -659,6 +661,18 @@ class ConvBNAct:
             dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
                      _fp(_act_alpha_grad(self.act)), 1)
         dy = y.empty_like()
+        if (FUSE_BN_BACKWARD and FUSE_BN_BACKWARD_C1 and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and not need_dx
+                and self.conv.cin == 1 and self.conv.k == (5, 5, 5) and self.conv.s == (1, 1, 1)):
+            # in_tr.conv1 (vnet.py:67; one input channel, no data gradient): dy is evaluated inside the weight-gradient kernel
+            # (msk_conv3d_bwd_bnact) -- the last weight gradient of the backward pass starts one full-resolution pass earlier
+            conv, x = self.conv, self.x
+            _count_flops(conv, x.n, y.d * y.h * y.w, 1)
+            dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                     _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
+                     _fp(sums_total), C.c_double(m_total), dy.msk(), NULL_TENSOR, 0, _fp(conv.weight.grad_ptr), 1, None, None, None)
+            conv._xform = None
+            self.dy = None
+            return
         if fuse:
             # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
             # of dy (msk_conv3d_bwd_bnact); dy itself reaches HBM only when the shape is not eligible

@@ -982,3 +982,48 @@ def test_gradient_maximum_from_the_pass_that_writes_dy(split):
     finally:
         d.set_option("conv_fp16", 0)
         d.set_option("wgrad_async", 1)
+
+
+@pytest.mark.parametrize("with_alpha", [0, 1])
+def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(with_alpha):
+    """msk_conv3d_bwd_bnact for in_tr.conv1 (1 -> 16 channels, no data gradient): the weight-gradient kernel evaluates dy from
+    (y, dout) itself -- same dw as msk_affine_act_bwd_apply + msk_conv3d_wgrad, dy_scratch left alone, and one kernel less."""
+    import ctypes as C
+    from medicalseg_amd._lib import NULL_TENSOR
+    cout, (N, D, H, W) = 16, (2, 9, 18, 37)
+    d = dev()
+    rng = np.random.default_rng(23 + with_alpha)
+    x = rng.standard_normal((N, 1, D, H, W)).astype(np.float32)
+    y = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    dout = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+    xt, yt, dt = t_from_ncdhw(x), t_from_ncdhw(y), t_from_ncdhw(dout, ld=32)      # dout: a slice of a wider gradient buffer
+    v = lambda lo, hi: vec(rng.uniform(lo, hi, cout).astype(np.float32))
+    scale, shift, alpha, mean, invstd, gamma = v(0.5, 1.5), v(-0.5, 0.5), v(0.1, 0.4), v(-0.2, 0.2), v(0.5, 1.5), v(0.5, 1.5)
+    sums = vec((rng.standard_normal(3 * cout) * 30).astype(np.float32))
+    w = vec((rng.standard_normal(cout * 125) / 11).astype(np.float32))
+    M = float(N * D * H * W)
+    cd = _desc((5,) * 3, (1,) * 3, (2,) * 3)
+    al = vp(alpha) if with_alpha else None
+    # reference: the two separate calls
+    dy = t_empty(N, cout, D, H, W, fill=0.0)
+    d.call("msk_affine_act_bwd_apply", yt.msk(), vp(scale), vp(shift), NULL_TENSOR, al, vp(mean), vp(invstd), vp(gamma), dt.msk(),
+           vp(sums), C.c_double(M), 1, dy.msk(), NULL_TENSOR, 0)
+    dw_ref = vec(np.full(cout * 125, 0.5, np.float32))
+    d.call("msk_conv3d_wgrad", cd, xt.msk(), dy.msk(), vp(dw_ref), None, 1)
+    # the one call
+    scratch = t_empty(N, cout, D, H, W, fill=-7.0)
+    dw = vec(np.full(cout * 125, 0.5, np.float32))
+    d.prof_reset()
+    d.prof_enable(True)
+    d.call("msk_conv3d_bwd_bnact", cd, xt.msk(), vp(w), yt.msk(), vp(scale), vp(shift), al, vp(mean), vp(invstd), vp(gamma), dt.msk(),
+           vp(sums), C.c_double(M), scratch.msk(), NULL_TENSOR, 0, vp(dw), 1, None, None, None)
+    d.sync()
+    d.prof_enable(False)
+    tags = set(d.prof_report())
+    assert "wgrad_c1_mfma" in tags and "affine_act_bwd_apply" not in tags, tags
+    a, b = vec_back(dw, cout * 125), vec_back(dw_ref, cout * 125)
+    assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    assert np.all(t_to_ncdhw(scratch) == -7.0)
+    dy64 = t_to_ncdhw(dy).astype(np.float64)
+    dw_or, _ = O.conv3d_wgrad(dy64, x.astype(np.float64), (5,) * 3, (1,) * 3, (2,) * 3)
+    assert rel_err(a.reshape(dw_or.shape) - 0.5, dw_or) < _conv_tol(M) * 2
