@@ -217,7 +217,8 @@ int msk_add_act_join_bwd_pg(msk_ctx* ctx, msk_tensor y, const float* scale, cons
  * run, i.e. until the next msk_sync / optimizer step) receives the second transform and `dy_scratch` is not written.
  * Otherwise (ybuf NULL, or the shape is not eligible) the three operations run one after the other with dy in `dy_scratch`
  * (a tensor of y's shape, required either way).  xform as in msk_conv3d_wgrad_ex.  Results agree with the separate calls
- * to fp32 rounding.                                                                                          */
+ * to fp32 rounding.  A convolution with ONE input channel and dx.p NULL (in_tr.conv1, vnet.py:67) evaluates dy inside its
+ * weight-gradient kernel as well (no ybuf / xform / maxes needed; dy_scratch is not written), on the calling stream.  */
 size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y);
 int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd,
