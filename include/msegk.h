@@ -226,6 +226,13 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
                          const void* xform /*nullable*/, void* ybuf /*nullable*/,
                          const float* maxes /*nullable: msk_affine_act_bwd_reduce_ex's, needed by the fused forms under "conv_split" 2*/);
+/* The in_tr.conv1 unit (vnet.py:57-79: out = PReLU(BN(conv5^3(x: ONE channel)) + tile(x)), no data gradient): weight gradient
+ * with dy evaluated inside the kernel from (y, dout); `res` is either a null tensor or x itself (the tiled residual, read from the
+ * kernel's own halo of x).  Returns 0 = done, 1 = not this class / declined (nothing was launched: use msk_affine_act_bwd_apply +
+ * msk_conv3d_wgrad), < 0 = error.  Runs on the calling stream.                                                     */
+int msk_conv3d_bwd_bnact_c1(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y, const float* scale, const float* shift,
+                            const float* alpha /*nullable*/, const float* mean, const float* invstd, msk_tensor res,
+                            msk_tensor dout, const float* sums_total, double M_total, float* dw, int dw_accumulate);
 /* autograd of the above (core/train.py:139 loss.backward()):
  *   dx (+)= conv^T(dy, w);  accumulate != 0 adds into dx                       */
 int msk_conv3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,

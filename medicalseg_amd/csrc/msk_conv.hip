@@ -1018,6 +1018,51 @@ int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy
   return run_wgrad(ctx, g, dy, db, accumulate);
 }
 
+}  // extern "C"
+
+// in_tr.conv1 class: weight gradient with dy = BatchNorm/PReLU backward of (y, dout) evaluated in the kernel.  0 done, 1 declined
+// (nothing launched), < 0 error.  It is the LAST weight gradient of a backward pass: it runs on the calling stream -- the side
+// stream may still be busy with the gradients queued before it, and nothing is left here for it to overlap with.
+static int bwd_bnact_c1(msk_ctx* ctx, const WGrad& gw, msk_tensor y, const float* scale, const float* shift, const float* alpha,
+                        const float* mean, const float* invstd, msk_tensor dout, const float* sums_total, double M_total,
+                        int res_is_input) {
+  if (ctx->bwd_fuse == 0 || ctx->conv_impl != 0) return 1;
+  WbfBnBwd bn{};
+  bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
+  bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
+  bn.invM = (float)(1.0 / M_total);
+  bn.res_is_input = res_is_input;
+  WGrad gc = gw;
+  gc.B = nullptr;
+  gc.xform = nullptr;
+  gc.yfuse = &bn;
+  const int r = msk_wgrad_c1(ctx, gc);   // 0: not its shape class
+  return r < 0 ? r : (r == 1 ? 0 : 1);
+}
+
+extern "C" {
+
+int msk_conv3d_bwd_bnact_c1(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y, const float* scale, const float* shift,
+                            const float* alpha, const float* mean, const float* invstd, msk_tensor res, msk_tensor dout,
+                            const float* sums_total, double M_total, float* dw, int dw_accumulate) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
+  MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
+  if (x.c != 1) return 1;
+  // the residual this class knows is the unit's own input, tiled over the channels (in_tr: out = PReLU(BN(conv(x)) + x))
+  if (res.p && !(res.p == x.p && res.ld == x.ld && res.c == 1 && res.n == x.n && res.d == x.d && res.h == x.h && res.w == x.w)) return 1;
+  const size_t per = (size_t)x.d * x.h * x.w * (x.ld > y.ld ? x.ld : y.ld) * sizeof(float);
+  if (per > 0 && (size_t)x.n > kChunkBytes / per) return 1;
+  WGrad gw{};
+  gw.A = (const float*)x.p; gw.ald = x.ld; gw.bld = y.ld;
+  gw.N = x.n; gw.AD = x.d; gw.AH = x.h; gw.AW = x.w; gw.BD = y.d; gw.BH = y.h; gw.BW = y.w;
+  gw.CA = x.c; gw.CB = y.c;
+  gw.kd = cd.kd; gw.kh = cd.kh; gw.kw = cd.kw; gw.sd = cd.sd; gw.sh = cd.sh; gw.sw = cd.sw;
+  gw.pd = cd.pd; gw.ph = cd.ph; gw.pw = cd.pw;
+  gw.dw = dw; gw.accumulate = dw_accumulate;
+  return bwd_bnact_c1(ctx, gw, y, scale, shift, alpha, mean, invstd, dout, sums_total, M_total, res.p ? 1 : 0);
+}
+
 size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y) {
   // the A dy transform has the layout of the transformed input of a conv over y's shape: same geometry by construction
   if (x.c != y.c || x.d != y.d || x.h != y.h || x.w != y.w) return 0;
@@ -1048,21 +1093,10 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
   gw.pd = cd.pd; gw.ph = cd.ph; gw.pw = cd.pw;
   gw.dw = dw; gw.accumulate = dw_accumulate;
   gw.xform = xform;
-  // ---- one input channel, no data gradient (in_tr.conv1, vnet.py:67): dy is evaluated inside the weight-gradient kernel.  It is
-  // the LAST weight gradient of a backward pass -- it runs on the calling stream: the side stream may still be busy with the
-  // gradients queued before it, and nothing is left here for it to overlap with
-  if (x.c == 1 && !dx.p && ctx->bwd_fuse != 0 && ctx->conv_impl == 0 && !(per > 0 && (size_t)x.n > kChunkBytes / per)) {
-    WbfBnBwd bn{};
-    bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
-    bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
-    bn.invM = (float)(1.0 / M_total);
-    WGrad gc = gw;
-    gc.B = nullptr;
-    gc.xform = nullptr;
-    gc.yfuse = &bn;
-    const int r = msk_wgrad_c1(ctx, gc);   // 0: not its shape class, nothing launched
-    if (r < 0) return r;
-    if (r == 1) return 0;
+  // ---- one input channel, no data gradient (in_tr.conv1, vnet.py:67): dy is evaluated inside the weight-gradient kernel
+  if (x.c == 1 && !dx.p && !(per > 0 && (size_t)x.n > kChunkBytes / per)) {
+    const int r = bwd_bnact_c1(ctx, gw, y, scale, shift, alpha, mean, invstd, dout, sums_total, M_total, 0);
+    if (r <= 0) return r;   // 0 done, < 0 error, 1 declined: the general forms below
   }
   size_t y_bytes = 0;
   if (fused && !msk_wgrad_wbf_fusable(ctx, gw, &y_bytes)) fused = false;

@@ -127,6 +127,9 @@ struct WbfBnBwd {
   // by the dual transform itself from the two amax arrays the reduce pass left (every block the same arithmetic on the same
   // inputs; block 0 stores it to `amax` for the kernels behind it) -- no separate bound kernel on the critical path
   const float* maxes;
+  // msk_wgrad_c1 only: the unit's pre-activation also adds its (one-channel, tiled) INPUT -- in_tr, vnet.py:75-78: the weight
+  // gradient's A operand itself, taken from the kernel's LDS halo
+  int res_is_input;
 };
 // writes B^T dy to a.V when write_v and A dy to bn.Y when that is non-null
 int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& a, const WbfBnBwd& bn, bool write_v);

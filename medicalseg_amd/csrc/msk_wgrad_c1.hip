@@ -103,7 +103,8 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
             const float yv = c1_load(rb, live ? (vx * (unsigned)yf.yld + r) * 4u : kOOB1);
             float d = c1_load(rd, live ? (vx * (unsigned)yf.dld + r) * 4u : kOOB1);
             if (has_alpha) {
-              const float uu = fmaf(yv, c_sc, c_sf);
+              float uu = fmaf(yv, c_sc, c_sf);
+              if (yf.res_is_input) uu += xs[bs[u] + (P * HH + P) * HW + P];   // + x at this voxel (the halo's centre tap)
               if (!(uu > 0.f)) d *= c_al;
             }
             const float xh = (yv - c_mu) * c_is;

@@ -18,6 +18,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import _lib
 from ._lib import NULL_TENSOR, MskBnFin, MskConvDesc, MskError
 from .device import Tensor, get_device
 
@@ -661,18 +662,23 @@ class ConvBNAct:
             dev.call("msk_affine_act_param_grads", Cn, _fp(sc["sums"]), _fp(bn.weight.grad_ptr), _fp(bn.bias.grad_ptr),
                      _fp(_act_alpha_grad(self.act)), 1)
         dy = y.empty_like()
-        if (FUSE_BN_BACKWARD and FUSE_BN_BACKWARD_C1 and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and not need_dx
-                and self.conv.cin == 1 and self.conv.k == (5, 5, 5) and self.conv.s == (1, 1, 1)):
-            # in_tr.conv1 (vnet.py:67; one input channel, no data gradient): dy is evaluated inside the weight-gradient kernel
-            # (msk_conv3d_bwd_bnact) -- the last weight gradient of the backward pass starts one full-resolution pass earlier
+        if (FUSE_BN_BACKWARD and FUSE_BN_BACKWARD_C1 and type(self.conv) is Conv3D and self.bn_mode == 1 and not need_dx
+                and self.conv.cin == 1 and self.conv.k == (5, 5, 5) and self.conv.s == (1, 1, 1)
+                and (res is None or (res.ptr == self.x.ptr and res.c == 1 and not res_needs_grad))):
+            # in_tr (vnet.py:57-79; one input channel, no data gradient, the residual is the tiled input itself): dy is evaluated
+            # inside the weight-gradient kernel -- the last weight gradient of the backward pass starts one full-resolution pass
+            # earlier.  1 = declined (nothing launched): the separate passes below
             conv, x = self.conv, self.x
-            _count_flops(conv, x.n, y.d * y.h * y.w, 1)
-            dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
-                     _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
-                     _fp(sums_total), C.c_double(m_total), dy.msk(), NULL_TENSOR, 0, _fp(conv.weight.grad_ptr), 1, None, None, None)
-            conv._xform = None
-            self.dy = None
-            return
+            rc = dev.lib.msk_conv3d_bwd_bnact_c1(dev.ctx, conv.desc(), x.msk(), y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                                                 _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), resm, dout.msk(),
+                                                 _fp(sums_total), C.c_double(m_total), _fp(conv.weight.grad_ptr), 1)
+            if rc < 0:
+                raise MskError(f"msk_conv3d_bwd_bnact_c1 failed: {_lib.last_error(dev.ctx)}")
+            if rc == 0:
+                _count_flops(conv, x.n, y.d * y.h * y.w, 1)
+                conv._xform = None
+                self.dy = None
+                return
         if fuse:
             # LUConv class (vnet.py:36-41): BatchNorm/PReLU backward evaluated inside the kernel that writes both transforms
             # of dy (msk_conv3d_bwd_bnact); dy itself reaches HBM only when the shape is not eligible

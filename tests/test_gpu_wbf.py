@@ -984,15 +984,16 @@ def test_gradient_maximum_from_the_pass_that_writes_dy(split):
         d.set_option("wgrad_async", 1)
 
 
-@pytest.mark.parametrize("with_alpha", [0, 1])
-def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(with_alpha):
-    """msk_conv3d_bwd_bnact for in_tr.conv1 (1 -> 16 channels, no data gradient): the weight-gradient kernel evaluates dy from
-    (y, dout) itself -- same dw as msk_affine_act_bwd_apply + msk_conv3d_wgrad, dy_scratch left alone, and one kernel less."""
+@pytest.mark.parametrize("mode", ["plain", "alpha", "alpha+input residual"])
+def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(mode):
+    """in_tr.conv1 (1 -> 16 channels, no data gradient): the weight-gradient kernel evaluates dy from (y, dout) itself -- same dw
+    as msk_affine_act_bwd_apply + msk_conv3d_wgrad, one kernel less.  Through msk_conv3d_bwd_bnact (no residual; dy_scratch left
+    alone) and through msk_conv3d_bwd_bnact_c1 with the unit's tiled one-channel input as the residual (vnet.py:75-78)."""
     import ctypes as C
     from medicalseg_amd._lib import NULL_TENSOR
     cout, (N, D, H, W) = 16, (2, 9, 18, 37)
     d = dev()
-    rng = np.random.default_rng(23 + with_alpha)
+    rng = np.random.default_rng(23 + len(mode))
     x = rng.standard_normal((N, 1, D, H, W)).astype(np.float32)
     y = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
     dout = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
@@ -1003,10 +1004,11 @@ def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(with_al
     w = vec((rng.standard_normal(cout * 125) / 11).astype(np.float32))
     M = float(N * D * H * W)
     cd = _desc((5,) * 3, (1,) * 3, (2,) * 3)
-    al = vp(alpha) if with_alpha else None
+    al = vp(alpha) if mode != "plain" else None
+    res = xt.msk() if "residual" in mode else NULL_TENSOR
     # reference: the two separate calls
     dy = t_empty(N, cout, D, H, W, fill=0.0)
-    d.call("msk_affine_act_bwd_apply", yt.msk(), vp(scale), vp(shift), NULL_TENSOR, al, vp(mean), vp(invstd), vp(gamma), dt.msk(),
+    d.call("msk_affine_act_bwd_apply", yt.msk(), vp(scale), vp(shift), res, al, vp(mean), vp(invstd), vp(gamma), dt.msk(),
            vp(sums), C.c_double(M), 1, dy.msk(), NULL_TENSOR, 0)
     dw_ref = vec(np.full(cout * 125, 0.5, np.float32))
     d.call("msk_conv3d_wgrad", cd, xt.msk(), dy.msk(), vp(dw_ref), None, 1)
@@ -1015,12 +1017,21 @@ def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(with_al
     dw = vec(np.full(cout * 125, 0.5, np.float32))
     d.prof_reset()
     d.prof_enable(True)
-    d.call("msk_conv3d_bwd_bnact", cd, xt.msk(), vp(w), yt.msk(), vp(scale), vp(shift), al, vp(mean), vp(invstd), vp(gamma), dt.msk(),
-           vp(sums), C.c_double(M), scratch.msk(), NULL_TENSOR, 0, vp(dw), 1, None, None, None)
+    if "residual" in mode:
+        rc = d.lib.msk_conv3d_bwd_bnact_c1(d.ctx, cd, xt.msk(), yt.msk(), vp(scale), vp(shift), al, vp(mean), vp(invstd), res, dt.msk(),
+                                           vp(sums), C.c_double(M), vp(dw), 1)
+        assert rc == 0
+        # a residual that is not the input itself is declined, nothing launched
+        other = t_from_ncdhw(x.copy())
+        assert d.lib.msk_conv3d_bwd_bnact_c1(d.ctx, cd, xt.msk(), yt.msk(), vp(scale), vp(shift), al, vp(mean), vp(invstd), other.msk(),
+                                             dt.msk(), vp(sums), C.c_double(M), vp(dw), 1) == 1
+    else:
+        d.call("msk_conv3d_bwd_bnact", cd, xt.msk(), vp(w), yt.msk(), vp(scale), vp(shift), al, vp(mean), vp(invstd), vp(gamma),
+               dt.msk(), vp(sums), C.c_double(M), scratch.msk(), NULL_TENSOR, 0, vp(dw), 1, None, None, None)
     d.sync()
     d.prof_enable(False)
-    tags = set(d.prof_report())
-    assert "wgrad_c1_mfma" in tags and "affine_act_bwd_apply" not in tags, tags
+    tags = d.prof_report()
+    assert tags["wgrad_c1_mfma"][0] == 1 and "affine_act_bwd_apply" not in tags, tags
     a, b = vec_back(dw, cout * 125), vec_back(dw_ref, cout * 125)
     assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
     assert np.all(t_to_ncdhw(scratch) == -7.0)
