@@ -46,7 +46,7 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
     c_sc = yf.scale[r]; c_sf = yf.shift[r]; c_al = yf.alpha ? yf.alpha[r] : 1.f; c_mu = yf.mean[r]; c_is = yf.invstd[r];
     c_s1 = yf.sums[r] * yf.invM; c_s2 = yf.sums[g.CB + r] * yf.invM;
   }
-  const bool has_alpha = FUSE && yf.alpha != nullptr;
+  const bool use_res = FUSE && yf.res_is_input != 0;
 
   for (int i = tid; i < RT * 16; i += 256)
     toff[i] = i < TAPS ? ((i / (KS * KS)) * HH + (i / KS) % KS) * HW + i % KS : NV;
@@ -102,13 +102,15 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
             const unsigned vx = (unsigned)(((n * D + gd) * H + gh) * W + gw);
             const float yv = c1_load(rb, live ? (vx * (unsigned)yf.yld + r) * 4u : kOOB1);
             float d = c1_load(rd, live ? (vx * (unsigned)yf.dld + r) * 4u : kOOB1);
-            if (has_alpha) {
-              float uu = fmaf(yv, c_sc, c_sf);
-              if (yf.res_is_input) uu += xs[bs[u] + (P * HH + P) * HW + P];   // + x at this voxel (the halo's centre tap)
-              if (!(uu > 0.f)) d *= c_al;
-            }
+            // branch-free (c_al = 1 without a PReLU, a select for the residual): a runtime branch here kept the batch's
+            // loads from being issued together (0.23 -> 0.41 ms)
+            const float xc = xs[bs[u] + (P * HH + P) * HW + P];
+            const float uu = fmaf(yv, c_sc, c_sf) + (use_res ? xc : 0.f);   // + x at this voxel (the halo's centre tap)
+            d *= (uu > 0.f) ? 1.f : c_al;
             const float xh = (yv - c_mu) * c_is;
-            bv[u] = live ? c_sc * (d - c_s1 - xh * c_s2) : 0.f;
+            // dead lanes loaded zeros (out-of-range offsets): a multiply instead of a select keeps the compiler from sinking the
+            // loads into a branch (which made every K-step wait for its own loads: 0.23 -> 0.41 ms)
+            bv[u] = (live ? 1.f : 0.f) * (c_sc * (d - c_s1 - xh * c_s2));
           }
         }
 #pragma unroll
