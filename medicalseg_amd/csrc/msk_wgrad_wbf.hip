@@ -251,14 +251,25 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
     const int ca = (int)(r_ % CA);
     const int row = (int)(r_ / CA);  // kd*K + kh
     const long off = ((((long)(ca >> 4) * ncob + cob) * T2 + row) * 16 + (ca & 15)) * 32 + lane;
+    {
+      // the NXI loads of a slab are issued together (one xi after the other left every load waiting for the one before: the
+      // additions of a point are a dependent chain); the order of the additions per point is unchanged
+      double acc[NXI];
 #pragma unroll
-    for (int xi = 0; xi < NXI; ++xi) {
-      double acc = 0.0;
+      for (int xi = 0; xi < NXI; ++xi) acc[xi] = 0.0;
       if (live) {
-        const float* p = P + (long)xi * ksplit * slab + off;
-        for (int z = slice; z < ksplit; z += NS) acc += (double)p[(long)z * slab];
+        const float* p = P + off;
+        const long xstep = (long)ksplit * slab;
+        for (int z = slice; z < ksplit; z += NS) {
+          float v[NXI];
+#pragma unroll
+          for (int xi = 0; xi < NXI; ++xi) v[xi] = p[(long)xi * xstep + (long)z * slab];
+#pragma unroll
+          for (int xi = 0; xi < NXI; ++xi) acc[xi] += (double)v[xi];
+        }
       }
-      sh[w8][xi][lane] = acc;
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) sh[w8][xi][lane] = acc[xi];
     }
     __syncthreads();
     if (slice == 0 && live) {
