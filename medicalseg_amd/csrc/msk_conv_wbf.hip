@@ -1131,17 +1131,28 @@ wbf_tout_k(ToutArgs a) {
     const int t = (int)(r_ % a.T);
     const int n = (int)(r_ / a.T);
     float mx[8], my[8], mz[8], mw[8];
+    {
+      // the NXI loads of one split-K slab are issued together, slab after slab in a fixed order (a point's slabs one after the
+      // other made every load wait for the previous one: the deep levels run with 2-16 slabs)
+      float4 s[NXI];
 #pragma unroll
-    for (int xi = 0; xi < 8; ++xi) {
-      if (xi < NXI) {
-        float4 s = *reinterpret_cast<const float4*>(a.M + (long)xi * a.m_xi + idx * 4);
-        for (int z = 1; z < a.ksplit; ++z) {  // fixed order
-          const float4 q = *reinterpret_cast<const float4*>(a.M + ((long)z * NXI + xi) * a.m_xi + idx * 4);
-          s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      for (int xi = 0; xi < NXI; ++xi) s[xi] = *reinterpret_cast<const float4*>(a.M + (long)xi * a.m_xi + idx * 4);
+      for (int z = 1; z < a.ksplit; ++z) {
+        float4 q[NXI];
+#pragma unroll
+        for (int xi = 0; xi < NXI; ++xi) q[xi] = *reinterpret_cast<const float4*>(a.M + ((long)z * NXI + xi) * a.m_xi + idx * 4);
+#pragma unroll
+        for (int xi = 0; xi < NXI; ++xi) {
+          s[xi].x += q[xi].x; s[xi].y += q[xi].y; s[xi].z += q[xi].z; s[xi].w += q[xi].w;
         }
-        mx[xi] = s.x; my[xi] = s.y; mz[xi] = s.z; mw[xi] = s.w;
-      } else {
-        mx[xi] = my[xi] = mz[xi] = mw[xi] = 0.f;
+      }
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) {
+        if (xi < NXI) {
+          mx[xi] = s[xi < NXI ? xi : 0].x; my[xi] = s[xi < NXI ? xi : 0].y; mz[xi] = s[xi < NXI ? xi : 0].z; mw[xi] = s[xi < NXI ? xi : 0].w;
+        } else {
+          mx[xi] = my[xi] = mz[xi] = mw[xi] = 0.f;
+        }
       }
     }
     float yx[4], yy[4], yz[4], yw[4];
@@ -1153,13 +1164,17 @@ wbf_tout_k(ToutArgs a) {
     if (a.bias) bv = reinterpret_cast<const float4*>(a.bias)[c4];
     if (a.prelu) sl = reinterpret_cast<const float4*>(a.prelu)[c4];
     float* o = a.dst + ((long)n * a.dvn + (long)d * a.dvd + (long)h * a.dvh + (long)(4 * t) * a.dvw) * a.dld + c4 * 4;
+    float4 old4[4];   // accumulate: the four old values are loaded before the first store (load -> add -> store per row serialised)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      old4[i] = (a.accumulate && 4 * t + i < a.LW) ? *reinterpret_cast<const float4*>(o + (long)i * a.dvw * a.dld) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (4 * t + i < a.LW) {
         float4* op = reinterpret_cast<float4*>(o + (long)i * a.dvw * a.dld);
         float4 r = make_float4(fmaf(yx[i], osc, bv.x), fmaf(yy[i], osc, bv.y), fmaf(yz[i], osc, bv.z), fmaf(yw[i], osc, bv.w));
         if (a.accumulate) {
-          const float4 e = *op;
+          const float4 e = old4[i];
           r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;
         }
         r.x = r.x > 0.f ? r.x : sl.x * r.x;
