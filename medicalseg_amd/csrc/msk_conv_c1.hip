@@ -88,12 +88,23 @@ conv_c1_mfma_k(C1Args a) {
     const int n = t_ / a.tiles_d;
     const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
     __syncthreads();  // the previous tile's readers are done
-    for (int hv = tid; hv < NV; hv += 256) {
-      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
-      const bool in = (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
-      xs[hv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                   rs, (int)(in ? (unsigned)((((n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld) * 4u : kOOBc), 0, 0));
+    {
+      // all of a thread's halo loads are issued before the first LDS store (one load -> store per trip left ~14 dependent
+      // round trips in front of every tile: tools/isa_scan.py)
+      constexpr int NLD = (NV + 255) / 256;
+      float hx[NLD];
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) {
+        const int hv = tid + 256 * q;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        const bool in = hv < NV && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+        hx[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (int)(in ? (unsigned)((((n * a.D + gd) * a.H + gh) * a.W + gw) * a.sld) * 4u : kOOBc), 0, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < NLD; ++q)
+        if (tid + 256 * q < NV) xs[tid + 256 * q] = hx[q];
     }
     __syncthreads();
     // a wavefront owns plane d0 + wave: 8 rows x 2 column tiles of 16 voxels

@@ -71,11 +71,22 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
     const int n = t_ / tiles_d;
     const int d0 = tdi * TD, h0 = thi * TH, w0 = twi * TW;
     __syncthreads();  // the previous tile's readers are done (and toff / xs[NV] are visible on the first trip)
-    for (int hv = tid; hv < NV; hv += 256) {
-      const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
-      const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
-      const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-      xs[hv] = c1_load(ra, in ? (unsigned)((((n * D + gd) * H + gh) * W + gw) * g.ald) * 4u : kOOB1);
+    {
+      // all of a thread's halo loads are issued before the first LDS store (tools/isa_scan.py: one load -> store per trip was
+      // ~14 dependent round trips in front of every tile)
+      constexpr int NLD = (NV + 255) / 256;
+      float hx[NLD];
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) {
+        const int hv = tid + 256 * q;
+        const int hd = hv / (HH * HW), rem = hv % (HH * HW), hh = rem / HW, hw = rem % HW;
+        const int gd = d0 - P + hd, gh = h0 - P + hh, gw = w0 - P + hw;
+        const bool in = hv < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        hx[q] = c1_load(ra, in ? (unsigned)((((n * D + gd) * H + gh) * W + gw) * g.ald) * 4u : kOOB1);
+      }
+#pragma unroll
+      for (int q = 0; q < NLD; ++q)
+        if (tid + 256 * q < NV) xs[tid + 256 * q] = hx[q];
     }
     __syncthreads();
     const int gd = d0 + wave;  // this wavefront's plane
