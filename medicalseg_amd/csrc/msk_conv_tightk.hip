@@ -249,22 +249,30 @@ conv_tk_h2_k(TKH2Args a) {
     st_v[j] = v < NV ? v : -1;
   }
   const long plane = (long)a.H * a.W * a.sld;
-  auto stage = [&](int p) {  // plane p (may lie outside the volume: zeros) -> ring slot p & 7
-    uint2* sl = lds + (p & (RING - 1)) * SLOT;
+  // a plane is staged in two halves: its loads are issued before the MFMAs of the plane in front of it, the conversion and the LDS
+  // stores follow them (loaded and stored in one piece the global round trip stood in front of every plane: tools/isa_scan.py)
+  auto stage_load = [&](int p, float (&c)[2][4]) {  // plane p (may lie outside the volume: zeros)
     const bool live = p >= 0 && p < a.D;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (st_v[j] < 0) continue;
-      float c[4] = {0.f, 0.f, 0.f, 0.f};
-      if (live && st_off[j] >= 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[j][q] = 0.f;
+      if (st_v[j] >= 0 && live && st_off[j] >= 0) {
         const float* sp = a.src + st_off[j] + (long)p * plane;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (q < a.CK) c[q] = sp[q] * sx;
+          if (q < a.CK) c[j][q] = sp[q];
       }
+    }
+  };
+  auto stage_store = [&](int p, const float (&c)[2][4]) {  // -> ring slot p & 7
+    uint2* sl = lds + (p & (RING - 1)) * SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (st_v[j] < 0) continue;
       uint2 hv, lv;
-      wbf_split2h_pair(c[0], c[1], hv.x, lv.x);
-      wbf_split2h_pair(c[2], c[3], hv.y, lv.y);
+      wbf_split2h_pair(c[j][0] * sx, c[j][1] * sx, hv.x, lv.x);
+      wbf_split2h_pair(c[j][2] * sx, c[j][3] * sx, hv.y, lv.y);
       sl[st_v[j]] = hv;
       sl[NV + st_v[j]] = lv;
     }
@@ -272,15 +280,18 @@ conv_tk_h2_k(TKH2Args a) {
 
   f32x4 acc[4][2];  // [row of the wave][output-channel tile]
   const int steps = (d_end - d_begin) + 4;
-  // planes d_begin-2 .. d_begin+1 first, then one new plane per output plane
+  float pre[2][4];
+  // planes d_begin-2 .. d_begin+2 first, then one new plane (d + 3: a sixth slot of the ring of eight) per output plane
 #pragma unroll 1
-  for (int s = 0; s < 4; ++s) stage(d_begin - 2 + s);
+  for (int s = 0; s < 5; ++s) {
+    stage_load(d_begin - 2 + s, pre);
+    stage_store(d_begin - 2 + s, pre);
+  }
+  __syncthreads();
 #pragma unroll 1
   for (int s = 4; s < steps; ++s) {
     const int d = d_begin + s - 4;  // output plane: needs planes d-2 .. d+2
-    __syncthreads();                // the previous plane's reads of the slot about to be overwritten are done
-    stage(d + 2);
-    __syncthreads();
+    stage_load(d + 3, pre);         // in flight during this plane's MFMAs
     // slots of this lane's two planes (kd = 2 lk, 2 lk + 1); padding lanes read the zero unit
     const int s0 = lk < 3 ? ((d - 2 + 2 * lk) & (RING - 1)) * SLOT : -1;
     const int s1 = lk < 2 ? ((d - 1 + 2 * lk) & (RING - 1)) * SLOT : -1;
@@ -345,6 +356,8 @@ conv_tk_h2_k(TKH2Args a) {
         }
       }
     }
+    stage_store(d + 3, pre);   // slot (d + 3) & 7 held plane d - 5: its last readers passed two barriers ago
+    __syncthreads();
   }
 }
 
