@@ -163,6 +163,12 @@ def main():
     ap.add_argument("--force-syncbn-collectives", action="store_true",
                     help="diagnostic (1 GPU): create a 1-rank RCCL communicator and run the 48 SyncBatchNorm collectives and the "
                          "gradient buckets of the multi-GPU step on it (identities) -- measures their stream hand-over / launch cost")
+    ap.add_argument("--dp-mode", type=int, default=None, choices=(0, 1, 2, 3),
+                    help="N > 1: stream / communicator arrangement of the collectives (msk_dp.hip): 0 = all on the compute stream, "
+                         "ONE gradient all-reduce after backward (default); 2 = gradient buckets on a second communicator + "
+                         "stream, overlapped with backward; 1 / 3 = single-communicator variants")
+    ap.add_argument("--skip-strict-fp32", action="store_true",
+                    help="skip the untimed extra pass behind roofline.strict_fp32 (the step with exact bf16 x 3 operand pieces)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msk_set_option knob for experiments, e.g. --opt wgrad_async=0 (not for the headline run)")
     args = ap.parse_args()
@@ -184,7 +190,7 @@ def main():
                              "got WORLD_SIZE=%d" % (args.gpus, args.gpus, world))
     dev = get_device()
     if world > 1:
-        parallel.init_parallel_env()
+        parallel.init_parallel_env(dp_mode=args.dp_mode)
 
     S, B, ncls = args.size, args.batch, args.num_classes
     ds = SyntheticCT(num_samples=B, shape=(S, S, S), num_classes=ncls, seed=1234 + 1000 * rank)
@@ -275,26 +281,63 @@ def main():
         prof_serial = dev.prof_report()
         dev.set_option("wgrad_async", 1)
 
+    # untimed extra pass with EXACT fp32 operands (conv_split 3: every fp32 operand as three bf16 pieces, six MFMAs per product,
+    # no dropped significand bits) -- the reference's arithmetic is plain fp32 (vnet.py:36, no AMP), the headline uses 22-bit
+    # operands (dtype_note); this is the same step at full operand precision, reported beside it, never as `value`
+    strict = None
+    if world == 1 and not args.skip_strict_fp32 and "conv_split=3" not in args.opt:
+        import ctypes as _C
+        dev.set_option("conv_split", 3)
+        for _ in range(2):
+            step()
+        dev.sync()
+        nst = 5
+        dev.call("msk_mark", 0)
+        for _ in range(nst):
+            step()
+        dev.call("msk_mark", 1)
+        ms = _C.c_float()
+        dev.call("msk_mark_elapsed", 0, 1, _C.byref(ms))
+        dev.set_option("conv_split", 2)
+        strict = {"ms_per_step": round(float(ms.value) / nst, 3), "value": round(B * S ** 3 / (float(ms.value) / nst * 1e-3), 1),
+                  "unit": "voxels/s", "steps": nst,
+                  "note": "untimed extra pass (stream marks): the same step with exact fp32 operands (option conv_split 3: bf16 x 3 "
+                          "pieces, 6 MFMAs per fp32 product)"}
+
     # max over ranks; per-rank time inside the RCCL collectives (HIP events on the stream each one is enqueued on: it
     # includes waiting for the slowest peer), so that the first multi-GPU run is diagnosable
     dp_info = None
     if world > 1:
         import ctypes as C
-        tags = ("rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather")
+        tags = ("rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather", "rccl_allreduce_bucket")
         mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags]
         sp, rp = dev.small(len(mine)), dev.small(world * len(mine))
         dev.h2d(sp, np.array(mine, np.float32))
         dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(len(mine)))
         allv = dev.d2h(rp, (world, len(mine)), np.float32)
         elapsed = max(elapsed, float(allv[:, 0].max()))
-        dp_info = {"per_rank_step_ms": [round(float(v) / args.steps * 1e3, 3) for v in allv[:, 0]],
+        arena_bytes = 4.0 * model.arena.count
+        ar_ms = [float(a + b) for a, b in zip(allv[:, 1], allv[:, 4])]    # one piece on the compute stream or buckets on the communication stream
+        dp_info = {"dp_mode": dev.get_option("dp_mode"), "overlap_buckets": bool(getattr(net, "overlap", False)),
+                   "gradient_arena_MB": round(arena_bytes / 1e6, 1),
+                   "buckets_last_step": len(getattr(net, "buckets_last_step", []) or []),
+                   # ring all-reduce: every GPU sends and receives 2 (N-1)/N x the buffer -> "bus bandwidth" as nccl-tests define it;
+                   # the HIP-event time of a collective includes waiting for the slowest peer to arrive
+                   "allreduce_busbw_GBps_per_rank": [round(2.0 * (world - 1) / world * arena_bytes / (t * 1e-3) / 1e9, 1) if t > 0 else None
+                                                     for t in ar_ms],
+                   "syncbn_collective_ms_per_step_per_rank": [round(float(a + b), 3) for a, b in zip(allv[:, 2], allv[:, 3])],
+                   "exposed_comm_budget_note": "north_star >= 6.5x at 8 GPUs holds while (rccl_allreduce, when not overlapped) + "
+                                               "syncbn collectives stay under ~4.7 ms per 20 ms step; DESIGN 7's model assumes "
+                                               "1.3-2.1 ms for the all-reduce and 20-30 us per statistics collective",
+                   "per_rank_step_ms": [round(float(v) / args.steps * 1e3, 3) for v in allv[:, 0]],
                    "per_rank_collective_ms_per_step": {t: [round(float(v), 3) for v in allv[:, 1 + i]] for i, t in enumerate(tags)},
                    "calls_per_step": {t: int(sum(v[0] for k, v in prof.items() if k == t) / args.steps) for t in tags},
-                   "overlap": os.environ.get("MSEGK_DP_OVERLAP", "default: off (one all-reduce after backward, every collective on "
-                                                                  "the compute stream; MSEGK_DP_MODE=2 MSEGK_DP_OVERLAP=1 = buckets on a "
-                                                                  "second communicator)"),
-                   "note": "rccl_allreduce = gradient arena (182 MB per step), rccl_allreduce_stats / rccl_allgather = "
-                           "SyncBatchNorm exchanges (2*C floats each)"}
+                   "how_to_ab": "--dp-mode 2 = gradient buckets on a second communicator + stream, overlapped with backward; "
+                                "--dp-mode 0 (default) = one all-reduce after backward, everything on the compute stream; "
+                                "--no-sync-bn = rank-local BatchNorm statistics (deviation from the reference)",
+                   "note": "rccl_allreduce = gradient arena (182 MB per step) in one piece on the compute stream, rccl_allreduce_bucket = "
+                           "its buckets on the communication stream (dp_mode 1-3; overlapped with backward, so their time is NOT "
+                           "exposed), rccl_allreduce_stats / rccl_allgather = SyncBatchNorm exchanges (2*C floats each)"}
 
     if rank != 0:
         return
@@ -368,6 +411,7 @@ def main():
                                              WGRAD_TAGS[split] + " in the same untimed pass (it runs on the side stream in the timed region)"),
                 # fraction of the step the EXECUTED work would take at the hardware peaks (bf16 pipe for the LUConv
                 # layers, fp32 MFMA peak for the remaining convolutions); <= 1
+                "strict_fp32": strict,
                 "hbm": hbm,
                 "step_executed_frac": round(t_floor / (ms_per_step * 1e-3), 4),
                 "step_algorithmic_speedup_vs_fp32_roofline": round(total_flops / (ms_per_step * 1e-3) / 1e12

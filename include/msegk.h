@@ -59,6 +59,15 @@ int msk_device_name(msk_ctx* ctx, char* buf, int buflen);
 int msk_malloc(msk_ctx* ctx, size_t bytes, void** out);
 int msk_free(msk_ctx* ctx, void* p);
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes);
+/* Packed-weight cache contract.  The 5x5x5 / 3x3x3 convolution pipeline keeps a transformed, packed copy of every weight
+ * tensor it has seen (keyed by its device address).  Every entry point of this library that WRITES caller memory
+ * (msk_h2d*, msk_d2d, msk_memset, msk_sgd_momentum, msk_adam, msk_conv_fold_bn, msk_dp_allreduce_*, msk_dp_broadcast)
+ * invalidates the copies of the bytes it writes, and msk_free drops those inside the freed allocation.  A caller that
+ * changes weights ANY OTHER WAY (its own kernel or hipMemcpy on the buffer, or a library pass such as msk_copy_scale /
+ * msk_interp_* / msk_ndhwc_to_ncdhw aimed at a weight tensor) must report the range here before the next convolution that
+ * reads it; without the call that convolution would run with the stale packed weights (forward, data gradient and the
+ * fused inference path -- the weight gradient never reads packed weights).  Cheap: a host-side table walk, no launch. */
+int msk_weights_changed(msk_ctx* ctx, const void* p, size_t bytes);
 /* host (pageable) -> device, ordered on the compute stream; src may be reused as soon as the call returns.
  * 64 KB .. 64 MB (the per-iteration batch upload of core/train.py:122-124) go through two internal pinned staging
  * buffers and do NOT synchronise the stream; other sizes copy and synchronise. */
@@ -113,6 +122,8 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels; "wgrad_wino_rounds" 0 = pick the
  *   split count that fills whole waves of resident workgroups, the default) */
 int msk_set_option(msk_ctx* ctx, const char* key, int value);
+/* effective value of "dp_mode" (after MSEGK_DP_MODE and msk_dp_init's fall-backs), "conv_split", "wgrad_async", "world", "rank" */
+int msk_get_option(msk_ctx* ctx, const char* key, int* value);
 
 /* ---- layout at the boundary ------------------------------------------------ */
 /* NCDHW (reference layout, core/train.py:123) <-> NDHWC (device layout) */

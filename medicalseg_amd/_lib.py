@@ -54,6 +54,7 @@ SIGNATURES = {
     "msk_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "msk_free": (_i, [_vp, _vp]),
     "msk_memset": (_i, [_vp, _vp, _i, _sz]),
+    "msk_weights_changed": (_i, [_vp, _vp, _sz]),
     "msk_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "msk_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "msk_h2d_async": (_i, [_vp, _vp, _vp, _sz]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "msk_prof_reset": (_i, [_vp]),
     "msk_prof_report": (_i, [_vp, C.c_char_p, _i, C.POINTER(_i)]),
     "msk_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "msk_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "msk_ncdhw_to_ndhwc": (_i, [_vp, _vp, _T]),
     "msk_ndhwc_to_ncdhw": (_i, [_vp, _T, _vp]),
     "msk_conv3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),

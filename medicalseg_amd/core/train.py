@@ -25,7 +25,7 @@ from .val import evaluate
 
 def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='output', iters=10000, batch_size=2,
           resume_model=None, save_interval=1000, log_iters=10, num_workers=0, use_vdl=False, losses=None,
-          keep_checkpoint_max=5, profiler_options=None, to_static_training=False):
+          keep_checkpoint_max=5, profiler_options=None, to_static_training=False, dp_mode=None):
     model.train()
     env = ParallelEnv()
     nranks, local_rank = env.nranks, env.local_rank
@@ -38,7 +38,7 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
         os.makedirs(save_dir, exist_ok=True)
     ddp_model = model
     if nranks > 1:
-        init_parallel_env()
+        init_parallel_env(dp_mode=dp_mode)    # train.py --dp_mode: 0 = one all-reduce after backward, 2 = overlapped buckets
         ddp_model = DataParallel(model)
     loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True, drop_last=False,
                         num_workers=num_workers)
@@ -131,7 +131,38 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
                                 .format(best_mean_dice, best_model_iter))
             batch_start = time.time()
     dev.sync()
+    # reference core/train.py:265-269: after the loop rank 0 reports paddle.flops(model, [1, c, d, h, w]) -- one batch-1
+    # forward.  Here: the analytic count of the convolutions of one real eval forward of that shape (nn.FLOPS, the table of
+    # SURVEY App. A), printed in paddle's "Total Flops / Total Params" form (paddle.flops counts multiply-accumulates).
+    if local_rank == 0 and it > start_iter:
+        try:
+            _report_flops(model, images.shape)
+        except Exception as e:     # a report must never fail a finished training run
+            logger.warning("FLOP report skipped: %r" % (e,))
     time.sleep(0.1)
+
+
+def _report_flops(model, shape):
+    from .. import nn as _nn
+    _, c, d, h, w = shape
+    dev = model.dev
+    was_training = getattr(model, "training", True)
+    keep = dict(_nn.FLOPS)
+    _nn.FLOPS.update(on=True, same_k5=0.0, same_k3=0.0, other=0.0)
+    try:
+        model.eval()
+        model(to_tensor(np.zeros((1, c, d, h, w), np.float32), dev))
+        dev.sync()
+        flops = _nn.FLOPS["same_k5"] + _nn.FLOPS["same_k3"] + _nn.FLOPS["other"]
+    finally:
+        _nn.FLOPS.update(keep)
+        if was_training:
+            model.train()
+    params = sum(int(np.prod(p.shape)) for p in model.parameters())
+    logger.info("Total Flops: {:d}     Total Params: {:d}".format(int(flops // 2), params))
+    logger.info("(convolution multiply-accumulates of one [1, {}, {}, {}, {}] forward, paddle.flops' convention; algorithmic "
+                "forward FLOPs {:.1f} G, training step fwd+bwd ~{:.1f} G per sample)".format(c, d, h, w, flops / 1e9, 3 * flops / 1e9))
+    return int(flops // 2), params
 
 
 def _snapshot(dev, loss, loss_list, per_channel_dice):

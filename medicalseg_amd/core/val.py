@@ -25,15 +25,23 @@ def _load_dataset_json(eval_dataset):
     return None
 
 
+_IDENTITY_GEOMETRY = {"spacing": (1.0, 1.0, 1.0), "direction": (1, 0, 0, 0, 1, 0, 0, 0, 1), "origin": (0.0, 0.0, 0.0),
+                      "format": "xyz"}
+_warned_geometry = [False]
+
+
 def _image_info(dataset_json, idx):
-    """spacing / direction / origin of one validation volume (reference core/val.py:96-97,149-154); identity geometry when
-    the dataset has no json (synthetic data)"""
-    try:
-        name = str(idx[0]).split("/")[-1].split(".")[0]
-        j = dataset_json["training"][name]
-        return {"spacing": j["spacing_resample"], "direction": j["direction"], "origin": j["origin"], "format": "xyz"}
-    except Exception:
-        return {"spacing": (1.0, 1.0, 1.0), "direction": (1, 0, 0, 0, 1, 0, 0, 0, 1), "origin": (0.0, 0.0, 0.0), "format": "xyz"}
+    """spacing / direction / origin of one validation volume (reference core/val.py:96-97,149-154).  Identity geometry only
+    when the dataset HAS no json (synthetic data); with a json, a volume or key that is missing raises KeyError as the
+    reference's dictionary lookups do -- a NIfTI file with a silently wrong geometry is worse than no file."""
+    if not dataset_json:
+        if not _warned_geometry[0]:
+            logger.warning("evaluate: the dataset has no dataset.json; predictions are saved with identity spacing / origin / direction.")
+            _warned_geometry[0] = True
+        return dict(_IDENTITY_GEOMETRY)
+    name = str(idx[0]).split("/")[-1].split(".")[0]
+    j = dataset_json["training"][name]
+    return {"spacing": j["spacing_resample"], "direction": j["direction"], "origin": j["origin"], "format": "xyz"}
 
 
 def evaluate(model, eval_dataset, losses, num_workers=0, print_detail=True, auc_roc=False, writer=None,

@@ -114,6 +114,7 @@ int msk_fail(msk_ctx* ctx, const char* file, int line, const char* what, const c
 void* msk_workspace(msk_ctx* ctx, size_t bytes);   // returns nullptr on failure (error set)
 void* msk_workspace2(msk_ctx* ctx, size_t bytes);
 void* msk_workspace3(msk_ctx* ctx, size_t bytes);
+hipEvent_t msk_prof_event(msk_ctx* ctx);   // a timing event from the profile's pool (for brackets on other streams)
 void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
@@ -121,7 +122,7 @@ int msk_join_side_impl(msk_ctx* ctx);
 void msk_set_ew_caps(int ew, int red);   // msk_elementwise.hip tuning knobs
 // caller memory that may hold convolution weights was (or is about to be) written / freed: derived forms are stale
 void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes);
-void msk_weights_freed_impl(msk_ctx* ctx, const void* p);
+void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes);  // msk_free: drop the rows inside [p, p + bytes)
 int msk_wbf_prepack_impl(msk_ctx* ctx);   // rebuild every stale packed-weight row in use (end of the optimizer kernels)
 void msk_wbf_pack_cache_free(msk_ctx* ctx);
 int msk_dp_wait_impl(msk_ctx* ctx);

@@ -1741,15 +1741,21 @@ void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
     if (a0 < b1 && b0 < a1) e.valid = false;
   }
 }
-void msk_weights_freed_impl(msk_ctx* ctx, const void* p) {
-  // the allocation's size is not known here: rows whose weights START inside any freed block cannot be told apart from rows
-  // of a later allocation at the same address once it is reused, so every row keyed at or after p up to the next h2d is at
-  // risk -- drop the rows whose weights begin exactly at p, invalidate nothing else (a reused address is always (re)written
-  // through msk_h2d / an optimizer kernel before it is used as weights, which invalidates by range)
+void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
+  // msk_free: every row whose weights lie (even partly) inside the freed allocation [p, p + bytes) is DROPPED -- a row that
+  // was only invalidated would be rebuilt by the next optimizer call (msk_wbf_prepack_impl) from freed memory, and its
+  // packed buffer would stay allocated until the LRU evicts it.  bytes == 0 (range unknown): the rows that begin at p.
   if (!ctx->wpack || !p) return;
   WbfPackCache* c = (WbfPackCache*)ctx->wpack;
-  for (int r = 0; r < WbfPackCache::kRows - 1; ++r)
-    if (c->e[r].live && (const void*)c->e[r].d.w == p) pack_row_drop(ctx, c->e[r]);
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r) {
+    WbfPackEntry& e = c->e[r];
+    if (!e.live) continue;
+    const char* b0 = (const char*)e.d.w;
+    const char* b1 = b0 + (size_t)e.d.count * sizeof(float);
+    if (bytes ? (a0 < b1 && b0 < a1) : b0 == a0) pack_row_drop(ctx, e);
+  }
 }
 int msk_wbf_prepack_impl(msk_ctx* ctx) {
   if (!ctx->wpack || !ctx->wbf_prepack) return 0;

@@ -63,6 +63,7 @@ static void drain_prof(msk_ctx* ctx) {
 
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s) { return ctx->tag_pool.insert(s).first->c_str(); }
 
+hipEvent_t msk_prof_event(msk_ctx* ctx) { return get_event(ctx); }
 void msk_prof_begin(msk_ctx* ctx, const char* tag) {
   msk_pending_event pe;
   pe.a = get_event(ctx);
@@ -225,11 +226,19 @@ int msk_free(msk_ctx* ctx, void* p) {
   {
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
-    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size > 0) msk_weights_changed_impl(ctx, base, size);
-    else (void)hipGetLastError();
-    msk_weights_freed_impl(ctx, p);
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size > 0) {
+      msk_weights_freed_impl(ctx, base, size);
+    } else {
+      (void)hipGetLastError();
+      msk_weights_freed_impl(ctx, p, 0);
+    }
   }
   MSK_CHECK_HIP(ctx, hipFree(p));
+  return 0;
+}
+int msk_weights_changed(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx) return -1;
+  if (p && bytes) msk_weights_changed_impl(ctx, p, bytes);
   return 0;
 }
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes) {
@@ -356,6 +365,17 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len) {
   return 0;
 }
 
+int msk_get_option(msk_ctx* ctx, const char* key, int* value) {
+  MSK_REQUIRE(ctx, key != nullptr && value != nullptr, "msk_get_option: null argument");
+  // the EFFECTIVE values (after environment overrides and fall-backs inside msk_dp_init), for callers that must agree with them
+  if (strcmp(key, "dp_mode") == 0) *value = ctx->dp_mode;
+  else if (strcmp(key, "conv_split") == 0) *value = ctx->conv_split;
+  else if (strcmp(key, "wgrad_async") == 0) *value = ctx->wgrad_async ? 1 : 0;
+  else if (strcmp(key, "world") == 0) *value = ctx->world;
+  else if (strcmp(key, "rank") == 0) *value = ctx->rank;
+  else return msk_fail(ctx, __FILE__, __LINE__, "msk_get_option", "unknown key");
+  return 0;
+}
 int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   if (strcmp(key, "conv_impl") == 0) {
     ctx->conv_impl = value;

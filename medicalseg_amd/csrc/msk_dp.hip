@@ -309,7 +309,21 @@ int msk_dp_allreduce_async(msk_ctx* ctx, float* buf, size_t count) {
     MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_side, 0));
   }
   msk_weights_changed_impl(ctx, buf, count * sizeof(float));
+  // HIP events on the COMMUNICATION stream (the launch scope's events sit on the compute stream): the bucket's own
+  // duration incl. the wait for the slowest peer, reported by bench.py as dp.per_rank_collective_ms_per_step
+  msk_pending_event pe;
+  const bool prof = ctx->prof;
+  if (prof) {
+    pe.a = msk_prof_event(ctx);
+    pe.b = msk_prof_event(ctx);
+    pe.tag = "rccl_allreduce_bucket";
+    hipEventRecord(pe.a, ctx->comm_stream);
+  }
   MSK_CHECK_NCCL(ctx, ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, bucket_comm, ctx->comm_stream));
+  if (prof) {
+    hipEventRecord(pe.b, ctx->comm_stream);
+    ctx->prof_pending.push_back(pe);
+  }
   ctx->comm_pending = true;
   return 0;
 }

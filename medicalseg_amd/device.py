@@ -83,6 +83,11 @@ class Device:
     def set_option(self, key: str, value: int):
         self.call("msk_set_option", key.encode(), int(value))
 
+    def get_option(self, key: str) -> int:
+        v = C.c_int(0)
+        self.call("msk_get_option", key.encode(), C.byref(v))
+        return v.value
+
     # -- timing / profiling ----------------------------------------------------------
     def timer_start(self):
         self.call("msk_timer_start")
@@ -180,7 +185,7 @@ class Tensor:
     ``shape`` reports the reference's logical NCDHW order so code written against the
     reference (``_, c, d, h, w = images.shape``; core/train.py:266) keeps working."""
 
-    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "amax")
+    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "_amax", "_amax_gen")
 
     def __init__(self, dev, ptr, n, d, h, w, c, ld=None, gen=None):
         self.dev, self.ptr = dev, ptr
@@ -194,7 +199,11 @@ class Tensor:
         # device "amax array" (msk_amax_new) that the passes WRITING this tensor fold max |value| into, or None.  A channel
         # slice shares its parent's array (the parent's maximum is the maximum over its slices' writers); it is only handed
         # to a consumer by code that knows every channel was written by such a pass (nn.ConvBNAct / AddAct / copy_scale).
-        self.amax = None
+        # The array is a slot of a ring that is recycled after ~500 requests (a few steps): it is stamped with the arena
+        # generation it was taken in and reads back as None afterwards, so a Tensor object that outlives its step (a
+        # persistent buffer, a user-held slice) gets a fresh slot / an absmax pass instead of a recycled one.
+        self._amax = None
+        self._amax_gen = -1
 
     # -- construction ------------------------------------------------------------------
     @staticmethod
@@ -206,6 +215,15 @@ class Tensor:
 
     def empty_like(self):
         return Tensor.empty(self.dev, self.n, self.d, self.h, self.w, self.c)
+
+    @property
+    def amax(self):
+        return self._amax if self._amax_gen == self.dev.arena.gen else None
+
+    @amax.setter
+    def amax(self, v):
+        self._amax = v
+        self._amax_gen = self.dev.arena.gen if v is not None else -1
 
     # -- views -----------------------------------------------------------------------------
     @property

@@ -119,13 +119,18 @@ def exchange_bytes(payload: bytes | None, rank: int, world: int, timeout=300.0) 
 _initialised = False
 
 
-def init_parallel_env():
-    """Create the RCCL communicator for this process's device (idempotent)."""
+def init_parallel_env(dp_mode=None):
+    """Create the RCCL communicator for this process's device (idempotent).  dp_mode (msk_dp.hip; train.py / bench.py
+    --dp-mode): 0 = every collective on the compute stream (default), 2 = gradient buckets on a second communicator and
+    stream, overlapped with backward (DataParallel then defaults to overlap=True); the environment variable MSEGK_DP_MODE
+    still overrides it inside msk_dp_init."""
     global _initialised
     env = ParallelEnv()
     dev = get_device()
     if _initialised or env.nranks == 1:
         return env
+    if dp_mode is not None:
+        dev.set_option("dp_mode", int(dp_mode))
     lib = _lib.load()
     uid = None
     if env.rank == 0:
@@ -182,8 +187,18 @@ class DataParallel:
             if fa is not None and fa.count:
                 dev.call("msk_dp_broadcast", C.c_void_p(fa.value_ptr), C.c_size_t(fa.count), 0)
             model.arena.grad_scale = 1.0 / dev.world
+            mode = dev.get_option("dp_mode")          # the EFFECTIVE arrangement (option, MSEGK_DP_MODE, fall-backs of msk_dp_init)
             if overlap is None:      # an explicit argument wins over the environment (advisor finding, round 2)
-                overlap = os.environ.get("MSEGK_DP_OVERLAP", "0") != "0"
+                env_o = os.environ.get("MSEGK_DP_OVERLAP")
+                overlap = (env_o != "0") if env_o is not None else mode != 0
+            if overlap and mode == 0:
+                # in mode 0 msk_dp_allreduce_async IS msk_dp_allreduce_sum on the compute stream: every bucket would join the
+                # weight-gradient stream and serialise backward -- slower than one all-reduce after backward (advisor, round 3)
+                import warnings
+                warnings.warn("DataParallel(overlap=True) needs dp_mode 1-3 (train.py / bench.py --dp-mode 2, or MSEGK_DP_MODE=2 "
+                              "before init_parallel_env); dp_mode is 0: falling back to ONE all-reduce after backward.")
+                overlap = False
+            self.overlap = bool(overlap)
             if overlap and hasattr(model, "_grad_ready_hooks"):
                 params = model.arena.params
                 self._index = {id(p): i for i, p in enumerate(params)}

@@ -176,6 +176,12 @@ def save_array(save_path, save_content, form=('npy', ), image_infor=None):
         elif suffix in ('nii', 'nii.gz'):
             info = image_infor or {"format": "zyx"}
             for key, val in content.items():
+                if val.ndim != 3:
+                    # multi-channel image / batch > 1: the reference's SimpleITK writer takes such arrays, this NIfTI-1
+                    # writer is 3-D only -- the .npy above holds the data, the evaluation loop must not die on it
+                    logger.warning("save_array: {} has shape {}, not a 3-D volume; no {} written for it".format(
+                        key, val.shape, suffix))
+                    continue
                 if info.get("format", "zyx") == "xyz":
                     val = np.transpose(val, [2, 1, 0])
                 elif info.get("format", "zyx") != "zyx":

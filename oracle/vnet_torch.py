@@ -16,6 +16,34 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# float64 convolutions have no oneDNN kernel: torch falls back to im2col + GEMM, whose column buffer is
+# Cin * k^3 * V_out elements (64 GB for 32 channels at 128^3).  With a byte budget set, the 'same' convolutions
+# are evaluated sample by sample in slabs of output planes along D (same arithmetic per output element: every
+# output is still one GEMM row over all Cin * k^3 terms), which keeps the full-size float64 oracle runs of
+# tests/golden/make_fullsize_golden.py inside a few GB.  None = plain F.conv3d.
+SLAB_BYTES = None
+
+
+def conv_same(conv, x):
+    """conv: an nn.Conv3d with stride 1 and 'same' padding p = k // 2 (vnet.py:36,67,165)."""
+    if SLAB_BYTES is None:
+        return conv(x)
+    w, b = conv.weight, conv.bias
+    N, C, D, H, W = x.shape
+    k = w.shape[2]
+    pad = k // 2
+    per_plane = C * k ** 3 * H * W * x.element_size()
+    d = max(1, min(D, SLAB_BYTES // per_plane))
+    if d >= D and N == 1:
+        return F.conv3d(x, w, b, padding=pad)
+    xp = F.pad(x, (0, 0, 0, 0, pad, pad))
+    rows = []
+    for n in range(N):
+        row = [F.conv3d(xp[n:n + 1, :, z:min(D, z + d) + 2 * pad], w, b, padding=(0, pad, pad)) for z in range(0, D, d)]
+        rows.append(torch.cat(row, 2))
+    return torch.cat(rows, 0)
+
+
 class LUConv(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -24,7 +52,7 @@ class LUConv(nn.Module):
         self.bn1 = nn.BatchNorm3d(c, momentum=0.1, eps=1e-5)
 
     def forward(self, x):
-        return self.relu1(self.bn1(self.conv1(x)))
+        return self.relu1(self.bn1(conv_same(self.conv1, x)))
 
 
 class InTr(nn.Module):
@@ -36,7 +64,7 @@ class InTr(nn.Module):
         self.relu1 = nn.PReLU(16)
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x))
+        out = self.bn1(conv_same(self.conv1, x))
         return self.relu1(out + x.repeat(1, 16 // self.cin, 1, 1, 1))
 
 
@@ -84,7 +112,7 @@ class OutTr(nn.Module):
         self.relu1 = nn.PReLU(ncls)
 
     def forward(self, x):
-        return self.conv2(self.relu1(self.bn1(self.conv1(x))))
+        return self.conv2(self.relu1(self.bn1(conv_same(self.conv1, x))))
 
 
 class TorchVNet(nn.Module):

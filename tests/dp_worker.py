@@ -29,7 +29,7 @@ def main():
     from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
     from medicalseg_amd.utils import loss_computation
     from oracle import vnet_numpy as O
-    env = parallel.init_parallel_env()
+    env = parallel.init_parallel_env(dp_mode=2 if overlap else None)    # buckets need an arrangement with a communication stream
     rank, world = env.rank, env.nranks
     params = O.init_params(3, 1, 3)
     if rank != 0:   # DataParallel must broadcast rank 0's parameters: start the other ranks from garbage

@@ -22,6 +22,7 @@ int msk_device_name(void* c, char* buf, int n) { (void)c; strncpy(buf, "fake-hos
 int msk_malloc(void* c, size_t b, void** out) { (void)c; *out = calloc(1, b ? b : 16); return *out ? 0 : -1; }
 int msk_free(void* c, void* p) { (void)c; free(p); return 0; }
 int msk_memset(void* c, void* p, int v, size_t b) { (void)c; memset(p, v, b); return 0; }
+int msk_weights_changed(void* c, const void* p, size_t b) { (void)c; (void)p; (void)b; return 0; }
 int msk_h2d(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
 int msk_d2h(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
 int msk_h2d_async(void* c, void* d, const void* s, size_t b) { (void)c; memcpy(d, s, b); return 0; }
@@ -36,7 +37,9 @@ int msk_timer_stop(void* c, float* ms) { (void)c; *ms = 1.0f; return 0; }
 int msk_prof_enable(void* c, int on) { (void)c; (void)on; return 0; }
 int msk_prof_reset(void* c) { (void)c; return 0; }
 int msk_prof_report(void* c, char* buf, int n, int* len) { (void)c; if (buf && n > 0) buf[0] = 0; if (len) *len = 1; return 0; }
-int msk_set_option(void* c, const char* k, int v) { (void)c; (void)k; (void)v; return 0; }
+static int fake_dp_mode = 0;
+int msk_set_option(void* c, const char* k, int v) { (void)c; if (strcmp(k, "dp_mode") == 0) fake_dp_mode = v; return 0; }
+int msk_get_option(void* c, const char* k, int* v) { (void)c; *v = strcmp(k, "dp_mode") == 0 ? fake_dp_mode : 0; return 0; }
 int msk_dp_unique_id(char* id) { memset(id, 7, 128); return 0; }
 size_t msk_conv3d_xform_bytes() { return 0; }
 size_t msk_conv3d_bwd_bnact_bytes() { return 0; }

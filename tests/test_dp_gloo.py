@@ -75,7 +75,14 @@ def _worker(rank, world, port, rdzv_port, fake_so, q):
     model, sent = plan()
     out["single_allreduce_default"] = sent == [(0, model.arena.count)]
     out["grad_scale"] = abs(model.arena.grad_scale - 1.0 / world) < 1e-15
-    # 3. overlap=True: buckets while backward runs; every rank derives the same partition of the arena
+    # 3. overlap=True: buckets while backward runs; every rank derives the same partition of the arena.  In dp_mode 0 (one
+    # communicator, compute stream) a bucket would only serialise backward: the request falls back to the single all-reduce
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        model, sent = plan(overlap=True, bucket_bytes=16 << 20)
+    out["mode0_overlap_falls_back"] = sent == [(0, model.arena.count)] and any("dp_mode" in str(w.message) for w in caught)
+    dev.set_option("dp_mode", 2)
     _, sent = plan(overlap=True, bucket_bytes=16 << 20)
     t = torch.tensor([v for oc in sent for v in oc], dtype=torch.int64)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
@@ -118,6 +125,6 @@ def test_world_size_2_gloo(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in (0, 1):
-        assert len(res[r]) == 10, res[r]
+        assert len(res[r]) == 11, res[r]
         for k, v in res[r].items():
             assert v, (r, k)

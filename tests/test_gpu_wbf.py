@@ -51,11 +51,18 @@ WBF_CASES = [
 ]
 
 
+# operand formats: 3 = exact bf16 x 3 pieces (A/B), 2 = fp16 x 2 pieces with tensor scales -- the PRODUCT default (round-3
+# verdict, weakness 3: the tile-variant matrix ran with the non-product format only)
+SPLIT_TAGS = {3: ("wbf_gemm_k", "wbf_wgrad_k"), 2: ("wbf_gemm_h2_k", "wbf_wgrad_h2_k")}
+
+
+@pytest.mark.parametrize("split", [2, 3])
 @pytest.mark.parametrize("case", WBF_CASES)
-def test_wbf_fwd_dgrad_match_oracle(case):
+def test_wbf_fwd_dgrad_match_oracle(case, split):
     cin, cout, (N, D, H, W) = case
     k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
     d = dev()
+    d.set_option("conv_split", split)
     rng = np.random.default_rng(cin * 11 + cout + D)
     x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
     w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
@@ -80,7 +87,7 @@ def test_wbf_fwd_dgrad_match_oracle(case):
         e_acc = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
         d.prof_enable(False)
         rep = d.prof_report()
-        assert rep.get("wbf_gemm_k", (0, 0))[0] >= 1, rep          # the pipeline really ran (the forward at least;
+        assert rep.get(SPLIT_TAGS[split][0], (0, 0))[0] >= 1, rep          # the pipeline really ran (the forward at least;
         # the data gradient swaps the channel roles and may pick another tile class or the fp32 kernels)
         # the exact-fp32 Winograd / direct kernels on the same inputs
         d.set_option("wino_bf3", 0)
@@ -91,7 +98,7 @@ def test_wbf_fwd_dgrad_match_oracle(case):
     finally:
         d.set_option("wino_bf3", 1)
         d.set_option("poison_scratch", -1)
-    print(f"\nwbf {case}: fwd {e_f:.2e} (fp32 kernels {o_f:.2e})  dgrad {e_d:.2e} ({o_d:.2e})  acc {e_acc:.2e}")
+    print(f"\nwbf {case} split {split}: fwd {e_f:.2e} (fp32 kernels {o_f:.2e})  dgrad {e_d:.2e} ({o_d:.2e})  acc {e_acc:.2e}")
     assert e_f < _conv_tol(cin * 125) and e_d < _conv_tol(cout * 125) and e_acc < _conv_tol(cout * 125)
     # fp32 class: within a small factor of the exact-fp32 kernels (direct MFMA ~5e-7, Winograd F(4,5) ~1.5e-6)
     assert e_f < 4e-6 and e_d < 4e-6
@@ -136,13 +143,15 @@ WGRAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("split", [2, 3])
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_wbf_wgrad_matches_oracle(case):
+def test_wbf_wgrad_matches_oracle(case, split):
     """wbf_wgrad_k (transposing LDS reads, v_mfma_f32_16x16x32_bf16, six products per fp32 product) + its split-K / G^T
     reduce against the float64 oracle, fresh and accumulating, and next to the exact-fp32 kernels on the same inputs."""
     cin, cout, (N, D, H, W) = case
     k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
     d = dev()
+    d.set_option("conv_split", split)
     rng = np.random.default_rng(cin * 13 + cout + H)
     x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
     dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
@@ -163,7 +172,7 @@ def test_wbf_wgrad_matches_oracle(case):
         got2 = d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape)
         d.prof_enable(False)
         rep = d.prof_report()
-        assert rep.get("wbf_wgrad_k", (0, 0))[0] == 2, rep
+        assert rep.get(SPLIT_TAGS[split][1], (0, 0))[0] == 2, rep
         d.set_option("wino_bf3", 0)
         d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
         old = d.d2h(dwp, (nw,), np.float32).reshape(dw_ref.shape)
@@ -172,7 +181,7 @@ def test_wbf_wgrad_matches_oracle(case):
         d.set_option("wgrad_async", 1)
     e, e2, eo = rel_err(got, dw_ref), rel_err(got2, 2 * dw_ref), rel_err(old, dw_ref)
     M = N * D * H * W
-    print(f"\nwbf wgrad {case}: {e:.2e} (accumulating {e2:.2e}; fp32 kernels {eo:.2e})")
+    print(f"\nwbf wgrad {case} split {split}: {e:.2e} (accumulating {e2:.2e}; fp32 kernels {eo:.2e})")
     assert e < _conv_tol(M) and e2 < _conv_tol(M)
     assert e < 4e-6
 
@@ -696,6 +705,64 @@ def test_wbf_packed_weight_cache_follows_every_weight_write():
         check(wp2, w5, "cache off")
     finally:
         d.set_option("wbf_pack_cache", 1)
+
+
+def test_wbf_packed_weight_cache_free_of_an_arena_and_foreign_writes():
+    """Round-3 advisor: (a) a weight tensor that lives INSIDE a larger allocation (the parameter arena) -- msk_free of the arena
+    must drop its cache row, not just invalidate it: the next optimizer call rebuilds every stale row in use and would read
+    freed memory (and the row's packed buffer would leak).  (b) weights changed behind the library's back (here: a library
+    pass that is not on the invalidation list, msk_copy_scale) need msk_weights_changed -- the stale result is demonstrated,
+    then the call fixes it."""
+    cin = cout = 32
+    N, D, H, W = 1, 16, 16, 8
+    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+    d = dev()
+    d.set_option("conv_split", 2)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    xt, yt = t_from_ncdhw(x), t_empty(N, cout, D, H, W)
+    cd = _desc(k, s_, p)
+    f8 = lambda a: a.astype(np.float64)
+    mkw = lambda sc: (rng.standard_normal((cout, cin) + k) * sc / np.sqrt(cin * 125)).astype(np.float32)
+    bp = vec(np.zeros(cout, np.float32))
+    count = cout * cin * 125
+
+    def run(wp):
+        d.call("msk_conv3d_fwd", cd, xt.msk(), vp(wp), vp(bp), yt.msk())
+        return t_to_ncdhw(yt)
+
+    def err(wp, w):
+        return rel_err(run(wp), O.conv3d(f8(x), f8(w), np.zeros(cout), s_, p))
+
+    # (a) weights at an offset inside an "arena"
+    off = 4096
+    arena = d.malloc(off * 4 + count * 4 + 1024)
+    w1 = mkw(1.0)
+    d.h2d(arena + off * 4, w1.ravel())
+    assert err(arena + off * 4, w1) < _conv_tol(cin * 125)
+    d.free(arena)
+    # an optimizer call on OTHER memory: rebuilds every stale live row in use -- the freed row must be gone by now
+    other = vec(mkw(1.0).ravel())
+    g, vel = vec(np.zeros(count, np.float32)), vec(np.zeros(count, np.float32))
+    d.call("msk_sgd_momentum", vp(other), vp(g), vp(vel), C.c_size_t(count), C.c_float(0.1), C.c_float(0.0), C.c_float(0.0), C.c_float(1.0))
+    d.sync()
+    arena2 = d.malloc(off * 4 + count * 4 + 1024)        # very likely the same address range
+    w2 = mkw(9.0)
+    d.h2d(arena2 + off * 4, w2.ravel())
+    assert err(arena2 + off * 4, w2) < _conv_tol(cin * 125)
+    # (b) a write the library does not track: copy_scale of another tensor over the weights
+    from medicalseg_amd.device import Tensor
+    w3 = mkw(0.25)
+    src = vec(w3.ravel())
+    wp = arena2 + off * 4
+    as_t = lambda ptr: Tensor(d, ptr, 1, 1, 1, count // 4, 4, 4, None)
+    d.call("msk_copy_scale", as_t(src).msk(), None, as_t(wp).msk(), 0)
+    assert np.array_equal(d.d2h(wp, (count,), np.float32), w3.ravel())
+    stale = err(wp, w3)
+    assert stale > 1e-2, stale                              # the convolution still used the packed copy of w2: the documented hazard
+    d.call("msk_weights_changed", vp(wp), C.c_size_t(count * 4))
+    assert err(wp, w3) < _conv_tol(cin * 125)
+    d.free(arena2)
 
 
 # ---------------------------------------------------------------------------------------------------------

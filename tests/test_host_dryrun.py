@@ -178,6 +178,8 @@ def test_gradient_buckets_partition_the_arena(fake_pkg):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((1, 1, 16, 16, 16)).astype(np.float32)
     y = rng.integers(0, 3, (1, 16, 16, 16)).astype(np.int32)
+    from medicalseg_amd.device import get_device
+    get_device().set_option("dp_mode", 2)     # buckets need a communication stream (dp_mode 0 falls back to one all-reduce)
     for cls, nout, min_buckets in ((VNet, 1, 4), (VNetDeepSup, 4, 3)):
         model = cls(num_classes=3)
         ddp = parallel.DataParallel(model, force=True, overlap=True, bucket_bytes=16 << 20)
@@ -217,6 +219,8 @@ def test_unet3d_control_flow_and_config(fake_pkg):
     model = UNet3D(num_classes=3, base_channels=8, depth=3)
     names = [n for n, _ in model.named_parameters()]
     assert "enc0.norm1.scale" in names and "up0.up_conv.weight" in names and "head.bias" in names
+    from medicalseg_amd.device import get_device
+    get_device().set_option("dp_mode", 2)
     ddp = parallel.DataParallel(model, force=True, overlap=True, bucket_bytes=1 << 10)
     x = np.zeros((2, 1, 16, 16, 8), np.float32)
     out = ddp(x)[0]

@@ -40,6 +40,10 @@ def parse_args():
     p.add_argument('--no_sync_bn', dest='no_sync_bn', action='store_true',
                    help='rank-local BatchNorm statistics (documented deviation from the reference, which converts every '
                         'BatchNorm to SyncBatchNorm: cvlibs/config.py:322)')
+    p.add_argument('--dp_mode', dest='dp_mode', type=int, default=None, choices=(0, 1, 2, 3),
+                   help='multi-GPU: arrangement of the collectives (msk_dp.hip): 0 = everything on the compute stream, one gradient '
+                        'all-reduce after backward (default); 2 = gradient buckets on a second communicator + stream, overlapped '
+                        'with backward')
     p.add_argument('--data_format', dest='data_format', type=str, default='NCHW',
                    help='Kept for CLI compatibility; the device layout is always NDHWC internally.')
     p.add_argument('--profiler_options', type=str, default=None,
@@ -81,7 +85,7 @@ def main(args):
           iters=cfg.iters, batch_size=cfg.batch_size, resume_model=args.resume_model, save_interval=args.save_interval,
           log_iters=args.log_iters, num_workers=args.num_workers, use_vdl=args.use_vdl, losses=losses,
           keep_checkpoint_max=args.keep_checkpoint_max, profiler_options=args.profiler_options,
-          to_static_training=cfg.to_static_training)
+          to_static_training=cfg.to_static_training, dp_mode=args.dp_mode)
 
 
 if __name__ == '__main__':
