@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsegk.so")
+LIB_PATH = os.environ.get("MSEGK_LIB") or os.path.join(_HERE, "lib", "libmsegk.so")   # MSEGK_LIB: A/B builds of tools/ab_build.sh
 
 
 class MskError(RuntimeError):

@@ -44,6 +44,7 @@ struct WGrad {
   const void* xform;  // msk_conv3d_wgrad_ex: transformed A written by msk_conv3d_fwd_ex for the same tensor, or null
   const void* yform;  // msk_conv3d_bwd_bnact: transformed B (A dy) already written by the dual transform, or null
   const float* y_amax;  // NP = 2: device scalar bounding max |B| when yform is given
+  const float* y_cmax;  // NP = 2: per-channel max |B| [CB] written with yform (wbf_chan_shift), or null
   const float* b_amax;  // NP = 2, small-channel kernels: max |B| when the caller already has it (amax array), or null
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]

@@ -1128,6 +1128,11 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     // auto: with the two-piece fp16 operands the one-kernel form wins even with the side stream on (24.1 vs 24.7 ms per
     // step: its transforms are a third cheaper); with the exact bf16 x 3 split form 2 does (30.1-30.2 vs 30.3-30.4)
     const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : ((side_on && !split2) ? 2 : 1);
+    if (wbf_pieces(ctx, cd.kd) == 2 && form == 1) {
+      // per-channel max |dy| for the weight gradient's renormalisation, folded in by the dual transform (compute stream)
+      bn.y_cmax = msk_scalar_slots(ctx, (y.c + kWbfAmaxWays - 1) / kWbfAmaxWays);
+      if (!bn.y_cmax) return -1;
+    }
     if (split2) {  // fp16 pieces: dy is scaled by a power of two from a device-side bound of its maximum
       if (form == 1) {
         // the dual transform evaluates the bound itself and leaves it in a (zeroed) ring array for the kernels behind it
@@ -1165,6 +1170,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
         msk_side_scope side(ctx, side_on);
         gw.yform = ybuf;
         gw.y_amax = bn.amax;
+        gw.y_cmax = bn.y_cmax;
         const int rw = msk_wgrad_wbf(ctx, gw);
         if (rw < 0) return rw;
         if (rw == 0) return msk_fail(ctx, __FILE__, __LINE__, "msk_conv3d_bwd_bnact", "weight-gradient pipeline declined a problem its plan accepted");

@@ -259,9 +259,15 @@ wbf_tin_k(WbfTinArgs a) {
   const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
   const int pos = pb * 64 + pl;
   const int n = blockIdx.y;
-  if (pos >= a.DP * a.HP) return;
-  const int dp = pos / a.HP, hp = pos - dp * a.HP;
   const int cg = cgb * 4 + cgl, kc = cg >> 1, khalf = cg & 1;
+  float cmx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NP = 2: max |source value| per channel (a.cmax)
+  const bool want_cmax = MODE == 1 && NP == 2 && a.cmax != nullptr;   // the dy side only (msk_wgrad_wbf.hip)
+  auto cmax_of = [&](const float4& e0, const float4& e1) {
+    cmx[0] = fmaxf(cmx[0], fabsf(e0.x)); cmx[1] = fmaxf(cmx[1], fabsf(e0.y)); cmx[2] = fmaxf(cmx[2], fabsf(e0.z)); cmx[3] = fmaxf(cmx[3], fabsf(e0.w));
+    cmx[4] = fmaxf(cmx[4], fabsf(e1.x)); cmx[5] = fmaxf(cmx[5], fabsf(e1.y)); cmx[6] = fmaxf(cmx[6], fabsf(e1.z)); cmx[7] = fmaxf(cmx[7], fabsf(e1.w));
+  };
+  if (pos < a.DP * a.HP) {
+  const int dp = pos / a.HP, hp = pos - dp * a.HP;
   const int d = dp - 2, h = hp - 2;
   const bool live = d >= 0 && d < a.LD && h >= 0 && h < a.LH;
   const long plane = (long)a.DP * a.HP * 16;
@@ -281,6 +287,7 @@ wbf_tin_k(WbfTinArgs a) {
       const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
       win[j][0] = p[0];
       win[j][1] = p[1];
+      if (want_cmax) cmax_of(win[j][0], win[j][1]);
     } else {
       win[j][0] = win[j][1] = z4;
     }
@@ -294,6 +301,7 @@ wbf_tin_k(WbfTinArgs a) {
         const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
         nxt[j][0] = p[0];
         nxt[j][1] = p[1];
+        if (want_cmax) cmax_of(nxt[j][0], nxt[j][1]);
       } else {
         nxt[j][0] = nxt[j][1] = z4;
       }
@@ -353,6 +361,8 @@ wbf_tin_k(WbfTinArgs a) {
       win[KEEP + j][1] = nxt[j][1];
     }
   }
+  }  // pos < DP * HP
+  if (want_cmax) wbf_cmax_commit(a.cmax, cg, cmx, a.lane_map != 0);
 }
 
 // Both transforms of dy = BatchNorm/PReLU-backward(y, dout) (WbfBnBwd, msk_wbf.h) in one pass: the thread mapping and
@@ -372,6 +382,7 @@ struct DualArgs {
   long y_xi;
   const float* amax;
   const float* maxes;  // see WbfBnBwd
+  float* y_cmax;       // see WbfBnBwd
 };
 
 template <int K, int NP>
@@ -403,8 +414,15 @@ __device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8
   }
 }
 
+#ifndef WBF_DUAL_LB
+#define WBF_DUAL_LB 3
+#endif
 template <int K, int NP, bool WV, bool WY>  // which of the two transforms are written (each stream may take its own)
+#if WBF_DUAL_LB > 0
+__global__ void __launch_bounds__(256, WBF_DUAL_LB)
+#else
 __global__ void __launch_bounds__(256)
+#endif
 wbf_tin_dual_k(DualArgs b) {
   constexpr int NXI = nxi_of(K), WIN = K + 3, PADW = (K - 1) / 2, KEEP = WIN - 4;
   const WbfTinArgs& a = b.t;
@@ -457,7 +475,9 @@ wbf_tin_dual_k(DualArgs b) {
     }
   }
   (void)sc2;
-  if (pos >= a.DP * a.HP) return;
+  float cmx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NP = 2, WY: max |dy| per channel (b.y_cmax)
+  const bool want_cmax = NP == 2 && WY && b.y_cmax != nullptr;
+  if (pos < a.DP * a.HP) {
   const int dp = pos / a.HP, hp = pos - dp * a.HP;
   const int d = dp - 2, h = hp - 2;
   const bool live = d >= 0 && d < a.LD && h >= 0 && h < a.LH;
@@ -491,6 +511,7 @@ wbf_tin_dual_k(DualArgs b) {
       if (!(u > 0.f)) dd *= al[j];
       const float xh = (xv[j] - mu[j]) * is[j];
       r[j] = sc[j] * (dd - s1[j] - xh * s2[j]);
+      if (want_cmax) cmx[j] = fmaxf(cmx[j], fabsf(r[j]));
     }
     o0 = make_float4(r[0], r[1], r[2], r[3]);
     o1 = make_float4(r[4], r[5], r[6], r[7]);
@@ -556,6 +577,8 @@ wbf_tin_dual_k(DualArgs b) {
       win[KEEP + j][1] = nxt[j][1];
     }
   }
+  }  // pos < DP * HP
+  if (want_cmax) wbf_cmax_commit(b.y_cmax, cg, cmx, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1654,6 +1677,7 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   da.y = bn.y; da.yld = bn.yld; da.dout = bn.dout; da.dld = bn.dld;
   da.scale = bn.scale; da.shift = bn.shift; da.alpha = bn.alpha; da.mean = bn.mean; da.invstd = bn.invstd; da.sums = bn.sums;
   da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax; da.maxes = bn.maxes;
+  da.y_cmax = bn.Y ? bn.y_cmax : nullptr;
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;

@@ -104,7 +104,43 @@ struct WbfTinArgs {
   int lane_map;
   const float* amax;  // NP = 2: device scalar, (bound of) max |value| of the source tensor -> wbf_scale_of; NULL = unscaled
   float* amax_copy;   // non-null: block 0 copies the amax array there (the header of a kept transform) -- no memcpy command
+  float* cmax;        // MODE 1, NP = 2, non-null: zeroed array [CK]; max |dy| PER CHANNEL is folded into it (wbf_cmax_commit) for the
+                      // weight gradient's per-channel renormalisation (msk_wgrad_wbf.hip)
 };
+// Per-channel maxima of the GRADIENT tensor dy, measured by the kernel that writes its transform Y = A dy (round 4).  The
+// weight-gradient kernel multiplies both fp16 pieces of output channel c by 2^s(c), s(c) = floor(log2(max |dy| / max |dy[c]|))
+// in [0, 15], before the matrix instructions and divides its sums by 2^s(c): every channel then sits as high in fp16's range
+// as the tensor's loudest one, and the in-register factors 2^-11 of the cross terms (both applied on this side) stay exact for
+// channels ANY factor below the loudest (round 3: exact only within 2^13, one bit lost per factor of two beyond).
+__device__ __forceinline__ int wbf_chan_shift(float tensor_amax, float chan_max) {
+  if (!(chan_max > 0.f) || !(tensor_amax > 0.f) || !(tensor_amax < 3.0e38f)) return 0;
+  int ea, ec;
+  (void)frexpf(tensor_amax, &ea);
+  (void)frexpf(chan_max, &ec);
+  const int s = ea - ec;        // chan_max * 2^s < 2^ea: below the tensor's power-of-two ceiling
+  return s < 0 ? 0 : (s > 15 ? 15 : s);
+}
+// mx[j] = this thread's max |value| of channel cg*8 + j (0 for idle threads).  Every lane of the wavefront must call it.
+// wave_cg: all 64 lanes share cg (one channel group per wavefront), else cg varies with lane & 3.
+__device__ __forceinline__ void wbf_cmax_commit(float* cmax, int cg, float (&mx)[8], bool wave_cg) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float m = mx[j];
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (wave_cg) {
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+    }
+    mx[j] = m;
+  }
+  const int lane = threadIdx.x & 63;
+  if (lane < (wave_cg ? 1 : 4)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (mx[j] > 0.f) atomicMax(reinterpret_cast<unsigned*>(cmax) + cg * 8 + j, __float_as_uint(mx[j]));  // non-negative floats order like their bits
+  }
+}
 // K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
 int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& a);
 
@@ -127,6 +163,7 @@ struct WbfBnBwd {
   // by the dual transform itself from the two amax arrays the reduce pass left (every block the same arithmetic on the same
   // inputs; block 0 stores it to `amax` for the kernels behind it) -- no separate bound kernel on the critical path
   const float* maxes;
+  float* y_cmax;      // NP = 2: zeroed array [C] that receives max |dy| per channel (WbfTinArgs::cmax), or null
   // msk_wgrad_c1 only: the unit's pre-activation also adds its (one-channel, tiled) INPUT -- in_tr, vnet.py:75-78: the weight
   // gradient's A operand itself, taken from the kernel's LDS halo
   int res_is_input;

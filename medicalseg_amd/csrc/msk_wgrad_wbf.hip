@@ -33,6 +33,9 @@ struct WgArgs {
   int tiles_d, tiles_h, ntiles, ksplit, tiles_per;
   int ncob;
   long v_xi, y_xi, plane;  // bytes
+  // NP = 2: per-channel renormalisation of the dy side (msk_wbf.h: wbf_chan_shift): y_cmax [CB] = max |dy| per channel,
+  // y_amax = the amax array the Y transform was scaled by.  Either null: no shifts.
+  const float *y_cmax, *y_amax;
 };
 
 __device__ __forceinline__ s16x4 tr_read(const char* lds_base, unsigned byte_off) {
@@ -46,8 +49,18 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, unsigned byte_off
 
 constexpr int wg_nxi(int K) { return K == 5 ? 8 : 6; }
 
+#ifndef WGW_LB
+#define WGW_LB 3
+#endif
+#ifndef WGW_PIPE
+#define WGW_PIPE 0
+#endif
 template <int TH, int K, int NP>
+#if WGW_LB > 0
+__global__ void __launch_bounds__(256, WGW_LB)   // three wavefronts per SIMD (<= 168 registers): two lose 8 % (round 2)
+#else
 __global__ void __launch_bounds__(256)
+#endif
 wbf_wgrad_k(WgArgs a) {
   constexpr int NXI = wg_nxi(K), T2 = K * K, PADK = (K - 1) / 2, NPL = 2 * NP;
   constexpr int NT0 = K == 5 ? 7 : 3, NT1 = K == 5 ? 6 : 2;            // taps of wavefront 0 / of the others
@@ -124,6 +137,23 @@ wbf_wgrad_k(WgArgs a) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // NP = 2, round 4: both in-register factors 2^-11 of the cross terms sit on the B (dy) side -- (lx' * (hy 2^-11)) and
+  // (hx * (ly' 2^-11)) -- and the B fragments of output channel co = cob*32 + c*16 + i (this lane's) are first multiplied by
+  // 2^shift(co) = floor(max |dy| / max |dy[co]|) (msk_wbf.h: wbf_chan_shift; exact: the result stays below the tensor's own
+  // ceiling), undone when the sums are stored.  The down-scaled pieces then underflow only for ELEMENTS 2^12 below their own
+  // channel's maximum, whose absolute error (2^-25 of the channel's ceiling per product) is far below the fp32 rounding of the
+  // sum; the A (x) side is used as stored, so a quiet input channel costs nothing either.  Round 3 scaled per tensor only and
+  // lost one bit per factor of two for channels more than 2^13 below the loudest.
+  int shb[2] = {0, 0};
+  if (NP == 2 && a.y_cmax && a.y_amax) {
+    const float ya_max = wbf_amax_of(a.y_amax);
+    shb[0] = wbf_chan_shift(ya_max, a.y_cmax[cob * 32 + i]);
+    shb[1] = wbf_chan_shift(ya_max, a.y_cmax[cob * 32 + 16 + i]);
+  }
+  const _Float16 mb[2] = {(_Float16)ldexpf(1.f, shb[0]), (_Float16)ldexpf(1.f, shb[1])};
+  const _Float16 mb_dn[2] = {(_Float16)ldexpf(1.f, shb[0] - 11), (_Float16)ldexpf(1.f, shb[1] - 11)};
+  auto fmul = [](s16x8 v, _Float16 m) { return __builtin_bit_cast(s16x8, __builtin_bit_cast(f16x8, v) * m); };
+
   const int t0 = ks * a.tiles_per;
   const int t1 = min(a.ntiles, t0 + a.tiles_per);
   const int tiles_nt = a.tiles_d * a.tiles_h;
@@ -147,22 +177,45 @@ wbf_wgrad_k(WgArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // B (dy) fragments of one K-step: high piece times 2^shift, and both pieces times 2^(shift - 11)
+    auto load_b = [&](int kst, s16x8 (&bq0)[2], s16x8 (&bq1)[2], s16x8 (&bq2)[2], s16x8 (&bdh)[2], s16x8 (&bdl)[2]) {
 #pragma unroll
-    for (int kst = 0; kst < KSTEPS; ++kst) {
-      s16x8 bq[2][NP];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c) {
+        s16x8 t[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           const unsigned o = ya + (unsigned)((c * NPL + p * 2) * PSY + kst * ROWS_PER_STEP * TH * 16);
           const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
-          bq[c][p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          t[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-      s16x8 bdown[2] = {bq[0][0], bq[1][0]};
-      if (NP == 2) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bdown[c] = __builtin_bit_cast(s16x8, wbf_hi_down(__builtin_bit_cast(uint4, bq[c][0])));
+        bq0[c] = t[0]; bq1[c] = t[NP / 2]; bq2[c] = t[NP - 1];
+        bdh[c] = t[0]; bdl[c] = t[0];
+        if (NP == 2) {
+          bdh[c] = fmul(t[0], mb_dn[c]);
+          bdl[c] = fmul(t[NP - 1], mb_dn[c]);
+          bq0[c] = fmul(t[0], mb[c]);
+        }
       }
+    };
+#if WGW_PIPE
+    s16x8 nb0[2], nb1[2], nb2[2], nbh[2], nbl[2];
+    load_b(0, nb0, nb1, nb2, nbh, nbl);
+#endif
+#pragma unroll
+    for (int kst = 0; kst < KSTEPS; ++kst) {
+      s16x8 bq[2][3], bdh[2], bdl[2];   // bq[c][0 / 1 / 2] = high / middle (NP = 3) / last piece
+#if WGW_PIPE
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { bq[c][0] = nb0[c]; bq[c][1] = nb1[c]; bq[c][2] = nb2[c]; bdh[c] = nbh[c]; bdl[c] = nbl[c]; }
+      if (kst + 1 < KSTEPS) load_b(kst + 1, nb0, nb1, nb2, nbh, nbl);
+#else
+      {
+        s16x8 t0[2], t1[2], t2[2];
+        load_b(kst, t0, t1, t2, bdh, bdl);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { bq[c][0] = t0[c]; bq[c][1] = t1[c]; bq[c][2] = t2[c]; }
+      }
+#endif
 #pragma unroll
       for (int j = 0; j < NT0; ++j) {
         if (j < ntap) {   // wave-uniform
@@ -174,25 +227,18 @@ wbf_wgrad_k(WgArgs a) {
             const s16x4 lo4 = tr_read(lds, o), hi4 = tr_read(lds, o + 64);
             aq[p] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           }
-          s16x8 adown = aq[0];
-          if (NP == 2) adown = __builtin_bit_cast(s16x8, wbf_hi_down(__builtin_bit_cast(uint4, aq[0])));
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             if (NP == 3) {
               WGW_MFMA(acc[j][c], aq[NP - 1], bq[c][0]);  // small terms first
-              WGW_MFMA(acc[j][c], aq[0], bq[c][NP - 1]);
-              WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][NP / 2]);
+              WGW_MFMA(acc[j][c], aq[0], bq[c][2]);
+              WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][1]);
               WGW_MFMA(acc[j][c], aq[NP / 2], bq[c][0]);
-              WGW_MFMA(acc[j][c], aq[0], bq[c][NP / 2]);
+              WGW_MFMA(acc[j][c], aq[0], bq[c][1]);
               WGW_MFMA(acc[j][c], aq[0], bq[c][0]);
             } else if (NP == 2) {
-              // both operands carry their low piece times 2^11 (msk_wbf.h): each meets the OTHER operand's high piece
-              // times 2^-11, made in registers.  (Exact while that high piece is >= 2^-3 in scaled units, i.e. within 2^13
-              // of its tensor's maximum; for quieter CHANNELS the cross terms fade out gradually -- measured in
-              // tests/test_gpu_wbf.py::test_wbf_fp16_split_quiet_channels_in_the_weight_gradient.  A second accumulator
-              // for the cross terms, scaled in fp32, removes the limit but costs 112 registers: 3 -> 1 wavefronts per SIMD.)
-              WGW_MFMA_H(acc[j][c], aq[NP - 1], bdown[c]);  // small terms first
-              WGW_MFMA_H(acc[j][c], adown, bq[c][NP - 1]);
+              WGW_MFMA_H(acc[j][c], aq[NP - 1], bdh[c]);  // small terms first
+              WGW_MFMA_H(acc[j][c], aq[0], bdl[c]);
               WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
             } else {
               WGW_MFMA_H(acc[j][c], aq[0], bq[c][0]);
@@ -205,13 +251,14 @@ wbf_wgrad_k(WgArgs a) {
 
   // partial dU[xi][ks][kci][cob][tap = tap0 + j][ci = 4 g + reg][co = c*16 + i]
   float* pb = a.P + (((((long)xi * a.ksplit + ks) * a.KCA + kci) * a.ncob + cob) * T2 + tap0) * 512;
+  const float undo[2] = {ldexpf(1.f, -shb[0]), ldexpf(1.f, -shb[1])};   // element (ci = 4 g + r, co = c*16 + i): this lane's co
 #pragma unroll
   for (int j = 0; j < NT0; ++j)
     if (j < ntap) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pb[j * 512 + (4 * g + r) * 32 + c * 16 + i] = acc[j][c][r];
+        for (int r = 0; r < 4; ++r) pb[j * 512 + (4 * g + r) * 32 + c * 16 + i] = acc[j][c][r] * undo[c];
     }
 }
 
@@ -343,6 +390,9 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   ta.svn = (long)g.BD * g.BH * g.BW; ta.svd = vstr[pm[0]]; ta.svh = vstr[pm[1]]; ta.svw = vstr[pm[2]];
   ta.N = g.N; ta.LD = LD; ta.LH = LH; ta.LW = LW; ta.T = T; ta.CK = g.CA; ta.KC = KCA;
   ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
+  // NP = 2: per-channel maxima of the dy side (msk_wbf.h: wbf_chan_shift), folded in by whichever kernel writes Y
+  const float* y_cmax = nullptr;
+  const int cmax_slots_b = (g.CB + kWbfAmaxWays - 1) / kWbfAmaxWays;
   if (!have_v) {  // else: V written by msk_conv3d_fwd_ex for this tensor
     if (NP != 3) {
       v_amax = msk_absmax(ctx, g.A, g.ald, g.CA, (long)g.N * g.AD * g.AH * g.AW);
@@ -358,15 +408,26 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
     bn.Y = Y;
     bn.y_xi = (long)y_xi;
     y_amax = bn.amax;
+    if (NP == 2) {
+      bn.y_cmax = msk_scalar_slots(ctx, cmax_slots_b);
+      if (!bn.y_cmax) return -1;
+      y_cmax = bn.y_cmax;
+    }
     if (msk_wbf_transform_dual(ctx, K, NP, ta, bn, false) != 0) return -1;
   } else if (have_y) {
     y_amax = g.y_amax;
+    y_cmax = NP == 2 ? g.y_cmax : nullptr;
   } else {
     if (NP != 3) {
       y_amax = g.b_amax ? g.b_amax : msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);   // the caller may hold it (amax array)
       if (!y_amax) return -1;
     }
     ta.amax = y_amax;
+    if (NP == 2) {
+      ta.cmax = msk_scalar_slots(ctx, cmax_slots_b);
+      if (!ta.cmax) return -1;
+      y_cmax = ta.cmax;
+    }
     if (msk_wbf_transform(ctx, 1, K, NP, ta) != 0) return -1;
   }
 
@@ -375,6 +436,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   wa.N = g.N; wa.T = T; wa.KCA = KCA; wa.KCB = KCB; wa.DP = DP; wa.HP = HP;
   wa.tiles_d = tiles_d; wa.tiles_h = tiles_h; wa.ntiles = (int)ntiles; wa.ksplit = (int)ksplit; wa.tiles_per = tiles_per;
   wa.ncob = ncob; wa.v_xi = (long)v_xi; wa.y_xi = (long)y_xi; wa.plane = (long)plane;
+  if (NP == 2 && ctx->wgrad_renorm) { wa.y_cmax = y_cmax; wa.y_amax = y_amax; }
   const long nblk = base_blocks * ksplit;
   {
     const char* tag = NP == 3 ? "wbf_wgrad_k" : (NP == 2 ? "wbf_wgrad_h2_k" : "wbf_wgrad_f16_k");
