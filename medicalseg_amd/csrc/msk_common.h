@@ -100,6 +100,9 @@ struct msk_ctx {
   void* comm_grad = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr, ev_comm_back = nullptr;
+  int wgrad_lds_pad = 0;  // bytes of dynamic LDS added to every wbf_wgrad_k launch: caps its workgroups per CU (33.5 KB static: 3 per CU
+                          // by registers; >= 20 KB of padding: 2 per CU, >= 47 KB: 1) so that the compute stream's HBM-bound passes find
+                          // free registers next to it (tools/stream_timeline.py)
   int wgrad_renorm = 1;  // NP = 2 weight gradient: per-channel renormalisation (msk_wbf.h: wbf_chan_shift); 0 = per-tensor scales only (A/B)
   int dp_mode = 0;   // msk_dp.hip: 0 = every collective on the compute stream (default), 1 = one communicator on the communication stream, 2 = two communicators, 3 = one communicator, buckets on the communication stream
   bool comm_pending = false;

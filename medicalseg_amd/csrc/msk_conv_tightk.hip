@@ -185,33 +185,41 @@ struct TKH2Args {
   float* dst;
   int dld;
   int N, D, H, W, CK;
-  const uint4* wb;  // [tap 25][n tile 2][piece 2][lane 64]: A fragment (8 fp16: K = 8*(lane/16) .. +7) of output channel 16*nt + lane%16
+  const uint4* wb;  // [step 16][n tile 2][piece 2][lane 64]: A fragment (8 fp16: K = 8*(lane/16) .. +7 = units 8 m + 2 (lane/16), + 1) of output channel 16*nt + lane%16
   int accumulate;
   int tiles_h, tiles_w, segs, seg_len, nblk;
   const float* x_amax;
   const float* w_amax;
 };
 
-// K index k = kd*4 + c (kd < 5, c < CK), zero elsewhere
+// Round 4: DENSE K.  A "unit" is the (<= 4)-channel vector of one voxel of one plane = 4 of the 32 K slots of
+// v_mfma_f32_16x16x32_f16; an output position needs the 125 units (kh, kw, kd) of its receptive field.  Round 3 gave every
+// (kh, kw) tap its own instruction with the five kd units in 20 of the 32 slots (25 matrix steps per plane, 47 % of the K slots
+// useful for three classes); the units are now numbered u = (kh*5 + kw)*5 + kd and packed EIGHT per instruction -- matrix step
+// m holds units 8 m .. 8 m + 7, lane group lk the two units 8 m + 2 lk, + 1 -- so a plane takes 16 steps instead of 25
+// (units 125..127 are zero).  A lane's fragment is still two 8-byte LDS reads per piece, only their addresses differ per lane
+// group (computed once per kernel: kTKUnitsPerStep tables in registers).
+constexpr int kTKSteps = 16;
 __global__ void __launch_bounds__(256)
 pack_tkh2_weights_k(const float* __restrict__ w, int A, int B, int swap, int flip, int CK, const float* __restrict__ w_amax,
                     unsigned short* __restrict__ out) {
   const float sw = wbf_scale_of(w_amax);
-  const int total = 25 * 2 * 64 * 8;
+  const int total = kTKSteps * 2 * 64 * 8;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int e = idx & 7, lane = (idx >> 3) & 63, nt = (idx >> 9) & 1, tap2 = idx >> 10;
-    const int n = nt * 16 + (lane & 15), k = 8 * (lane >> 4) + e;
-    const int kd = k >> 2, c = k & 3;
+    const int e = idx & 7, lane = (idx >> 3) & 63, nt = (idx >> 9) & 1, m = idx >> 10;
+    const int n = nt * 16 + (lane & 15);
+    const int u = 8 * m + 2 * (lane >> 4) + (e >> 2), c = e & 3;   // K slot 8 (lane / 16) + e of step m
     float v = 0.f;
-    if (kd < 5 && c < CK) {
+    if (u < 125 && c < CK) {
+      const int kd = u % 5, tap2 = u / 5;
       int tap = kd * 25 + tap2;
       if (flip) tap = 124 - tap;
       const int ia = swap ? n : c, ib = swap ? c : n;
       v = w[((long)ia * B + ib) * 125 + tap] * sw;
     }
     const _Float16 h = (_Float16)v;
-    out[(((tap2 * 2 + nt) * 2 + 0) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, h);
-    out[(((tap2 * 2 + nt) * 2 + 1) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+    out[(((m * 2 + nt) * 2 + 0) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+    out[(((m * 2 + nt) * 2 + 1) * 64 + lane) * 8 + e] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
   }
 }
 
@@ -292,49 +300,55 @@ conv_tk_h2_k(TKH2Args a) {
   for (int s = 4; s < steps; ++s) {
     const int d = d_begin + s - 4;  // output plane: needs planes d-2 .. d+2
     stage_load(d + 3, pre);         // in flight during this plane's MFMAs
-    // slots of this lane's two planes (kd = 2 lk, 2 lk + 1); padding lanes read the zero unit
-    const int s0 = lk < 3 ? ((d - 2 + 2 * lk) & (RING - 1)) * SLOT : -1;
-    const int s1 = lk < 2 ? ((d - 1 + 2 * lk) & (RING - 1)) * SLOT : -1;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int kh = 0; kh < 5; ++kh) {
+    const int dring = (d - 2) & (RING - 1);
+#pragma unroll 2
+    for (int m = 0; m < kTKSteps; ++m) {
+      uint4 wf[2][2];
 #pragma unroll
-      for (int kw = 0; kw < 5; ++kw) {
-        const int tap = kh * 5 + kw;
-        uint4 wf[2][2];
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) wf[nt][pc] = a.wb[((m * 2 + nt) * 2 + pc) * 64 + lane];
+      // LDS unit index of this lane's two units (u = 8 m + 2 lk, + 1) for row 0: ring slot of plane d - 2 + kd, voxel
+      // (4 wave + kh, li + kw); units 125.. read the zero unit
+      int b0, b1, st0, st1, lo0, lo1;
+      {
+        const int u0 = 8 * m + 2 * lk, u1 = u0 + 1;
+        const int t0 = u0 / 5, t1 = u1 / 5;
+        const int k0 = u0 - 5 * t0, k1 = u1 - 5 * t1;
+        const int v0 = (4 * wave + t0 / 5) * HW + li + t0 % 5, v1 = (4 * wave + t1 / 5) * HW + li + t1 % 5;
+        const bool z0 = u0 >= 125, z1 = u1 >= 125;
+        b0 = z0 ? ZERO : ((dring + k0) & (RING - 1)) * SLOT + v0;
+        b1 = z1 ? ZERO : ((dring + k1) & (RING - 1)) * SLOT + v1;
+        st0 = z0 ? 0 : HW; st1 = z1 ? 0 : HW; lo0 = z0 ? 0 : NV; lo1 = z1 ? 0 : NV;
+      }
+      uint4 xh[4], xl[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint2 h0v = lds[b0 + r * st0], h1v = lds[b1 + r * st1];
+        const uint2 l0v = lds[b0 + lo0 + r * st0], l1v = lds[b1 + lo1 + r * st1];
+        xh[r] = make_uint4(h0v.x, h0v.y, h1v.x, h1v.y);
+        xl[r] = make_uint4(l0v.x, l0v.y, l1v.x, l1v.y);
+      }
+      // the three piece products as three sweeps over the eight accumulators: consecutive MFMAs never share one
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][1]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
 #pragma unroll
-          for (int pc = 0; pc < 2; ++pc) wf[nt][pc] = a.wb[((tap * 2 + nt) * 2 + pc) * 64 + lane];
-        uint4 xh[4], xl[4];
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int vox = (4 * wave + r + kh) * HW + li + kw;
-          const uint2 h0v = lds[s0 >= 0 ? s0 + vox : ZERO], h1v = lds[s1 >= 0 ? s1 + vox : ZERO];
-          const uint2 l0v = lds[s0 >= 0 ? s0 + NV + vox : ZERO], l1v = lds[s1 >= 0 ? s1 + NV + vox : ZERO];
-          xh[r] = make_uint4(h0v.x, h0v.y, h1v.x, h1v.y);
-          xl[r] = make_uint4(l0v.x, l0v.y, l1v.x, l1v.y);
-        }
-        // the three piece products as three sweeps over the eight accumulators: consecutive MFMAs never share one
+        for (int nt = 0; nt < 2; ++nt)
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xl[r]), acc[r][nt], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][1]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xl[r]), acc[r][nt], 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
-      }
+        for (int nt = 0; nt < 2; ++nt)
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tk_f16x8, wf[nt][0]), __builtin_bit_cast(tk_f16x8, xh[r]), acc[r][nt], 0, 0, 0);
     }
     // D[row = output channel 16 nt + 4 lk + e][col = position li]
     if (d < d_end) {
@@ -370,7 +384,7 @@ int msk_gconv_tk_h2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, i
   if (g.CK < 1 || g.CK > 4 || g.CN != 32 || g.bias || g.prelu) return 0;
   if (g.DW < 12 || g.DH < 8 || g.DD < 4) return 0;
   if (g.dld % 4 || (((uintptr_t)g.dst) & 15)) return 0;
-  unsigned short* wb = (unsigned short*)msk_workspace2(ctx, (size_t)25 * 2 * 2 * 64 * 8 * sizeof(unsigned short));
+  unsigned short* wb = (unsigned short*)msk_workspace2(ctx, (size_t)kTKSteps * 2 * 2 * 64 * 8 * sizeof(unsigned short));
   if (!wb) return -1;
   const float* x_amax = g.in_amax ? g.in_amax : msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW);
   const float* w_amax = msk_absmax(ctx, w_canon, 4, 4, (125L * g.CK * g.CN + 3) / 4);

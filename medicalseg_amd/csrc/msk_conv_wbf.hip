@@ -415,7 +415,7 @@ __device__ __forceinline__ void store_xi(char* o, long plane, const float (&v)[8
 }
 
 #ifndef WBF_DUAL_LB
-#define WBF_DUAL_LB 3
+#define WBF_DUAL_LB 0   // 3 = force three wavefronts per SIMD: the one-kernel form then spills 8 registers and is 6 % SLOWER (A/B, round 4)
 #endif
 template <int K, int NP, bool WV, bool WY>  // which of the two transforms are written (each stream may take its own)
 #if WBF_DUAL_LB > 0

@@ -439,6 +439,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(0, value);
     return 0;
   }
+  if (strcmp(key, "wgrad_lds_pad") == 0) {
+    ctx->wgrad_lds_pad = value > 0 ? value : 0;
+    return 0;
+  }
   if (strcmp(key, "wgrad_renorm") == 0) {
     ctx->wgrad_renorm = value != 0;
     return 0;

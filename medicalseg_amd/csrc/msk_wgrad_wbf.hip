@@ -446,8 +446,9 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
       tag = msk_intern_tag(ctx, buf);
     }
     msk_launch_scope ls(ctx, tag);
-    if (TH == 16) hipLaunchKernelGGL((wbf_wgrad_k<16, K, NP>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
-    else hipLaunchKernelGGL((wbf_wgrad_k<8, K, NP>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, wa);
+    const unsigned pad = (unsigned)ctx->wgrad_lds_pad;
+    if (TH == 16) hipLaunchKernelGGL((wbf_wgrad_k<16, K, NP>), dim3((unsigned)nblk), dim3(256), pad, ctx->stream, wa);
+    else hipLaunchKernelGGL((wbf_wgrad_k<8, K, NP>), dim3((unsigned)nblk), dim3(256), pad, ctx->stream, wa);
     MSK_LAUNCH_CHECK(ctx);
   }
   {

@@ -7,6 +7,11 @@ import csv
 import sys
 from collections import defaultdict
 
+def short(n):
+    n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("<")[0].split("(")[0][-40:]
+
+
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -66,7 +71,7 @@ if len(qs) >= 2:
         for ms, me, mn in byq[main]:
             o = min(e, me) - max(s, ms)
             if o > 0:
-                acc[(n.split("<")[0].split("(")[0][-40:], mn.split("<")[0].split("(")[0][-40:])] += o
+                acc[(short(n), short(mn))] += o
     print("side kernel  next to  main kernel: overlap ms")
     for (a, b), v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
         print("  %-40s %-40s %.3f" % (a, b, v / 1e6))
@@ -78,7 +83,19 @@ if len(qs) >= 2:
     alone = defaultdict(float)
     for s, e, n in byq[side]:
         o = inter([[s, e]], U[main])
-        alone[n.split("<")[0].split("(")[0][-40:]] += (e - s) - o
+        alone[short(n)] += (e - s) - o
     print("side kernels running ALONE (no compute-queue kernel at the same time):")
     for k, v in sorted(alone.items(), key=lambda kv: -kv[1])[:10]:
         print("  %-40s %.3f ms" % (k, v / 1e6))
+
+    # main-queue kernels: time while a side kernel is co-resident vs alone, per kernel class
+    co = defaultdict(lambda: [0.0, 0.0, 0])
+    for s, e, n in byq[main]:
+        o = inter([[s, e]], U[side])
+        c = co[short(n)]
+        c[0] += o
+        c[1] += (e - s) - o
+        c[2] += 1
+    print("compute-queue kernels: launches, total ms, of which next to a side kernel")
+    for k, (a, b, cnt) in sorted(co.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:30]:
+        print("  %-40s %4d %8.3f %8.3f" % (k, cnt, (a + b) / 1e6, a / 1e6))
