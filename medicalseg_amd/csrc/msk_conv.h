@@ -92,6 +92,8 @@ bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes);  // s
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // kernel == stride forward gather (down-convs, up-conv data gradients): flattened K, two operand batches in flight (msk_conv_ksfwd.hip)
 int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// transposed gather with kernel == stride along D, H and stride 1 along W: the anisotropic MRI levels (msk_conv_ksfwd.hip)
+int msk_gconv_kst(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);
 bool msk_gconv_foldn_h2_accepts(const msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, int cout);
 int msk_wgrad_cbs(msk_ctx* ctx, const WGrad& g); // <= 4 output channels, 5^3 same (msk_wgrad_cbs.hip)

@@ -519,6 +519,9 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
       r = msk_gconv_ks_fwd(ctx, g, w, A, B, swap);
       if (r < 0) return r;
       if (r == 1) return 0;
+      r = msk_gconv_kst(ctx, g, w, A, B, swap);
+      if (r < 0) return r;
+      if (r == 1) return 0;
     }
     r = msk_gconv_gather_mfma(ctx, g, w, A, B, swap);
     if (r < 0) return r;

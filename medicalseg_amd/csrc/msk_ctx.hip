@@ -439,6 +439,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(0, value);
     return 0;
   }
+  if (strcmp(key, "ks_nr_max") == 0) {
+    ctx->ks_nr_max = value >= 4 ? 4 : (value >= 2 ? 2 : 1);
+    return 0;
+  }
   if (strcmp(key, "wgrad_lds_pad") == 0) {
     ctx->wgrad_lds_pad = value > 0 ? value : 0;
     return 0;

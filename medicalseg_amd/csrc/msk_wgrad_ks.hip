@@ -334,7 +334,7 @@ wgrad_ks2_k(WGrad g, Ks2Args a) {
 
 
 // fine levels: rows = (tap, ca); 1 handled, 0 not eligible, < 0 error
-int wgrad_ks2(msk_ctx* ctx, const WGrad& g, int taps, long M, size_t abytes, size_t bbytes) {
+int wgrad_ks2(msk_ctx* ctx, const WGrad& g, int taps, long M, size_t abytes, size_t bbytes, bool k_eq_s) {
   if (ctx->ks_legacy & 1) return 0;                         // the one-tap-per-tile kernel everywhere (A/B)
   if (g.CA > 32 || g.CB > 128 || g.CB % 4 || M < 4096) return 0;
   const int rtiles = (taps * g.CA + 31) / 32, cbt = (g.CB + 31) / 32;
@@ -344,7 +344,8 @@ int wgrad_ks2(msk_ctx* ctx, const WGrad& g, int taps, long M, size_t abytes, siz
   const int rgroups = (rtiles + RT - 1) / RT;
   // the bias gradient rides along when this problem has one (run_wgrad): column sums of B, or of A when one row group holds all taps
   int bias_mode = 0;
-  if (g.db) bias_mode = g.db_src == 1 ? 1 : (rgroups == 1 ? 2 : 0);
+  // (sums of A over every tap count each fine voxel once only when kernel == stride)
+  if (g.db) bias_mode = g.db_src == 1 ? 1 : ((rgroups == 1 && k_eq_s) ? 2 : 0);
   const int nbias = bias_mode == 1 ? g.CB : (bias_mode == 2 ? g.CA : 0);
   const long per = (long)taps * g.CA * g.CB;
   const long pitch = per + ((nbias + 3) & ~3);
@@ -391,7 +392,9 @@ int wgrad_ks2(msk_ctx* ctx, const WGrad& g, int taps, long M, size_t abytes, siz
 
 // returns 1 when handled, 0 when not eligible, < 0 on error
 int msk_wgrad_ks(msk_ctx* ctx, const WGrad& g) {
-  if (!(g.kd == g.sd && g.kh == g.sh && g.kw == g.sw && g.pd == 0 && g.ph == 0 && g.pw == 0)) return 0;
+  // unpadded windows inside A; round 4: any stride (the anisotropic MRI levels overlap along W, see msk_gconv_ks_fwd)
+  if (!(g.pd == 0 && g.ph == 0 && g.pw == 0)) return 0;
+  const bool k_eq_s = g.kd == g.sd && g.kh == g.sh && g.kw == g.sw;
   const int taps = g.kd * g.kh * g.kw;
   if (taps < 2 || taps > 32) return 0;
   if ((g.BD - 1) * g.sd + g.kd > g.AD || (g.BH - 1) * g.sh + g.kh > g.AH || (g.BW - 1) * g.sw + g.kw > g.AW) return 0;
@@ -399,7 +402,7 @@ int msk_wgrad_ks(msk_ctx* ctx, const WGrad& g) {
   const size_t abytes = (size_t)g.N * g.AD * g.AH * g.AW * g.ald * sizeof(float);
   const size_t bbytes = (size_t)M * g.bld * sizeof(float);
   if (M >= (1L << 31) || abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull) return 0;
-  if (int r2 = wgrad_ks2(ctx, g, taps, M, abytes, bbytes)) return r2;
+  if (int r2 = wgrad_ks2(ctx, g, taps, M, abytes, bbytes, k_eq_s)) return r2;
   constexpr int KT = 8;
   const int tgroups = (taps + KT - 1) / KT;
   const int ca_tiles = (g.CA + 31) / 32, cb_tiles = (g.CB + 31) / 32;

@@ -38,6 +38,8 @@ CONV_CASES = [
     (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 16, 64, 64)),   # MRI out_tr.conv2 (20 classes): MFMA gather kernel
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
+    (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 32, 64, 12)),   # the same at a size the fine-level weight-gradient kernel takes (M >= 4096)
+    (32, 64, (2, 2, 2), (2, 2, 1), (0, 0, 0), (2, 16, 32, 9)),    # MRI level 2: kernel (2, 2, 2), stride (2, 2, 1)
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 6, 7, 9)),        # 3x3x3 (deep-sup head shape class)
     (32, 40, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 7, 30, 4)),     # MRI slab depth 4 -> halo tile <4,16,4>
     (24, 32, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 15, 31, 2)),    # MRI slab depth 2 -> halo tile <8,16,2>
@@ -98,9 +100,48 @@ def test_conv3d_fwd_dgrad_wgrad(case, impl):
         d.set_option("conv_impl", 0)
 
 
+def test_mri_anisotropic_levels_take_the_streaming_kernels():
+    """Round 4: kernel (2, 2, 4) / stride (2, 2, 1) and (2, 2, 2) / (2, 2, 1) (vnet_mri_spine_seg_512_512_12_15k.yml:9-10) are not
+    kernel == stride; they ran on the general parity-class / tap-row kernels (6.5 ms of the 33 ms MRI step).  The streaming
+    kernels never depended on kernel == stride for unpadded windows -- gconv_ks_fwd (forward, up-conv data gradient),
+    wgrad_ks2 (both weight gradients) -- and gconv_kst is the transposed form with the overlap along W; the numbers are
+    checked by the CONV_CASES / CONVT_CASES entries above, here that the product dispatch really selects them."""
+    d = dev()
+    rng = np.random.default_rng(3)
+    k, s, p0 = (2, 2, 4), (2, 2, 1), (0, 0, 0)
+    N, D, H, W = 1, 32, 64, 12
+    x = rng.standard_normal((N, 16, D, H, W)).astype(np.float32)
+    w = rng.standard_normal((32, 16) + k).astype(np.float32)
+    xt, yt = t_from_ncdhw(x), t_empty(N, 32, D // 2, H // 2, W - 3)
+    dyt = t_from_ncdhw(rng.standard_normal((N, 32, D // 2, H // 2, W - 3)).astype(np.float32))
+    dxt = t_empty(N, 16, D, H, W)
+    wp, dwp, dbp = vec(w.ravel()), vec(np.zeros(w.size, np.float32)), vec(np.zeros(32, np.float32))
+    wt = rng.standard_normal((32, 16) + k).astype(np.float32)      # Conv3DTranspose weight [Cin = 32][Cout = 16]
+    wtp, dwtp, dbtp = vec(wt.ravel()), vec(np.zeros(wt.size, np.float32)), vec(np.zeros(16, np.float32))
+    d.set_option("prof_only_halo", 0)
+    d.set_option("prof_shapes", 0)
+    d.prof_reset()
+    d.prof_enable(True)
+    d.call("msk_conv3d_fwd", _desc(k, s, p0), xt.msk(), vp(wp), None, yt.msk())
+    d.call("msk_conv3d_dgrad", _desc(k, s, p0), dyt.msk(), vp(wp), dxt.msk(), 0)
+    d.call("msk_conv3d_wgrad", _desc(k, s, p0), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 0)
+    d.call("msk_convT3d_fwd", _desc(k, s, p0), dyt.msk(), vp(wtp), None, dxt.msk())
+    d.call("msk_convT3d_dgrad", _desc(k, s, p0), xt.msk(), vp(wtp), yt.msk(), 0)
+    d.call("msk_convT3d_wgrad", _desc(k, s, p0), dyt.msk(), xt.msk(), vp(dwtp), vp(dbtp), 0)
+    d.sync()
+    d.prof_enable(False)
+    rep = d.prof_report()
+    assert rep.get("gconv_ks_fwd", (0, 0))[0] == 2, rep          # conv forward + convT data gradient
+    assert rep.get("gconv_kst", (0, 0))[0] == 2, rep             # conv data gradient + convT forward
+    assert rep.get("wgrad_ks2_mfma", (0, 0))[0] == 2, rep
+    assert "gconv_gather_mfma" not in rep and "wgrad_mfma" not in rep, rep
+
+
 CONVT_CASES = [
     (32, 16, (2, 2, 2), (2, 2, 2), (2, 4, 4, 4)),
     (64, 16, (2, 2, 4), (2, 2, 1), (1, 4, 4, 9)),     # MRI up conv (overlap-add along W)
+    (64, 16, (2, 2, 4), (2, 2, 1), (1, 16, 32, 9)),   # the same at a size the fine-level weight-gradient kernel takes
+    (128, 32, (2, 2, 2), (2, 2, 1), (2, 8, 16, 8)),   # MRI level 2 up conv
     (6, 5, (3, 2, 2), (2, 2, 1), (1, 3, 4, 5)),
     # kernel == stride: taps-folded scatter kernel (msk_conv_scatter.hip)
     (64, 16, (2, 2, 2), (2, 2, 2), (1, 4, 8, 32)),    # up_tr32.up_conv class

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--iso", action="store_true", help="isotropic 2x2x2 kernels/strides (lung) instead of the MRI ones")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="msk_set_option knob for experiments")
     ap.add_argument("--profile-out", default=None)
     ap.add_argument("--json-out", default=None, help="write ms/step, algorithmic FLOP rates and the roofline fraction here")
     a = ap.parse_args()
@@ -34,6 +35,9 @@ def main():
     K = [[2, 2, 2]] * 4 if a.iso else [[2, 2, 4], [2, 2, 2], [2, 2, 2], [2, 2, 2]]
     S = [[2, 2, 2]] * 4 if a.iso else [[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]
     dev = get_device()
+    for kv in a.opt:
+        key, val = kv.split("=")
+        dev.set_option(key, int(val))
     if a.model == "UNet3D":   # builder-defined (no reference model): python tools/bench_workloads.py --model UNet3D --shape 192,192,64 --num-classes 3 --batch 2
         model = models.UNet3D(num_classes=a.num_classes, base_channels=32, depth=4, precision=a.precision)
     else:
