@@ -360,7 +360,7 @@ def main():
     kms = line["avg_launch_ms"] * line["launches"]
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic, traffic_src, hbm = None, None, None
-    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
                                   os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) if os.path.exists(pth)), None)
     if tpath and S == 128 and B == 2:   # PMC passes of this exact workload (tools/profile_gpu.sh, tools/summarize_rocprof.py)
         try:
