@@ -214,6 +214,63 @@ pointwise_small_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   }
 }
 
+// 1x1x1 convolution with up to 32 channels on both sides (out_tr.conv2 of the 20-class MRI model, vnet.py:169, and its data
+// gradient): 400 FMAs and 160 bytes per voxel -- HBM streaming.  One thread per voxel, the voxel's channels in registers
+// (16-byte loads), the CK x CN weight block in LDS read as broadcast quads.  The general gather kernel spent 0.43 / 0.20 ms
+// on the two 512 x 512 x 12 problems (251 MB in, 251 MB out: 0.1 ms at HBM speed).
+template <int Q>   // channel quads per side held in registers (CK, CN <= 4 Q)
+__global__ void __launch_bounds__(kThreads)
+pointwise_mid_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
+  __shared__ float4 ws[4 * Q * Q];   // [k][n quad]
+  __shared__ float4 bs[Q];
+  const int kq = g.CK >> 2, nq = g.CN >> 2;
+  for (int i = threadIdx.x; i < 4 * Q * Q; i += blockDim.x) {
+    const int k = i / Q, q = i % Q;
+    ws[i] = (k < g.CK && q < nq) ? *reinterpret_cast<const float4*>(wp + k * g.CN + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = threadIdx.x; i < Q; i += blockDim.x)
+    bs[i] = (g.bias && i < nq) ? *reinterpret_cast<const float4*>(g.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const long M = (long)g.N * g.DD * g.DH * g.DW;
+  for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+    float4 x[Q];
+    const float4* sp = reinterpret_cast<const float4*>(g.src + m * g.sld);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[q] = q < kq ? sp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = bs[q];
+#pragma unroll
+    for (int kk = 0; kk < Q; ++kk) {
+      if (kk < kq) {   // uniform
+        const float xv[4] = {x[kk].x, x[kk].y, x[kk].z, x[kk].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float4 w4 = ws[(4 * kk + e) * Q + q];
+            acc[q].x = fmaf(xv[e], w4.x, acc[q].x);
+            acc[q].y = fmaf(xv[e], w4.y, acc[q].y);
+            acc[q].z = fmaf(xv[e], w4.z, acc[q].z);
+            acc[q].w = fmaf(xv[e], w4.w, acc[q].w);
+          }
+      }
+    }
+    float4* dp = reinterpret_cast<float4*>(g.dst + m * g.dld);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q < nq) {
+        float4 v = acc[q];
+        if (g.accumulate) {
+          const float4 o = dp[q];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        dp[q] = v;
+      }
+    }
+  }
+}
+
 // Weight gradient of the 1x1x1 convolution with few channels (out_tr.conv2, ncls -> ncls, vnet.py:169):
 // dW[cb][ca] = sum_v dy[v][cb] * x[v][ca] -- two streams of 12-16 B per voxel and CA x CB <= 16 running sums per thread
 // (the generic split-K MFMA kernel spent 0.20 ms on 100 MB; this is one pass at HBM speed).
@@ -470,6 +527,22 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_small");
     hipLaunchKernelGGL(pointwise_small_k, dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && ctx->conv_impl != 6 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 0 &&
+      g.pw == 0 && g.CK <= 32 && g.CN <= 32 && g.CK % 4 == 0 && g.CN % 4 == 0 && g.sld % 4 == 0 && g.dld % 4 == 0 &&
+      (((uintptr_t)g.src) & 15) == 0 && (((uintptr_t)g.dst) & 15) == 0 && (!g.bias || (((uintptr_t)g.bias) & 15) == 0)) {
+    // 1x1x1 with 12 .. 32 channels (the 20-class heads): streaming VALU kernel; 6 = A/B: the general gather kernel
+    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    if (!wp1) return -1;
+    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
+    const long M = (long)g.N * g.DD * g.DH * g.DW;
+    msk_launch_scope ls(ctx, "pointwise_mid");
+    const int cmax = g.CK > g.CN ? g.CK : g.CN;
+    if (cmax <= 16) hipLaunchKernelGGL((pointwise_mid_k<4>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    else if (cmax <= 24) hipLaunchKernelGGL((pointwise_mid_k<6>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    else hipLaunchKernelGGL((pointwise_mid_k<8>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
