@@ -212,6 +212,14 @@ int msk_conv3d_fwd_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float
                        msk_tensor y, float* stats_local /*nullable*/, void* xform /*nullable*/, const float* x_amax /*nullable*/,
                        const msk_bn_fin* fin /*nullable*/);
 int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_bn_fin* fin /*nullable*/);
+/* Convolution followed by INSTANCE statistics (paddle.nn.InstanceNorm3D: per (sample, channel) over D*H*W; the builder-defined
+ * UNet3D of BASELINE configs[3]): stats is [N][2 Cout]; fin describes sample 0 (count = D*H*W, running_* ignored when NULL) and
+ * sample n's save_mean / save_invstd / scale / shift lie fin_stride floats further per sample.  When the convolution kernel
+ * keeps per-tile records (the one-kernel matrix stage, <= 64 channels) the N merges read those; otherwise one statistics pass
+ * per sample runs on y -- the results are the same to fp32 rounding either way.                                              */
+int msk_conv3d_fwd_in(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias /*nullable*/, msk_tensor y,
+                      float* stats, void* xform /*nullable*/, const float* x_amax /*nullable*/, const msk_bn_fin* fin,
+                      int fin_stride);
 int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
                                  const float* alpha, const float* mean, const float* invstd, msk_tensor dout, float* sums,
                                  float* maxes /*nullable*/, int clear_maxes, float* dgamma, float* dbeta, float* dalpha);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "msk_conv3d_wgrad_ex": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp]),
     "msk_amax_new": (_vp, [_vp, _i]),
     "msk_conv3d_fwd_ex3": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp, _vp, _vp]),
+    "msk_conv3d_fwd_in": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp, _vp, _vp, _i]),
     "msk_bn_stats_fin": (_i, [_vp, _T, _vp, _vp]),
     "msk_affine_act_bwd_reduce_pg": (_i, [_vp, _T, _vp, _vp, _T, _vp, _vp, _vp, _T, _vp, _vp, _i, _vp, _vp, _vp]),
     "msk_add_act_join_bwd_pg": (_i, [_vp, _T, _vp, _vp, _vp, _T, _vp, _vp, _vp, _T, _T, _T, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -27,6 +27,8 @@ struct GConv {
   const float* in_amax;  // NP = 2 pipelines: device scalar bounding max |src| (scales the source transform, undone in the output stage); NULL = unscaled
   const struct WbfBnBwd* fuse;  // msk_conv3d_bwd_bnact: src is not read; the input transform evaluates dy from (y, dout) on the fly
   const msk_bn_fin* fin;  // msk_conv3d_fwd_ex3: BatchNorm finalisation to run in the statistics merge (with stats), or null
+  int stats_ps;       // msk_conv3d_fwd_in: statistics PER SAMPLE -- stats is [N][2 CN], fin's save_mean / save_invstd / scale / shift
+  int fin_stride;     // advance by fin_stride floats per sample (InstanceNorm); only kernels whose records are per tile serve it
   bool w_persistent;  // the weights are the caller's tensor (covered by msk_weights_changed): derived forms may be cached
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.

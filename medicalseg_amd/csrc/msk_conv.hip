@@ -1062,6 +1062,52 @@ int msk_conv3d_fwd_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float
   return 0;
 }
 
+int msk_conv3d_fwd_in(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                      float* stats, void* xform, const float* x_amax, const msk_bn_fin* fin, int fin_stride) {
+  if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  MSK_REQUIRE(ctx, stats != nullptr && fin != nullptr && fin->scale != nullptr && fin_stride >= 0, "msk_conv3d_fwd_in: stats and fin required");
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
+  g.transposed = 0; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.w_persistent = true;
+  const size_t sper = (size_t)g.SD * g.SH * g.SW * g.sld * sizeof(float), dper = (size_t)g.DD * g.DH * g.DW * g.dld * sizeof(float);
+  const size_t per = sper > dper ? sper : dper;
+  const bool chunked = per > 0 && (size_t)g.N > kChunkBytes / per;
+  ctx->stats_fused = false;
+  ctx->xform_written = false;
+  if (!chunked) {
+    g.stats = stats;
+    g.stats_ps = 1;
+    g.fin = fin;
+    g.fin_stride = fin_stride;
+    g.xform = xform;
+  }
+  g.in_amax = x_amax;
+  if (int rc = run_gconv(ctx, g, w, y.c, x.c, 1, "conv3d_fwd_direct")) return rc;
+  if (xform) {
+    if (ctx->xform_ok.size() > 8192) ctx->xform_ok.clear();
+    if (ctx->xform_written) ctx->xform_ok.insert(xform);
+    else ctx->xform_ok.erase(xform);
+  }
+  if (ctx->stats_fused) return 0;
+  // the kernel that ran keeps no per-tile records: one statistics pass per sample
+  const size_t svox = (size_t)y.d * y.h * y.w;
+  for (int n = 0; n < y.n; ++n) {
+    msk_tensor yn = y;
+    yn.p = (float*)y.p + (size_t)n * svox * y.ld;
+    yn.n = 1;
+    msk_bn_fin fn = *fin;
+    const long o = (long)n * fin_stride;
+    fn.save_mean += o; fn.save_invstd += o; fn.scale += o; fn.shift += o;
+    if (int rc = msk_bn_stats_fin(ctx, yn, stats + (size_t)n * 2 * y.c, &fn)) return rc;
+  }
+  return 0;
+}
+
 int msk_conv3d_wgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
                         const void* xform) {
   return conv3d_wgrad_impl(ctx, cd, x, dy, dw, db, accumulate, xform, nullptr);

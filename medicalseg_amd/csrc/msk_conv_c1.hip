@@ -232,7 +232,7 @@ int msk_gconv_c1_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A,
     snprintf(buf, sizeof(buf), "conv_c1_mfma[cn=%d,n=%d,dhw=%dx%dx%d]", g.CN, g.N, g.DD, g.DH, g.DW);
     tag = msk_intern_tag(ctx, buf);
   }
-  const bool want_stats = g.stats != nullptr && !g.prelu && g.CN == 16;   // (all four channel quads live: the LDS record table is full)
+  const bool want_stats = g.stats != nullptr && !g.stats_ps && !g.prelu && g.CN == 16;   // (all four channel quads live: the LDS record table is full)
   if (want_stats) {
     a.stat_partial = (float*)msk_workspace(ctx, (size_t)blocks * g.CN * 3 * sizeof(float));
     if (!a.stat_partial) return -1;

@@ -1513,7 +1513,8 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   long tout_blocks = ((long)m_xi / 4 + 255) / 256;
   if (tout_blocks > 16L * ctx->num_cu) tout_blocks = 16L * ctx->num_cu;
   const int c4n = g.CN / 4;
-  const bool fuse_stats = g.stats != nullptr && !g.accumulate && !g.prelu && (fuse_out || (c4n <= 256 && (c4n & (c4n - 1)) == 0));
+  // per-sample statistics (InstanceNorm): only the one-kernel form, whose records are per TILE and the tiles sample-major
+  const bool fuse_stats = g.stats != nullptr && !g.accumulate && !g.prelu && (fuse_out || (!g.stats_ps && c4n <= 256 && (c4n & (c4n - 1)) == 0));
   const long stat_rows = fuse_out ? base_blocks / NXI : tout_blocks;
   const size_t s_bytes = fuse_stats ? (size_t)stat_rows * g.CN * 3 * sizeof(float) : 0;
   char* wsp = (char*)msk_workspace(ctx, (g.xform ? 0 : v_bytes) + m_bytes + s_bytes + 256);
@@ -1615,7 +1616,20 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       MSK_LAUNCH_CHECK(ctx);
     }
     if (fuse_stats) {
-      if (msk_bn_stats_merge(ctx, SP, fa.g.nblk, g.CN, g.stats, g.fin) != 0) return -1;
+      if (g.stats_ps) {
+        const int tps = fa.g.nblk / g.N;   // tiles per sample: tile id = ((n T + t) tiles_d + td) tiles_h + th
+        for (int n = 0; n < g.N; ++n) {
+          msk_bn_fin fn{};
+          if (g.fin) {
+            fn = *g.fin;
+            const long o = (long)n * g.fin_stride;
+            fn.save_mean += o; fn.save_invstd += o; fn.scale += o; fn.shift += o;
+          }
+          if (msk_bn_stats_merge(ctx, SP + (size_t)n * tps * g.CN * 3, tps, g.CN, g.stats + (size_t)n * 2 * g.CN, g.fin ? &fn : nullptr) != 0) return -1;
+        }
+      } else if (msk_bn_stats_merge(ctx, SP, fa.g.nblk, g.CN, g.stats, g.fin) != 0) {
+        return -1;
+      }
       ctx->stats_fused = true;
     }
     if (g.xform) ctx->xform_written = true;

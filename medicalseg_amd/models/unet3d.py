@@ -19,7 +19,10 @@ import numpy as np
 from .. import nn
 from ..cvlibs import manager
 from ..device import Tensor, to_tensor
+from .._lib import MskBnFin
 from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _amax_for, _fp, copy_scale
+
+INSTANCE_STATS_IN_CONV = True   # False = statistics + finalisation as separate passes per sample (A/B, tests)
 from .vnet import VNet
 
 
@@ -49,6 +52,12 @@ class InstanceNorm3D(nn.Layer):
             self._scratch = s
         return self._scratch
 
+    def sample_stats(self, dev, n):
+        """[n][2C] statistics records (mean, M2) of msk_conv3d_fwd_in"""
+        if getattr(self, "_sstats", None) is None or self._sstats[0] < n:
+            self._sstats = (n, dev.small(n * 2 * self.num_features))
+        return self._sstats[1]
+
     def sample_coeffs(self, sc, i):
         Cn, p = self.num_features, sc["per"] + 4 * i * 4 * self.num_features
         return {"scale": p, "shift": p + 4 * Cn, "mean": p + 8 * Cn, "invstd": p + 12 * Cn}
@@ -69,13 +78,41 @@ class ConvINAct(ConvBNAct):
             raise ValueError("ConvINAct has no residual input")
         dev, norm = x.dev, self.bn
         self.x, self.res = x, None
+        alpha = self.act._weight.ptr if self.act is not None else None
+        if type(self.conv) is nn.Conv3D and INSTANCE_STATS_IN_CONV:
+            # round 4: the instance statistics AND their finalisation come out of the convolution call -- from the per-tile
+            # records of the one-kernel matrix stage where it runs (<= 64 channels: the two fine levels), else from one statistics
+            # pass per sample inside the call (msk_conv3d_fwd_in); the transformed input is kept for the weight gradient
+            conv = self.conv
+            od, oh, ow = conv.out_dims(x)
+            y = Tensor.empty(dev, x.n, od, oh, ow, conv.cout)
+            sc, Cn = norm.scratch(dev, y.n), norm.num_features
+            nn._count_flops(conv, x.n, od * oh * ow, 1)
+            nbytes = int(dev.lib.msk_conv3d_xform_bytes(dev.ctx, conv.desc(), x.msk(), conv.cout))
+            xf = dev.arena.alloc(nbytes) if nbytes > 0 else None
+            co0 = norm.sample_coeffs(sc, 0)
+            fin = MskBnFin(norm.scale.ptr, norm.bias.ptr, norm.epsilon, 1.0, float(od * oh * ow), None, None, co0["mean"],
+                           co0["invstd"], co0["scale"], co0["shift"])
+            dev.call("msk_conv3d_fwd_in", conv.desc(), x.msk(), _fp(conv.weight.ptr), _fp(conv.bias.ptr), y.msk(),
+                     _fp(norm.sample_stats(dev, y.n)), _fp(xf), _fp(x.amax) if (x.amax and nn.PRODUCER_AMAX) else None,
+                     C.byref(fin), 4 * Cn)
+            conv._xform = (xf, x.ptr, dev.arena.gen) if xf else None
+            self.y = y
+            if out is None:
+                out = y.empty_like()
+            am = _amax_for(out)
+            for i in range(y.n):
+                co = norm.sample_coeffs(sc, i)
+                dev.call("msk_affine_act_fwd_amax", _sample(y, i).msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                         _sample(out, i).msk(), am)
+            self.out, self.bn_mode = out, 1
+            return out
         # a Conv3D keeps its transformed input for the weight gradient when the bf16x3 / fp16 pipeline takes the shape
         y = self.conv.run_forward(x, keep_xform=True) if type(self.conv) is nn.Conv3D else self.conv.run_forward(x)
         self.y = y
         if out is None:
             out = y.empty_like()
         sc, Cn = norm.scratch(dev, y.n), norm.num_features
-        alpha = self.act._weight.ptr if self.act is not None else None
         vox = float(y.d * y.h * y.w)
         am = _amax_for(out)   # max |out| over all samples rides in the normalise passes (the next 3^3 conv scales by it)
         for i in range(y.n):

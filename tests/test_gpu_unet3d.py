@@ -150,3 +150,53 @@ def test_unet3d_fp16_path_matches_torch_at_the_stated_fp16_tolerance():
             assert e_lg < 2e-4 and e_ls < 1e-4 and l2[worst] < 3e-3
         else:
             assert e_lg < 1.5e-2 and e_ls < 5e-3 and l2[worst] < 1e-1
+
+
+@pytest.mark.parametrize("cin,cout,shape,records", [(32, 32, (2, 64, 128, 32), True), (64, 64, (2, 64, 64, 32), True), (32, 32, (2, 16, 32, 16), False),
+                                                    (64, 32, (2, 16, 16, 16), False), (32, 128, (2, 8, 16, 8), False), (8, 8, (2, 6, 8, 8), False)])
+def test_instance_statistics_from_the_convolution_call(cin, cout, shape, records):
+    """Round 4: msk_conv3d_fwd_in -- convolution + per-sample statistics + their finalisation in one call.  For <= 64 output
+    channels the statistics come from the per-tile records of the one-kernel matrix stage (no read of y: no bn_stats_partial
+    launch), else from one statistics pass per sample inside the call; either way the unit's output and the per-sample
+    coefficients must equal the separate passes (msk_bn_stats + msk_bn_finalize per sample) to fp32 rounding."""
+    from helpers import dev
+    from medicalseg_amd import nn
+    from medicalseg_amd.device import to_tensor
+    from medicalseg_amd.models import unet3d as U
+    d = dev()
+    N, D, H, W = shape
+    rng = np.random.default_rng(cin + cout)
+    nn.seed(1)
+    conv, norm, act = nn.Conv3D(cin, cout, 3, padding=1), U.InstanceNorm3D(cout), nn.PReLU(cout)
+    unit = U.ConvINAct(conv, norm, act)
+    params = [conv.weight, conv.bias, norm.scale, norm.bias, act._weight]
+    arena = nn.ParamArena(d, params)
+    norm.scale.set_value(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    norm.bias.set_value((rng.standard_normal(cout) * 0.1).astype(np.float32))
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    x[1] = x[1] * 3.0 + 0.5                      # the two instances have different statistics
+    outs, coefs, tags = {}, {}, {}
+    for mode in (False, True):
+        U.INSTANCE_STATS_IN_CONV = mode
+        try:
+            d.arena.reset()
+            d.prof_reset()
+            d.set_option("prof_only_halo", 0)
+            d.prof_enable(True)
+            out = unit.forward(to_tensor(x))
+            d.sync()
+            d.prof_enable(False)
+            tags[mode] = d.prof_report()
+            outs[mode] = out.numpy()
+            sc = norm.scratch(d, N)
+            coefs[mode] = d.d2h(sc["per"], (N, 4, cout), np.float32)
+        finally:
+            U.INSTANCE_STATS_IN_CONV = True
+    scale = np.abs(outs[False]).max()
+    assert np.abs(outs[True] - outs[False]).max() <= 2e-5 * scale
+    assert np.abs(coefs[True] - coefs[False]).max() <= 2e-5 * np.abs(coefs[False]).max()
+    assert np.abs(coefs[True][0] - coefs[True][1]).max() > 1e-2          # really per sample
+    if records:   # enough tiles for the one-kernel matrix stage (>= 2 per CU): the statistics come from its tile records
+        assert "bn_stats_partial" not in tags[True], tags[True]
+        assert tags[True].get("bn_stats_merge", (0, 0))[0] == N
+    del arena
