@@ -22,6 +22,7 @@ from ..device import Tensor, to_tensor
 from .._lib import MskBnFin
 from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _amax_for, _fp, copy_scale
 
+ZERO_COPY_SKIPS = True          # False = the skip tensors are copied into / out of the concat buffers (A/B, tests)
 INSTANCE_STATS_IN_CONV = True   # False = statistics + finalisation as separate passes per sample (A/B, tests)
 from .vnet import VNet
 
@@ -198,24 +199,45 @@ class Up(nn.Layer):
         self.c_lo = c_lo
         self._up = ConvINAct(self.up_conv, self.norm, self.relu)
 
+    def reserve_concat(self, dev, n, d, h, w):
+        """Zero-copy skip connection (round 4; the VNet blocks do the same): allocate this block's concat buffer AHEAD of the
+        encoder that produces the skip tensor and return the channel slice that encoder writes its output into -- the skip
+        half is then never copied (forward) and its gradient never copied back (backward)."""
+        xcat = Tensor.empty(dev, n, d, h, w, 2 * self.c_lo)
+        _amax_for(xcat)   # one amax array for the buffer: both producers fold into it through their slices
+        self._reserved = xcat
+        return xcat.channel_slice(self.c_lo, 2 * self.c_lo)
+
     def forward(self, x, skip):
         od, oh, ow = self.up_conv.out_dims(x)
         if (od, oh, ow) != (skip.d, skip.h, skip.w) or skip.c != self.c_lo:
             raise ValueError(f"skip connection shape {skip.shape} does not match the up-sampled "
                              f"({x.n}, {self.c_lo}, {od}, {oh}, {ow}): every input side must be a multiple of 2^(depth-1)")
         self._x, self._skip = x, skip
-        xcat = Tensor.empty(x.dev, x.n, od, oh, ow, 2 * self.c_lo)
-        _amax_for(xcat)   # one amax array for the buffer: both producers below fold into it through their slices
+        res = getattr(self, "_reserved", None)
+        self._reserved = None
+        self._in_place = (res is not None and res.gen == x.dev.arena.gen and skip.ld == res.ld and
+                          skip.ptr == res.ptr + 4 * self.c_lo and (res.n, res.d, res.h, res.w) == (x.n, od, oh, ow))
+        if self._in_place:
+            xcat = res
+        else:
+            xcat = Tensor.empty(x.dev, x.n, od, oh, ow, 2 * self.c_lo)
+            _amax_for(xcat)
         self._up.forward(x, out=xcat.channel_slice(0, self.c_lo))
-        copy_scale(skip, None, xcat.channel_slice(self.c_lo, 2 * self.c_lo))
+        if not self._in_place:
+            copy_scale(skip, None, xcat.channel_slice(self.c_lo, 2 * self.c_lo))
         self._xcat = xcat
         return self.ops.forward(xcat)
 
     def backward(self, dout):
         self.ops.backward(dout)
         gcat, skip = self._xcat.grad, self._skip
-        sg = skip.ensure_grad()
-        copy_scale(gcat.channel_slice(self.c_lo, 2 * self.c_lo), None, sg, accumulate=skip.grad_written)
+        if self._in_place and skip.grad is None:
+            # the skip tensor IS the second half of the concat buffer: so is its gradient (the down path accumulates into the slice)
+            skip.grad = gcat.channel_slice(self.c_lo, 2 * self.c_lo)
+        else:
+            sg = skip.ensure_grad()
+            copy_scale(gcat.channel_slice(self.c_lo, 2 * self.c_lo), None, sg, accumulate=skip.grad_written)
         skip.grad_written = True
         self._up.backward(gcat.channel_slice(0, self.c_lo))
 
@@ -279,7 +301,11 @@ class UNet3D(VNet):
         skips, t = [], x
         for i, enc in enumerate(self.encoders):
             # the first encoder's input is the image: it needs no data gradient
-            t = enc.forward(t)
+            if i < self.depth - 1 and ZERO_COPY_SKIPS:
+                # the skip tensor is produced straight into the concat buffer of the decoder block that consumes it
+                t = enc.forward(t, out=self.ups[self.depth - 2 - i].reserve_concat(self.dev, t.n, t.d, t.h, t.w))
+            else:
+                t = enc.forward(t)
             if i < self.depth - 1:
                 skips.append(t)
                 t = self.downs[i].forward(t)
