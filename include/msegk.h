@@ -249,6 +249,15 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
  * with dy evaluated inside the kernel from (y, dout); `res` is either a null tensor or x itself (the tiled residual, read from the
  * kernel's own halo of x).  Returns 0 = done, 1 = not this class / declined (nothing was launched: use msk_affine_act_bwd_apply +
  * msk_conv3d_wgrad), < 0 = error.  Runs on the calling stream.                                                     */
+/* The same unit with INSTANCE statistics (conv -> InstanceNorm -> PReLU; builder-defined UNet3D): sample n's scale / shift / mean /
+ * invstd lie n * coef_stride floats after the given pointers, its sums (msk_affine_act_bwd_reduce* of that sample) n * sums_stride
+ * floats, M_sample = D*H*W.  Only the fused form exists: returns 1 with NOTHING launched when it is not eligible (the caller then
+ * runs msk_affine_act_bwd_apply per sample and the separate gradient calls), 0 when done.  maxes: the two amax arrays the
+ * reduce passes of ALL samples folded into (required for the fp16 operand formats).                                         */
+int msk_conv3d_bwd_inact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                         const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd, int coef_stride,
+                         msk_tensor dout, const float* sums, int sums_stride, double M_sample, msk_tensor dx, int dx_accumulate,
+                         float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes /*nullable*/);
 int msk_conv3d_bwd_bnact_c1(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor y, const float* scale, const float* shift,
                             const float* alpha /*nullable*/, const float* mean, const float* invstd, msk_tensor res,
                             msk_tensor dout, const float* sums_total, double M_total, float* dw, int dw_accumulate);

@@ -1194,15 +1194,41 @@ size_t msk_conv3d_bwd_bnact_bytes(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, 
   return msk_conv3d_xform_bytes(ctx, cd, y, y.c);
 }
 
+// coef_stride / sums_stride != 0: per-sample statistics (msk_conv3d_bwd_inact) -- only the one-kernel fused form serves them;
+// fused_only: return 1 with nothing launched when that form is not eligible
+static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                                 const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                                 msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                                 int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
+                                 int coef_stride, int sums_stride, bool fused_only);
+
 int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
                          msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
                          int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes) {
+  return conv3d_bwd_bnact_impl(ctx, cd, x, w, y, scale, shift, alpha, mean, invstd, gamma, dout, sums_total, M_total, dy_scratch, dx,
+                               dx_accumulate, dw, dw_accumulate, xform, ybuf, maxes, 0, 0, false);
+}
+
+int msk_conv3d_bwd_inact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                         const float* shift, const float* alpha, const float* mean, const float* invstd, int coef_stride,
+                         msk_tensor dout, const float* sums, int sums_stride, double M_sample, msk_tensor dx, int dx_accumulate,
+                         float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes) {
+  MSK_REQUIRE(ctx, coef_stride >= y.c && sums_stride >= 2 * y.c, "msk_conv3d_bwd_inact: strides smaller than the records");
+  return conv3d_bwd_bnact_impl(ctx, cd, x, w, y, scale, shift, alpha, mean, invstd, nullptr, dout, sums, M_sample, msk_tensor{}, dx,
+                               dx_accumulate, dw, dw_accumulate, xform, ybuf, maxes, coef_stride, sums_stride, true);
+}
+
+static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                                 const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                                 msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                                 int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
+                                 int coef_stride, int sums_stride, bool fused_only) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
   MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
   MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
-  MSK_REQUIRE(ctx, dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
-                       dy_scratch.c == y.c, "dy_scratch must match y");
+  MSK_REQUIRE(ctx, fused_only || (dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
+                                  dy_scratch.c == y.c), "dy_scratch must match y");
   if (xform && !ctx->xform_ok.count(xform)) xform = nullptr;   // never filled by msk_conv3d_fwd_ex*
   // ---- fused form: conditions under which BOTH gradient pipelines take pre-written transforms
   const bool split2 = wbf_pieces(ctx, cd.kd) != 3;   // fp16 operands (two pieces, or one: conv_fp16): power-of-two tensor scales
@@ -1219,7 +1245,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
   gw.dw = dw; gw.accumulate = dw_accumulate;
   gw.xform = xform;
   // ---- one input channel, no data gradient (in_tr.conv1, vnet.py:67): dy is evaluated inside the weight-gradient kernel
-  if (x.c == 1 && !dx.p && !(per > 0 && (size_t)x.n > kChunkBytes / per)) {
+  if (x.c == 1 && !dx.p && !fused_only && !(per > 0 && (size_t)x.n > kChunkBytes / per)) {
     const int r = bwd_bnact_c1(ctx, gw, y, scale, shift, alpha, mean, invstd, dout, sums_total, M_total, 0);
     if (r <= 0) return r;   // 0 done, < 0 error, 1 declined: the general forms below
   }
@@ -1239,6 +1265,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
     bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
     bn.invM = (float)(1.0 / M_total);
     bn.Y = (char*)ybuf;
+    bn.coef_stride = coef_stride; bn.sums_stride = sums_stride;
     bn.y_xi = (long)(y_bytes / ((cd.kd == 5) ? 8 : 6));
     if (split2) g.w_amax = (const float*)xform + kWbfAmaxWays;  // max |w| of this layer, left there by the forward pass
 
@@ -1249,7 +1276,9 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          (ctx->wgrad_async_max_m <= 0 || msk_voxels(y) <= ctx->wgrad_async_max_m);
     // auto: with the two-piece fp16 operands the one-kernel form wins even with the side stream on (24.1 vs 24.7 ms per
     // step: its transforms are a third cheaper); with the exact bf16 x 3 split form 2 does (30.1-30.2 vs 30.3-30.4)
-    const int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : ((side_on && !split2) ? 2 : 1);
+    int form = ctx->bwd_fuse > 0 ? ctx->bwd_fuse : ((side_on && !split2) ? 2 : 1);
+    if (fused_only) form = 1;   // per-sample statistics: the one-kernel form (the separate bound kernel of form 2 knows no strides)
+    if (fused_only && split2 && !maxes) return 1;
     if (wbf_pieces(ctx, cd.kd) == 2 && form == 1) {
       // per-channel max |dy| for the weight gradient's renormalisation, folded in by the dual transform (compute stream)
       bn.y_cmax = msk_scalar_slots(ctx, (y.c + kWbfAmaxWays - 1) / kWbfAmaxWays);
@@ -1300,6 +1329,7 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
       }
     }
   }
+  if (fused_only) return 1;   // declined, nothing launched: the caller runs its own passes
   // ---- three-kernel form: dy through HBM
   (void)gamma;
   if (int rc = msk_affine_act_bwd_apply(ctx, y, scale, shift, msk_tensor{}, alpha, mean, invstd, gamma, dout, sums_total, M_total, 1,

@@ -389,6 +389,7 @@ struct DualArgs {
   const float* amax;
   const float* maxes;  // see WbfBnBwd
   float* y_cmax;       // see WbfBnBwd
+  int coef_stride, sums_stride;
 };
 
 template <int K, int NP>
@@ -440,16 +441,17 @@ wbf_tin_dual_k(DualArgs b) {
   const int cg = cgb * 4 + cgl, kc = cg >> 1, khalf = cg & 1;
   // per-channel coefficients of this wavefront's 8 channels: wave-uniform -> scalar registers
   float sc[8], sf[8], al[8], mu[8], is[8], s1[8], s2[8];
+  const long co = (long)n * b.coef_stride, so = (long)n * b.sums_stride;   // per-sample statistics (InstanceNorm): this block's sample
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    sc[j] = b.scale[c];
-    sf[j] = b.shift[c];
+    sc[j] = b.scale[co + c];
+    sf[j] = b.shift[co + c];
     al[j] = b.alpha ? b.alpha[c] : 1.f;
-    mu[j] = b.mean[c];
-    is[j] = b.invstd[c];
-    s1[j] = b.sums[c] * b.invM;
-    s2[j] = b.sums[b.C + c] * b.invM;
+    mu[j] = b.mean[co + c];
+    is[j] = b.invstd[co + c];
+    s1[j] = b.sums[so + c] * b.invM;
+    s2[j] = b.sums[so + b.C + c] * b.invM;
   }
   // NP = 2: power-of-two scale of dy from (a bound of) its maximum: given (b.amax), or evaluated here (b.maxes)
   float sc2 = 1.f;
@@ -457,10 +459,12 @@ wbf_tin_dual_k(DualArgs b) {
     if (b.maxes) {
       __shared__ float shb[3][4];
       float ma = 0.f, mb = 0.f, mc = 0.f;
-      for (int c = threadIdx.x; c < b.C; c += 256) {
-        ma = fmaxf(ma, fabsf(b.scale[c]));
-        mb = fmaxf(mb, fabsf(b.sums[c] * b.invM));
-        mc = fmaxf(mc, fabsf(b.sums[b.C + c] * b.invM));
+      const int sets = (b.coef_stride || b.sums_stride) ? a.N : 1;   // every block bounds the WHOLE tensor: all samples' coefficients
+      for (int i = threadIdx.x; i < sets * b.C; i += 256) {
+        const int sn = i / b.C, c = i - sn * b.C;
+        ma = fmaxf(ma, fabsf(b.scale[(long)sn * b.coef_stride + c]));
+        mb = fmaxf(mb, fabsf(b.sums[(long)sn * b.sums_stride + c] * b.invM));
+        mc = fmaxf(mc, fabsf(b.sums[(long)sn * b.sums_stride + b.C + c] * b.invM));
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -1704,6 +1708,7 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   da.scale = bn.scale; da.shift = bn.shift; da.alpha = bn.alpha; da.mean = bn.mean; da.invstd = bn.invstd; da.sums = bn.sums;
   da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax; da.maxes = bn.maxes;
   da.y_cmax = bn.Y ? bn.y_cmax : nullptr;
+  da.coef_stride = bn.coef_stride; da.sums_stride = bn.sums_stride;
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;

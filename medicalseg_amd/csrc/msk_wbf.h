@@ -164,6 +164,8 @@ struct WbfBnBwd {
   // inputs; block 0 stores it to `amax` for the kernels behind it) -- no separate bound kernel on the critical path
   const float* maxes;
   float* y_cmax;      // NP = 2: zeroed array [C] that receives max |dy| per channel (WbfTinArgs::cmax), or null
+  int coef_stride;    // InstanceNorm (msk_conv3d_bwd_inact): sample n's scale / shift / mean / invstd lie n * coef_stride floats further,
+  int sums_stride;    // its sums n * sums_stride floats further; 0 = one set for the batch (BatchNorm)
   // msk_wgrad_c1 only: the unit's pre-activation also adds its (one-channel, tiled) INPUT -- in_tr, vnet.py:75-78: the weight
   // gradient's A operand itself, taken from the kernel's LDS halo
   int res_is_input;

@@ -22,6 +22,7 @@ from ..device import Tensor, to_tensor
 from .._lib import MskBnFin
 from ..nn import NULL_TENSOR, ConvBNAct, Parameter, _amax_for, _fp, copy_scale
 
+FUSED_IN_BACKWARD = True        # False = InstanceNorm backward as reduce + apply passes with dy in HBM everywhere (A/B, tests)
 ZERO_COPY_SKIPS = True          # False = the skip tensors are copied into / out of the concat buffers (A/B, tests)
 INSTANCE_STATS_IN_CONV = True   # False = statistics + finalisation as separate passes per sample (A/B, tests)
 from .vnet import VNet
@@ -58,6 +59,12 @@ class InstanceNorm3D(nn.Layer):
         if getattr(self, "_sstats", None) is None or self._sstats[0] < n:
             self._sstats = (n, dev.small(n * 2 * self.num_features))
         return self._sstats[1]
+
+    def sample_sums(self, dev, n):
+        """[n][3C] backward sums (sum du, sum du xhat, alpha gradient) kept per sample for msk_conv3d_bwd_inact"""
+        if getattr(self, "_ssums", None) is None or self._ssums[0] < n:
+            self._ssums = (n, dev.small(n * 3 * self.num_features))
+        return self._ssums[1]
 
     def sample_coeffs(self, sc, i):
         Cn, p = self.num_features, sc["per"] + 4 * i * 4 * self.num_features
@@ -132,6 +139,53 @@ class ConvINAct(ConvBNAct):
         sc, Cn = norm.scratch(dev, y.n), norm.num_features
         alpha = self.act._weight.ptr if self.act is not None else None
         vox = float(y.d * y.h * y.w)
+        conv, x = self.conv, self.x
+        xf = getattr(conv, "_xform", None)
+        xfp = xf[0] if (xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen) else None
+        vec = Cn % 4 == 0 and y.ld % 4 == 0 and dout.ld % 4 == 0 and y.ptr % 16 == 0 and dout.ptr % 16 == 0
+        if (FUSED_IN_BACKWARD and type(conv) is nn.Conv3D and conv.cin == conv.cout and conv.s == (1, 1, 1) and need_dx
+                and xfp is not None and vec):
+            # round 4: the InstanceNorm / PReLU backward is evaluated inside the kernel that writes both transforms of dy, with
+            # the coefficients and sums of the block's own sample (msk_conv3d_bwd_inact): per sample only the reduce pass is left
+            agrad = _fp(self.act._weight.grad_ptr) if self.act is not None else None
+            sums, stride = norm.sample_sums(dev, y.n), 3 * Cn
+            maxes = dev.amax_new(2)      # zeroed ring arrays: the reduce passes of all samples fold into them
+            for i in range(y.n):
+                yv, dv, co = _sample(y, i), _sample(dout, i), norm.sample_coeffs(sc, i)
+                dev.call("msk_affine_act_bwd_reduce_pg", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                         _fp(co["mean"]), _fp(co["invstd"]), dv.msk(), _fp(sums + 4 * i * stride), _fp(maxes), 0,
+                         _fp(norm.scale.grad_ptr), _fp(norm.bias.grad_ptr), agrad)
+            nbytes = int(dev.lib.msk_conv3d_bwd_bnact_bytes(dev.ctx, conv.desc(), x.msk(), y.msk()))
+            rc = 1
+            if nbytes > 0:
+                ybuf = dev.arena.alloc(nbytes)
+                dx = x.ensure_grad()
+                co0 = norm.sample_coeffs(sc, 0)
+                rc = dev.lib.msk_conv3d_bwd_inact(dev.ctx, conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(co0["scale"]),
+                                                  _fp(co0["shift"]), _fp(alpha), _fp(co0["mean"]), _fp(co0["invstd"]), 4 * Cn,
+                                                  dout.msk(), _fp(sums), stride, C.c_double(vox), dx.msk(),
+                                                  1 if x.grad_written else 0, _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf),
+                                                  _fp(maxes))
+                if rc < 0:
+                    from .._lib import MskError, last_error
+                    raise MskError(f"msk_conv3d_bwd_inact failed: {last_error(dev.ctx)}")
+            if rc == 0:
+                nn._count_flops(conv, x.n, y.d * y.h * y.w, 2)
+                x.grad_written = True
+                conv._xform = None
+                self.dy = None
+                return
+            # declined (nothing launched): dy through HBM from the sums already taken
+            dy = y.empty_like()
+            dya = _amax_for(dy)
+            for i in range(y.n):
+                yv, dv, co = _sample(y, i), _sample(dout, i), norm.sample_coeffs(sc, i)
+                dev.call("msk_affine_act_bwd_apply_amax", yv.msk(), _fp(co["scale"]), _fp(co["shift"]), NULL_TENSOR, _fp(alpha),
+                         _fp(co["mean"]), _fp(co["invstd"]), _fp(norm.scale.ptr), dv.msk(), _fp(sums + 4 * i * stride),
+                         C.c_double(vox), 1, _sample(dy, i).msk(), NULL_TENSOR, 0, dya)
+            self.dy = dy
+            self.conv.run_backward(self.x, dy, need_dx=need_dx, bias_grad=False)
+            return
         dy = y.empty_like()
         dya = _amax_for(dy) if type(self.conv) is nn.Conv3D and self.conv.s == (1, 1, 1) else None
         for i in range(y.n):

@@ -102,13 +102,18 @@ def test_unet3d_fp16_path_matches_torch_at_the_stated_fp16_tolerance():
     from medicalseg_amd.utils import loss_computation
     from oracle.unet3d_torch import TorchUNet3D
     from helpers import dev
-    ncls, shape, depth, base = 3, (1, 1, 16, 16, 16), 2, 32
+    ncls, shape, depth, base = 3, (2, 1, 16, 16, 16), 2, 32     # batch 2: two instances with their own statistics
     rng = np.random.default_rng(7)
     nn.seed(0)
     x = rng.standard_normal(shape).astype(np.float32)
+    x[1] = 2.0 * x[1] - 0.3
     y = rng.integers(0, ncls, (shape[0],) + shape[2:]).astype(np.int32)
     res = {}
-    for prec in ("fp32", "fp16"):
+    from medicalseg_amd.models import unet3d as U
+    for prec in ("fp32-unfused", "fp32", "fp16"):
+        # "fp32-unfused": the InstanceNorm backward as separate reduce / apply passes with dy in HBM (A/B of round 4's fused form)
+        U.FUSED_IN_BACKWARD = prec != "fp32-unfused"
+        unfused, prec = prec == "fp32-unfused", prec.split("-")[0]
         nn.seed(0)
         model = UNet3D(in_channels=1, num_classes=ncls, base_channels=base, depth=depth, precision=prec)
         state = model.state_dict()
@@ -133,6 +138,8 @@ def test_unet3d_fp16_path_matches_torch_at_the_stated_fp16_tolerance():
         tags = d.prof_report()
         ran16 = any(k.startswith("wbf_gemm_f16_k") for k in tags) and any(k.startswith("wbf_wgrad_f16_k") for k in tags)
         assert ran16 == (prec == "fp16"), sorted(tags)
+        # round 4: the square 3x3x3 units take the InstanceNorm backward inside the dual transform (msk_conv3d_bwd_inact)
+        assert ("wbf_tin_dual_k" in tags) == (not unfused), sorted(tags)
         ref_logits, ref_loss = res["ref"]
         e_lg = np.abs(got - ref_logits).max() / np.abs(ref_logits).max()
         e_ls = abs(lv - ref_loss) / abs(ref_loss)
@@ -144,12 +151,20 @@ def test_unet3d_fp16_path_matches_torch_at_the_stated_fp16_tolerance():
             g = p.grad_numpy().astype(np.float64)
             l2[name] = float(np.linalg.norm(g - r) / np.linalg.norm(r))
         worst = max(l2, key=l2.get)
-        print("\nUNet3D %s: logits %.2e loss %.2e grads rel-L2 worst %.2e (%s) median %.2e" %
-              (prec, e_lg, e_ls, l2[worst], worst, float(np.median(list(l2.values())))))
+        print("\nUNet3D %s%s: logits %.2e loss %.2e grads rel-L2 worst %.2e (%s) median %.2e" %
+              (prec, " (unfused backward)" if unfused else "", e_lg, e_ls, l2[worst], worst, float(np.median(list(l2.values())))))
+        if unfused:
+            res["l2_unfused"] = l2
+            continue
         if prec == "fp32":
             assert e_lg < 2e-4 and e_ls < 1e-4 and l2[worst] < 3e-3
+            # tensor by tensor no worse than the separate passes (the bias of a norm in front of another instance norm has a
+            # nearly vanishing true gradient: its relative error is large in ANY fp32 evaluation)
+            for name, e in l2.items():
+                assert e <= 3 * res["l2_unfused"][name] + 2e-5, (name, e, res["l2_unfused"][name])
         else:
             assert e_lg < 1.5e-2 and e_ls < 5e-3 and l2[worst] < 1e-1
+    U.FUSED_IN_BACKWARD = True
 
 
 @pytest.mark.parametrize("cin,cout,shape,records", [(32, 32, (2, 64, 128, 32), True), (64, 64, (2, 64, 64, 32), True), (32, 32, (2, 16, 32, 16), False),
