@@ -271,6 +271,75 @@ pointwise_mid_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   }
 }
 
+// 1x1x1 convolution between a THICK side (8 .. 32 channels, a multiple of 4: 16-byte accesses) and a THIN side (<= 4 channels):
+// the segmentation head of the builder-defined UNet3D (32 -> ncls and its data gradient ncls -> 32).  HBM streaming; the general
+// gather kernel spent 0.38 / 0.48 ms on the two 2 x 192 x 192 x 64 problems (604 MB on the thick side: 0.12 ms at HBM speed).
+template <bool THIN_OUT>
+__global__ void __launch_bounds__(kThreads)
+pointwise_thin_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
+  __shared__ __attribute__((aligned(16))) float ws[32 * 4];
+  __shared__ float bs[32];
+  const int thick = THIN_OUT ? g.CK : g.CN, thin = THIN_OUT ? g.CN : g.CK;
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+    // ws[t * 4 + j]: thick channel t, thin channel j
+    const int t = i >> 2, j = i & 3;
+    const bool ok = t < thick && j < thin;
+    ws[i] = ok ? (THIN_OUT ? wp[t * g.CN + j] : wp[j * g.CN + t]) : 0.f;
+  }
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) bs[i] = (g.bias && i < g.CN) ? g.bias[i] : 0.f;
+  __syncthreads();
+  const int tq = thick >> 2;
+  const long M = (long)g.N * g.DD * g.DH * g.DW;
+  for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+    if (THIN_OUT) {
+      const float4* sp = reinterpret_cast<const float4*>(g.src + m * g.sld);
+      float acc[4] = {bs[0], bs[1], bs[2], bs[3]};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < tq) {   // uniform
+          const float4 x = sp[q];
+          const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&ws[(4 * q + e) * 4]);
+            acc[0] = fmaf(xv[e], w4.x, acc[0]);
+            acc[1] = fmaf(xv[e], w4.y, acc[1]);
+            acc[2] = fmaf(xv[e], w4.z, acc[2]);
+            acc[3] = fmaf(xv[e], w4.w, acc[3]);
+          }
+        }
+      }
+      float* dp = g.dst + m * g.dld;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < thin) dp[j] = g.accumulate ? dp[j] + acc[j] : acc[j];
+    } else {
+      const float* sp = g.src + m * g.sld;
+      float xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = j < thin ? sp[j] : 0.f;
+      float4* dp = reinterpret_cast<float4*>(g.dst + m * g.dld);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < tq) {   // uniform
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&ws[(4 * q + e) * 4]);
+            o[e] = fmaf(xv[3], w4.w, fmaf(xv[2], w4.z, fmaf(xv[1], w4.y, fmaf(xv[0], w4.x, bs[4 * q + e]))));
+          }
+          float4 v = make_float4(o[0], o[1], o[2], o[3]);
+          if (g.accumulate) {
+            const float4 old = dp[q];
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+          }
+          dp[q] = v;
+        }
+      }
+    }
+  }
+}
+
 // Weight gradient of the 1x1x1 convolution with few channels (out_tr.conv2, ncls -> ncls, vnet.py:169):
 // dW[cb][ca] = sum_v dy[v][cb] * x[v][ca] -- two streams of 12-16 B per voxel and CA x CB <= 16 running sums per thread
 // (the generic split-K MFMA kernel spent 0.20 ms on 100 MB; this is one pass at HBM speed).
@@ -527,6 +596,20 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_small");
     hipLaunchKernelGGL(pointwise_small_k, dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
+  if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && ctx->conv_impl != 6 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 0 &&
+      g.pw == 0 && ((g.CN <= 4 && g.CK > 8 && g.CK <= 32 && g.CK % 4 == 0 && g.sld % 4 == 0 && (((uintptr_t)g.src) & 15) == 0) ||
+                    (g.CK <= 4 && g.CN > 8 && g.CN <= 32 && g.CN % 4 == 0 && g.dld % 4 == 0 && (((uintptr_t)g.dst) & 15) == 0))) {
+    // thick <-> thin 1x1x1 (the 32 -> ncls head of UNet3D and its data gradient): streaming VALU kernel; 6 = A/B: the general gather kernel
+    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    if (!wp1) return -1;
+    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
+    const long M = (long)g.N * g.DD * g.DH * g.DW;
+    msk_launch_scope ls(ctx, "pointwise_thin");
+    if (g.CN <= 4) hipLaunchKernelGGL((pointwise_thin_k<true>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    else hipLaunchKernelGGL((pointwise_thin_k<false>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }

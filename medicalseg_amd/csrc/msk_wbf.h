@@ -184,6 +184,7 @@ struct WbfGeom {
   int perm[3];        // logical (d, h, w) <- tensor axis
   int LD, LH, LW, T;
   int DP, HP;         // plane dims: tile-rounded + 4 halo slots
+  double max_pad;     // the padding limit this geometry was accepted under (kWbfMaxPad, or kWbfMaxPadLast on the second try)
 };
 // (minTD, minTH): the coarsest position tile a consumer of this geometry needs -- a function of the layer's OUTPUT channel
 // count (wbf_min_tile), so that the forward pass and the weight gradient of one layer agree.
@@ -192,22 +193,28 @@ inline void wbf_min_tile(int cout, int* td, int* th) {
   *th = cout <= 64 ? 16 : 8;
 }
 // Padding of the (d, h) position planes up to whole tiles that is still worth it: the 16-bit pipeline is 4-5x faster than the
-// fp32 Winograd kernels a declined layer falls back to, so up to 80 % padded matrix work wins (MRI level 256 x 256 x 9:
-// 9 -> 16 planes, 12.9 -> ~5 ms for its three kernels); 35 % was the round-1 break-even against the bf16x3 pipeline.
-constexpr double kWbfMaxPad = 1.8;
+// fp32 Winograd / direct kernels a declined layer falls back to, so up to 80 % padded matrix work wins clearly (MRI level
+// 256 x 256 x 9: 9 -> 16 planes, 12.9 -> ~5 ms for its three kernels; round 2) and even the 4x of the 2-voxel-deep MRI bottom
+// level (256 channels at 32 x 32 x 2: planes 32 x 2 -> 32 x 8) still does (round 4, A/B on one box: step 30.8 -> 30.0 ms;
+// 35 % was the round-1 break-even against the bf16x3 pipeline).
+constexpr double kWbfMaxPad = 1.8;       // the limit every shape is tried with first
+constexpr double kWbfMaxPadLast = 4.0;   // second try for shapes nothing accepted (the geometry remembers which limit it was made with)
 inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* out) {
   static const int kPerms[6][3] = {{0, 1, 2}, {1, 0, 2}, {0, 2, 1}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};
   const int dims[3] = {D, H, W};
   int best = -1;
-  double best_cost = 0;
-  for (int i = 0; i < 6; ++i) {
-    const int ld = dims[kPerms[i][0]], lh = dims[kPerms[i][1]], lw = dims[kPerms[i][2]];
-    if (lw % 4) continue;
-    if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > kWbfMaxPad * (double)ld * lh) continue;
-    const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) / ((double)ld * lh);  // padding at the finest tile
-    if (best < 0 || cost < best_cost - 1e-9) {
-      best = i;
-      best_cost = cost;
+  double best_cost = 0, limit = kWbfMaxPad;
+  for (int pass = 0; pass < 2 && best < 0; ++pass) {
+    limit = pass == 0 ? kWbfMaxPad : kWbfMaxPadLast;
+    for (int i = 0; i < 6; ++i) {
+      const int ld = dims[kPerms[i][0]], lh = dims[kPerms[i][1]], lw = dims[kPerms[i][2]];
+      if (lw % 4) continue;
+      if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > limit * (double)ld * lh) continue;
+      const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) / ((double)ld * lh);  // padding at the finest tile
+      if (best < 0 || cost < best_cost - 1e-9) {
+        best = i;
+        best_cost = cost;
+      }
     }
   }
   if (best < 0) return false;
@@ -216,15 +223,16 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
   out->LH = dims[out->perm[1]];
   out->LW = dims[out->perm[2]];
   out->T = out->LW / 4;
+  out->max_pad = limit;
   const int rd = out->LD >= 16 ? 16 : 8, rh = out->LH >= 32 ? 32 : (out->LH >= 16 ? 16 : 8);
   out->DP = (out->LD + rd - 1) / rd * rd + 4;
   out->HP = (out->LH + rh - 1) / rh * rh + 4;
   return true;
 }
-// a (TD x TH) position tiling fits the planes and wastes at most 35 % of the matrix work on padding
+// a (TD x TH) position tiling fits the planes and wastes no more of the matrix work on padding than the geometry's limit
 inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
   const int td = (g.LD + TD - 1) / TD * TD, th = (g.LH + TH - 1) / TH * TH;
-  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= kWbfMaxPad * (double)g.LD * g.LH;
+  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= g.max_pad * (double)g.LD * g.LH;
 }
 size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP);
 size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K);

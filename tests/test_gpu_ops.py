@@ -35,7 +35,10 @@ CONV_CASES = [
     (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),      # out_tr.conv2
     (3, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 6)),
     (4, 2, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 19, 33, 47)),     # wgrad_pw_small_k: several blocks, CA != CB
-    (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 16, 64, 64)),   # MRI out_tr.conv2 (20 classes): MFMA gather kernel
+    (20, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 16, 64, 64)),   # MRI out_tr.conv2 (20 classes): streaming pointwise_mid kernel
+    (32, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 9, 33, 17)),     # UNet3D head 32 -> ncls (and ncls -> 32 as its data gradient): pointwise_thin
+    (16, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 8, 8, 40)),
+    (24, 12, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 6, 7)),      # pointwise_mid with unequal sides
     (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 8, 8)),      # down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 8, 8, 12)),     # MRI anisotropic down conv
     (16, 32, (2, 2, 4), (2, 2, 1), (0, 0, 0), (1, 32, 64, 12)),   # the same at a size the fine-level weight-gradient kernel takes (M >= 4096)
