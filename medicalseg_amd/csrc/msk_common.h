@@ -85,6 +85,13 @@ struct msk_ctx {
   void* ws3_side = nullptr;  // the side stream's third scratch (wgrad_wbf_padded)
   size_t ws3_side_bytes = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // "late" weight gradient (round 4): the in_tr.conv1 gradient is the LAST of a backward pass; it runs at the end of the side stream
+  // behind ev_late, so that the optimizer kernel of everything else (and the weight re-pack in its epilogue) overlaps it
+  hipEvent_t ev_late = nullptr;
+  bool late_valid = false;
+  const float* late_ptr = nullptr;   // gradient tensor still being written behind ev_late
+  size_t late_count = 0;
+  int late_split = 1;                // option "late_split": 0 = the late gradient on the calling stream, one optimizer launch (A/B)
   bool wgrad_async = false;
   bool side_dirty = false;
   bool fork_recorded = false;  // ev_fork already recorded at the point the next side scope has to wait for (msk_conv3d_bwd_bnact)

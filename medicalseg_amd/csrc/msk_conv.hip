@@ -1244,6 +1244,20 @@ static int bwd_bnact_c1(msk_ctx* ctx, const WGrad& gw, msk_tensor y, const float
   gc.B = nullptr;
   gc.xform = nullptr;
   gc.yfuse = &bn;
+  if (ctx->late_split && ctx->wgrad_async && ctx->side != nullptr) {
+    // round 4: at the END of the side stream, behind an event that marks everything queued before it -- msk_sgd_momentum waits
+    // for that event only, updates every other parameter and re-packs the weights while this kernel (matrix-bound) still runs,
+    // then joins and updates this tensor (msk_loss_optim.hip)
+    msk_side_scope side(ctx, true);
+    if (side.active) hipEventRecord(ctx->ev_late, ctx->stream);
+    const int r = msk_wgrad_c1(ctx, gc);
+    if (r == 1 && side.active) {
+      ctx->late_valid = true;
+      ctx->late_ptr = gw.dw;
+      ctx->late_count = (size_t)gw.CA * gw.CB * gw.kd * gw.kh * gw.kw;
+    }
+    return r < 0 ? r : (r == 1 ? 0 : 1);
+  }
   const int r = msk_wgrad_c1(ctx, gc);   // 0: not its shape class
   return r < 0 ? r : (r == 1 ? 0 : 1);
 }

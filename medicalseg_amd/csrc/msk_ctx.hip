@@ -87,6 +87,7 @@ int msk_dp_wait_impl(msk_ctx* ctx) {
 }
 
 int msk_join_side_impl(msk_ctx* ctx) {
+  ctx->late_valid = false;   // a full join covers the late gradient as well
   if (ctx->side_dirty) {
     MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
     MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -156,6 +157,7 @@ int msk_ctx_create(int device, msk_ctx** out) {
   }
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_late, hipEventDisableTiming));
   MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t0));
   MSK_CHECK_HIP(ctx, hipEventCreate(&ctx->t1));
   hipDeviceProp_t prop;
@@ -187,6 +189,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   }
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_late) hipEventDestroy(ctx->ev_late);
   hipEventDestroy(ctx->t0);
   hipEventDestroy(ctx->t1);
   hipStreamDestroy(ctx->stream);
@@ -437,6 +440,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 8)
     msk_set_ew_caps(0, value);
+    return 0;
+  }
+  if (strcmp(key, "late_split") == 0) {
+    ctx->late_split = value != 0;
     return 0;
   }
   if (strcmp(key, "ks_nr_max") == 0) {

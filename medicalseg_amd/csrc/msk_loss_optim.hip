@@ -533,23 +533,45 @@ int msk_loss_bwd(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, const f
   return msk_loss_bwd_ex(ctx, logits, labels, weights, ignore_index, 0, nullptr, stats, coef_ce, coef_dice, dlogits);
 }
 
-int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
-                     float momentum, float weight_decay, float grad_scale) {
+static int sgd_launch(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr, float momentum,
+                      float weight_decay, float grad_scale) {
   if (count == 0) return 0;
-  if (msk_join_side_impl(ctx) != 0) return -1;  // weight gradients may still be running on the side stream
-  MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
-              "arenas must be 16-byte aligned");
   size_t n4 = count / 4;
   long blocks = (long)((n4 + kThreads - 1) / kThreads);
   long cap = (long)ctx->num_cu * 16;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  {
   msk_launch_scope ls(ctx, "sgd_momentum");
   hipLaunchKernelGGL(sgd_momentum_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, param, grad, velocity, n4,
                      count, lr, momentum, weight_decay, grad_scale);
   MSK_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
+                     float momentum, float weight_decay, float grad_scale) {
+  if (count == 0) return 0;
+  MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
+              "arenas must be 16-byte aligned");
+  // the "late" weight gradient (in_tr.conv1, the last of the backward pass: msk_conv.hip bwd_bnact_c1) may still be running at
+  // the end of the side stream: everything else is complete behind ev_late -- update it and re-pack the weights now, the late
+  // tensor after the join
+  size_t lo = 0, hi = 0;
+  if (ctx->late_valid && ctx->late_ptr >= grad && ctx->late_ptr + ctx->late_count <= grad + count &&
+      ((ctx->late_ptr - grad) & 3) == 0) {
+    lo = (size_t)(ctx->late_ptr - grad);
+    hi = (lo + ctx->late_count + 3) & ~(size_t)3;
+    if (hi > count) hi = count;
+    MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_late, 0));
+    if (sgd_launch(ctx, param, grad, velocity, lo, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+    if (sgd_launch(ctx, param + hi, grad + hi, velocity + hi, count - hi, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+    msk_weights_changed_impl(ctx, param, count * sizeof(float));
+    if (msk_wbf_prepack_impl(ctx) != 0) return -1;
+    if (msk_join_side_impl(ctx) != 0) return -1;
+    return sgd_launch(ctx, param + lo, grad + lo, velocity + lo, hi - lo, lr, momentum, weight_decay, grad_scale);
   }
+  if (msk_join_side_impl(ctx) != 0) return -1;  // weight gradients may still be running on the side stream
+  if (sgd_launch(ctx, param, grad, velocity, count, lr, momentum, weight_decay, grad_scale) != 0) return -1;
   // the packed / transformed forms of the convolution weights inside [param, param + count) are stale now: rebuild the ones
   // in use in one go (two launches instead of one pack + one maximum per layer and direction inside the next step)
   msk_weights_changed_impl(ctx, param, count * sizeof(float));
