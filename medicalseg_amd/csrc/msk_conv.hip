@@ -274,11 +274,14 @@ pointwise_mid_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
 // 1x1x1 convolution between a THICK side (8 .. 32 channels, a multiple of 4: 16-byte accesses) and a THIN side (<= 4 channels):
 // the segmentation head of the builder-defined UNet3D (32 -> ncls and its data gradient ncls -> 32).  HBM streaming; the general
 // gather kernel spent 0.38 / 0.48 ms on the two 2 x 192 x 192 x 64 problems (604 MB on the thick side: 0.12 ms at HBM speed).
-template <bool THIN_OUT>
+// TQ > 0: TQ (= thick / 4, a power of two) adjacent lanes share a voxel, each owns one 16-byte quad of the thick side -- a
+// wavefront's accesses are contiguous (one thread per voxel walked its 128-byte row alone: 64 lines per instruction, 1.9 TB/s);
+// thin outputs are summed over the TQ lanes with shuffles.  TQ == 0: any thick width, one thread per voxel.
+template <bool THIN_OUT, int TQ>
 __global__ void __launch_bounds__(kThreads)
 pointwise_thin_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   __shared__ __attribute__((aligned(16))) float ws[32 * 4];
-  __shared__ float bs[32];
+  __shared__ __attribute__((aligned(16))) float bs[32];
   const int thick = THIN_OUT ? g.CK : g.CN, thin = THIN_OUT ? g.CN : g.CK;
   for (int i = threadIdx.x; i < 128; i += blockDim.x) {
     // ws[t * 4 + j]: thick channel t, thin channel j
@@ -288,8 +291,59 @@ pointwise_thin_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   }
   for (int i = threadIdx.x; i < 32; i += blockDim.x) bs[i] = (g.bias && i < g.CN) ? g.bias[i] : 0.f;
   __syncthreads();
-  const int tq = thick >> 2;
   const long M = (long)g.N * g.DD * g.DH * g.DW;
+  if (TQ > 0) {
+    const int q = threadIdx.x % TQ;
+    float4 wq[4];   // this lane's quad: weights of thick channels 4 q .. 4 q + 3 against the (<= 4) thin channels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wq[e] = *reinterpret_cast<const float4*>(&ws[(4 * q + e) * 4]);
+    const long total = M * TQ, stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i - q < total; i += stride) {   // the TQ lanes of a voxel stay together
+      const long m = i / TQ;
+      const bool live = m < M;
+      if (THIN_OUT) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) x = reinterpret_cast<const float4*>(g.src + m * g.sld)[q];
+        float acc[4];
+        acc[0] = fmaf(x.w, wq[3].x, fmaf(x.z, wq[2].x, fmaf(x.y, wq[1].x, x.x * wq[0].x)));
+        acc[1] = fmaf(x.w, wq[3].y, fmaf(x.z, wq[2].y, fmaf(x.y, wq[1].y, x.x * wq[0].y)));
+        acc[2] = fmaf(x.w, wq[3].z, fmaf(x.z, wq[2].z, fmaf(x.y, wq[1].z, x.x * wq[0].z)));
+        acc[3] = fmaf(x.w, wq[3].w, fmaf(x.z, wq[2].w, fmaf(x.y, wq[1].w, x.x * wq[0].w)));
+#pragma unroll
+        for (int o = 1; o < TQ; o <<= 1)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (live && q == 0) {
+          float* dp = g.dst + m * g.dld;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < thin) {
+              const float v = acc[j] + bs[j];
+              dp[j] = g.accumulate ? dp[j] + v : v;
+            }
+        }
+      } else if (live) {
+        const float* sp = g.src + m * g.sld;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = j < thin ? sp[j] : 0.f;
+        const float4 b4 = *reinterpret_cast<const float4*>(&bs[4 * q]);
+        float4 v;
+        v.x = fmaf(xv[3], wq[0].w, fmaf(xv[2], wq[0].z, fmaf(xv[1], wq[0].y, fmaf(xv[0], wq[0].x, b4.x))));
+        v.y = fmaf(xv[3], wq[1].w, fmaf(xv[2], wq[1].z, fmaf(xv[1], wq[1].y, fmaf(xv[0], wq[1].x, b4.y))));
+        v.z = fmaf(xv[3], wq[2].w, fmaf(xv[2], wq[2].z, fmaf(xv[1], wq[2].y, fmaf(xv[0], wq[2].x, b4.z))));
+        v.w = fmaf(xv[3], wq[3].w, fmaf(xv[2], wq[3].z, fmaf(xv[1], wq[3].y, fmaf(xv[0], wq[3].x, b4.w))));
+        float4* dp = reinterpret_cast<float4*>(g.dst + m * g.dld) + q;
+        if (g.accumulate) {
+          const float4 old = *dp;
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        *dp = v;
+      }
+    }
+    return;
+  }
+  const int tq = thick >> 2;
   for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
     if (THIN_OUT) {
       const float4* sp = reinterpret_cast<const float4*>(g.src + m * g.sld);
@@ -608,8 +662,16 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_thin");
-    if (g.CN <= 4) hipLaunchKernelGGL((pointwise_thin_k<true>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
-    else hipLaunchKernelGGL((pointwise_thin_k<false>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    const int thick = g.CN <= 4 ? g.CK : g.CN;
+    const int TQ = thick == 32 ? 8 : (thick == 16 ? 4 : 0);
+    const dim3 grid(grid_for(M * (TQ ? TQ : 1), ctx->num_cu));
+#define PW_THIN(out_, tq_) hipLaunchKernelGGL((pointwise_thin_k<out_, tq_>), grid, dim3(kThreads), 0, ctx->stream, g, (const float*)wp1)
+    if (g.CN <= 4) {
+      if (TQ == 8) PW_THIN(true, 8); else if (TQ == 4) PW_THIN(true, 4); else PW_THIN(true, 0);
+    } else {
+      if (TQ == 8) PW_THIN(false, 8); else if (TQ == 4) PW_THIN(false, 4); else PW_THIN(false, 0);
+    }
+#undef PW_THIN
     MSK_LAUNCH_CHECK(ctx);
     return 0;
   }
