@@ -107,6 +107,7 @@ struct msk_ctx {
   void* comm_grad = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr, ev_comm_back = nullptr;
+  int c1_h2 = 1;          // one-input-channel convolutions on the 16-bit pipe (conv_c1_h2_k): 1 = the 3^3 class (UNet3D), 2 = also 5^3 (in_tr), 0 = off
   int ks_nr_max = 4;      // gconv_ks_fwd / gconv_kst: most N tiles per workgroup (4: x read once but 160 registers -- such a wavefront finds no room
                           // on a SIMD that holds three weight-gradient wavefronts of the side stream; 2: 94 registers)
   int wgrad_lds_pad = 0;  // bytes of dynamic LDS added to every wbf_wgrad_k launch: caps its workgroups per CU (33.5 KB static: 3 per CU

@@ -76,6 +76,8 @@ int msk_gconv_halo_tightk(msk_ctx* ctx, const GConv& g, const float* w_canon, in
 int msk_gconv_tk_h2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv with ONE input channel (in_tr.conv1) on the fp32 matrix pipe, weights and tap offsets in registers (msk_conv_c1.hip)
 int msk_gconv_c1_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// the same class (and 3^3 with <= 32 output channels) on the 16-bit matrix pipe with fp16 operand pieces (msk_conv_c1.hip)
+int msk_gconv_c1_h2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv 32 -> (<= 4) channels, two voxels per thread on the VALU (msk_conv_valu2.hip)
 int msk_gconv_halo_valu2(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // 'same' 5^3 conv 32 -> (<= 3) channels on the fp32 matrix pipe, kd taps folded into the MFMA columns, marching along D

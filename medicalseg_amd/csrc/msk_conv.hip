@@ -692,7 +692,10 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     return 0;
   }
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4) {
-    int r = ctx->conv_impl == 23 ? 0 : msk_gconv_c1_mfma(ctx, g, w, A, B, swap);  // 23 = A/B: VALU kernel for 1 -> 16
+    int r = ctx->conv_impl == 23 ? 0 : msk_gconv_c1_h2(ctx, g, w, A, B, swap);    // 27 = A/B: the fp32-MFMA kernel below
+    if (r < 0) return r;
+    if (r == 1) return 0;
+    r = ctx->conv_impl == 23 ? 0 : msk_gconv_c1_mfma(ctx, g, w, A, B, swap);  // 23 = A/B: VALU kernel for 1 -> 16
     if (r < 0) return r;
     if (r == 1) return 0;
     r = ctx->conv_impl == 8 ? 0 : msk_gconv_tk_h2(ctx, g, w, A, B, swap);

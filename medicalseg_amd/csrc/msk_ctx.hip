@@ -446,6 +446,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->late_split = value != 0;
     return 0;
   }
+  if (strcmp(key, "c1_h2") == 0) {
+    ctx->c1_h2 = value < 0 ? 0 : (value > 2 ? 2 : value);
+    return 0;
+  }
   if (strcmp(key, "ks_nr_max") == 0) {
     ctx->ks_nr_max = value >= 4 ? 4 : (value >= 2 ? 2 : 1);
     return 0;

@@ -149,13 +149,16 @@ wgrad_c1_mfma_k(WGrad g, int ntiles, int tiles_d, int tiles_h, int tiles_w, floa
 }  // namespace
 
 // returns 1 when handled, 0 when not eligible, < 0 on error
+// round 4: also 3^3 (the first convolution of the builder-defined UNet3D, 1 -> 32), and more than 16 output channels as blocks of
+// 16 (one launch per block: dy is still read once in total, the one-channel x once per block)
 int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
-  if (!(g.CA == 1 && g.CB >= 1 && g.CB <= 16)) return 0;
-  if (!(g.kd == 5 && g.kh == 5 && g.kw == 5 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 2 && g.ph == 2 && g.pw == 2))
-    return 0;
+  const bool k5 = g.kd == 5 && g.kh == 5 && g.kw == 5 && g.pd == 2 && g.ph == 2 && g.pw == 2;
+  const bool k3 = g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1;
+  const WbfBnBwd* yf = g.yfuse;   // msk_conv3d_bwd_bnact: dy evaluated in the kernel (B is not read)
+  if (!(g.CA == 1 && g.CB >= 1 && g.CB <= (yf ? 16 : 64))) return 0;
+  if (!(k5 || (k3 && !yf)) || !(g.sd == 1 && g.sh == 1 && g.sw == 1)) return 0;
   if (!(g.AD == g.BD && g.AH == g.BH && g.AW == g.BW)) return 0;
   const long M = (long)g.N * g.BD * g.BH * g.BW;
-  const WbfBnBwd* yf = g.yfuse;   // msk_conv3d_bwd_bnact: dy evaluated in the kernel (B is not read)
   const size_t abytes = (size_t)M * g.ald * sizeof(float), bbytes = (size_t)M * (yf ? yf->yld : g.bld) * sizeof(float);
   const size_t dbytes = yf ? (size_t)M * yf->dld * sizeof(float) : 0;
   if (M >= (1L << 30) || abytes >= 0xFFFFFFF0ull || bbytes >= 0xFFFFFFF0ull || dbytes >= 0xFFFFFFF0ull) return 0;
@@ -164,26 +167,37 @@ int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
   if (ntiles > 0x7fffffff) return 0;
   long splits = 2L * ctx->num_cu;  // persistent workgroups (LDS: 13.8 KB halo + 32 KB reduction buffer -> 3 per CU)
   if (splits > ntiles) splits = ntiles;
-  const int taps = 125;
-  const size_t per = (size_t)taps * g.CB * sizeof(float);
-  float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
-  if (!partial) return -1;
-  {
-    const char* tag = "wgrad_c1_mfma";
-    if (ctx->prof && ctx->prof_shapes) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "wgrad_c1_mfma[cb=%d,M=%ld,splits=%ld%s]", g.CB, M, splits, yf ? ",bn-fused" : "");
-      tag = msk_intern_tag(ctx, buf);
+  const int taps = k5 ? 125 : 27;
+  for (int cb0 = 0; cb0 < g.CB; cb0 += 16) {
+    WGrad gb = g;
+    gb.CB = g.CB - cb0 < 16 ? g.CB - cb0 : 16;
+    if (gb.B) gb.B = g.B + cb0;
+    gb.dw = g.dw + (size_t)cb0 * taps;
+    const size_t per = (size_t)taps * gb.CB * sizeof(float);
+    float* partial = (float*)msk_workspace(ctx, (size_t)splits * per);
+    if (!partial) return -1;
+    {
+      const char* tag = "wgrad_c1_mfma";
+      if (ctx->prof && ctx->prof_shapes) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "wgrad_c1_mfma[cb=%d,k=%d,M=%ld,splits=%ld%s]", gb.CB, g.kd, M, splits, yf ? ",bn-fused" : "");
+        tag = msk_intern_tag(ctx, buf);
+      }
+      msk_launch_scope ls(ctx, tag);
+      const unsigned bb = (unsigned)(bbytes - (size_t)cb0 * sizeof(float));
+      if (yf)
+        hipLaunchKernelGGL((wgrad_c1_mfma_k<5, true>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, gb, (int)ntiles, tiles_d, tiles_h,
+                           tiles_w, partial, (unsigned)abytes, bb, *yf, (unsigned)dbytes);
+      else if (k5)
+        hipLaunchKernelGGL((wgrad_c1_mfma_k<5, false>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, gb, (int)ntiles, tiles_d, tiles_h,
+                           tiles_w, partial, (unsigned)abytes, bb, WbfBnBwd{}, 0u);
+      else
+        hipLaunchKernelGGL((wgrad_c1_mfma_k<3, false>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, gb, (int)ntiles, tiles_d, tiles_h,
+                           tiles_w, partial, (unsigned)abytes, bb, WbfBnBwd{}, 0u);
+      MSK_LAUNCH_CHECK(ctx);
     }
-    msk_launch_scope ls(ctx, tag);
-    if (yf)
-      hipLaunchKernelGGL((wgrad_c1_mfma_k<5, true>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
-                         tiles_w, partial, (unsigned)abytes, (unsigned)bbytes, *yf, (unsigned)dbytes);
-    else
-      hipLaunchKernelGGL((wgrad_c1_mfma_k<5, false>), dim3((unsigned)splits), dim3(256), 0, ctx->stream, g, (int)ntiles, tiles_d, tiles_h,
-                         tiles_w, partial, (unsigned)abytes, (unsigned)bbytes, WbfBnBwd{}, 0u);
-    MSK_LAUNCH_CHECK(ctx);
+    const int rc = msk_wgrad_reduce(ctx, partial, (int)splits, taps, 1, gb.CB, gb.dw, g.accumulate);
+    if (rc != 0) return rc;
   }
-  const int rc = msk_wgrad_reduce(ctx, partial, (int)splits, taps, 1, g.CB, g.dw, g.accumulate);
-  return rc == 0 ? 1 : rc;
+  return 1;
 }

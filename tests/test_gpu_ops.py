@@ -28,6 +28,8 @@ CONV_CASES = [
     (64, 64, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 5, 10, 16)),    # TW=16
     (128, 96, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 4, 8, 8)),     # TW=8, Cout not multiple of 64
     (1, 16, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 8, 8, 12)),      # in_tr: Cin=1
+    (1, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 6, 9, 34)),      # UNet3D first convolution: conv_c1_h2 (two channel tiles), wgrad_c1 in two blocks of 16
+    (1, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 5, 8, 16)),
     (32, 3, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 6, 8, 33)),      # out_tr: Cout=3
     (32, 4, (5, 5, 5), (1, 1, 1), (2, 2, 2), (1, 5, 9, 17)),      # two-voxel VALU kernel: CN even, ragged tiles
     (32, 1, (5, 5, 5), (1, 1, 1), (2, 2, 2), (2, 4, 8, 16)),
@@ -744,38 +746,53 @@ def test_conv_foldn_out_tr_class(case):
     assert np.all(got[:, 0] == 5.0) and np.all(got[:, -1] == 5.0)
 
 
-@pytest.mark.parametrize("case", [(16, (2, 9, 13, 37)), (16, (1, 4, 8, 32)), (12, (1, 6, 8, 16)), (5, (2, 5, 9, 40))])
-def test_conv_c1_mfma_in_tr_class(case):
-    """conv_c1_mfma_k (1 -> <= 16 channels, 5^3 same: in_tr.conv1, vnet.py:67) against the float64 oracle and the VALU kernel it
-    replaced (conv_impl 23), incl. output-channel counts that are not a multiple of 4 and a strided destination."""
-    cout, (N, D, H, W) = case
+@pytest.mark.parametrize("case", [(5, 16, (2, 9, 13, 37)), (5, 16, (1, 4, 8, 32)), (5, 12, (1, 6, 8, 16)), (5, 5, (2, 5, 9, 40)),
+                                  (3, 32, (2, 9, 13, 37)), (3, 16, (1, 6, 8, 33)), (3, 22, (1, 5, 9, 40))])
+def test_conv_c1_in_tr_class(case):
+    """One input channel, 5^3 -> <= 16 channels (in_tr.conv1, vnet.py:67) or 3^3 -> <= 32 (first convolution of the builder-defined
+    UNet3D) against the float64 oracle: conv_c1_h2_k (round 4: 16-bit matrix pipe, fp16 x 2 operand pieces -- the product), the
+    fp32-MFMA kernel it replaced (conv_impl 27, 5^3 only) and the VALU / general kernels (conv_impl 23), incl. output-channel
+    counts that are not a multiple of 4 and a strided destination; and the single-fp16 form (conv_fp16, 3^3) at the stated
+    fp16 tolerance."""
+    ks, cout, (N, D, H, W) = case
     d = dev()
-    rng = np.random.default_rng(cout + D)
-    k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
-    x = rng.standard_normal((N, 1, D, H, W)).astype(np.float32)
-    w = (rng.standard_normal((cout, 1) + k) / np.sqrt(125)).astype(np.float32)
+    rng = np.random.default_rng(cout + D + ks)
+    k, s_, p = (ks,) * 3, (1, 1, 1), (ks // 2,) * 3
+    x = (rng.standard_normal((N, 1, D, H, W)) * 3.0 + 0.7).astype(np.float32)
+    w = (rng.standard_normal((cout, 1) + k) / np.sqrt(ks ** 3)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     ref = O.conv3d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s_, p)
     xt, wp, bp = t_from_ncdhw(x), vec(w.ravel()), vec(b)
     ld = (cout + 3) // 4 * 4 + 4
     d.set_option("prof_shapes", 0)
     d.set_option("prof_only_halo", 0)
+    d.set_option("c1_h2", 2)     # the product default (1) keeps the fp32-MFMA kernel for 5^3: cover both instantiations here
     try:
-        for impl in (0, 23):
+        for impl, fp16 in ((0, 0), (27, 0), (23, 0), (0, 1)):
+            if fp16 and ks != 3:
+                continue
             d.set_option("conv_impl", impl)
+            d.set_option("conv_fp16", fp16)
             yt = t_empty(N, cout, D, H, W, ld=ld, fill=7.0)
             d.prof_reset()
             d.prof_enable(True)
             d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
             got = yt.numpy()
             d.prof_enable(False)
-            assert ("conv_c1_mfma" in d.prof_report()) == (impl == 0)
-            assert rel_err(got, ref) < _conv_tol(125)
+            rep = d.prof_report()
+            assert ("conv_c1_h2" in rep) == (impl == 0), rep
+            if ks == 5:
+                assert ("conv_c1_mfma" in rep) == (impl == 27), rep
+            e = rel_err(got, ref)
+            print("conv c1 k=%d cout=%d impl %d fp16 %d: %.2e" % (ks, cout, impl, fp16, e))
+            assert e < (3e-3 if fp16 else _conv_tol(ks ** 3)), (impl, fp16, e)
             full = d.d2h(yt.ptr, (N, D, H, W, ld), np.float32)
             assert np.all(full[..., cout:] == 7.0)          # the padding channels of the strided destination are untouched
     finally:
         d.prof_enable(False)
         d.set_option("conv_impl", 0)
+        d.set_option("conv_fp16", 0)
+        d.set_option("c1_h2", 1)
 
 
 FOLD_CASES = [
