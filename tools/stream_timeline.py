@@ -1,6 +1,6 @@
 """Two-stream picture of ONE training step from a rocprofv3 --kernel-trace csv of bench.py (default launch mode):
    python tools/stream_timeline.py <kernel_trace.csv> [step_index_from_end=1]
-Steps are cut at the optimizer kernel (sgd_momentum_k).  Per hardware queue: busy time, the kernels' own time; then how long
+Steps are cut at the weight re-pack that ends the optimizer call (wbf_pack_weights_k).  Per hardware queue: busy time, the kernels' own time; then how long
 both queues are busy at once, how long the side queue runs ALONE (exposed weight-gradient tail) and which compute-queue
 kernels the side queue's kernels ran next to (by overlap time)."""
 import csv
@@ -17,7 +17,8 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-cuts = [i for i, r in enumerate(rows) if "sgd_momentum_k" in r[2]]
+# one weight re-pack per step, in the optimizer's epilogue (the optimizer itself is two or three launches since the late-gradient split)
+cuts = [i for i, r in enumerate(rows) if "wbf_pack_weights_k" in r[2]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lo, hi = cuts[-back - 1] + 1, cuts[-back] + 1
 step = rows[lo:hi]
@@ -76,8 +77,8 @@ if len(qs) >= 2:
     for (a, b), v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]:
         print("  %-40s %-40s %.3f" % (a, b, v / 1e6))
     # exposed tail: time after the last main-queue kernel before the optimizer during which only the side queue runs
-    last_main_before_opt = max(e for s, e, n in byq[main] if "sgd_momentum_k" not in n)
-    opt_start = min(s for s, e, n in byq[main] if "sgd_momentum_k" in n)
+    opt_start = min(s for s, e, n in byq[main] if "sgd_momentum_k" in n and s > (t0 + t1) // 2)   # (the step opens with the previous step's late-gradient update)
+    last_main_before_opt = max(e for s, e, n in byq[main] if e <= opt_start)
     print("last compute-queue kernel ends %.3f ms before the optimizer starts (side-queue tail + join)" % ((opt_start - last_main_before_opt) / 1e6))
     # alone-time of the side queue by kernel
     alone = defaultdict(float)
