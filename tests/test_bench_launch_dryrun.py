@@ -40,6 +40,21 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["unit"] == "voxels/s" and rec["higher_is_better"] is True and "roofline" in rec
     assert "cpu_baseline" not in rec                         # rank 0 at N=1 only
+    # round 4: the first multi-GPU run must be diagnosable from the line alone
+    dp = rec["dp"]
+    assert dp["dp_mode"] == 0 and dp["overlap_buckets"] is False and dp["buckets_last_step"] == 1
+    assert len(dp["allreduce_busbw_GBps_per_rank"]) == 2 and len(dp["syncbn_collective_ms_per_step_per_rank"]) == 2
+    assert set(dp["per_rank_collective_ms_per_step"]) == {"rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather", "rccl_allreduce_bucket"}
+    assert rec["roofline"]["strict_fp32"] is None            # the exact-operand pass is a 1-GPU extra
+    # --dp-mode 2: gradient buckets on the communication stream, overlapped with backward
+    cmd2 = cmd[:cmd.index(os.path.join(HERE, "run_bench_fake.py"))]
+    cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
+    cmd2 += [os.path.join(HERE, "run_bench_fake.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "16", "--no-cpu-baseline",
+             "--dp-mode", "2"]
+    out2 = subprocess.run(cmd2, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    rec2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
+    assert rec2["dp"]["dp_mode"] == 2 and rec2["dp"]["overlap_buckets"] is True and rec2["dp"]["buckets_last_step"] >= 2
 
 
 def test_bench_single_process_defaults(tmp_path):
