@@ -186,6 +186,9 @@ int msk_conv3d_dgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const flo
                         const float* dy_amax /*nullable*/);
 int msk_conv3d_wgrad_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
                          int accumulate, const void* xform /*nullable*/, const float* dy_amax /*nullable*/);
+/* ... and x_amax (nullable): the amax array of x from the pass that produced it, used when no kept transform brings the scale */
+int msk_conv3d_wgrad_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db /*nullable*/,
+                         int accumulate, const void* xform /*nullable*/, const float* dy_amax /*nullable*/, const float* x_amax /*nullable*/);
 /* Launch diet (round 3): the per-channel epilogues of a BatchNorm layer ride in the merge kernels that precede them.
  *   msk_bn_fin              the arguments of msk_bn_finalize(world = 1, count) as a struct;
  *   msk_conv3d_fwd_ex3      msk_conv3d_fwd_ex2, and with fin != NULL (stats_local required) the finalisation runs in the

@@ -48,6 +48,7 @@ struct WGrad {
   const float* y_amax;  // NP = 2: device scalar bounding max |B| when yform is given
   const float* y_cmax;  // NP = 2: per-channel max |B| [CB] written with yform (wbf_chan_shift), or null
   const float* b_amax;  // NP = 2, small-channel kernels: max |B| when the caller already has it (amax array), or null
+  const float* a_amax;  // NP = 2: max |A| when the caller already has it and no kept transform brings it (msk_conv3d_wgrad_ex3), or null
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]
   int accumulate;

@@ -615,7 +615,7 @@ int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   WGrad gp = g;
   if (ta) { gp.A = ta; gp.ald = CAp; }
   if (tb) { gp.B = tb; gp.bld = CBp; }
-  gp.CA = CAp; gp.CB = CBp; gp.dw = dwp; gp.accumulate = 0; gp.b_amax = nullptr;
+  gp.CA = CAp; gp.CB = CBp; gp.dw = dwp; gp.accumulate = 0;   // (a_amax / b_amax stay: zero padding does not change a maximum)
   if (!msk_wgrad_wbf_accepts(ctx, gp)) return 0;
   if (ta) {
     msk_launch_scope ls(ctx, "pad_channels");
@@ -1076,7 +1076,7 @@ int run_wgrad(msk_ctx* ctx, const WGrad& g, const msk_tensor& bias_src, float* d
 
 // msk_conv3d_wgrad_ex / msk_conv3d_dgrad with the maximum |dy| the caller may already hold (an amax array, msk_wbf.h)
 int conv3d_wgrad_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
-                      const void* xform, const float* dy_amax) {
+                      const void* xform, const float* dy_amax, const float* x_amax = nullptr) {
   if (check_conv_shapes(ctx, cd, x, dy, false) != 0) return -1;
   if (xform && !ctx->xform_ok.count(xform)) xform = nullptr;   // never filled by msk_conv3d_fwd_ex*
   msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(dy) <= ctx->wgrad_async_max_m);
@@ -1089,6 +1089,7 @@ int conv3d_wgrad_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor d
   g.dw = dw; g.accumulate = accumulate;
   g.xform = xform;
   g.b_amax = dy_amax;
+  g.a_amax = x_amax;
   return run_wgrad(ctx, g, dy, db, accumulate);
 }
 
@@ -1273,6 +1274,11 @@ int msk_conv3d_dgrad_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const flo
 int msk_conv3d_wgrad_ex2(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
                          const void* xform, const float* dy_amax) {
   return conv3d_wgrad_impl(ctx, cd, x, dy, dw, db, accumulate, xform, dy_amax);
+}
+
+int msk_conv3d_wgrad_ex3(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate,
+                         const void* xform, const float* dy_amax, const float* x_amax) {
+  return conv3d_wgrad_impl(ctx, cd, x, dy, dw, db, accumulate, xform, dy_amax, x_amax);
 }
 
 int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {

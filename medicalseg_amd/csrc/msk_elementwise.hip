@@ -1492,7 +1492,13 @@ const float* msk_absmax(msk_ctx* ctx, const float* x, int ld, int C, long voxels
     slot = msk_scalar_slots(ctx, 1);
   }
   if (!slot) return nullptr;
-  msk_launch_scope ls(ctx, "absmax");
+  const char* tag = "absmax";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[96];
+    snprintf(buf, sizeof(buf), "absmax[c=%d,ld=%d,voxels=%ld]", C, ld, voxels);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
   long ab = (voxels * C / 4 + kThreads - 1) / kThreads;
   if (ab > 8L * ctx->num_cu) ab = 8L * ctx->num_cu;
   if (ab < 1) ab = 1;

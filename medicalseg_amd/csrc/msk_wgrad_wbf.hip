@@ -395,7 +395,7 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   const int cmax_slots_b = (g.CB + kWbfAmaxWays - 1) / kWbfAmaxWays;
   if (!have_v) {  // else: V written by msk_conv3d_fwd_ex for this tensor
     if (NP != 3) {
-      v_amax = msk_absmax(ctx, g.A, g.ald, g.CA, (long)g.N * g.AD * g.AH * g.AW);
+      v_amax = g.a_amax ? g.a_amax : msk_absmax(ctx, g.A, g.ald, g.CA, (long)g.N * g.AD * g.AH * g.AW);   // the caller may hold it
       if (!v_amax) return -1;
       ta.amax = v_amax;
     }

@@ -284,9 +284,10 @@ class Conv3D(Layer):
         xfp = C.c_void_p(xf[0]) if (xf is not None and xf[1] == x.ptr and xf[2] == dev.arena.gen) else None   # same tensor, same arena generation
         # max |dy| folded in by the pass that wrote dy (msk_affine_act_bwd_apply_amax): no absmax pass of their own below
         dya = C.c_void_p(dy.amax) if (dy.amax and PRODUCER_AMAX) else None
-        if xfp is not None or dya is not None:
-            dev.call("msk_conv3d_wgrad_ex2", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
-                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1, xfp, dya)
+        xa = C.c_void_p(x.amax) if (x.amax and PRODUCER_AMAX and xfp is None) else None   # (a kept transform carries its own scale)
+        if xfp is not None or dya is not None or xa is not None:
+            dev.call("msk_conv3d_wgrad_ex3", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
+                     C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1, xfp, dya, xa)
         else:
             dev.call("msk_conv3d_wgrad", self.desc(), x.msk(), dy.msk(), C.c_void_p(self.weight.grad_ptr),
                      C.c_void_p(self.bias.grad_ptr) if bias_grad else None, 1)
