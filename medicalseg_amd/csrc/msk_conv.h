@@ -27,6 +27,7 @@ struct GConv {
   const float* in_amax;  // NP = 2 pipelines: device scalar bounding max |src| (scales the source transform, undone in the output stage); NULL = unscaled
   const struct WbfBnBwd* fuse;  // msk_conv3d_bwd_bnact: src is not read; the input transform evaluates dy from (y, dout) on the fly
   const msk_bn_fin* fin;  // msk_conv3d_fwd_ex3: BatchNorm finalisation to run in the statistics merge (with stats), or null
+  int ck_real;        // > 0: src holds only ck_real (< CK, % 4 == 0) channels per voxel, the others count as zeros (gconv_wbf_padded)
   int stats_ps;       // msk_conv3d_fwd_in: statistics PER SAMPLE -- stats is [N][2 CN], fin's save_mean / save_invstd / scale / shift
   int fin_stride;     // advance by fin_stride floats per sample (InstanceNorm); only kernels whose records are per tile serve it
   bool w_persistent;  // the weights are the caller's tensor (covered by msk_weights_changed): derived forms may be cached
@@ -48,6 +49,7 @@ struct WGrad {
   const float* y_amax;  // NP = 2: device scalar bounding max |B| when yform is given
   const float* y_cmax;  // NP = 2: per-channel max |B| [CB] written with yform (wbf_chan_shift), or null
   const float* b_amax;  // NP = 2, small-channel kernels: max |B| when the caller already has it (amax array), or null
+  int cb_real;          // > 0: B holds only cb_real (< CB, % 4 == 0) channels per voxel, the others count as zeros (wgrad_wbf_padded)
   const float* a_amax;  // NP = 2: max |A| when the caller already has it and no kept transform brings it (msk_conv3d_wgrad_ex3), or null
   const struct WbfBnBwd* yfuse;  // msk_conv3d_bwd_bnact (split form): B is not read; its transform evaluates dy from (y, dout)
   float* dw;  // canonical [CB][CA][taps]

@@ -535,7 +535,9 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   if (voxels < ctx->wbf_pad_min_voxels) return 0;  // small problems: the two extra passes cost more than the kernels differ
   const int Ap = (A + 31) / 32 * 32, Bp = (B + 31) / 32 * 32;
   const size_t wb = ((size_t)Ap * Bp * taps * sizeof(float) + 255) & ~(size_t)255;
-  const size_t sb = CKp != g.CK ? (((size_t)voxels * CKp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  // round 4: a narrower SOURCE needs no padded copy -- the input transform reads the ck_real channels that exist and takes the rest
+  // as zeros (WbfTinArgs::c_real); only a narrower destination still goes through a 32-channel scratch
+  const size_t sb = 0;
   const size_t db = CNp != g.CN ? (((size_t)voxels * CNp * sizeof(float) + 255) & ~(size_t)255) : 0;
   // the eligibility test needs the final pointers (alignment): reserve first -- grow-only, kept for the next call
   char* ws = (char*)msk_workspace3(ctx, wb + sb + db);
@@ -546,6 +548,7 @@ int gconv_wbf_padded(msk_ctx* ctx, const GConv& g, const float* w, int A, int B,
   GConv gp = g;
   if (tsrc) { gp.src = tsrc; gp.sld = CKp; }
   if (tdst) { gp.dst = tdst; gp.dld = CNp; gp.accumulate = 0; gp.bias = nullptr; }
+  if (CKp != g.CK) gp.ck_real = g.CK;
   gp.CK = CKp; gp.CN = CNp;
   gp.stats = nullptr;
   gp.w_persistent = false;  // wpad is scratch, rewritten per call
@@ -606,7 +609,7 @@ int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   if (voxels < ctx->wbf_pad_min_voxels) return 0;
   const size_t wb = ((size_t)CAp * CBp * taps * sizeof(float) + 255) & ~(size_t)255;
   const size_t ab = CAp != g.CA ? (((size_t)voxels * CAp * sizeof(float) + 255) & ~(size_t)255) : 0;
-  const size_t bb = CBp != g.CB ? (((size_t)voxels * CBp * sizeof(float) + 255) & ~(size_t)255) : 0;
+  const size_t bb = 0;   // round 4: a narrower dy needs no padded copy (WGrad::cb_real: the A dy transform takes the missing channels as zeros)
   char* ws = (char*)msk_workspace3(ctx, wb + ab + bb);
   if (!ws) return -1;
   float* dwp = (float*)ws;
@@ -615,6 +618,7 @@ int wgrad_wbf_padded(msk_ctx* ctx, const WGrad& g) {
   WGrad gp = g;
   if (ta) { gp.A = ta; gp.ald = CAp; }
   if (tb) { gp.B = tb; gp.bld = CBp; }
+  if (CBp != g.CB) gp.cb_real = g.CB;
   gp.CA = CAp; gp.CB = CBp; gp.dw = dwp; gp.accumulate = 0;   // (a_amax / b_amax stay: zero padding does not change a maximum)
   if (!msk_wgrad_wbf_accepts(ctx, gp)) return 0;
   if (ta) {

@@ -279,6 +279,8 @@ wbf_tin_k(WbfTinArgs a) {
   const float* xb = a.src + ((long)n * a.svn + (long)d * a.svd + (long)h * a.svh) * a.sld + cg * 8;
   const long wstep = (long)a.svw * a.sld;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int creal = a.c_real > 0 ? a.c_real : a.CK;          // channels that exist in the source (the others are zeros)
+  const bool q0ok = cg * 8 < creal, q1ok = cg * 8 + 4 < creal;
   const float sc2 = NP != 3 ? wbf_scale_of(a.amax) : 1.f;  // fp16 operands: the tensor's power-of-two scale (round 3: also the single-fp16 form -- gradients of ~1e-7 sit inside fp16's subnormal range)
   (void)sc2;
 
@@ -288,8 +290,8 @@ wbf_tin_k(WbfTinArgs a) {
     const int w = MODE == 0 ? j - PADW : j;
     if (live && w >= 0 && w < a.LW) {
       const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
-      win[j][0] = p[0];
-      win[j][1] = p[1];
+      win[j][0] = q0ok ? p[0] : z4;
+      win[j][1] = q1ok ? p[1] : z4;
       if (want_cmax) cmax_of(win[j][0], win[j][1]);
     } else {
       win[j][0] = win[j][1] = z4;
@@ -305,8 +307,8 @@ wbf_tin_k(WbfTinArgs a) {
       const int w = 4 * (t + 1) + (MODE == 0 ? KEEP - PADW : 0) + j;  // the part of tile t + 1 not yet in registers
       if (live && t + 1 < a.T && w < a.LW) {
         const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
-        nxt[j][0] = p[0];
-        nxt[j][1] = p[1];
+        nxt[j][0] = q0ok ? p[0] : z4;
+        nxt[j][1] = q1ok ? p[1] : z4;
         if (want_cmax) cmax_of(nxt[j][0], nxt[j][1]);
       } else {
         nxt[j][0] = nxt[j][1] = z4;
@@ -1565,7 +1567,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   if (NP != 3) {
     if (g.fuse) in_amax = g.fuse->amax;
     else if (g.in_amax) in_amax = g.in_amax;
-    else in_amax = msk_absmax(ctx, g.src, g.sld, g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
+    else in_amax = msk_absmax(ctx, g.src, g.sld, g.ck_real > 0 ? g.ck_real : g.CK, (long)g.N * g.SD * g.SH * g.SW, g.xform ? (float*)g.xform : nullptr);
     if (!in_amax) return -1;
   }
   // the kept transform's header carries the maximum it was scaled by (the weight gradient undoes it): copied by the input
@@ -1580,6 +1582,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     ta.DP = DP; ta.HP = HP; ta.V = V; ta.v_xi = (long)v_xi;
     ta.amax = in_amax;
     ta.amax_copy = hdr_copy;
+    ta.c_real = g.ck_real;
     if (g.fuse) {
       if (msk_wbf_transform_dual(ctx, K, NP, ta, *g.fuse, true) != 0) return -1;
       // one-kernel form: the weight gradient (side stream) may start as soon as both transforms are written: fork here,

@@ -104,6 +104,8 @@ struct WbfTinArgs {
   int lane_map;
   const float* amax;  // NP = 2: device scalar, (bound of) max |value| of the source tensor -> wbf_scale_of; NULL = unscaled
   float* amax_copy;   // non-null: block 0 copies the amax array there (the header of a kept transform) -- no memcpy command
+  int c_real;         // > 0: only the first c_real channels of a source voxel exist (c_real % 4 == 0), the rest of the CK are zeros -- the
+                      // zero-padded problems of msk_conv.hip (20-class heads) without a padded copy of the tensor; 0 = all CK
   float* cmax;        // MODE 1, NP = 2, non-null: zeroed array [CK]; max |dy| PER CHANNEL is folded into it (wbf_cmax_commit) for the
                       // weight gradient's per-channel renormalisation (msk_wgrad_wbf.hip)
 };

@@ -419,10 +419,11 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
     y_cmax = NP == 2 ? g.y_cmax : nullptr;
   } else {
     if (NP != 3) {
-      y_amax = g.b_amax ? g.b_amax : msk_absmax(ctx, g.B, g.bld, g.CB, (long)g.N * g.BD * g.BH * g.BW);   // the caller may hold it (amax array)
+      y_amax = g.b_amax ? g.b_amax : msk_absmax(ctx, g.B, g.bld, g.cb_real > 0 ? g.cb_real : g.CB, (long)g.N * g.BD * g.BH * g.BW);   // the caller may hold it (amax array)
       if (!y_amax) return -1;
     }
     ta.amax = y_amax;
+    ta.c_real = g.cb_real;
     if (NP == 2) {
       ta.cmax = msk_scalar_slots(ctx, cmax_slots_b);
       if (!ta.cmax) return -1;

@@ -524,7 +524,8 @@ def test_wbf_channel_padding_wrapper(case):
         d.prof_enable(False)
         rep = d.prof_report()
         assert "wbf_gemm_h2_k" in rep and "pad_weights" in rep, rep
-        assert ("pad_channels" in rep) == (cin % 32 != 0) and ("unpad_channels" in rep) == (cout % 32 != 0), rep
+        # (round 4: a narrow SOURCE is read in place -- the transform takes its missing channels as zeros -- no padded copy)
+        assert "pad_channels" not in rep and ("unpad_channels" in rep) == (cout % 32 != 0), rep
         e_f = rel_err(t_to_ncdhw(yt), y_ref)
         dxt = t_empty(N, cin, D, H, W, fill=5.0)
         d.prof_reset()
@@ -533,7 +534,7 @@ def test_wbf_channel_padding_wrapper(case):
         d.prof_enable(False)
         rep = d.prof_report()
         assert "wbf_gemm_h2_k" in rep, rep
-        assert ("pad_channels" in rep) == (cout % 32 != 0) and ("unpad_channels" in rep) == (cin % 32 != 0), rep
+        assert "pad_channels" not in rep and ("unpad_channels" in rep) == (cin % 32 != 0), rep
         e_d = rel_err(t_to_ncdhw(dxt), dx_ref)
         d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 1)
         e_a = rel_err(t_to_ncdhw(dxt), 2 * dx_ref)
@@ -546,6 +547,7 @@ def test_wbf_channel_padding_wrapper(case):
         d.prof_enable(False)
         rep = d.prof_report()
         assert "unpad_dw" in rep and "wbf_wgrad_h2_k" in rep, rep
+        assert ("pad_channels" in rep) == (cin % 32 != 0), rep   # a narrow dy is read in place, a narrow x still padded
         from helpers import vec_back
         e_w = rel_err(vec_back(dwp, w.size).reshape(w.shape), dw_ref)
         d.call("msk_conv3d_wgrad", _desc(k, s_, p), xt.msk(), dyt.msk(), vp(dwp), vp(dbp), 1)
