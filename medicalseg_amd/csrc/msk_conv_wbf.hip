@@ -1680,7 +1680,13 @@ int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& t
   ta.lane_map = ctx->wbf_tin_map;
   const int pblocks = (ta.DP * ta.HP + 63) / 64;
   const dim3 grid((unsigned)(pblocks * (ta.CK / 32)), ta.N);
-  msk_launch_scope ls(ctx, mode == 0 ? "wbf_tin_k" : "wbf_ty_k");
+  const char* tag = mode == 0 ? "wbf_tin_k" : "wbf_ty_k";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s[c=%d,n=%d,l=%dx%dx%d,k=%d,np=%d]", tag, ta.CK, ta.N, ta.LD, ta.LH, ta.LW, K, NP);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
 #define WBF_TIN_LAUNCH(M_, K_, P_) hipLaunchKernelGGL((wbf_tin_k<M_, K_, P_>), grid, dim3(256), 0, ctx->stream, ta)
   if (K == 5 && NP == 2) {
     if (mode == 0) WBF_TIN_LAUNCH(0, 5, 2);
@@ -1716,7 +1722,13 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;
   const dim3 grid((unsigned)(pblocks * (da.t.CK / 32)), da.t.N);
-  msk_launch_scope ls(ctx, write_v ? (write_y ? "wbf_tin_dual_k" : "wbf_tin_bn_k") : "wbf_ty_bn_k");
+  const char* tag = write_v ? (write_y ? "wbf_tin_dual_k" : "wbf_tin_bn_k") : "wbf_ty_bn_k";
+  if (ctx->prof && ctx->prof_shapes) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s[c=%d,n=%d,l=%dx%dx%d,k=%d,np=%d]", tag, da.t.CK, da.t.N, da.t.LD, da.t.LH, da.t.LW, K, NP);
+    tag = msk_intern_tag(ctx, buf);
+  }
+  msk_launch_scope ls(ctx, tag);
 #define WBF_DUAL_LAUNCH(K_, P_)                                                                                        \
   do {                                                                                                                 \
     if (write_v && write_y) hipLaunchKernelGGL((wbf_tin_dual_k<K_, P_, true, true>), grid, dim3(256), 0, ctx->stream, da);   \

@@ -67,6 +67,7 @@ def main():
     dev.sync()
     if a.profile_out:
         dev.set_option("prof_shapes", 1)
+        dev.set_option("wgrad_async", 0)      # one stream: a kernel's HIP-event time is its own (as bench.py's serialized pass)
         dev.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
