@@ -124,7 +124,21 @@ __device__ __forceinline__ int wbf_chan_shift(float tensor_amax, float chan_max)
 }
 // mx[j] = this thread's max |value| of channel cg*8 + j (0 for idle threads).  Every lane of the wavefront must call it.
 // wave_cg: all 64 lanes share cg (one channel group per wavefront), else cg varies with lane & 3.
+#ifndef WBF_CMAX_PRECHECK
+#define WBF_CMAX_PRECHECK 1   // 0: A/B only (tools/ab_build.sh ... -DWBF_CMAX_PRECHECK=0)
+#endif
 __device__ __forceinline__ void wbf_cmax_commit(float* cmax, int cg, float (&mx)[8], bool wave_cg) {
+  unsigned* q = reinterpret_cast<unsigned*>(cmax) + cg * 8;
+#if WBF_CMAX_PRECHECK
+  // (only launches of more workgroups than are resident together: in a single round every workgroup reads the initial zeros and
+  // the reads are pure latency at the kernel's tail -- 128^3 batch 2: 546 workgroups, +0.05 ms per step with the reads)
+  const bool precheck = gridDim.x * gridDim.y > 1024u;
+  unsigned cur[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // requested before the wavefront reduction below, which covers part of their latency
+  if (precheck) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float m = mx[j];
@@ -138,9 +152,20 @@ __device__ __forceinline__ void wbf_cmax_commit(float* cmax, int cg, float (&mx)
   }
   const int lane = threadIdx.x & 63;
   if (lane < (wave_cg ? 1 : 4)) {
+    // the 8 C words of a tensor sit in one or two cache lines = one or two L2 channels, and atomics on a line are served one
+    // after the other (measured: ~4 ns each; 4160 workgroups of the 512 x 512 x 12 slab = 133 k atomics = 0.5 of the 0.79 ms of
+    // its A dy transform).  The maximum only grows: relaxed reads first (all 8 in flight together, above), the atomic only where this
+    // wavefront would raise the value -- after the first few workgroups almost none does.  (A stale read costs one needless
+    // atomic, never a missed one.)
+#if WBF_CMAX_PRECHECK
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (mx[j] > 0.f) atomicMax(reinterpret_cast<unsigned*>(cmax) + cg * 8 + j, __float_as_uint(mx[j]));  // non-negative floats order like their bits
+      if (mx[j] > 0.f && __float_as_uint(mx[j]) > cur[j]) atomicMax(q + j, __float_as_uint(mx[j]));  // non-negative floats order like their bits
+#else
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (mx[j] > 0.f) atomicMax(q + j, __float_as_uint(mx[j]));
+#endif
   }
 }
 // K = 5 | 3 (Winograd F(4,5) / F(4,3)); NP = 3 (exact bf16 split) | 1 (fp16 operands, K = 3 only)
