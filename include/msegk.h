@@ -118,6 +118,7 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *     "foldn_wgs" (workgroups per CU targeted by the D segmentation of conv_foldn_k, 0 = 2);
  *     "wbf_pad_min_voxels" (smallest 5^3 problem whose channel counts are not multiples of 32 that is run through the
  *         16-bit pipeline on a zero-padded copy, default 2^18);
+ *     "wbf_tin_groups" (workgroups below which the pipeline's transform kernels cut their W tiles into chunks, -1 = 8 per CU, 0 = never);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
  *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels; "wgrad_wino_rounds" 0 = pick the
  *   split count that fills whole waves of resident workgroups, the default) */

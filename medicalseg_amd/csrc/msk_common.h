@@ -34,6 +34,7 @@ struct msk_ctx {
   size_t ws2_bytes = 0;
   void* ws3 = nullptr;  // third: channel-padded operands of the wbf pipeline (msk_conv.hip, gconv_wbf_padded)
   size_t ws3_bytes = 0;
+  long wbf_tin_groups = -1;        // option "wbf_tin_groups": workgroups below which the transform kernels cut their W tiles into chunks (-1 = 8 per CU, 0 = never)
   long wbf_pad_min_voxels = 1L << 18;  // option "wbf_pad_min_voxels"
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -256,7 +256,8 @@ wbf_tin_k(WbfTinArgs a) {
   // lane mapping (A/B, option "wbf_tin_map"): 0 = 4 channel groups fastest (reads: full 128-byte lines per 4 lanes;
   // stores: 4 runs of 256 B per wavefront), 1 = one channel group per wavefront (stores: one 1 KiB run; reads: 32 of
   // every 128 bytes per lane, the rest of the line goes to the block's other wavefronts through L1/L2)
-  if (a.amax_copy && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kWbfAmaxWays) a.amax_copy[threadIdx.x] = a.amax[threadIdx.x];
+  if (a.amax_copy && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kWbfAmaxWays) a.amax_copy[threadIdx.x] = a.amax[threadIdx.x];
+  const int t0 = blockIdx.z * a.t_per, t1 = min(a.T, t0 + a.t_per);   // this workgroup's W tiles
   const int cgl = a.lane_map ? (threadIdx.x >> 6) : (threadIdx.x & 3), pl = a.lane_map ? (threadIdx.x & 63) : (threadIdx.x >> 2);
   const int ncgb = a.CK >> 5;
   const int cgb = blockIdx.x % ncgb, pb = blockIdx.x / ncgb;
@@ -287,7 +288,7 @@ wbf_tin_k(WbfTinArgs a) {
   float4 win[WIN][2];
 #pragma unroll
   for (int j = 0; j < WIN; ++j) {
-    const int w = MODE == 0 ? j - PADW : j;
+    const int w = 4 * t0 + (MODE == 0 ? j - PADW : j);
     if (live && w >= 0 && w < a.LW) {
       const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
       win[j][0] = q0ok ? p[0] : z4;
@@ -297,7 +298,7 @@ wbf_tin_k(WbfTinArgs a) {
       win[j][0] = win[j][1] = z4;
     }
   }
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = t0; t < t1; ++t) {
 #if WBF_TIN_SYNC
     if (a.lane_map) __builtin_amdgcn_s_barrier();   // see wbf_tin_dual_k: the four quarters of a line are requested together
 #endif
@@ -305,7 +306,7 @@ wbf_tin_k(WbfTinArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int w = 4 * (t + 1) + (MODE == 0 ? KEEP - PADW : 0) + j;  // the part of tile t + 1 not yet in registers
-      if (live && t + 1 < a.T && w < a.LW) {
+      if (live && t + 1 < t1 && w < a.LW) {
         const float4* p = reinterpret_cast<const float4*>(xb + w * wstep);
         nxt[j][0] = q0ok ? p[0] : z4;
         nxt[j][1] = q1ok ? p[1] : z4;
@@ -480,7 +481,7 @@ wbf_tin_dual_k(DualArgs b) {
       mb = fmaxf(fmaxf(shb[1][0], shb[1][1]), fmaxf(shb[1][2], shb[1][3]));
       mc = fmaxf(fmaxf(shb[2][0], shb[2][1]), fmaxf(shb[2][2], shb[2][3]));
       const float bound = ma * (wbf_amax_of(b.maxes) + mb + wbf_amax_of(b.maxes + kWbfAmaxWays) * mc);
-      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) const_cast<float*>(b.amax)[0] = bound;  // zeroed ring array
+      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) const_cast<float*>(b.amax)[0] = bound;  // zeroed ring array
       sc2 = wbf_scale_from(bound);
     } else {
       sc2 = wbf_scale_of(b.amax);
@@ -530,9 +531,10 @@ wbf_tin_dual_k(DualArgs b) {
   };
 
   float4 win[WIN][2];
+  const int t0 = blockIdx.z * a.t_per, t1 = min(a.T, t0 + a.t_per);   // this workgroup's W tiles
 #pragma unroll
-  for (int j = 0; j < WIN; ++j) dy_at(j - PADW, win[j][0], win[j][1]);
-  for (int t = 0; t < a.T; ++t) {
+  for (int j = 0; j < WIN; ++j) dy_at(4 * t0 + j - PADW, win[j][0], win[j][1]);
+  for (int t = t0; t < t1; ++t) {
 #if WBF_TIN_SYNC
     // the block's four wavefronts read the four 32-byte quarters of the same 128-byte lines: kept in step, the quarters reach
     // L2 together and the line is fetched once (PMC, round 3: this kernel fetched 1.67x its inputs; A/B round 4: transforms
@@ -543,7 +545,7 @@ wbf_tin_dual_k(DualArgs b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int w = 4 * (t + 1) + KEEP - PADW + j;  // the part of tile t + 1 not yet in registers
-      if (t + 1 < a.T) dy_at(w, nxt[j][0], nxt[j][1]);
+      if (t + 1 < t1) dy_at(w, nxt[j][0], nxt[j][1]);
       else nxt[j][0] = nxt[j][1] = z4;
     }
     float v[8][8];  // [channel][xi]
@@ -1412,7 +1414,7 @@ int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows)
       if (blocks > most) most = blocks;
     }
     if (l.n == 0) continue;
-    if (most > 4L * ctx->num_cu) most = 4L * ctx->num_cu;
+    if (most > 8L * ctx->num_cu) most = 8L * ctx->num_cu;
     const dim3 grid((unsigned)most, (unsigned)l.n);
     if (one) l.n = -1;
     msk_launch_scope ls(ctx, "wbf_pack_weights");
@@ -1494,7 +1496,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   const long base_blocks = (long)NXI * ngrp * tiles_h * tiles_d * T * g.N;
   int ksplit = 1, kc_per = KC;
   if (base_blocks < 3L * ctx->num_cu && ctx->wbf_fuse != 2) {  // ("wbf_fuse" 2: tests force the one-kernel form, which has no split-K)
-    long want = (4L * ctx->num_cu + base_blocks - 1) / base_blocks;
+    long want = (8L * ctx->num_cu + base_blocks - 1) / base_blocks;
     if (want > KC) want = KC;
     kc_per = (int)((KC + want - 1) / want);
     ksplit = (KC + kc_per - 1) / kc_per;
@@ -1675,11 +1677,24 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
 
 }  // namespace
 
+// W tiles per workgroup of the transform kernels: all T of them (one sliding window, every source voxel read once) unless the
+// launch then has fewer workgroups than option "wbf_tin_groups" (default 8 per CU): the tiles are cut into chunks, each chunk
+// re-reading the K - 1 window positions it shares with its neighbour (chunks of >= 2 tiles: <= (K-1)/8 more source reads).
+static int wbf_tiles_per_group(const msk_ctx* ctx, long groups, int T) {
+  const long want = ctx->wbf_tin_groups >= 0 ? ctx->wbf_tin_groups : 8L * ctx->num_cu;
+  if (groups >= want || T <= 2) return T;
+  long chunks = (want + groups - 1) / groups;
+  int per = (int)((T + chunks - 1) / chunks);
+  if (per < 2) per = 2;
+  return per;
+}
+
 int msk_wbf_transform(msk_ctx* ctx, int mode, int K, int NP, const WbfTinArgs& ta_in) {
   WbfTinArgs ta = ta_in;
   ta.lane_map = ctx->wbf_tin_map;
   const int pblocks = (ta.DP * ta.HP + 63) / 64;
-  const dim3 grid((unsigned)(pblocks * (ta.CK / 32)), ta.N);
+  ta.t_per = wbf_tiles_per_group(ctx, (long)pblocks * (ta.CK / 32) * ta.N, ta.T);
+  const dim3 grid((unsigned)(pblocks * (ta.CK / 32)), ta.N, (unsigned)((ta.T + ta.t_per - 1) / ta.t_per));
   const char* tag = mode == 0 ? "wbf_tin_k" : "wbf_ty_k";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[160];
@@ -1721,7 +1736,8 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;
-  const dim3 grid((unsigned)(pblocks * (da.t.CK / 32)), da.t.N);
+  da.t.t_per = wbf_tiles_per_group(ctx, (long)pblocks * (da.t.CK / 32) * da.t.N, da.t.T);
+  const dim3 grid((unsigned)(pblocks * (da.t.CK / 32)), da.t.N, (unsigned)((da.t.T + da.t.t_per - 1) / da.t.t_per));
   const char* tag = write_v ? (write_y ? "wbf_tin_dual_k" : "wbf_tin_bn_k") : "wbf_ty_bn_k";
   if (ctx->prof && ctx->prof_shapes) {
     char buf[160];

@@ -416,6 +416,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->no_winograd = value != 0;
     return 0;
   }
+  if (strcmp(key, "wbf_tin_groups") == 0) {  // see wbf_tiles_per_group (msk_conv_wbf.hip); -1 = default
+    ctx->wbf_tin_groups = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_pad_min_voxels") == 0) {  // smallest problem the channel-padding wrapper of the wbf pipeline takes
     ctx->wbf_pad_min_voxels = value > 0 ? value : 0;
     return 0;

@@ -104,6 +104,8 @@ struct WbfTinArgs {
   int lane_map;
   const float* amax;  // NP = 2: device scalar, (bound of) max |value| of the source tensor -> wbf_scale_of; NULL = unscaled
   float* amax_copy;   // non-null: block 0 copies the amax array there (the header of a kept transform) -- no memcpy command
+  int t_per;          // W tiles per workgroup (grid.z = ceil(T / t_per) chunks; msk_wbf_transform* fill it): planes of few positions and many
+                      // tiles (MRI level 256 x 256 x 9 tiled along 256: 82 workgroups of 64 tiles) otherwise leave most of the chip idle
   int c_real;         // > 0: only the first c_real channels of a source voxel exist (c_real % 4 == 0), the rest of the CK are zeros -- the
                       // zero-padded problems of msk_conv.hip (20-class heads) without a padded copy of the tensor; 0 = all CK
   float* cmax;        // MODE 1, NP = 2, non-null: zeroed array [CK]; max |dy| PER CHANNEL is folded into it (wbf_cmax_commit) for the
@@ -132,7 +134,7 @@ __device__ __forceinline__ void wbf_cmax_commit(float* cmax, int cg, float (&mx)
 #if WBF_CMAX_PRECHECK
   // (only launches of more workgroups than are resident together: in a single round every workgroup reads the initial zeros and
   // the reads are pure latency at the kernel's tail -- 128^3 batch 2: 546 workgroups, +0.05 ms per step with the reads)
-  const bool precheck = gridDim.x * gridDim.y > 1024u;
+  const bool precheck = gridDim.x * gridDim.y * gridDim.z > 1024u;
   unsigned cur[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // requested before the wavefront reduction below, which covers part of their latency
   if (precheck) {
 #pragma unroll
