@@ -1399,7 +1399,8 @@ int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows)
     const unsigned ny = (unsigned)l.n;
     if (one) l.n = -1;
     msk_launch_scope ls(ctx, "wbf_pack_absmax");
-    hipLaunchKernelGGL(wbf_pack_absmax_k, dim3(64, ny), dim3(256), 0, ctx->stream, c->table, l, single);
+    // (round 4: 256 workgroups per row instead of 64 -- the eight 33 MB tensors of the 256-channel layers set this launch's time)
+    hipLaunchKernelGGL(wbf_pack_absmax_k, dim3(256, ny), dim3(256), 0, ctx->stream, c->table, l, single);
     MSK_LAUNCH_CHECK(ctx);
   }
   static const int kClasses[5][2] = {{5, 2}, {5, 3}, {3, 2}, {3, 3}, {3, 1}};
@@ -1680,12 +1681,15 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
 // W tiles per workgroup of the transform kernels: all T of them (one sliding window, every source voxel read once) unless the
 // launch then has fewer workgroups than option "wbf_tin_groups" (default 8 per CU): the tiles are cut into chunks, each chunk
 // re-reading the K - 1 window positions it shares with its neighbour (chunks of >= 2 tiles: <= (K-1)/8 more source reads).
+#ifndef WBF_TIN_MIN_PER
+#define WBF_TIN_MIN_PER 2   // smallest chunk (tiles); 1 = A/B: one-tile chunks read their sources twice and lose (transforms 3.0 -> 3.2 ms)
+#endif
 static int wbf_tiles_per_group(const msk_ctx* ctx, long groups, int T) {
   const long want = ctx->wbf_tin_groups >= 0 ? ctx->wbf_tin_groups : 8L * ctx->num_cu;
-  if (groups >= want || T <= 2) return T;
+  if (groups >= want || T <= WBF_TIN_MIN_PER) return T;
   long chunks = (want + groups - 1) / groups;
   int per = (int)((T + chunks - 1) / chunks);
-  if (per < 2) per = 2;
+  if (per < WBF_TIN_MIN_PER) per = WBF_TIN_MIN_PER;
   return per;
 }
 

@@ -442,6 +442,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(value, 0);
     return 0;
   }
+  if (strcmp(key, "reduce_vpl") == 0) {  // tuning: voxels per lane of the per-channel reduction kernels before more workgroups are added
+    msk_set_reduce_vpl(value);
+    return 0;
+  }
   if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 8)
     msk_set_ew_caps(0, value);
     return 0;

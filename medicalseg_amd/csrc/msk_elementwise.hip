@@ -32,8 +32,9 @@ inline ChanGeom chan_geom(int C) {
 }
 
 int g_ew_cap = 4, g_reduce_cap = 8;   // blocks per CU of the elementwise / reduction kernels (options "ew_cap", "reduce_cap"); measured: 4 resident blocks per CU with grid-stride loops beat 32 queued ones by 0.25 ms per step
+int g_reduce_vpl = 8;   // option "reduce_vpl": voxels per lane the reduction kernels aim for before they add workgroups (round 4: 64 left the deep levels with 4-64 workgroups of 32-64 dependent iterations: 40-110 us per pass for tensors of 2-30 MB; A/B 64 / 32 / 16 / 8 / 4: bn_prelu_join bucket 3.97 / 3.70 / 3.61 / 3.59 / 3.63 ms)
 inline int reduce_blocks(long voxels, int VPB, int num_cu) {
-  long want = (voxels + (long)VPB * 64 - 1) / ((long)VPB * 64);  // >= 64 voxels per lane
+  long want = (voxels + (long)VPB * g_reduce_vpl - 1) / ((long)VPB * g_reduce_vpl);  // >= g_reduce_vpl voxels per lane
   long cap = (long)num_cu * g_reduce_cap;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -606,23 +607,23 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
   }
 }
 
-// One block per output (q, c): 64 lanes stride over the nb block partials in double, fixed-order
-// tree over the lanes (deterministic).
-__global__ void __launch_bounds__(64)
+// One block per output (q, c): the lanes stride over the nb block partials in double, fixed-order tree over the lanes
+// (deterministic).  64 lanes, or 256 when there are many partials (round 4: "reduce_vpl" 8 gives the small tensors up to 2048 of them).
+__global__ void __launch_bounds__(256)
 sums_merge_k(const float* __restrict__ partial, int nb, int C, int CB, int nq, float* __restrict__ sums /*[nq][C]*/,
              int accumulate, float* __restrict__ g0 = nullptr, float* __restrict__ g1 = nullptr, float* __restrict__ g2 = nullptr,
              float* __restrict__ g3 = nullptr) {
   // g0..g3 (nullable): quantity q of channel c is also ADDED to gq[c] -- the parameter gradients that
   // msk_affine_act_param_grads would take from sums afterwards (d beta, d gamma, d alpha; the join's d alpha)
-  __shared__ double sh[64];
-  const int i = blockIdx.x, t = threadIdx.x;
+  __shared__ double sh[256];
+  const int i = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   const int q = i / C, c = i % C;
   const int cb = c / CB, cl = c % CB;
   double s = 0;
-  for (int b = t; b < nb; b += 64) s += partial[(((long)cb * nb + b) * nq + q) * CB + cl];
+  for (int b = t; b < nb; b += nt) s += partial[(((long)cb * nb + b) * nq + q) * CB + cl];
   sh[t] = s;
   __syncthreads();
-  for (int k = 32; k > 0; k >>= 1) {
+  for (int k = nt >> 1; k > 0; k >>= 1) {
     if (t < k) sh[t] += sh[t + k];
     __syncthreads();
   }
@@ -1143,7 +1144,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0, dbeta, dgamma,
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0, dbeta, dgamma,
                        dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
@@ -1162,7 +1163,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
   }
   {
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(64), 0, ctx->stream, partial, nb, x.c,
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c,
                        g.CB, 3, sums, 0, dbeta, dgamma, dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
   }
@@ -1241,7 +1242,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
     msk_launch_scope ls(ctx, "sums_merge");
     // quantities 0..2 -> unit_sums[3C] (overwritten), quantity 3 -> dalpha of the join (accumulated)
     // ... and the parameter gradients ride along: the unit's (d beta, d gamma, d alpha_inner; nullable) and the join's d alpha
-    hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0, u_dbeta,
+    hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0, u_dbeta,
                        u_dgamma, u_dalpha, dalpha);
     MSK_LAUNCH_CHECK(ctx);
     return 0;
@@ -1257,7 +1258,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
     MSK_LAUNCH_CHECK(ctx);
   }
   msk_launch_scope ls(ctx, "sums_merge");
-  hipLaunchKernelGGL(sums_merge_k, dim3(a.c), dim3(64), 0, ctx->stream, partial, nb, a.c, 4 * QCB, 1, dalpha, 1);
+  hipLaunchKernelGGL(sums_merge_k, dim3(a.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, a.c, 4 * QCB, 1, dalpha, 1);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -1355,7 +1356,7 @@ int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
   }
   {
     msk_launch_scope ls(ctx, "sums_merge");
-    hipLaunchKernelGGL(sums_merge_k, dim3(x.c), dim3(64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
+    hipLaunchKernelGGL(sums_merge_k, dim3(x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
                        out, accumulate);
     MSK_LAUNCH_CHECK(ctx);
   }
@@ -1585,6 +1586,7 @@ int msk_elu_bwd(msk_ctx* ctx, msk_tensor out, msk_tensor dout, float alpha, msk_
 }
 }  // extern "C"
 
+void msk_set_reduce_vpl(int v) { if (v > 0) g_reduce_vpl = v; }
 void msk_set_ew_caps(int ew, int red) {
   if (ew > 0) g_ew_cap = ew;
   if (red > 0) g_reduce_cap = red;
