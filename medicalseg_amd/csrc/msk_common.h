@@ -134,7 +134,8 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 int msk_join_side_impl(msk_ctx* ctx);
-void msk_set_reduce_vpl(int v);          // option "reduce_vpl"
+void msk_set_reduce_vpl(int v);
+void msk_set_reduce_vpl_site(int v);   // option "reduce_vpl_site"          // option "reduce_vpl"
 void msk_set_ew_caps(int ew, int red);   // msk_elementwise.hip tuning knobs
 // caller memory that may hold convolution weights was (or is about to be) written / freed: derived forms are stale
 void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes);

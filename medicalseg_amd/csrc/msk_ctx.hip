@@ -446,6 +446,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_reduce_vpl(value);
     return 0;
   }
+  if (strcmp(key, "reduce_vpl_site") == 0) {  // debug: site * 1000 + voxels per lane (0 = follow reduce_vpl); sites in msk_elementwise.hip
+    msk_set_reduce_vpl_site(value);
+    return 0;
+  }
   if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 8)
     msk_set_ew_caps(0, value);
     return 0;

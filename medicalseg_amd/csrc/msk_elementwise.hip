@@ -33,8 +33,10 @@ inline ChanGeom chan_geom(int C) {
 
 int g_ew_cap = 4, g_reduce_cap = 8;   // blocks per CU of the elementwise / reduction kernels (options "ew_cap", "reduce_cap"); measured: 4 resident blocks per CU with grid-stride loops beat 32 queued ones by 0.25 ms per step
 int g_reduce_vpl = 8;   // option "reduce_vpl": voxels per lane the reduction kernels aim for before they add workgroups (round 4: 64 left the deep levels with 4-64 workgroups of 32-64 dependent iterations: 40-110 us per pass for tensors of 2-30 MB; A/B 64 / 32 / 16 / 8 / 4: bn_prelu_join bucket 3.97 / 3.70 / 3.61 / 3.59 / 3.63 ms)
-inline int reduce_blocks(long voxels, int VPB, int num_cu) {
-  long want = (voxels + (long)VPB * g_reduce_vpl - 1) / ((long)VPB * g_reduce_vpl);  // >= g_reduce_vpl voxels per lane
+int g_reduce_vpl_site[4] = {0, 0, 0, 0};   // debug option "reduce_vpl_site" (site * 1000 + voxels per lane): 0 statistics, 1 BatchNorm backward sums, 2 joins, 3 channel sums
+inline int reduce_blocks(long voxels, int VPB, int num_cu, int site) {
+  const int vpl = g_reduce_vpl_site[site] > 0 ? g_reduce_vpl_site[site] : g_reduce_vpl;
+  long want = (voxels + (long)VPB * vpl - 1) / ((long)VPB * vpl);  // >= vpl voxels per lane
   long cap = (long)num_cu * g_reduce_cap;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -996,7 +998,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
   MSK_REQUIRE(ctx, voxels > 0 && x.c > 0, "empty tensor");
   if (x.c % 4 == 0 && x.c / 4 <= kThreads && vec4_ok(x)) {
     const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
-    const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+    const int nb = reduce_blocks(voxels, VL, ctx->num_cu, 0);
     float* partial = (float*)msk_workspace(ctx, (size_t)nb * 4 * QCB * 3 * sizeof(float));
     if (!partial) return -1;
     {
@@ -1012,7 +1014,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
     return 0;
   }
   ChanGeom g = chan_geom(x.c);
-  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu, 0);
   size_t bytes = (size_t)g.cblocks * nb * g.CB * 3 * sizeof(float);
   float* partial = (float*)msk_workspace(ctx, bytes);
   if (!partial) return -1;
@@ -1132,7 +1134,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
   }
   if (v4) {
     const int QCB = pow2ceil(x.c / 4), VL = kThreads / QCB;
-    const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+    const int nb = reduce_blocks(voxels, VL, ctx->num_cu, 1);
     float* partial = (float*)msk_workspace(ctx, (size_t)nb * 3 * 4 * QCB * sizeof(float));
     if (!partial) return -1;
     {
@@ -1150,7 +1152,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
     return 0;
   }
   ChanGeom g = chan_geom(x.c);
-  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu, 1);
   size_t bytes = (size_t)g.cblocks * nb * 3 * g.CB * sizeof(float);
   float* partial = (float*)msk_workspace(ctx, bytes);
   if (!partial) return -1;
@@ -1227,7 +1229,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
                        vec4_ok(db), "join backward needs float4-aligned tensors with C % 4 == 0");
   const long voxels = msk_voxels(a);
   const int QCB = pow2ceil(a.c / 4), VL = kThreads / QCB;
-  const int nb = reduce_blocks(voxels, VL, ctx->num_cu);
+  const int nb = reduce_blocks(voxels, VL, ctx->num_cu, 2);
   if (unit_sums) {  // the unit's BatchNorm/PReLU sums in the same pass
     float* partial4 = (float*)msk_workspace(ctx, (size_t)nb * 4 * 4 * QCB * sizeof(float));
     if (!partial4) return -1;
@@ -1345,7 +1347,7 @@ int msk_dropout_mask(msk_ctx* ctx, uint64_t seed, uint64_t step, uint32_t site, 
 int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
   const long voxels = msk_voxels(x);
   ChanGeom g = chan_geom(x.c);
-  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu);
+  int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu, 3);
   float* partial = (float*)msk_workspace(ctx, (size_t)g.cblocks * nb * g.CB * sizeof(float));
   if (!partial) return -1;
   {
@@ -1587,6 +1589,7 @@ int msk_elu_bwd(msk_ctx* ctx, msk_tensor out, msk_tensor dout, float alpha, msk_
 }  // extern "C"
 
 void msk_set_reduce_vpl(int v) { if (v > 0) g_reduce_vpl = v; }
+void msk_set_reduce_vpl_site(int v) { if (v >= 0 && v < 4000) g_reduce_vpl_site[v / 1000] = v % 1000; }
 void msk_set_ew_caps(int ew, int red) {
   if (ew > 0) g_ew_cap = ew;
   if (red > 0) g_reduce_cap = red;
