@@ -31,6 +31,16 @@ inline ChanGeom chan_geom(int C) {
   return g;
 }
 
+// Register budget of the big HBM-bound passes (A/B: tools/ab_build.sh ... -DEW_LB=n): they share the chip with the weight-gradient
+// stream, whose three resident wavefronts per SIMD leave 104 of 512 vector registers
+#ifndef EW_LB
+#define EW_LB 0
+#endif
+#if EW_LB > 0
+#define EW_BOUNDS __launch_bounds__(kThreads, EW_LB)
+#else
+#define EW_BOUNDS __launch_bounds__(kThreads)
+#endif
 int g_ew_cap = 4, g_reduce_cap = 8;   // blocks per CU of the elementwise / reduction kernels (options "ew_cap", "reduce_cap"); measured: 4 resident blocks per CU with grid-stride loops beat 32 queued ones by 0.25 ms per step
 int g_reduce_vpl = 8;   // option "reduce_vpl": voxels per lane the reduction kernels aim for before they add workgroups (round 4: 64 left the deep levels with 4-64 workgroups of 32-64 dependent iterations: 40-110 us per pass for tensors of 2-30 MB; A/B 64 / 32 / 16 / 8 / 4: bn_prelu_join bucket 3.97 / 3.70 / 3.61 / 3.59 / 3.63 ms)
 int g_reduce_vpl_site[4] = {0, 0, 0, 0};   // debug option "reduce_vpl_site" (site * 1000 + voxels per lane): 0 statistics, 1 BatchNorm backward sums, 2 joins, 3 channel sums
@@ -362,7 +372,7 @@ affine_act_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__
 // ONE channel quad and strides over voxels, so the per-channel coefficients are loaded once into
 // registers instead of 3-7 cached loads per element (the element-indexed kernels were bound by the
 // texture-address path: 2.3 TB/s for bwd_apply vs 5 TB/s for a plain copy), two voxels in flight.
-__global__ void __launch_bounds__(kThreads)
+__global__ void EW_BOUNDS
 affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                     const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift,
@@ -480,7 +490,7 @@ affine_act_bwd_reduce_k(const float* __restrict__ x, int ldx, const float* __res
 //                 sums (and maxima) of du = da * prelu'(.) -- the unit's reduce pass disappears.
 //                 partial quantities: [0] sum du, [1] sum du*xhat, [2] d alpha_in, [3] d alpha (join)
 template <int MODE>
-__global__ void __launch_bounds__(kThreads)
+__global__ void EW_BOUNDS
 affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                            const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                            const float* __restrict__ alpha, const float* __restrict__ mean,
@@ -707,7 +717,7 @@ affine_act_bwd_apply_k(const float* __restrict__ x, int ldx, const float* __rest
   if (dx_amax) block_atomic_max(dx_amax, mx);   // max |dx| for the gradient kernels that scale it into fp16 range (msk_amax_new)
 }
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void EW_BOUNDS
 affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                           const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                           const float* __restrict__ alpha, const float* __restrict__ mean,
