@@ -845,6 +845,7 @@ struct FusedArgs {
   int scaled;
   float* stat_partial;  // STATS: [tiles][CN][3] = (n, mean, M2) of the stored values
   int per_xcd;          // tiles per XCD
+  int LW;               // extent of the transform axis: the last W tile may reach beyond it (ragged: stores and statistics stop there)
 };
 
 struct WfRec {
@@ -1033,6 +1034,7 @@ wbf_gemm_fused_k(FusedArgs f) {
   const float sl = f.prelu ? f.prelu[co] : 1.f;
   float* obase = f.dst + ((long)n * f.dvn + (long)(4 * t) * f.dvw) * f.dld + co;
   const long wst = (long)f.dvw * f.dld;
+  const int wlim = f.LW - 4 * t;   // W outputs of this tile inside the volume (wave-uniform; >= 4 except in a ragged last tile)
   float sk = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
@@ -1055,13 +1057,14 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) old[jj][i] = ok[jj] ? __builtin_nontemporal_load(op[jj] + i * wst) : 0.f;
+          for (int i = 0; i < 4; ++i) old[jj][i] = (ok[jj] && i < wlim) ? __builtin_nontemporal_load(op[jj] + i * wst) : 0.f;
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         if (!ok[jj]) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (i >= wlim) break;
           float r = fmaf(yo[i][mr][jq * 4 + jj], osc, bv);
           if (f.accumulate) r += old[jj][i];
           if (f.prelu) r = r > 0.f ? r : sl * r;
@@ -1620,6 +1623,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP != 3 ? 1 : 0;
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
+    fa.LW = LW;
     {
       msk_launch_scope ls(ctx, tag);
       launch_fused_variant<K, NP>(ctx, variant, fa, fuse_stats);

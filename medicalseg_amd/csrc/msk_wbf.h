@@ -207,7 +207,7 @@ inline int wbf_pieces(const msk_ctx* ctx, int K) { return (K == 3 && ctx->conv_f
 
 // Geometry shared by the forward / data-gradient pipeline and the weight gradient (so that V = B^T x written by the forward
 // pass can be handed to the weight gradient, msk_conv3d_fwd_ex / msk_conv3d_wgrad_ex): which tensor axes play the
-// logical (d, h, w) roles -- the transform runs along w, a multiple of 4; (d, h) carry the position tiles -- and the padded
+// logical (d, h, w) roles -- the transform runs along w in T = ceil(w / 4) tiles; (d, h) carry the position tiles -- and the padded
 // plane dims of the transformed tensor.  Depends on the spatial dims only.
 struct WbfGeom {
   int perm[3];        // logical (d, h, w) <- tensor axis
@@ -226,6 +226,10 @@ inline void wbf_min_tile(int cout, int* td, int* th) {
 // 256 x 256 x 9: 9 -> 16 planes, 12.9 -> ~5 ms for its three kernels; round 2) and even the 4x of the 2-voxel-deep MRI bottom
 // level (256 channels at 32 x 32 x 2: planes 32 x 2 -> 32 x 8) still does (round 4, A/B on one box: step 30.8 -> 30.0 ms;
 // 35 % was the round-1 break-even against the bf16x3 pipeline).
+#ifndef WBF_RAGGED_W
+#define WBF_RAGGED_W 1   // 0 = A/B: the transform axis must be a multiple of 4 (rounds 1-3)
+#endif
+constexpr bool kWbfRaggedW = WBF_RAGGED_W != 0;
 constexpr double kWbfMaxPad = 1.8;       // the limit every shape is tried with first
 constexpr double kWbfMaxPadLast = 4.0;   // second try for shapes nothing accepted (the geometry remembers which limit it was made with)
 inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* out) {
@@ -237,9 +241,14 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
     limit = pass == 0 ? kWbfMaxPad : kWbfMaxPadLast;
     for (int i = 0; i < 6; ++i) {
       const int ld = dims[kPerms[i][0]], lh = dims[kPerms[i][1]], lw = dims[kPerms[i][2]];
-      if (lw % 4) continue;
-      if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) > limit * (double)ld * lh) continue;
-      const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) / ((double)ld * lh);  // padding at the finest tile
+      // the transform axis may be RAGGED (round 4): its last tile of 4 outputs is then partly outside the volume -- the transform
+      // kernels read zeros there and the output transforms store and count only what exists -- and the padded matrix work of
+      // that tile enters limit and cost like the position tiles' (MRI level 256 x 256 x 9: transform along 9 -> 12 with whole
+      // 256 x 256 planes = 1.33x instead of planes 256 x 9 -> 16 = 1.78x; bottom level 32 x 32 x 2: 2x instead of 4x)
+      const int lw4 = (lw + 3) / 4 * 4;
+      if (lw % 4 && !kWbfRaggedW) continue;
+      if ((double)((ld + minTD - 1) / minTD * minTD) * ((lh + minTH - 1) / minTH * minTH) * lw4 > limit * (double)ld * lh * lw) continue;
+      const double cost = (double)((ld + 7) / 8 * 8) * ((lh + 7) / 8 * 8) * lw4 / ((double)ld * lh * lw);  // padding at the finest tile
       if (best < 0 || cost < best_cost - 1e-9) {
         best = i;
         best_cost = cost;
@@ -251,7 +260,7 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
   out->LD = dims[out->perm[0]];
   out->LH = dims[out->perm[1]];
   out->LW = dims[out->perm[2]];
-  out->T = out->LW / 4;
+  out->T = (out->LW + 3) / 4;
   out->max_pad = limit;
   const int rd = out->LD >= 16 ? 16 : 8, rh = out->LH >= 32 ? 32 : (out->LH >= 16 ? 16 : 8);
   out->DP = (out->LD + rd - 1) / rd * rd + 4;

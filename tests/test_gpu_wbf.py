@@ -48,6 +48,10 @@ WBF_CASES = [
     (256, 128, (2, 8, 8, 8)),       # 8 x 8 tile (MR = 2), 16 chunks split
     (128, 128, (1, 16, 8, 7)),      # W % 4 != 0: transform along H, tile roles (7, 16)
     (64, 64, (1, 12, 16, 15)),      # transform along D
+    (32, 32, (1, 32, 32, 9)),       # RAGGED transform axis (round 4): 9 -> three W tiles, the last with one output inside the volume
+    (64, 64, (2, 16, 16, 6)),       # ragged, T = 2, the last tile half inside
+    (256, 256, (1, 16, 16, 2)),     # the MRI bottom level's shape class: T = 1, two of four outputs exist (2x padding, second-try limit)
+    (32, 64, (1, 9, 24, 16)),       # ragged along D: the transform axis is a strided one
 ]
 
 
@@ -140,6 +144,9 @@ WGRAD_CASES = [
     (128, 128, (1, 8, 16, 4)),      # T = 1
     (32, 32, (1, 16, 8, 7)),        # W % 4 != 0: transform along another axis
     (64, 64, (1, 12, 16, 15)),      # transform along D
+    (32, 32, (1, 32, 32, 9)),       # ragged transform axis: A dy of a tile's missing outputs is zero
+    (64, 64, (2, 16, 16, 6)),
+    (256, 256, (1, 16, 16, 2)),
 ]
 
 
@@ -187,6 +194,7 @@ def test_wbf_wgrad_matches_oracle(case, split):
 
 
 @pytest.mark.parametrize("case", [(32, 32, (2, 16, 32, 16)), (64, 128, (1, 8, 16, 8)), (32, 64, (1, 14, 30, 8)),
+                                  (32, 32, (1, 32, 32, 9)), (64, 64, (2, 16, 16, 6)),   # ragged transform axis: statistics count what exists
                                   (16, 16, (1, 8, 8, 8)), (1, 16, (2, 9, 20, 40))])   # last: in_tr.conv1, statistics in conv_c1_mfma_k's epilogue (ragged tiles)
 def test_conv3d_fwd_ex_stats_and_kept_transform(case):
     """msk_conv3d_fwd_ex: (a) the BatchNorm statistics record taken in the output transform equals msk_bn_stats of the
@@ -297,7 +305,7 @@ def test_wbf_3x3x3_pipeline(case, fp16, dy_mag):
 
 @pytest.mark.parametrize("split", [3, 2])
 @pytest.mark.parametrize("case", [(32, 5, (2, 16, 32, 16)), (64, 5, (1, 8, 16, 16)), (128, 5, (1, 8, 16, 8)), (32, 3, (2, 16, 16, 16)),
-                                  (32, 5, (1, 30, 60, 8)), (16, 5, (1, 8, 8, 8))])
+                                  (32, 5, (1, 30, 60, 8)), (32, 5, (1, 32, 32, 9)), (64, 5, (2, 16, 16, 6)), (16, 5, (1, 8, 8, 8))])
 def test_conv3d_bwd_bnact_fused_equals_three_call_form(case, split):
     """msk_conv3d_bwd_bnact (backward of a LUConv unit, vnet.py:36-41): the fused form -- BatchNorm/PReLU backward evaluated
     inside wbf_tin_dual_k, which writes both transforms of dy; dy never stored -- against (a) the same entry point without
@@ -578,6 +586,8 @@ FUSED_CASES = [
     (32, 32, (1, 30, 60, 8)),       # ragged d and h tiles: masked rows in the epilogue and in the statistics
     (64, 64, (1, 20, 13, 16)),      # CN 64 (two column fragments per workgroup), transform along D
     (64, 32, (1, 15, 30, 12)),      # 4 chunks
+    (32, 32, (1, 32, 32, 9)),       # ragged transform axis: stores and statistics of the one-kernel form stop at the volume's edge
+    (64, 64, (2, 16, 16, 6)),
 ]
 
 
