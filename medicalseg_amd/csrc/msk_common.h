@@ -114,6 +114,7 @@ struct msk_ctx {
   int wgrad_lds_pad = 0;  // bytes of dynamic LDS added to every wbf_wgrad_k launch: caps its workgroups per CU (33.5 KB static: 3 per CU
                           // by registers; >= 20 KB of padding: 2 per CU, >= 47 KB: 1) so that the compute stream's HBM-bound passes find
                           // free registers next to it (tools/stream_timeline.py)
+  int tile_staging = 1;  // option "tile_staging": dense 5..32-channel voxel records through an LDS tile (msk_tile_load); 0 = one thread per voxel straight from HBM (A/B)
   int wgrad_renorm = 1;  // NP = 2 weight gradient: per-channel renormalisation (msk_wbf.h: wbf_chan_shift); 0 = per-tensor scales only (A/B)
   int dp_mode = 0;   // msk_dp.hip: 0 = every collective on the compute stream (default), 1 = one communicator on the communication stream, 2 = two communicators, 3 = one communicator, buckets on the communication stream
   bool comm_pending = false;
@@ -211,6 +212,31 @@ static inline int msk_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long msk_voxels(const msk_tensor& t) { return (long)t.n * t.d * t.h * t.w; }
 
 // device helpers ------------------------------------------------------------
+// Dense voxel records of rq float4 quads (rq <= 8) between HBM and an LDS tile of 256 records with WHOLE-LINE accesses (round 4):
+// a thread-per-voxel kernel whose lane reads its own 80-byte record touches 40 lines per 1 KiB load instruction and ran at
+// 1-1.9 TB/s (the 20-class MRI head and its loss: pointwise_mid_k, loss_*_tpv_k); here consecutive lanes move consecutive
+// 16-byte quads and a thread then takes its record from LDS.  pitch = rq | 1 slots: 16 consecutive records sit on 16 distinct
+// 16-byte bank groups, so the per-record ds_read_b128 / ds_write_b128 are conflict-free.
+__device__ __forceinline__ void msk_tile_load(const float* __restrict__ src, int nquads, int rq, int pitch, float4* __restrict__ tile) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  for (int i = threadIdx.x; i < nquads; i += blockDim.x) {
+    const int v = i / rq, q = i - v * rq;
+    tile[v * pitch + q] = s4[i];
+  }
+}
+__device__ __forceinline__ void msk_tile_store(float* __restrict__ dst, int nquads, int rq, int pitch, const float4* __restrict__ tile, bool accumulate) {
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int i = threadIdx.x; i < nquads; i += blockDim.x) {
+    const int v = i / rq, q = i - v * rq;
+    float4 r = tile[v * pitch + q];
+    if (accumulate) {
+      const float4 o = d4[i];
+      r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    d4[i] = r;
+  }
+}
+
 __device__ __forceinline__ float msk_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

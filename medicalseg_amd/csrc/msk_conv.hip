@@ -271,6 +271,62 @@ pointwise_mid_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
   }
 }
 
+// The same problem on DENSE tensors (sld == CK, dld == CN: the 20-class head of the MRI model): the voxel records travel through
+// an LDS tile with whole-line accesses (msk_tile_load / msk_tile_store) -- one thread per voxel straight from HBM moved 0.5 GB
+// in 0.345 ms (1.46 TB/s: a lane's 80-byte record makes every load instruction touch 40 lines).
+template <int Q>
+__global__ void __launch_bounds__(kThreads)
+pointwise_mid_staged_k(GConv g, const float* __restrict__ wp /*[CK][CN]*/) {
+  constexpr int P = Q | 1;
+  __shared__ float4 ws[4 * Q * Q];   // [k][n quad]
+  __shared__ float4 bs[Q];
+  __shared__ float4 tile[kThreads * P];
+  const int kq = g.CK >> 2, nq = g.CN >> 2;
+  for (int i = threadIdx.x; i < 4 * Q * Q; i += blockDim.x) {
+    const int k = i / Q, q = i % Q;
+    ws[i] = (k < g.CK && q < nq) ? *reinterpret_cast<const float4*>(wp + k * g.CN + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = threadIdx.x; i < Q; i += blockDim.x)
+    bs[i] = (g.bias && i < nq) ? *reinterpret_cast<const float4*>(g.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const long M = (long)g.N * g.DD * g.DH * g.DW;
+  const long tiles = (M + kThreads - 1) / kThreads;
+  for (long tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
+    const long v0 = tl * kThreads;
+    const int nv = (int)(M - v0 < kThreads ? M - v0 : kThreads);
+    __syncthreads();   // the previous tile's store pass is done with the LDS tile (first pass: the weights are in place)
+    msk_tile_load(g.src + v0 * g.CK, nv * kq, kq, P, tile);
+    __syncthreads();
+    float4 x[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[q] = (q < kq && (int)threadIdx.x < nv) ? tile[threadIdx.x * P + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = bs[q];
+#pragma unroll
+    for (int kk = 0; kk < Q; ++kk) {
+      if (kk < kq) {   // uniform
+        const float xv[4] = {x[kk].x, x[kk].y, x[kk].z, x[kk].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float4 w4 = ws[(4 * kk + e) * Q + q];
+            acc[q].x = fmaf(xv[e], w4.x, acc[q].x);
+            acc[q].y = fmaf(xv[e], w4.y, acc[q].y);
+            acc[q].z = fmaf(xv[e], w4.z, acc[q].z);
+            acc[q].w = fmaf(xv[e], w4.w, acc[q].w);
+          }
+      }
+    }
+    __syncthreads();   // every thread has taken its record
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (q < nq) tile[threadIdx.x * P + q] = acc[q];
+    __syncthreads();
+    msk_tile_store(g.dst + v0 * g.CN, nv * nq, nq, P, tile, g.accumulate != 0);
+  }
+}
+
 // 1x1x1 convolution between a THICK side (8 .. 32 channels, a multiple of 4: 16-byte accesses) and a THIN side (<= 4 channels):
 // the segmentation head of the builder-defined UNet3D (32 -> ncls and its data gradient ncls -> 32).  HBM streaming; the general
 // gather kernel spent 0.38 / 0.48 ms on the two 2 x 192 x 192 x 64 problems (604 MB on the thick side: 0.12 ms at HBM speed).
@@ -689,6 +745,13 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_mid");
     const int cmax = g.CK > g.CN ? g.CK : g.CN;
+    if (g.sld == g.CK && g.dld == g.CN && ctx->tile_staging) {   // dense on both sides: records through an LDS tile
+      const long tiles = (M + kThreads - 1) / kThreads;
+      const unsigned gb = (unsigned)(tiles < 8L * ctx->num_cu ? tiles : 8L * ctx->num_cu);
+      if (cmax <= 16) hipLaunchKernelGGL((pointwise_mid_staged_k<4>), dim3(gb), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+      else if (cmax <= 24) hipLaunchKernelGGL((pointwise_mid_staged_k<6>), dim3(gb), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+      else hipLaunchKernelGGL((pointwise_mid_staged_k<8>), dim3(gb), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
+    } else
     if (cmax <= 16) hipLaunchKernelGGL((pointwise_mid_k<4>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
     else if (cmax <= 24) hipLaunchKernelGGL((pointwise_mid_k<6>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
     else hipLaunchKernelGGL((pointwise_mid_k<8>), dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);

@@ -197,18 +197,39 @@ loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labe
 // reductions per voxel and leave 12 of 32 lanes idle: 0.45 + 0.49 ms per output at 512 x 512 x 12, four outputs with deep
 // supervision).  A thread owns a voxel: its C logits sit in registers (float4 loads), softmax / sigmoid run over them in
 // place, the per-class sums are per-thread registers reduced once per block.
-template <int CM>
+// ST (round 4): dense logits (ld == C, C % 4 == 0) travel through an LDS tile of 256 voxel records with whole-line accesses
+// (msk_tile_load) -- a lane reading its own 80-byte record straight from HBM held these passes at 1.0 / 1.9 TB/s.
+template <int CM, bool ST>
 __global__ void __launch_bounds__(kThreads)
 loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels, const float* __restrict__ weights,
                  int ignore_index, long voxels, int C, int CB, float* __restrict__ partial /*[nb][5][CB]*/, int dice_softmax) {
+  constexpr int P = (CM / 4) | 1;
+  __shared__ float4 tile[ST ? kThreads * P : 1];
   float aI[CM], aS[CM], aT[CM], cen = 0.f, ced = 0.f;
 #pragma unroll
   for (int c = 0; c < CM; ++c) aI[c] = aS[c] = aT[c] = 0.f;
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)z) & 15) == 0);
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (long)gridDim.x * blockDim.x) {
+  const long ntile = (voxels + kThreads - 1) / kThreads;
+  for (long it = blockIdx.x; it < ntile; it += gridDim.x) {
+    const long v = it * kThreads + threadIdx.x;
+    if (ST) {
+      const long v0 = it * kThreads;
+      const int nv = (int)(voxels - v0 < kThreads ? voxels - v0 : kThreads);
+      __syncthreads();   // the previous tile's records have been taken
+      msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
+      __syncthreads();
+    }
+    if (v >= voxels) continue;   // (after the barriers: every thread of the block reaches them)
     float zz[CM];
     const float* zp = z + v * ld;
-    if (v4) {
+    if (ST) {
+#pragma unroll
+      for (int c = 0; c < CM; c += 4) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) q = tile[threadIdx.x * P + (c >> 2)];
+        zz[c] = q.x; zz[c + 1] = q.y; zz[c + 2] = q.z; zz[c + 3] = q.w;
+      }
+    } else if (v4) {
 #pragma unroll
       for (int c = 0; c < CM; c += 4) {
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -289,7 +310,7 @@ loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict_
   }
 }
 
-template <int CM>
+template <int CM, bool ST>
 __global__ void __launch_bounds__(kThreads)
 loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels, const float* __restrict__ weights,
                int ignore_index, const double* __restrict__ stats, float coef_ce, float coef_dice, float* __restrict__ dz, int lddz,
@@ -314,10 +335,33 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
   const float inv_den = cden != 0 ? (float)(1.0 / cden) : 0.f;
   const float kd = -coef_dice / (float)C;
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && (lddz % 4 == 0) && (((((uintptr_t)z) | ((uintptr_t)dz)) & 15) == 0);
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (long)gridDim.x * blockDim.x) {
+  constexpr int P = (CM / 4) | 1;
+  __shared__ float4 tile[ST ? kThreads * P : 1];
+  const long ntile = (voxels + kThreads - 1) / kThreads;
+  for (long it = blockIdx.x; it < ntile; it += gridDim.x) {
+    const long v = it * kThreads + threadIdx.x;
+    const long v0 = it * kThreads;
+    const int nv = (int)(voxels - v0 < kThreads ? voxels - v0 : kThreads);
+    if (ST) {
+      __syncthreads();   // the previous tile's store pass is done
+      msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
+      __syncthreads();
+    }
+    const bool mine = v < voxels;
     float zz[CM], g[CM];
-    const float* zp = z + v * ld;
-    if (v4) {
+#pragma unroll
+    for (int c = 0; c < CM; ++c) g[c] = 0.f;
+    const float* zp = z + (mine ? v : 0) * ld;
+    if (ST) {
+#pragma unroll
+      for (int c = 0; c < CM; c += 4) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C && mine) q = tile[threadIdx.x * P + (c >> 2)];
+        zz[c] = q.x; zz[c + 1] = q.y; zz[c + 2] = q.z; zz[c + 3] = q.w;
+      }
+    } else if (!mine) {
+      continue;
+    } else if (v4) {
 #pragma unroll
       for (int c = 0; c < CM; c += 4) {
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -328,7 +372,7 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CM; ++c) zz[c] = c < C ? zp[c] : 0.f;
     }
-    const int y = labels[v];
+    const int y = mine ? labels[v] : -1;
     float m = -INFINITY, m2 = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CM; ++c)
@@ -368,6 +412,15 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CM; ++c)
         if (c < C) g[c] += zz[c] * (gp[c] - dot);  // p = softmax(z): dL/dz_k = p_k (g_k - sum_j g_j p_j)
+    }
+    if (ST) {
+      __syncthreads();   // every thread has taken its record
+#pragma unroll
+      for (int c = 0; c < CM; c += 4)
+        if (c < C) tile[threadIdx.x * P + (c >> 2)] = make_float4(g[c], g[c + 1], g[c + 2], g[c + 3]);
+      __syncthreads();
+      msk_tile_store(dz + v0 * C, nv * (C >> 2), C >> 2, P, tile, false);
+      continue;
     }
     float* dp = dz + v * lddz;
     if (v4) {
@@ -472,12 +525,13 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   {
     msk_launch_scope ls(ctx, "loss_fwd_stats");
     if (C > 4 && C <= 32) {  // thread-per-voxel form
-      if (C <= 8)
-        hipLaunchKernelGGL(loss_stats_tpv_k<8>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, labels,
-                           weights, ignore_index, voxels, C, CB, partial, dice_softmax);
-      else
-        hipLaunchKernelGGL(loss_stats_tpv_k<32>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, labels,
-                           weights, ignore_index, voxels, C, CB, partial, dice_softmax);
+      const bool st = ctx->tile_staging && logits.ld == C && C % 4 == 0 && (((uintptr_t)logits.p) & 15) == 0;
+#define LOSS_STATS_TPV(CM_, ST_)                                                                                               \
+  hipLaunchKernelGGL((loss_stats_tpv_k<CM_, ST_>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
+                     labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax)
+      if (C <= 8) { if (st) LOSS_STATS_TPV(8, true); else LOSS_STATS_TPV(8, false); }
+      else { if (st) LOSS_STATS_TPV(32, true); else LOSS_STATS_TPV(32, false); }
+#undef LOSS_STATS_TPV
     } else {
       hipLaunchKernelGGL(loss_stats_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
                          logits.ld, labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax);
@@ -512,14 +566,15 @@ int msk_loss_bwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   if (C > 4 && C <= 32) {  // thread-per-voxel form
     long tb = (voxels + kThreads - 1) / kThreads;
     if (tb > (long)ctx->num_cu * 16) tb = (long)ctx->num_cu * 16;
-    if (C <= 8)
-      hipLaunchKernelGGL(loss_bwd_tpv_k<8>, dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, labels,
-                         weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C, dice_softmax,
-                         dice_weight);
-    else
-      hipLaunchKernelGGL(loss_bwd_tpv_k<32>, dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, labels,
-                         weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C, dice_softmax,
-                         dice_weight);
+    const bool st = ctx->tile_staging && logits.ld == C && dlogits.ld == C && C % 4 == 0 &&
+                    ((((uintptr_t)logits.p) | ((uintptr_t)dlogits.p)) & 15) == 0;
+#define LOSS_BWD_TPV(CM_, ST_)                                                                                                  \
+  hipLaunchKernelGGL((loss_bwd_tpv_k<CM_, ST_>), dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
+                     labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C,        \
+                     dice_softmax, dice_weight)
+    if (C <= 8) { if (st) LOSS_BWD_TPV(8, true); else LOSS_BWD_TPV(8, false); }
+    else { if (st) LOSS_BWD_TPV(32, true); else LOSS_BWD_TPV(32, false); }
+#undef LOSS_BWD_TPV
   } else
   hipLaunchKernelGGL(loss_bwd_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
                      logits.ld, labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p,

@@ -387,7 +387,8 @@ def test_copy_scale_channel_sum_argmax_layout():
     assert np.array_equal(to_tensor(x).numpy(), x)  # NCDHW -> NDHWC -> NCDHW
 
 
-@pytest.mark.parametrize("ncls,shape", [(3, (2, 6, 7, 8)), (20, (1, 5, 6, 12)), (2, (1, 4, 4, 4))])
+@pytest.mark.parametrize("ncls,shape", [(3, (2, 6, 7, 8)), (20, (1, 5, 6, 12)), (2, (1, 4, 4, 4)),
+                                        (20, (1, 9, 40, 50)), (8, (2, 5, 7, 11)), (12, (1, 6, 9, 10))])   # thread-per-voxel forms through the LDS tile: many tiles, ragged last tile, both register classes
 def test_loss_fwd_bwd(ncls, shape):
     d = dev()
     N, D, H, W = shape
@@ -1154,3 +1155,45 @@ def test_out_tr_amax_travels_in_xform_header():
     assert np.array_equal(outs[0], outs[1])
     ref = O.conv3d_wgrad(dy.astype(np.float64), x.astype(np.float64), k, s_, p)[0]
     assert rel_err(outs[0].reshape(ref.shape), ref) < 2 * _conv_tol(N * D * H * W)
+
+
+def test_tile_staged_records_equal_the_direct_form_bitwise():
+    """Option "tile_staging" (round 4): the dense 20-class head (pointwise_mid) and its loss kernels move their voxel records
+    through an LDS tile with whole-line accesses; the arithmetic per voxel and the order of every sum are those of the
+    one-thread-per-voxel form reading HBM directly, so the results are the same bits."""
+    d = dev()
+    ncls, (N, D, H, W) = 20, (1, 7, 33, 41)
+    rng = np.random.default_rng(77)
+    z = (rng.standard_normal((N, ncls, D, H, W)) * 2).astype(np.float32)
+    y = rng.integers(0, ncls, (N, D, H, W)).astype(np.int32)
+    w = (rng.standard_normal((ncls, ncls, 1, 1, 1)) / np.sqrt(ncls)).astype(np.float32)
+    b = rng.standard_normal(ncls).astype(np.float32)
+    from medicalseg_amd._lib import MskConvDesc
+    cd = MskConvDesc(1, 1, 1, 1, 1, 1, 0, 0, 0)
+    zt = t_from_ncdhw(z)
+    yp = d.malloc(y.nbytes)
+    d.h2d(yp, y)
+    wp, bp = vec(w.ravel()), vec(b)
+    res = {}
+    try:
+        for mode in (1, 0):
+            d.set_option("tile_staging", mode)
+            lt, acc = t_empty(N, ncls, D, H, W, fill=5.0), t_from_ncdhw(z)
+            d.prof_reset()
+            d.prof_enable(True)
+            d.call("msk_conv3d_fwd", cd, zt.msk(), vp(wp), vp(bp), lt.msk())
+            d.call("msk_conv3d_dgrad", cd, zt.msk(), vp(wp), acc.msk(), 1)       # accumulating store pass
+            d.prof_enable(False)
+            assert d.prof_report().get("pointwise_mid", (0, 0))[0] == 2
+            wv = vec(np.ones(ncls))
+            out, stats = vec(np.zeros(2 + ncls)), d.malloc((3 * ncls + 2) * 8)
+            d.call("msk_loss_fwd", lt.msk(), vp(yp), vp(wv), 255, vp(out), vp(stats))
+            dz = t_empty(N, ncls, D, H, W, fill=9.0)
+            d.call("msk_loss_bwd", lt.msk(), vp(yp), vp(wv), 255, vp(stats), C.c_float(1.0), C.c_float(1.0), dz.msk())
+            res[mode] = (lt.numpy(), acc.numpy(), vec_back(out, 2 + ncls), dz.numpy())
+    finally:
+        d.set_option("tile_staging", 1)
+    for a, b_ in zip(res[1], res[0]):
+        assert np.array_equal(a, b_)
+    ref = O.conv3d(z.astype(np.float64), w.astype(np.float64), b.astype(np.float64), (1, 1, 1), (0, 0, 0))
+    assert rel_err(res[1][0], ref) < 1e-5
