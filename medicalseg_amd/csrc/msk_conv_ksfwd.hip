@@ -128,15 +128,19 @@ gconv_ks_fwd_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigne
 // i.e. per (a, b) parity class a 1-D convolution along W.  Same streaming structure as gconv_ks_fwd_k (D transposed, two
 // operand batches in flight, 16-byte stores); a wavefront's 32 destination voxels share their parity class, so the weight
 // fragments stay wave-uniform.  The general parity-class kernel took 1.21 / 0.75 ms for the two 512 x 512 x 12 problems.
-template <int NR, int KB>
+// PAIR (CN <= 16, kh == sh == 2): the 32 rows of the matrix instruction carry the output channels of BOTH h-parity classes of
+// one d-parity -- rows 0-15 class (ra, 0), rows 16-31 class (ra, 1); they read the same source voxels -- instead of 16 channels
+// and 16 rows of zero padding: half the matrix instructions and half the source reads (64 -> 16 channels at 512 x 512 x 12:
+// the kernel is bound by the fp32 matrix pipe).
+template <int NR, int KB, bool PAIR = false>
 __global__ void __launch_bounds__(256, NR == 1 ? 4 : (NR == 2 ? 4 : 2))
 gconv_kst_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned src_bytes, int waves_per_class) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const long gw = (long)blockIdx.x * 4 + wave;
   const int cls = (int)(gw / waves_per_class);
-  if (cls >= g.sd * g.sh) return;
-  const int ra = cls / g.sh, rb = cls - ra * g.sh;
+  if (cls >= (PAIR ? g.sd : g.sd * g.sh)) return;
+  const int ra = PAIR ? cls : cls / g.sh, rb = PAIR ? 0 : cls - ra * g.sh;
   const long per_class = (long)g.N * g.SD * g.SH * g.DW;
   const long q = (gw - (long)cls * waves_per_class) * 32 + li;
   const bool mok = q < per_class;
@@ -153,7 +157,8 @@ gconv_kst_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned s
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.src, 0, src_bytes, 0x00020000);
   const int nt0 = blockIdx.y * NR;
   const int T = g.kw * KC;
-  const float4* wl = wm + ((long)(ra * g.kh + rb) * g.kw * KC) * 2 * npad + (long)lh * npad + nt0 * 32 + li;
+  const float4* wl = PAIR ? wm + ((long)(ra * g.kh + (li >> 4)) * g.kw * KC) * 2 * npad + (long)lh * npad + (li & 15)
+                          : wm + ((long)(ra * g.kh + rb) * g.kw * KC) * 2 * npad + (long)lh * npad + nt0 * 32 + li;
 
   f32x16 acc[NR];
 #pragma unroll
@@ -201,21 +206,24 @@ gconv_kst_k(GConv g, const float4* __restrict__ wm, int KC, int npad, unsigned s
   if (!mok) return;
 
   const long dvox = (((long)n * g.DD + d * g.sd + ra) * g.DH + h * g.sh + rb) * g.DW + W;
-  float* orow = g.dst + dvox * g.dld;
+  float* orow0 = g.dst + dvox * g.dld;
+  const long pair_step = (long)g.DW * g.dld;   // PAIR: the voxel of class (ra, 1) is one destination row further
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     float4 old[4];
     bool ok[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      const int cn = (nt0 + r) * 32 + 8 * qd + 4 * lh;
+      const int cn = PAIR ? 8 * (qd & 1) + 4 * lh : (nt0 + r) * 32 + 8 * qd + 4 * lh;
+      const float* orow = PAIR ? orow0 + (qd >> 1) * pair_step : orow0;
       ok[qd] = cn < g.CN;  // CN % 4 == 0
       old[qd] = (g.accumulate && ok[qd]) ? *reinterpret_cast<const float4*>(orow + cn) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       if (ok[qd]) {
-        const int cn = (nt0 + r) * 32 + 8 * qd + 4 * lh;
+        const int cn = PAIR ? 8 * (qd & 1) + 4 * lh : (nt0 + r) * 32 + 8 * qd + 4 * lh;
+        float* orow = PAIR ? orow0 + (qd >> 1) * pair_step : orow0;
         const float4 bv = g.bias ? make_float4(g.bias[cn], g.bias[cn + 1], g.bias[cn + 2], g.bias[cn + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v;
         v.x = acc[r][4 * qd + 0] + bv.x + old[qd].x;
@@ -247,7 +255,8 @@ int msk_gconv_kst(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int
   if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
   const int ntn = npad / 32;
   const long wpc = (per_class + 31) / 32;                 // wavefronts per parity class
-  const long blocks = (wpc * g.sd * g.sh + 3) / 4;
+  const bool pair = g.CN <= 16 && g.kh == 2 && g.sh == 2 && ctx->kst_pair;
+  const long blocks = (wpc * g.sd * (pair ? 1 : g.sh) + 3) / 4;
   int NR = ntn % 4 == 0 ? 4 : (ntn % 2 == 0 ? 2 : 1);
   while (NR > ctx->ks_nr_max) NR >>= 1;
   while (NR > 1 && blocks * (ntn / NR) < 2L * ctx->num_cu) NR >>= 1;
@@ -261,6 +270,11 @@ int msk_gconv_kst(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int
   msk_launch_scope ls(ctx, tag);
   dim3 grid((unsigned)blocks, ntn / NR);
   const float4* w4 = reinterpret_cast<const float4*>(wm);
+  if (pair) {
+    hipLaunchKernelGGL((gconv_kst_k<1, 4, true>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, (int)wpc);
+    MSK_LAUNCH_CHECK(ctx);
+    return 1;
+  }
   switch (NR) {
     case 4: hipLaunchKernelGGL((gconv_kst_k<4, 2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, (int)wpc); break;
     case 2: hipLaunchKernelGGL((gconv_kst_k<2, 2>), grid, dim3(256), 0, ctx->stream, g, w4, KC, npad, (unsigned)sbytes, (int)wpc); break;

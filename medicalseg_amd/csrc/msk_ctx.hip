@@ -470,6 +470,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wgrad_lds_pad = value > 0 ? value : 0;
     return 0;
   }
+  if (strcmp(key, "kst_pair") == 0) {
+    ctx->kst_pair = value != 0;
+    return 0;
+  }
   if (strcmp(key, "tile_staging") == 0) {
     ctx->tile_staging = value != 0;
     return 0;
