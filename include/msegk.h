@@ -119,6 +119,13 @@ int msk_prof_report(msk_ctx* ctx, char* buf, int buflen, int* len);
  *     "wbf_pad_min_voxels" (smallest 5^3 problem whose channel counts are not multiples of 32 that is run through the
  *         16-bit pipeline on a zero-padded copy, default 2^18);
  *     "wbf_tin_groups" (workgroups below which the pipeline's transform kernels cut their W tiles into chunks, -1 = 8 per CU, 0 = never);
+ *     "tile_staging" 0|1 (dense 5..32-channel voxel records -- the 20-class 1x1x1 head and its loss kernels -- through an LDS tile with
+ *         whole-line accesses; 0 = one thread per voxel straight from HBM, bitwise the same results), "kst_pair" 0|1 (gconv_kst_k:
+ *         both h-parity classes of <= 16 output channels in one matrix instruction);
+ *     "reduce_vpl" (voxels per lane the per-channel reduction kernels aim for before they add workgroups, default 8),
+ *         "reduce_vpl_site" (site * 1000 + voxels per lane for ONE family of reductions -- 0 forward statistics, 1 BatchNorm backward
+ *         sums, 2 joins, 3 channel sums; 0 = follow "reduce_vpl" -- another summation order of the same sums: the full-size parity
+ *         test measures the distance between two fp32 evaluations of a step with it);
  *   tuning: "halo_tile" / "wgrad_chunk" (-1 auto or table index), "wgrad_rounds" / "wgrad_wino_rounds" (workgroups
  *   per CU targeted by the split-K of the direct / Winograd weight-gradient kernels; "wgrad_wino_rounds" 0 = pick the
  *   split count that fills whole waves of resident workgroups, the default) */
