@@ -745,7 +745,7 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_mid");
     const int cmax = g.CK > g.CN ? g.CK : g.CN;
-    if (g.sld == g.CK && g.dld == g.CN && ctx->tile_staging) {   // dense on both sides: records through an LDS tile
+    if (g.sld == g.CK && g.dld == g.CN && (ctx->tile_staging & 1)) {   // dense on both sides: records through an LDS tile
       const long tiles = (M + kThreads - 1) / kThreads;
       const unsigned gb = (unsigned)(tiles < 8L * ctx->num_cu ? tiles : 8L * ctx->num_cu);
       if (cmax <= 16) hipLaunchKernelGGL((pointwise_mid_staged_k<4>), dim3(gb), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);

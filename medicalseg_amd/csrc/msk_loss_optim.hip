@@ -310,8 +310,11 @@ loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict_
   }
 }
 
+#ifndef LOSS_BWD_LB
+#define LOSS_BWD_LB 3   // wavefronts per SIMD the register allocation aims for (A/B: -DLOSS_BWD_LB=2 = the compiler's own choice, 230-249 registers)
+#endif
 template <int CM, bool ST>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, ST ? LOSS_BWD_LB : 2)
 loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels, const float* __restrict__ weights,
                int ignore_index, const double* __restrict__ stats, float coef_ce, float coef_dice, float* __restrict__ dz, int lddz,
                long voxels, int C, int dice_softmax, const float* __restrict__ dice_weight) {
@@ -525,12 +528,15 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   {
     msk_launch_scope ls(ctx, "loss_fwd_stats");
     if (C > 4 && C <= 32) {  // thread-per-voxel form
-      const bool st = ctx->tile_staging && logits.ld == C && C % 4 == 0 && (((uintptr_t)logits.p) & 15) == 0;
+      const bool st = (ctx->tile_staging & 2) && logits.ld == C && C % 4 == 0 && (((uintptr_t)logits.p) & 15) == 0;
 #define LOSS_STATS_TPV(CM_, ST_)                                                                                               \
   hipLaunchKernelGGL((loss_stats_tpv_k<CM_, ST_>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
                      labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax)
-      if (C <= 8) { if (st) LOSS_STATS_TPV(8, true); else LOSS_STATS_TPV(8, false); }
-      else { if (st) LOSS_STATS_TPV(32, true); else LOSS_STATS_TPV(32, false); }
+      // register arrays sized to the class count in steps of a quad (round 4: 20 classes ran the 32-slot instantiation)
+#define LOSS_STATS_CM(CM_) { if (st) LOSS_STATS_TPV(CM_, true); else LOSS_STATS_TPV(CM_, false); }
+      if (C <= 8) LOSS_STATS_CM(8) else if (C <= 12) LOSS_STATS_CM(12) else if (C <= 16) LOSS_STATS_CM(16)
+      else if (C <= 20) LOSS_STATS_CM(20) else if (C <= 24) LOSS_STATS_CM(24) else LOSS_STATS_CM(32)
+#undef LOSS_STATS_CM
 #undef LOSS_STATS_TPV
     } else {
       hipLaunchKernelGGL(loss_stats_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
@@ -566,14 +572,16 @@ int msk_loss_bwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   if (C > 4 && C <= 32) {  // thread-per-voxel form
     long tb = (voxels + kThreads - 1) / kThreads;
     if (tb > (long)ctx->num_cu * 16) tb = (long)ctx->num_cu * 16;
-    const bool st = ctx->tile_staging && logits.ld == C && dlogits.ld == C && C % 4 == 0 &&
+    const bool st = (ctx->tile_staging & 2) && logits.ld == C && dlogits.ld == C && C % 4 == 0 &&
                     ((((uintptr_t)logits.p) | ((uintptr_t)dlogits.p)) & 15) == 0;
 #define LOSS_BWD_TPV(CM_, ST_)                                                                                                  \
   hipLaunchKernelGGL((loss_bwd_tpv_k<CM_, ST_>), dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
                      labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C,        \
                      dice_softmax, dice_weight)
-    if (C <= 8) { if (st) LOSS_BWD_TPV(8, true); else LOSS_BWD_TPV(8, false); }
-    else { if (st) LOSS_BWD_TPV(32, true); else LOSS_BWD_TPV(32, false); }
+#define LOSS_BWD_CM(CM_) { if (st) LOSS_BWD_TPV(CM_, true); else LOSS_BWD_TPV(CM_, false); }
+    if (C <= 8) LOSS_BWD_CM(8) else if (C <= 12) LOSS_BWD_CM(12) else if (C <= 16) LOSS_BWD_CM(16)
+    else if (C <= 20) LOSS_BWD_CM(20) else if (C <= 24) LOSS_BWD_CM(24) else LOSS_BWD_CM(32)
+#undef LOSS_BWD_CM
 #undef LOSS_BWD_TPV
   } else
   hipLaunchKernelGGL(loss_bwd_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
