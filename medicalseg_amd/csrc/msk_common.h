@@ -115,7 +115,7 @@ struct msk_ctx {
                           // by registers; >= 20 KB of padding: 2 per CU, >= 47 KB: 1) so that the compute stream's HBM-bound passes find
                           // free registers next to it (tools/stream_timeline.py)
   int kst_pair = 1;      // option "kst_pair": gconv_kst_k carries both h-parity classes of <= 16 output channels in one matrix instruction; 0 = one class per wavefront (A/B)
-  int tile_staging = 3;  // option "tile_staging": dense 5..32-channel voxel records through an LDS tile (msk_tile_load); 0 = one thread per voxel straight from HBM (A/B)
+  int tile_staging = 7;  // option "tile_staging": dense 5..32-channel voxel records through an LDS tile (msk_tile_load); bit mask: 1 the 1x1x1 head, 2 the 5..32-class loss kernels, 4 the 2..4-class loss kernels (thread per voxel through a flat tile instead of the lane-per-class kernels); 0 = the direct forms (A/B)
   int wgrad_renorm = 1;  // NP = 2 weight gradient: per-channel renormalisation (msk_wbf.h: wbf_chan_shift); 0 = per-tensor scales only (A/B)
   int dp_mode = 0;   // msk_dp.hip: 0 = every collective on the compute stream (default), 1 = one communicator on the communication stream, 2 = two communicators, 3 = one communicator, buckets on the communication stream
   bool comm_pending = false;

@@ -475,7 +475,7 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     return 0;
   }
   if (strcmp(key, "tile_staging") == 0) {
-    ctx->tile_staging = value;   // bit 0: the 1x1x1 head, bit 1: the loss kernels
+    ctx->tile_staging = value;   // bit 0: the 1x1x1 head, bit 1: the 5..32-class loss kernels, bit 2: the 2..4-class loss kernels
     return 0;
   }
   if (strcmp(key, "wgrad_renorm") == 0) {

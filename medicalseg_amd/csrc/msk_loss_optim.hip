@@ -197,14 +197,29 @@ loss_bwd_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labe
 // reductions per voxel and leave 12 of 32 lanes idle: 0.45 + 0.49 ms per output at 512 x 512 x 12, four outputs with deep
 // supervision).  A thread owns a voxel: its C logits sit in registers (float4 loads), softmax / sigmoid run over them in
 // place, the per-class sums are per-thread registers reduced once per block.
+// flat form of msk_tile_load for records that are not whole quads (3 classes: 12 bytes): the tile's floats are copied as they
+// lie (16-byte accesses, scalar tail), a thread's record starts at float tid * C -- an odd stride for C = 3: conflict-free
+__device__ __forceinline__ void tile_load_flat(const float* __restrict__ src, int nfloats, float* __restrict__ tile) {
+  const int nq = nfloats >> 2;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+  for (int i = 4 * nq + threadIdx.x; i < nfloats; i += blockDim.x) tile[i] = src[i];
+}
+__device__ __forceinline__ void tile_store_flat(float* __restrict__ dst, int nfloats, const float* __restrict__ tile) {
+  const int nq = nfloats >> 2;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(tile)[i];
+  for (int i = 4 * nq + threadIdx.x; i < nfloats; i += blockDim.x) dst[i] = tile[i];
+}
+
 // ST (round 4): dense logits (ld == C, C % 4 == 0) travel through an LDS tile of 256 voxel records with whole-line accesses
 // (msk_tile_load) -- a lane reading its own 80-byte record straight from HBM held these passes at 1.0 / 1.9 TB/s.
-template <int CM, bool ST>
+// ST = 2: the flat form for C <= 4 (tile_load_flat): the 3-class head of the lung model ran the lane-per-class kernels above
+// (four lanes per voxel, one idle, 192 bytes per load instruction: 60 + 67 us per step at 2 x 128^3).
+template <int CM, int ST>
 __global__ void __launch_bounds__(kThreads)
 loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels, const float* __restrict__ weights,
                  int ignore_index, long voxels, int C, int CB, float* __restrict__ partial /*[nb][5][CB]*/, int dice_softmax) {
   constexpr int P = (CM / 4) | 1;
-  __shared__ float4 tile[ST ? kThreads * P : 1];
+  __shared__ float4 tile[ST == 1 ? kThreads * P : (ST == 2 ? kThreads * CM / 4 : 1)];
   float aI[CM], aS[CM], aT[CM], cen = 0.f, ced = 0.f;
 #pragma unroll
   for (int c = 0; c < CM; ++c) aI[c] = aS[c] = aT[c] = 0.f;
@@ -216,13 +231,17 @@ loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict_
       const long v0 = it * kThreads;
       const int nv = (int)(voxels - v0 < kThreads ? voxels - v0 : kThreads);
       __syncthreads();   // the previous tile's records have been taken
-      msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
+      if (ST == 2) tile_load_flat(z + v0 * C, nv * C, reinterpret_cast<float*>(tile));
+      else msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
       __syncthreads();
     }
     if (v >= voxels) continue;   // (after the barriers: every thread of the block reaches them)
     float zz[CM];
     const float* zp = z + v * ld;
-    if (ST) {
+    if (ST == 2) {
+#pragma unroll
+      for (int c = 0; c < CM; ++c) zz[c] = c < C ? reinterpret_cast<const float*>(tile)[threadIdx.x * C + c] : 0.f;
+    } else if (ST) {
 #pragma unroll
       for (int c = 0; c < CM; c += 4) {
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -313,7 +332,7 @@ loss_stats_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict_
 #ifndef LOSS_BWD_LB
 #define LOSS_BWD_LB 3   // wavefronts per SIMD the register allocation aims for (A/B: -DLOSS_BWD_LB=2 = the compiler's own choice, 230-249 registers)
 #endif
-template <int CM, bool ST>
+template <int CM, int ST>
 __global__ void __launch_bounds__(kThreads, ST ? LOSS_BWD_LB : 2)
 loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ labels, const float* __restrict__ weights,
                int ignore_index, const double* __restrict__ stats, float coef_ce, float coef_dice, float* __restrict__ dz, int lddz,
@@ -339,7 +358,7 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
   const float kd = -coef_dice / (float)C;
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && (lddz % 4 == 0) && (((((uintptr_t)z) | ((uintptr_t)dz)) & 15) == 0);
   constexpr int P = (CM / 4) | 1;
-  __shared__ float4 tile[ST ? kThreads * P : 1];
+  __shared__ float4 tile[ST == 1 ? kThreads * P : (ST == 2 ? kThreads * CM / 4 : 1)];
   const long ntile = (voxels + kThreads - 1) / kThreads;
   for (long it = blockIdx.x; it < ntile; it += gridDim.x) {
     const long v = it * kThreads + threadIdx.x;
@@ -347,7 +366,8 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
     const int nv = (int)(voxels - v0 < kThreads ? voxels - v0 : kThreads);
     if (ST) {
       __syncthreads();   // the previous tile's store pass is done
-      msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
+      if (ST == 2) tile_load_flat(z + v0 * C, nv * C, reinterpret_cast<float*>(tile));
+      else msk_tile_load(z + v0 * C, nv * (C >> 2), C >> 2, P, tile);
       __syncthreads();
     }
     const bool mine = v < voxels;
@@ -355,7 +375,10 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
 #pragma unroll
     for (int c = 0; c < CM; ++c) g[c] = 0.f;
     const float* zp = z + (mine ? v : 0) * ld;
-    if (ST) {
+    if (ST == 2) {
+#pragma unroll
+      for (int c = 0; c < CM; ++c) zz[c] = (c < C && mine) ? reinterpret_cast<const float*>(tile)[threadIdx.x * C + c] : 0.f;
+    } else if (ST) {
 #pragma unroll
       for (int c = 0; c < CM; c += 4) {
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -415,6 +438,15 @@ loss_bwd_tpv_k(const float* __restrict__ z, int ld, const int32_t* __restrict__ 
 #pragma unroll
       for (int c = 0; c < CM; ++c)
         if (c < C) g[c] += zz[c] * (gp[c] - dot);  // p = softmax(z): dL/dz_k = p_k (g_k - sum_j g_j p_j)
+    }
+    if (ST == 2) {
+      __syncthreads();   // every thread has taken its record
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) reinterpret_cast<float*>(tile)[threadIdx.x * C + c] = g[c];
+      __syncthreads();
+      tile_store_flat(dz + v0 * C, nv * C, reinterpret_cast<const float*>(tile));
+      continue;
     }
     if (ST) {
       __syncthreads();   // every thread has taken its record
@@ -533,11 +565,15 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   hipLaunchKernelGGL((loss_stats_tpv_k<CM_, ST_>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
                      labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax)
       // register arrays sized to the class count in steps of a quad (round 4: 20 classes ran the 32-slot instantiation)
-#define LOSS_STATS_CM(CM_) { if (st) LOSS_STATS_TPV(CM_, true); else LOSS_STATS_TPV(CM_, false); }
+#define LOSS_STATS_CM(CM_) { if (st) LOSS_STATS_TPV(CM_, 1); else LOSS_STATS_TPV(CM_, 0); }
       if (C <= 8) LOSS_STATS_CM(8) else if (C <= 12) LOSS_STATS_CM(12) else if (C <= 16) LOSS_STATS_CM(16)
       else if (C <= 20) LOSS_STATS_CM(20) else if (C <= 24) LOSS_STATS_CM(24) else LOSS_STATS_CM(32)
 #undef LOSS_STATS_CM
 #undef LOSS_STATS_TPV
+    } else if ((ctx->tile_staging & 4) && C >= 2 && C <= 4 && logits.ld == C && (((uintptr_t)logits.p) & 15) == 0) {
+      // dense 2..4-class logits (the lung model's head): thread per voxel, records through a flat LDS tile
+      hipLaunchKernelGGL((loss_stats_tpv_k<4, 2>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld,
+                         labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax);
     } else {
       hipLaunchKernelGGL(loss_stats_k<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
                          logits.ld, labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax);
@@ -578,11 +614,18 @@ int msk_loss_bwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   hipLaunchKernelGGL((loss_bwd_tpv_k<CM_, ST_>), dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld, \
                      labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C,        \
                      dice_softmax, dice_weight)
-#define LOSS_BWD_CM(CM_) { if (st) LOSS_BWD_TPV(CM_, true); else LOSS_BWD_TPV(CM_, false); }
+#define LOSS_BWD_CM(CM_) { if (st) LOSS_BWD_TPV(CM_, 1); else LOSS_BWD_TPV(CM_, 0); }
     if (C <= 8) LOSS_BWD_CM(8) else if (C <= 12) LOSS_BWD_CM(12) else if (C <= 16) LOSS_BWD_CM(16)
     else if (C <= 20) LOSS_BWD_CM(20) else if (C <= 24) LOSS_BWD_CM(24) else LOSS_BWD_CM(32)
 #undef LOSS_BWD_CM
 #undef LOSS_BWD_TPV
+  } else if ((ctx->tile_staging & 4) && C >= 2 && C <= 4 && logits.ld == C && dlogits.ld == C &&
+             ((((uintptr_t)logits.p) | ((uintptr_t)dlogits.p)) & 15) == 0) {
+    long tb = (voxels + kThreads - 1) / kThreads;
+    if (tb > (long)ctx->num_cu * 16) tb = (long)ctx->num_cu * 16;
+    hipLaunchKernelGGL((loss_bwd_tpv_k<4, 2>), dim3((int)tb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld,
+                       labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p, dlogits.ld, voxels, C,
+                       dice_softmax, dice_weight);
   } else
   hipLaunchKernelGGL(loss_bwd_k, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, (const float*)logits.p,
                      logits.ld, labels, weights, ignore_index, stats, coef_ce, coef_dice, (float*)dlogits.p,

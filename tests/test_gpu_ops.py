@@ -1177,7 +1177,7 @@ def test_tile_staged_records_equal_the_direct_form_bitwise():
     res = {}
     try:
         for mode in (1, 0):
-            d.set_option("tile_staging", 3 if mode else 0)
+            d.set_option("tile_staging", 7 if mode else 0)
             lt, acc = t_empty(N, ncls, D, H, W, fill=5.0), t_from_ncdhw(z)
             d.prof_reset()
             d.prof_enable(True)
@@ -1192,7 +1192,7 @@ def test_tile_staged_records_equal_the_direct_form_bitwise():
             d.call("msk_loss_bwd", lt.msk(), vp(yp), vp(wv), 255, vp(stats), C.c_float(1.0), C.c_float(1.0), dz.msk())
             res[mode] = (lt.numpy(), acc.numpy(), vec_back(out, 2 + ncls), dz.numpy())
     finally:
-        d.set_option("tile_staging", 3)
+        d.set_option("tile_staging", 7)
     for a, b_ in zip(res[1], res[0]):
         assert np.array_equal(a, b_)
     ref = O.conv3d(z.astype(np.float64), w.astype(np.float64), b.astype(np.float64), (1, 1, 1), (0, 0, 0))
