@@ -554,7 +554,14 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
   MSK_REQUIRE(ctx, C >= 1 && C <= 64, "num_classes must be in [1,64]");
   const int CB = pow2ceil(C);
   const long voxels = msk_voxels(logits);
-  const int nb = stat_blocks(voxels, kThreads / CB, ctx->num_cu);
+  int nb = stat_blocks(voxels, kThreads / CB, ctx->num_cu);
+  const bool flat4 = (ctx->tile_staging & 4) && C >= 2 && C <= 4 && logits.ld == C && (((uintptr_t)logits.p) & 15) == 0;
+  if ((C > 4 && C <= 32) || flat4) {
+    // thread-per-voxel forms: a workgroup covers 256 voxels per round, three workgroups per CU are resident -- more records only
+    // lengthen the one-workgroup merge (20 classes: 2048 records x 160 values took loss_final_k 107 us per output)
+    const long tiles = (voxels + kThreads - 1) / kThreads;
+    nb = (int)(tiles < 3L * ctx->num_cu ? tiles : 3L * ctx->num_cu);
+  }
   float* partial = (float*)msk_workspace(ctx, (size_t)nb * 5 * CB * sizeof(float));
   if (!partial) return -1;
   {
@@ -570,7 +577,7 @@ int msk_loss_fwd_ex(msk_ctx* ctx, msk_tensor logits, const int32_t* labels, cons
       else if (C <= 20) LOSS_STATS_CM(20) else if (C <= 24) LOSS_STATS_CM(24) else LOSS_STATS_CM(32)
 #undef LOSS_STATS_CM
 #undef LOSS_STATS_TPV
-    } else if ((ctx->tile_staging & 4) && C >= 2 && C <= 4 && logits.ld == C && (((uintptr_t)logits.p) & 15) == 0) {
+    } else if (flat4) {
       // dense 2..4-class logits (the lung model's head): thread per voxel, records through a flat LDS tile
       hipLaunchKernelGGL((loss_stats_tpv_k<4, 2>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)logits.p, logits.ld,
                          labels, weights, ignore_index, voxels, C, CB, partial, dice_softmax);
