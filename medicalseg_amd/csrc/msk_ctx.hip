@@ -450,7 +450,7 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_reduce_vpl_site(value);
     return 0;
   }
-  if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 8)
+  if (strcmp(key, "reduce_cap") == 0) {  // tuning: blocks per CU of the per-channel reduction kernels (default 4)
     msk_set_ew_caps(0, value);
     return 0;
   }

@@ -41,7 +41,7 @@ inline ChanGeom chan_geom(int C) {
 #else
 #define EW_BOUNDS __launch_bounds__(kThreads)
 #endif
-int g_ew_cap = 4, g_reduce_cap = 8;   // blocks per CU of the elementwise / reduction kernels (options "ew_cap", "reduce_cap"); measured: 4 resident blocks per CU with grid-stride loops beat 32 queued ones by 0.25 ms per step
+int g_ew_cap = 4, g_reduce_cap = 4;   // blocks per CU of the elementwise / reduction kernels (options "ew_cap", "reduce_cap"); measured: 4 resident blocks per CU with grid-stride loops beat 32 queued ones by 0.25 ms per step; reduction kernels (round 4, after reduce_vpl 8; A/B on two boxes, two repetitions each, tools/ab_opt_sweep.sh): 8 / 6 / 5 / 4 / 3 / 2 per CU = 19.31 / -- / 19.34 / 19.24 / 19.26 / 19.40 ms and 18.87 / 18.89 / -- / 18.67 / -- / -- ms -- half the partial records for the merges, same serialized time
 int g_reduce_vpl = 8;   // option "reduce_vpl": voxels per lane the reduction kernels aim for before they add workgroups (round 4: 64 left the deep levels with 4-64 workgroups of 32-64 dependent iterations: 40-110 us per pass for tensors of 2-30 MB; A/B 64 / 32 / 16 / 8 / 4: bn_prelu_join bucket 3.97 / 3.70 / 3.61 / 3.59 / 3.63 ms)
 int g_reduce_vpl_site[4] = {0, 0, 0, 0};   // debug option "reduce_vpl_site" (site * 1000 + voxels per lane): 0 statistics, 1 BatchNorm backward sums, 2 joins, 3 channel sums
 inline int reduce_blocks(long voxels, int VPB, int num_cu, int site) {
