@@ -5,9 +5,10 @@ already resident in HBM (BASELINE.json configs[1]; configs[2] at --gpus 8).
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py
---gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is
-not imported).  Rank 0 prints ONE JSON line.  Extra objects:
+N > 1: either under an external launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`:
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read from the environment; torch is not imported), or PLAIN `python bench.py --gpus N`:
+with WORLD_SIZE unset the process spawns the N ranks itself (medicalseg_amd.parallel.spawn_ranks: one process per GPU, own TCP
+rendezvous on 127.0.0.1).  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- the dominant kernel (wbf_gemm_h2_k / wbf_gemm_k: the matrix stage of the 5x5x5 convs and their data gradients),
                   HIP-event time over the timed region; achieved/frac = EXECUTED bf16 FLOPs against the 2.5 PFLOP/s
                   dense bf16 MFMA peak, the algorithmic (direct-convolution) rate under its own keys;
@@ -138,7 +139,16 @@ def cpu_baseline(size=128, ncls=3):
         step(x, y)
         nstep += 1
     dt = (time.time() - t0) / nstep
-    return {"value": float(size ** 3 / dt), "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), None)
+    except OSError:
+        pass
+    # nproc, CPU model and the threads really used, so that box-to-box variance of this line can be read off it
+    return {"value": float(size ** 3 / dt), "unit": "voxels/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "nproc": os.cpu_count(), "cpu_model": cpu_model, "gflops": round(step_flops_per_sample() * (size / 128.0) ** 3 / dt / 1e9, 1),
+            "kind": "port",
             "sample": "torch-CPU/oneDNN restatement (oracle/vnet_torch.py), %d train step(s), batch 1, %d^3 fp32: "
                       "%.1f s per step" % (nstep, size, dt)}
 
@@ -163,10 +173,14 @@ def main():
     ap.add_argument("--force-syncbn-collectives", action="store_true",
                     help="diagnostic (1 GPU): create a 1-rank RCCL communicator and run the 48 SyncBatchNorm collectives and the "
                          "gradient buckets of the multi-GPU step on it (identities) -- measures their stream hand-over / launch cost")
-    ap.add_argument("--dp-mode", type=int, default=None, choices=(0, 1, 2, 3),
-                    help="N > 1: stream / communicator arrangement of the collectives (msk_dp.hip): 0 = all on the compute stream, "
-                         "ONE gradient all-reduce after backward (default); 2 = gradient buckets on a second communicator + "
-                         "stream, overlapped with backward; 1 / 3 = single-communicator variants")
+    ap.add_argument("--dp-mode", default="auto", choices=("auto", "0", "1", "2", "3"),
+                    help="N > 1: stream / communicator arrangement of the collectives (msk_dp.hip): auto (default) = 2 when there is "
+                         "more than one rank (falls back to 0 with a logged reason when ncclCommSplit fails); 2 = gradient buckets on a "
+                         "second communicator + stream, overlapped with backward; 0 = all on the compute stream, ONE gradient "
+                         "all-reduce after backward; 1 / 3 = single-communicator variants")
+    ap.add_argument("--eager-opt", type=int, default=None, choices=(0, 1),
+                    help="optimizer update + weight re-pack of a block on the weight-gradient stream right behind that block's weight "
+                         "gradients (Momentum.enable_eager): default 1 at one rank, 0 otherwise")
     ap.add_argument("--skip-strict-fp32", action="store_true",
                     help="skip the untimed extra pass behind roofline.strict_fp32 (the step with exact bf16 x 3 operand pieces)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
@@ -183,11 +197,11 @@ def main():
     env = parallel.ParallelEnv()
     world, rank = env.nranks, env.rank
     if world != args.gpus:
-        if args.gpus == 1 and world == 1:
-            pass
-        else:
-            raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); "
-                             "got WORLD_SIZE=%d" % (args.gpus, args.gpus, world))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: no external launcher -- become the launcher (one rank per GPU, same command line)
+            raise SystemExit(parallel.spawn_ranks(args.gpus))
+        raise SystemExit("bench.py --gpus %d under a launcher that set WORLD_SIZE=%d: the two must agree (or unset WORLD_SIZE and "
+                         "let bench.py spawn its ranks itself)" % (args.gpus, world))
     dev = get_device()
     if world > 1:
         parallel.init_parallel_env(dp_mode=args.dp_mode)
@@ -214,6 +228,8 @@ def main():
         nn.BatchNorm3D.force_collectives = True
         net = parallel.DataParallel(model, force=True)
     model.train()
+    eager = args.eager_opt if args.eager_opt is not None else (1 if (world == 1 and not args.force_syncbn_collectives) else 0)
+    eager = bool(eager) and opt.enable_eager(model)
 
     def step():
         logits_list = net(images)
@@ -285,8 +301,10 @@ def main():
     # no dropped significand bits) -- the reference's arithmetic is plain fp32 (vnet.py:36, no AMP), the headline uses 22-bit
     # operands (dtype_note); this is the same step at full operand precision, reported beside it, never as `value`
     strict = None
-    if world == 1 and not args.skip_strict_fp32 and "conv_split=3" not in args.opt:
+    # (skipped whenever the run itself experiments with the operand format; the option is put back to what it was -- advisor, round 4)
+    if world == 1 and not args.skip_strict_fp32 and not any(o.split("=")[0] in ("conv_split", "conv_fp16") for o in args.opt):
         import ctypes as _C
+        split_before = dev.get_option("conv_split")
         dev.set_option("conv_split", 3)
         for _ in range(2):
             step()
@@ -298,7 +316,7 @@ def main():
         dev.call("msk_mark", 1)
         ms = _C.c_float()
         dev.call("msk_mark_elapsed", 0, 1, _C.byref(ms))
-        dev.set_option("conv_split", 2)
+        dev.set_option("conv_split", split_before)
         strict = {"ms_per_step": round(float(ms.value) / nst, 3), "value": round(B * S ** 3 / (float(ms.value) / nst * 1e-3), 1),
                   "unit": "voxels/s", "steps": nst,
                   "note": "untimed extra pass (stream marks): the same step with exact fp32 operands (option conv_split 3: bf16 x 3 "
@@ -309,8 +327,25 @@ def main():
     dp_info = None
     if world > 1:
         import ctypes as C
+        # compute-only replay (untimed extra pass): the same step with NO collective issued (rank-local statistics, no gradient
+        # exchange) -- step minus this is the communication that is NOT hidden, whatever the arrangement
+        n_buckets = len(getattr(net, "buckets_last_step", []) or [])
+        parallel.set_dry_run(True)
+        for _ in range(2):
+            step()
+        parallel.barrier()
+        ndry = max(3, min(10, args.steps))
+        dev.call("msk_mark", 0)
+        for _ in range(ndry):
+            step()
+        dev.call("msk_mark", 1)
+        msd = C.c_float()
+        dev.call("msk_mark_elapsed", 0, 1, C.byref(msd))
+        parallel.set_dry_run(False)
+        compute_only_ms = float(msd.value) / ndry
+        parallel.barrier()
         tags = ("rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather", "rccl_allreduce_bucket")
-        mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags]
+        mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags] + [compute_only_ms]
         sp, rp = dev.small(len(mine)), dev.small(world * len(mine))
         dev.h2d(sp, np.array(mine, np.float32))
         dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(len(mine)))
@@ -318,9 +353,16 @@ def main():
         elapsed = max(elapsed, float(allv[:, 0].max()))
         arena_bytes = 4.0 * model.arena.count
         ar_ms = [float(a + b) for a, b in zip(allv[:, 1], allv[:, 4])]    # one piece on the compute stream or buckets on the communication stream
-        dp_info = {"dp_mode": dev.get_option("dp_mode"), "overlap_buckets": bool(getattr(net, "overlap", False)),
+        co_ms = float(allv[:, 5].max())
+        dp_info = {"dp_mode": dev.get_option("dp_mode"), "dp_mode_requested": args.dp_mode,
+                   "overlap_buckets": bool(getattr(net, "overlap", False)),
+                   # the step (max over ranks) minus the same step with every collective removed (max over ranks): what the
+                   # collectives cost on the critical path in THIS arrangement; budget for >= 6.5x at 8 GPUs: 4.45 ms at 19.3 ms/step
+                   "exposed_comm_ms_per_step": round(elapsed / args.steps * 1e3 - co_ms, 3),
+                   "compute_only_ms_per_step": round(co_ms, 3),
+                   "compute_only_ms_per_step_per_rank": [round(float(v), 3) for v in allv[:, 5]],
                    "gradient_arena_MB": round(arena_bytes / 1e6, 1),
-                   "buckets_last_step": len(getattr(net, "buckets_last_step", []) or []),
+                   "buckets_last_step": n_buckets,
                    # ring all-reduce: every GPU sends and receives 2 (N-1)/N x the buffer -> "bus bandwidth" as nccl-tests define it;
                    # the HIP-event time of a collective includes waiting for the slowest peer to arrive
                    "allreduce_busbw_GBps_per_rank": [round(2.0 * (world - 1) / world * arena_bytes / (t * 1e-3) / 1e9, 1) if t > 0 else None
@@ -425,7 +467,10 @@ def main():
            "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes (BASELINE configs[%d])"
                       % (S, S, S, B, 1 if world == 1 else 2),
                       "global_batch": world * B, "num_classes": ncls, "parallelism": "dp%d" % world,
-                      "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn},
+                      "step": "fwd+loss+bwd+allreduce+sgd_momentum", "sync_bn": not args.no_sync_bn,
+                      # the optimizer update of a block runs on the weight-gradient stream right behind that block's weight
+                      # gradients (same arithmetic, same results; optimizer.Momentum.enable_eager)
+                      "eager_optimizer": bool(eager)},
            # per-step times from stream marks (no synchronisation inside the timed region): SURVEY 8 d1 asks for the median;
            # `value` stays the contract's K-steps-between-two-synchronisations figure
            "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,

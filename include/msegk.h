@@ -392,6 +392,17 @@ int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* veloc
                      size_t count, float lr, float momentum, float weight_decay,
                      float grad_scale);
 
+/* The same update for ONE slice of the arena as soon as everything that produces its gradients has been enqueued
+ * (core/train.py:139-140: loss.backward(); optimizer.step() -- nothing reads a block's weights between its data gradient and the
+ * next forward).  The update and the re-pack of the slice's convolution weights run at the end of the internal weight-gradient
+ * stream, behind an event on the calling stream's current tail; the calling stream does not wait.  Opt-in
+ * (optimizer.Momentum.enable_eager): parameters change during backward, and the gradients must be final when the call is made
+ * (one rank, or after the slice's all-reduce).  msk_sgd_momentum_finish joins: call it where optimizer.step() stands. */
+int msk_sgd_momentum_eager(msk_ctx* ctx, float* param, const float* grad, float* velocity,
+                           size_t count, float lr, float momentum, float weight_decay,
+                           float grad_scale);
+int msk_sgd_momentum_finish(msk_ctx* ctx);
+
 /* paddle.optimizer.Adam(beta1, beta2, epsilon, weight_decay=L2) over one flat arena (cvlibs/config.py:214-216):
  * g = grad_scale*grad + wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  * p -= lr sqrt(1-beta2_pow)/(1-beta1_pow) * m / (sqrt(v) + epsilon sqrt(1-beta2_pow));

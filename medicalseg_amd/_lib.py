@@ -128,6 +128,8 @@ SIGNATURES = {
     "msk_loss_fwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "msk_loss_bwd_ex": (_i, [_vp, _T, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _T]),
     "msk_sgd_momentum": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f]),
+    "msk_sgd_momentum_eager": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f]),
+    "msk_sgd_momentum_finish": (_i, [_vp]),
     "msk_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _d, _d, _f, _f]),
     "msk_resample3d": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),
     "msk_crop_resample3d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i]),

@@ -25,7 +25,7 @@ from .val import evaluate
 
 def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='output', iters=10000, batch_size=2,
           resume_model=None, save_interval=1000, log_iters=10, num_workers=0, use_vdl=False, losses=None,
-          keep_checkpoint_max=5, profiler_options=None, to_static_training=False, dp_mode=None):
+          keep_checkpoint_max=5, profiler_options=None, to_static_training=False, dp_mode='auto'):
     model.train()
     env = ParallelEnv()
     nranks, local_rank = env.nranks, env.local_rank
@@ -38,8 +38,12 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
         os.makedirs(save_dir, exist_ok=True)
     ddp_model = model
     if nranks > 1:
-        init_parallel_env(dp_mode=dp_mode)    # train.py --dp_mode: 0 = one all-reduce after backward, 2 = overlapped buckets
+        init_parallel_env(dp_mode=dp_mode)    # train.py --dp_mode: auto = 2 (overlapped buckets) when there are several ranks; 0 = one all-reduce after backward
         ddp_model = DataParallel(model)
+    elif hasattr(optimizer, "enable_eager") and os.environ.get("MSEGK_EAGER_OPT", "1") != "0":
+        # one rank: a block's parameters are updated on the weight-gradient stream as soon as its backward is enqueued;
+        # optimizer.step() below joins.  This loop never looks at parameters between backward() and step().
+        optimizer.enable_eager(model)
     loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True, drop_last=False,
                         num_workers=num_workers)
     if use_vdl:

@@ -117,6 +117,7 @@ struct msk_ctx {
   int kst_pair = 1;      // option "kst_pair": gconv_kst_k carries both h-parity classes of <= 16 output channels in one matrix instruction; 0 = one class per wavefront (A/B)
   int tile_staging = 7;  // option "tile_staging": dense 5..32-channel voxel records through an LDS tile (msk_tile_load); bit mask: 1 the 1x1x1 head, 2 the 5..32-class loss kernels, 4 the 2..4-class loss kernels (thread per voxel through a flat tile instead of the lane-per-class kernels); 0 = the direct forms (A/B)
   int wgrad_renorm = 1;  // NP = 2 weight gradient: per-channel renormalisation (msk_wbf.h: wbf_chan_shift); 0 = per-tensor scales only (A/B)
+  int dy_bound_shift = 0;   // debug option "dy_bound_shift": the dual transform's bound of max |dy| times 2^shift
   int dp_mode = 0;   // msk_dp.hip: 0 = every collective on the compute stream (default), 1 = one communicator on the communication stream, 2 = two communicators, 3 = one communicator, buckets on the communication stream
   bool comm_pending = false;
   bool host_transport = false;   // env MSEGK_DP_TRANSPORT=host: collectives through host staging + TCP (single-GPU test tier)
@@ -143,6 +144,7 @@ void msk_set_ew_caps(int ew, int red);   // msk_elementwise.hip tuning knobs
 void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes);
 void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes);  // msk_free: drop the rows inside [p, p + bytes)
 int msk_wbf_prepack_impl(msk_ctx* ctx);   // rebuild every stale packed-weight row in use (end of the optimizer kernels)
+int msk_wbf_prepack_range_impl(msk_ctx* ctx, const void* p, size_t bytes);   // the stale rows inside [p, p + bytes), current stream
 void msk_wbf_pack_cache_free(msk_ctx* ctx);
 int msk_dp_wait_impl(msk_ctx* ctx);
 

@@ -393,6 +393,7 @@ struct DualArgs {
   const float* maxes;  // see WbfBnBwd
   float* y_cmax;       // see WbfBnBwd
   int coef_stride, sums_stride;
+  int bound_shift;     // debug option "dy_bound_shift": the bound of max |dy| times 2^shift (tools/diag_fullsize_flip.py)
 };
 
 template <int K, int NP>
@@ -480,7 +481,7 @@ wbf_tin_dual_k(DualArgs b) {
       ma = fmaxf(fmaxf(shb[0][0], shb[0][1]), fmaxf(shb[0][2], shb[0][3]));
       mb = fmaxf(fmaxf(shb[1][0], shb[1][1]), fmaxf(shb[1][2], shb[1][3]));
       mc = fmaxf(fmaxf(shb[2][0], shb[2][1]), fmaxf(shb[2][2], shb[2][3]));
-      const float bound = ma * (wbf_amax_of(b.maxes) + mb + wbf_amax_of(b.maxes + kWbfAmaxWays) * mc);
+      const float bound = ldexpf(ma * (wbf_amax_of(b.maxes) + mb + wbf_amax_of(b.maxes + kWbfAmaxWays) * mc), b.bound_shift);
       if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) const_cast<float*>(b.amax)[0] = bound;  // zeroed ring array
       sc2 = wbf_scale_from(bound);
     } else {
@@ -1741,6 +1742,7 @@ int msk_wbf_transform_dual(msk_ctx* ctx, int K, int NP, const WbfTinArgs& ta_in,
   da.invM = bn.invM; da.C = ta_in.CK; da.Y = bn.Y; da.y_xi = bn.y_xi; da.amax = bn.amax; da.maxes = bn.maxes;
   da.y_cmax = bn.Y ? bn.y_cmax : nullptr;
   da.coef_stride = bn.coef_stride; da.sums_stride = bn.sums_stride;
+  da.bound_shift = ctx->dy_bound_shift;
   const bool write_y = bn.Y != nullptr;
   if (!write_v && !write_y) return 0;
   const int pblocks = (da.t.DP * da.t.HP + 63) / 64;
@@ -1860,6 +1862,23 @@ int msk_wbf_prepack_impl(msk_ctx* ctx) {
     if (e.live && !e.valid && e.last_use >= c->epoch - 1) rows.push_back(r);  // rows used since the previous rebuild
   }
   c->epoch += 1;
+  return pack_rows_build(ctx, c, rows);
+}
+// the rows whose weights lie inside [p, p + bytes) only, on the CURRENT stream; the use epoch does not advance
+// (msk_sgd_momentum_eager: one call per block of the model, msk_wbf_prepack_impl closes the step)
+int msk_wbf_prepack_range_impl(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->wpack || !ctx->wbf_prepack || !p) return 0;
+  WbfPackCache* c = (WbfPackCache*)ctx->wpack;
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  std::vector<int> rows;
+  for (int r = 0; r < WbfPackCache::kRows - 1; ++r) {
+    const WbfPackEntry& e = c->e[r];
+    if (!e.live || e.valid || e.last_use < c->epoch - 1) continue;
+    const char* b0 = (const char*)e.d.w;
+    const char* b1 = b0 + (size_t)e.d.count * sizeof(float);
+    if (b0 >= a0 && b1 <= a1) rows.push_back(r);   // wholly inside: a row that straddles the slice waits for the full rebuild
+  }
   return pack_rows_build(ctx, c, rows);
 }
 void msk_wbf_pack_cache_free(msk_ctx* ctx) {

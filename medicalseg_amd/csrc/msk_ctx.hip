@@ -454,6 +454,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(0, value);
     return 0;
   }
+  if (strcmp(key, "dy_bound_shift") == 0) {   // debug: scale dy (fused BatchNorm backward, NP = 2) as if its bound were 2^value larger
+    ctx->dy_bound_shift = value;
+    return 0;
+  }
   if (strcmp(key, "late_split") == 0) {
     ctx->late_split = value != 0;
     return 0;

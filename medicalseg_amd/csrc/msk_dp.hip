@@ -268,9 +268,15 @@ int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   }
   ncclComm_t comm_grad = nullptr;
   if (ctx->dp_mode == 2) {
-    if (ncclCommSplit(comm, 0, rank, &comm_grad, nullptr) != ncclSuccess || comm_grad == nullptr) {
+    const ncclResult_t sr = ncclCommSplit(comm, 0, rank, &comm_grad, nullptr);
+    if (sr != ncclSuccess || comm_grad == nullptr) {
+      // no second communicator: back to the arrangement with the fewest moving parts (mode 0: one all-reduce after backward on
+      // the compute stream) -- NOT to the single-communicator variants, which cost +15 ... +22 ms per step where they were
+      // measured (header comment); the effective mode is what msk_get_option("dp_mode") and bench.py's dp.dp_mode report
+      fprintf(stderr, "[msegk] rank %d: dp_mode 2 requested but ncclCommSplit failed (%s): falling back to dp_mode 0\n", rank,
+              sr != ncclSuccess ? ncclGetErrorString(sr) : "null communicator");
       comm_grad = nullptr;
-      ctx->dp_mode = 1;   // no second communicator: the single-communicator arrangement
+      ctx->dp_mode = 0;
     }
   }
   ctx->comm_grad = (void*)comm_grad;

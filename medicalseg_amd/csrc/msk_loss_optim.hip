@@ -681,13 +681,44 @@ int msk_sgd_momentum(msk_ctx* ctx, float* param, const float* grad, float* veloc
     msk_weights_changed_impl(ctx, param, count * sizeof(float));
     if (msk_wbf_prepack_impl(ctx) != 0) return -1;
     if (msk_join_side_impl(ctx) != 0) return -1;
-    return sgd_launch(ctx, param + lo, grad + lo, velocity + lo, hi - lo, lr, momentum, weight_decay, grad_scale);
+    if (sgd_launch(ctx, param + lo, grad + lo, velocity + lo, hi - lo, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+    // the late slice changes AFTER the re-pack above: a packed row over it (none today -- the late tensor is in_tr.conv1, one
+    // input channel, which never enters the pack cache) must not be left marked valid (advisor, round 4)
+    msk_weights_changed_impl(ctx, param + lo, (hi - lo) * sizeof(float));
+    return msk_wbf_prepack_range_impl(ctx, param + lo, (hi - lo) * sizeof(float));
   }
   if (msk_join_side_impl(ctx) != 0) return -1;  // weight gradients may still be running on the side stream
   if (sgd_launch(ctx, param, grad, velocity, count, lr, momentum, weight_decay, grad_scale) != 0) return -1;
   // the packed / transformed forms of the convolution weights inside [param, param + count) are stale now: rebuild the ones
   // in use in one go (two launches instead of one pack + one maximum per layer and direction inside the next step)
   msk_weights_changed_impl(ctx, param, count * sizeof(float));
+  return msk_wbf_prepack_impl(ctx);
+}
+
+// Eager update of ONE slice of the arena (round 5; round-4 "measured but not built (i)"): everything that produces the
+// gradients of [param, param + count) has been enqueued -- the weight gradients on the side stream, the BatchNorm / PReLU
+// parameter gradients and the data gradients that READ these weights on the compute stream.  The update and the re-pack of
+// the slice's convolution weights go to the END OF THE SIDE STREAM behind an event on the compute stream's current tail:
+// nothing on the compute stream waits for them until msk_sgd_momentum_finish, so 0.165 (update) + 0.33 (pack) + 0.08 ms
+// (maxima) leave the tail of the step's critical path.  Same kernel, same arithmetic per element as msk_sgd_momentum.
+int msk_sgd_momentum_eager(msk_ctx* ctx, float* param, const float* grad, float* velocity, size_t count, float lr,
+                           float momentum, float weight_decay, float grad_scale) {
+  if (count == 0) return 0;
+  MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
+              "arena slices must be 16-byte aligned");
+  {
+    msk_side_scope side(ctx);   // (no side stream: the same launches on the calling stream, in order)
+    if (sgd_launch(ctx, param, grad, velocity, count, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+    msk_weights_changed_impl(ctx, param, count * sizeof(float));
+    if (msk_wbf_prepack_range_impl(ctx, param, count * sizeof(float)) != 0) return -1;
+  }
+  return 0;
+}
+
+// End of an eagerly updated step: the compute stream waits for the side stream (updates, re-packs, a late weight gradient),
+// packed rows that are still stale are rebuilt and the pack cache's use epoch advances as in msk_sgd_momentum.
+int msk_sgd_momentum_finish(msk_ctx* ctx) {
+  if (msk_join_side_impl(ctx) != 0) return -1;
   return msk_wbf_prepack_impl(ctx);
 }
 

@@ -360,6 +360,8 @@ class BatchNorm3D(Layer):
     # tests: run the SyncBatchNorm collectives (all-gather of the statistics, all-reduce of the backward sums) also on a
     # 1-rank communicator, where they are identities -- exercises the communication-stream hand-over inside a real step
     force_collectives = False
+    # bench.py's compute-only replay (parallel.set_dry_run): no statistics collective is issued, the statistics stay rank-local
+    dry_run = False
 
     def __init__(self, num_features, momentum=BN_MOMENTUM, epsilon=BN_EPS):
         super().__init__()
@@ -563,7 +565,7 @@ class ConvBNAct:
         Cn = bn.num_features
         # one rank (or rank-local statistics): the finalisation rides in the launch that merges the statistics
         fin = None
-        multi = (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync
+        multi = (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync and not BatchNorm3D.dry_run
         if bn.training and FUSE_SMALL and not multi:
             od, oh, ow = self.conv.out_dims(x)
             fin = MskBnFin(bn.weight.ptr, bn.bias.ptr, bn.epsilon, bn.momentum, float(x.n * od * oh * ow), bn._mean.ptr,
@@ -655,7 +657,8 @@ class ConvBNAct:
             dev.call("msk_affine_act_bwd_reduce", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), resm, _fp(alpha),
                      _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), _fp(sc["sums"]))
         sums_total, m_total = sc["sums"], float(y.voxels)
-        if self.bn_mode == 1 and (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync:
+        if (self.bn_mode == 1 and (dev.world > 1 or BatchNorm3D.force_collectives) and BatchNorm3D.sync
+                and not BatchNorm3D.dry_run):
             dev.d2d(sc["sums_total"], sc["sums"], 2 * Cn * 4)
             dev.call("msk_dp_allreduce_stats", _fp(sc["sums_total"]), C.c_size_t(2 * Cn))
             sums_total, m_total = sc["sums_total"], float(y.voxels) * dev.world

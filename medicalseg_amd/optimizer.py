@@ -110,6 +110,9 @@ class Momentum:
         self.velocity_ptr = dev.malloc(max(self.arena.count, 4) * 4)
         dev.memset(self.velocity_ptr, 0, max(self.arena.count, 4) * 4)
 
+        self._eager = False
+        self._eager_done = []     # [(lo, hi)] slices of the arena already updated during this backward pass
+
     def get_lr(self):
         if isinstance(self._learning_rate, _LR.LRScheduler):
             return self._learning_rate()
@@ -118,8 +121,70 @@ class Momentum:
     def set_lr(self, value):
         self._learning_rate = float(value)
 
+    # -- eager mode (round 5) ---------------------------------------------------------------
+    def enable_eager(self, model, on=True):
+        """Opt-in: update a block's parameters (and re-pack its convolution weights) on the weight-gradient stream as soon as
+        that block's backward has been enqueued (`model._grad_ready_hooks`, the hook data parallelism uses for its buckets),
+        instead of one pass over the arena at `step()` -- which then only joins.  The reference's loop is loss.backward();
+        optimizer.step() (core/train.py:139-140): nothing reads a block's weights between its data gradient and the next
+        forward, so the results are bitwise those of the plain order (tests/test_gpu_model.py); what changes is WHEN the
+        parameters change -- during backward -- hence a caller that inspects parameters between backward() and step(), or
+        calls backward() without step() (gradient accumulation), must leave it off.  One rank only: with more ranks the
+        gradients are final after the all-reduce, not after backward.  core.train() and bench.py switch it on at one rank."""
+        if not on:
+            self._eager = False
+            return False
+        if getattr(model, "arena", None) is not self.arena or not hasattr(model, "_grad_ready_hooks"):
+            return False
+        if self.arena.dev.world > 1:
+            return False
+        if not any(getattr(h, "__self__", None) is self for h in model._grad_ready_hooks):
+            model._grad_ready_hooks.append(self._block_ready)
+        self._eager = True
+        self._slices = {}
+        return True
+
+    def _block_slice(self, block):
+        """[lo, hi) floats of the arena that hold exactly this block's parameters (None when they are not one run)"""
+        key = id(block)
+        if key not in self._slices:
+            ps = [p for p in block.parameters() if p.arena is self.arena]
+            sl = None
+            if ps:
+                lo = min(p.offset for p in ps)
+                hi = max(p.offset + ((p.size + 3) & ~3) for p in ps)
+                if sum((p.size + 3) & ~3 for p in ps) == hi - lo:
+                    sl = (lo, hi)
+            self._slices[key] = sl
+        return self._slices[key]
+
+    def _block_ready(self, model, block):
+        if not self._eager or not model.training:
+            return
+        sl = self._block_slice(block)
+        if sl is None or any(lo < sl[1] and sl[0] < hi for lo, hi in self._eager_done):
+            return
+        a = self.arena
+        lo, hi = sl
+        a.dev.call("msk_sgd_momentum_eager", C.c_void_p(a.value_ptr + 4 * lo), C.c_void_p(a.grad_ptr + 4 * lo),
+                   C.c_void_p(self.velocity_ptr + 4 * lo), C.c_size_t(hi - lo), C.c_float(self.get_lr()),
+                   C.c_float(self.momentum), C.c_float(self.weight_decay), C.c_float(a.grad_scale))
+        self._eager_done.append(sl)
+
     def step(self):
         a = self.arena
+        if self._eager_done:
+            # what the hooks did not cover (parameters outside the reported blocks), then the join
+            done, self._eager_done = sorted(self._eager_done), []
+            pos = 0
+            for lo, hi in done + [(a.count, a.count)]:
+                if lo > pos:
+                    a.dev.call("msk_sgd_momentum_eager", C.c_void_p(a.value_ptr + 4 * pos), C.c_void_p(a.grad_ptr + 4 * pos),
+                               C.c_void_p(self.velocity_ptr + 4 * pos), C.c_size_t(lo - pos), C.c_float(self.get_lr()),
+                               C.c_float(self.momentum), C.c_float(self.weight_decay), C.c_float(a.grad_scale))
+                pos = max(pos, hi)
+            a.dev.call("msk_sgd_momentum_finish")
+            return
         a.dev.call("msk_sgd_momentum", C.c_void_p(a.value_ptr), C.c_void_p(a.grad_ptr), C.c_void_p(self.velocity_ptr),
                    C.c_size_t(a.count), C.c_float(self.get_lr()), C.c_float(self.momentum),
                    C.c_float(self.weight_decay), C.c_float(a.grad_scale))

@@ -116,7 +116,80 @@ def exchange_bytes(payload: bytes | None, rank: int, world: int, timeout=300.0) 
     raise TimeoutError("rendezvous with rank 0 timed out")
 
 
+def spawn_ranks(n, argv=None, env=None, timeout=None):
+    """Self-launch: run `argv` (default: this process's own command line) as n ranks of ONE node, one process per GPU --
+    what `python -m torch.distributed.run --nproc-per-node n` would do for this package's launch contract, without torch:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT=<a free port> in each child's environment (the
+    RCCL id then travels over `exchange_bytes` on MASTER_PORT+1..).  The children inherit stdout / stderr, so rank 0's
+    single JSON line is this process's.  If a rank fails the others are terminated (a rank that died before the
+    rendezvous would otherwise leave its peers waiting).  Returns the largest exit code.
+    Replaces `python -m paddle.distributed.launch train.py ...` (reference README / run-vnet.sh) for bench.py and
+    train.py when no external launcher set WORLD_SIZE."""
+    import subprocess
+    import sys
+    argv = list(argv) if argv is not None else [sys.executable] + sys.argv
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSEGK_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(argv, env=e))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = max(rc, code if code > 0 else 1)
+                for o in live:              # a failed rank takes the job down: its peers would wait in a collective
+                    procs[o].terminate()
+        if deadline is not None and time.time() > deadline:
+            for o in live:
+                procs[o].kill()
+            return 124
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
 _initialised = False
+DRY_RUN = False     # bench.py's compute-only replay: True = no collective is issued (BatchNorm statistics stay rank-local,
+                    # the gradient exchange is skipped) -- what the step costs WITHOUT communication, for dp.exposed_comm_ms_per_step
+
+
+def set_dry_run(on):
+    """Compute-only replay for bench.py's dp.exposed_comm_ms_per_step: while on, neither the SyncBatchNorm exchanges nor the
+    gradient all-reduce / buckets are issued (every rank runs the step on its own data with rank-local statistics)."""
+    global DRY_RUN
+    from . import nn
+    DRY_RUN = bool(on)
+    nn.BatchNorm3D.dry_run = bool(on)
+
+
+def resolve_dp_mode(dp_mode, world):
+    """'auto' (bench.py / train.py --dp-mode auto, the default): gradient buckets overlapped with backward on a second
+    communicator + stream (mode 2) whenever there is more than one rank -- the exposed-communication budget for >= 6.5x at
+    8 GPUs is 19.3 ms x (8 / 6.5 - 1) = 4.45 ms per step and mode 0 leaves the whole 182 MB all-reduce exposed; msk_dp_init
+    falls back to mode 0 (and says so on stderr) when ncclCommSplit cannot give it the second communicator.  None = leave
+    the library's current setting (0 unless MSEGK_DP_MODE / msk_set_option changed it)."""
+    if dp_mode is None:
+        return None
+    if isinstance(dp_mode, str):
+        if dp_mode == "auto":
+            return 2 if world > 1 else 0
+        dp_mode = int(dp_mode)
+    if dp_mode not in (0, 1, 2, 3):
+        raise ValueError("dp_mode must be 'auto', 0, 1, 2 or 3, got %r" % (dp_mode,))
+    return dp_mode
 
 
 def init_parallel_env(dp_mode=None):
@@ -127,7 +200,14 @@ def init_parallel_env(dp_mode=None):
     global _initialised
     env = ParallelEnv()
     dev = get_device()
+    dp_mode = resolve_dp_mode(dp_mode, env.nranks)
     if _initialised or env.nranks == 1:
+        # the arrangement is fixed when the communicators are created (mode 2's second one): a later request cannot take
+        # effect -- say so instead of ignoring it (advisor, round 4)
+        if dp_mode is not None and _initialised and dp_mode != dev.get_option("dp_mode"):
+            import warnings
+            warnings.warn("init_parallel_env(dp_mode=%d) after the communicators were created: dp_mode stays %d"
+                          % (dp_mode, dev.get_option("dp_mode")))
         return env
     if dp_mode is not None:
         dev.set_option("dp_mode", int(dp_mode))
@@ -198,8 +278,8 @@ class DataParallel:
                 warnings.warn("DataParallel(overlap=True) needs dp_mode 1-3 (train.py / bench.py --dp-mode 2, or MSEGK_DP_MODE=2 "
                               "before init_parallel_env); dp_mode is 0: falling back to ONE all-reduce after backward.")
                 overlap = False
-            self.overlap = bool(overlap)
-            if overlap and hasattr(model, "_grad_ready_hooks"):
+            self.overlap = bool(overlap and hasattr(model, "_grad_ready_hooks"))   # what really runs (a model without block hooks: one all-reduce)
+            if self.overlap:
                 params = model.arena.params
                 self._index = {id(p): i for i, p in enumerate(params)}
                 self._start = [p.offset for p in params] + [model.arena.count]
@@ -215,6 +295,9 @@ class DataParallel:
     # -- single all-reduce (overlap=False) ------------------------------------------------
     def _allreduce(self, model):
         a = model.arena
+        if DRY_RUN:
+            self.buckets_last_step = []
+            return
         self.dev.call("msk_dp_allreduce_sum", C.c_void_p(a.grad_ptr), C.c_size_t(a.count))
         self.buckets_last_step = [(0, a.count)]
 
@@ -222,7 +305,7 @@ class DataParallel:
     def _send(self, lo_idx, hi_idx):
         a = self._layers.arena
         lo, hi = self._start[lo_idx], self._start[hi_idx]
-        if hi > lo:
+        if hi > lo and not DRY_RUN:
             self.dev.call("msk_dp_allreduce_async", C.c_void_p(a.grad_ptr + 4 * lo), C.c_size_t(hi - lo))
             self._sent.append((lo, hi - lo))
         self._tail = lo_idx

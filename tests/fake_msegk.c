@@ -54,7 +54,7 @@ NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
 NOOP(msk_bn_stats) NOOP(msk_bn_finalize) NOOP(msk_bn_eval_coeffs)
 NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_reduce_ex) NOOP(msk_affine_act_join_fwd) NOOP(msk_add_act_join_bwd) NOOP(msk_add_act_join_bwd_ex) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)
 NOOP(msk_add_act_bwd) NOOP(msk_bn_bias_grad) NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c) NOOP(msk_softmax_c)
-NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum) NOOP(msk_loss_fwd_ex) NOOP(msk_loss_bwd_ex) NOOP(msk_adam) NOOP(msk_elu_fwd) NOOP(msk_elu_bwd)
+NOOP(msk_class_weights) NOOP(msk_loss_fwd) NOOP(msk_loss_bwd) NOOP(msk_sgd_momentum) NOOP(msk_sgd_momentum_eager) NOOP(msk_sgd_momentum_finish) NOOP(msk_loss_fwd_ex) NOOP(msk_loss_bwd_ex) NOOP(msk_adam) NOOP(msk_elu_fwd) NOOP(msk_elu_bwd)
 NOOP(msk_resample3d) NOOP(msk_hu_norm) NOOP(msk_minmax_norm) NOOP(msk_max_norm) NOOP(msk_label_remap)
 NOOP(msk_crop_resample3d) NOOP(msk_flip3d) NOOP(msk_rotate3d)
 NOOP(msk_interp_trilinear_fwd) NOOP(msk_interp_trilinear_bwd)

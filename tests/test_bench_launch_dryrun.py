@@ -41,20 +41,45 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     assert rec["unit"] == "voxels/s" and rec["higher_is_better"] is True and "roofline" in rec
     assert "cpu_baseline" not in rec                         # rank 0 at N=1 only
     # round 4: the first multi-GPU run must be diagnosable from the line alone
+    # round 5: the default arrangement is decided from the communication budget -- `--dp-mode auto` = overlapped buckets (mode 2)
+    # whenever there is more than one rank -- and the line carries the exposed communication (step minus a compute-only replay)
     dp = rec["dp"]
-    assert dp["dp_mode"] == 0 and dp["overlap_buckets"] is False and dp["buckets_last_step"] == 1
+    assert dp["dp_mode_requested"] == "auto" and dp["dp_mode"] == 2 and dp["overlap_buckets"] is True and dp["buckets_last_step"] >= 2
+    assert "exposed_comm_ms_per_step" in dp and len(dp["compute_only_ms_per_step_per_rank"]) == 2
+    assert rec["config"]["eager_optimizer"] is False          # gradients are final only after the all-reduce
     assert len(dp["allreduce_busbw_GBps_per_rank"]) == 2 and len(dp["syncbn_collective_ms_per_step_per_rank"]) == 2
     assert set(dp["per_rank_collective_ms_per_step"]) == {"rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather", "rccl_allreduce_bucket"}
     assert rec["roofline"]["strict_fp32"] is None            # the exact-operand pass is a 1-GPU extra
-    # --dp-mode 2: gradient buckets on the communication stream, overlapped with backward
+    # --dp-mode 0: ONE all-reduce after backward, everything on the compute stream
     cmd2 = cmd[:cmd.index(os.path.join(HERE, "run_bench_fake.py"))]
     cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
     cmd2 += [os.path.join(HERE, "run_bench_fake.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "16", "--no-cpu-baseline",
-             "--dp-mode", "2"]
+             "--dp-mode", "0"]
     out2 = subprocess.run(cmd2, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
     rec2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
-    assert rec2["dp"]["dp_mode"] == 2 and rec2["dp"]["overlap_buckets"] is True and rec2["dp"]["buckets_last_step"] >= 2
+    assert rec2["dp"]["dp_mode"] == 0 and rec2["dp"]["overlap_buckets"] is False and rec2["dp"]["buckets_last_step"] == 1
+
+
+def test_bench_plain_python_gpus_2_spawns_its_own_ranks(tmp_path):
+    """round-4 verdict, Weak 9: `python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset) must not die on the launch
+    contract -- it becomes the launcher (parallel.spawn_ranks: one process per GPU, own rendezvous) and rank 0 prints the line."""
+    env = dict(os.environ, MSK_FAKE_LIB=_fake_lib(tmp_path), OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "run_bench_fake.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--size", "16", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["dp"]["dp_mode"] == 2 and len(rec["dp"]["per_rank_step_ms"]) == 2
+    # a rank that fails takes the job down with a non-zero exit code instead of leaving its peers in the rendezvous
+    bad = subprocess.run([sys.executable, os.path.join(HERE, "run_bench_fake.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--size", "16", "--no-cpu-baseline", "--opt", "broken"], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert bad.returncode != 0
 
 
 def test_bench_single_process_defaults(tmp_path):
@@ -67,7 +92,9 @@ def test_bench_single_process_defaults(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["dtype"] == "f32" and rec["data"] == "synthetic" and rec["vs_baseline"] is None
-    # asking for more GPUs than the launcher provided is an error, not a silent single-GPU run
+    assert rec["config"]["eager_optimizer"] is True
+    # a launcher that provided FEWER ranks than --gpus asks for is an error, not a silent smaller run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(HERE, "run_bench_fake.py"), "--gpus", "2", "--size", "16"],
-                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                         env=env2, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0

@@ -183,6 +183,55 @@ def test_training_trajectory_matches_oracle():
             assert e <= 4 * e32 + 1e-6, (k, e, e32)
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 16), (32, 32, 32)])
+def test_eager_optimizer_is_bitwise_the_plain_order(shape):
+    """optimizer.Momentum.enable_eager (round 5): every block's update + weight re-pack runs on the weight-gradient stream as soon
+    as that block's backward is enqueued, step() only joins.  Four training steps (train-mode BatchNorm, dropout masks from the
+    device RNG) must leave EVERY parameter, velocity and BatchNorm buffer bitwise equal to the plain loss.backward();
+    optimizer.step() order (core/train.py:139-140), and the loss of every step equal."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    ncls, K, S, N = 3, ((2, 2, 2),) * 4, ((2, 2, 2),) * 4, 2
+    results = []
+    for eager in (False, True):
+        rng = np.random.default_rng(5)
+        nn.Dropout3D._site_counter = 0          # the mask stream is keyed by (seed, step, site): both models get sites 1..6
+        model, _ = _build(ncls, K, S, seed=6)
+        sched = optim.lr.PolynomialDecay(1e-2, decay_steps=100, end_lr=0, power=0.9)
+        opt = optim.Momentum(sched, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        if eager:
+            assert opt.enable_eager(model) is True
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+        model.train()
+        model.set_dropout_masks(None)
+        nn.Dropout3D.step, nn.Dropout3D.seed = 0, 3
+        vals = []
+        for step in range(4):
+            x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+            y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+            logits = model(x)
+            loss_list, per = loss_computation(logits, to_labels(y), losses)
+            loss = sum(loss_list)
+            loss.backward()
+            if eager:
+                assert len(opt._eager_done) == 10          # every block of the network reported and was updated
+            opt.step()
+            sched.step()
+            model.clear_gradients()
+            vals.append(float(loss))
+        sd = model.state_dict()
+        vel = dev().d2h(opt.velocity_ptr, (model.arena.count,), np.float32)
+        results.append((vals, sd, vel))
+    (va, sda, vela), (vb, sdb, velb) = results
+    assert va == vb, (va, vb)
+    for k in sda:
+        assert np.array_equal(sda[k], sdb[k]), k
+    assert np.array_equal(vela, velb)
+    assert any(np.abs(vela).max() > 0 for _ in (0,))
+
+
 def test_eval_mdice_matches_oracle():
     """core.val.evaluate's mDice on a synthetic validation set == oracle soft dice."""
     from medicalseg_amd.core import evaluate

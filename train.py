@@ -40,10 +40,13 @@ def parse_args():
     p.add_argument('--no_sync_bn', dest='no_sync_bn', action='store_true',
                    help='rank-local BatchNorm statistics (documented deviation from the reference, which converts every '
                         'BatchNorm to SyncBatchNorm: cvlibs/config.py:322)')
-    p.add_argument('--dp_mode', dest='dp_mode', type=int, default=None, choices=(0, 1, 2, 3),
-                   help='multi-GPU: arrangement of the collectives (msk_dp.hip): 0 = everything on the compute stream, one gradient '
-                        'all-reduce after backward (default); 2 = gradient buckets on a second communicator + stream, overlapped '
-                        'with backward')
+    p.add_argument('--dp_mode', dest='dp_mode', default='auto', choices=('auto', '0', '1', '2', '3'),
+                   help='multi-GPU: arrangement of the collectives (msk_dp.hip): auto (default) = 2 with more than one rank; 2 = '
+                        'gradient buckets on a second communicator + stream, overlapped with backward; 0 = everything on the '
+                        'compute stream, one gradient all-reduce after backward')
+    p.add_argument('--gpus', dest='gpus', type=int, default=None,
+                   help='spawn this many ranks (one per GPU) when no launcher set WORLD_SIZE -- replaces '
+                        '`python -m paddle.distributed.launch train.py ...`')
     p.add_argument('--data_format', dest='data_format', type=str, default='NCHW',
                    help='Kept for CLI compatibility; the device layout is always NDHWC internally.')
     p.add_argument('--profiler_options', type=str, default=None,
@@ -53,6 +56,9 @@ def parse_args():
 
 
 def main(args):
+    if args.gpus and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from medicalseg_amd.parallel import spawn_ranks
+        raise SystemExit(spawn_ranks(args.gpus))
     if args.seed is not None:
         np.random.seed(args.seed)
         random.seed(args.seed)
