@@ -374,8 +374,8 @@ def main():
                    "per_rank_step_ms": [round(float(v) / args.steps * 1e3, 3) for v in allv[:, 0]],
                    "per_rank_collective_ms_per_step": {t: [round(float(v), 3) for v in allv[:, 1 + i]] for i, t in enumerate(tags)},
                    "calls_per_step": {t: int(sum(v[0] for k, v in prof.items() if k == t) / args.steps) for t in tags},
-                   "how_to_ab": "--dp-mode 2 = gradient buckets on a second communicator + stream, overlapped with backward; "
-                                "--dp-mode 0 (default) = one all-reduce after backward, everything on the compute stream; "
+                   "how_to_ab": "--dp-mode auto (default) = 2 with more than one rank: gradient buckets on a second communicator + stream, "
+                                "overlapped with backward; --dp-mode 0 = one all-reduce after backward, everything on the compute stream; "
                                 "--no-sync-bn = rank-local BatchNorm statistics (deviation from the reference)",
                    "note": "rccl_allreduce = gradient arena (182 MB per step) in one piece on the compute stream, rccl_allreduce_bucket = "
                            "its buckets on the communication stream (dp_mode 1-3; overlapped with backward, so their time is NOT "

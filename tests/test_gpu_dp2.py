@@ -133,4 +133,14 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and len(j["dp"]["per_rank_step_ms"]) == 2
     assert j["dp"]["calls_per_step"]["rccl_allgather"] == 24 and j["dp"]["calls_per_step"]["rccl_allreduce_stats"] == 24
-    assert j["dp"]["calls_per_step"]["rccl_allreduce"] == 1        # default: one all-reduce of the arena after backward
+    # default (--dp-mode auto, more than one rank): gradient buckets on the communication stream, overlapped with backward;
+    # a fall-back to mode 0 (second communicator refused) shows as ONE all-reduce of the arena after backward
+    calls = j["dp"]["calls_per_step"]
+    if j["dp"]["dp_mode"] == 2:
+        assert j["dp"]["dp_mode_requested"] == "auto" and j["dp"]["overlap_buckets"]
+        # (the host transport of this test runs a bucket through msk_dp_allreduce_sum on the compute stream: tag rccl_allreduce;
+        # on RCCL the same buckets are tagged rccl_allreduce_bucket)
+        assert calls["rccl_allreduce"] + calls["rccl_allreduce_bucket"] == j["dp"]["buckets_last_step"] >= 2
+    else:
+        assert j["dp"]["dp_mode"] == 0 and calls["rccl_allreduce"] == 1
+    assert j["dp"]["exposed_comm_ms_per_step"] is not None and j["dp"]["compute_only_ms_per_step"] > 0
