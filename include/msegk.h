@@ -88,6 +88,11 @@ int msk_timer_stop(msk_ctx* ctx, float* ms);     /* records + synchronises; elap
  * run without a host synchronisation inside it (the reference's per-iteration batch_cost, core/train.py:172-173)        */
 int msk_mark(msk_ctx* ctx, int idx /* 0..1023 */);
 int msk_mark_elapsed(msk_ctx* ctx, int a, int b, float* ms);   /* waits for mark b */
+/* ctx's compute stream waits (on the device, no host synchronisation) for everything enqueued so far on `other`'s compute
+ * stream.  A second context = a second stream: the in-loop preprocessing of the NEXT sample (pinned H2D -> normalise ->
+ * resample, tools/prepare_mri_spine_seg.py:71-80) runs there beside the training step and is handed over with two of these
+ * (tools/bench_workloads.py --inloop-preprocess).  Both contexts must be on the same device. */
+int msk_ctx_wait(msk_ctx* ctx, msk_ctx* other);
 /* per-kernel profile: when enabled every launch is bracketed by events and its
  * duration accumulated under the kernel's tag. */
 int msk_prof_enable(msk_ctx* ctx, int on);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "msk_timer_start": (_i, [_vp]),
     "msk_timer_stop": (_i, [_vp, C.POINTER(_f)]),
     "msk_mark": (_i, [_vp, _i]),
+    "msk_ctx_wait": (_i, [_vp, _vp]),
     "msk_mark_elapsed": (_i, [_vp, _i, _i, C.POINTER(_f)]),
     "msk_prof_enable": (_i, [_vp, _i]),
     "msk_prof_reset": (_i, [_vp]),

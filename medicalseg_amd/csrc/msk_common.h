@@ -38,6 +38,7 @@ struct msk_ctx {
   long wbf_pad_min_voxels = 1L << 18;  // option "wbf_pad_min_voxels"
   // timing
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t ev_xctx = nullptr;   // msk_ctx_wait: recorded on ANOTHER context's stream, waited for on this one's
   // profiling
   bool prof = false;
   std::map<std::string, msk_prof_entry> prof_map;
@@ -63,11 +64,16 @@ struct msk_ctx {
   long wgrad_async_max_m = 0;  // side stream only for weight gradients over <= this many voxels (0 = all)
   float* scalar_ring = nullptr;  // 1024 device floats handed out round-robin (msk_scalar_slots): amax scalars of the NP = 2 pipelines
   int scalar_next = 0;
+  long scalar_served = 0;            // arrays handed out from this ring so far (msk_get_option "scalar_ring_served": the host checks a step's requests against the ring, advisor round 4)
   float* scalar_ring_side = nullptr;  // the weight-gradient stream's own ring (swapped with the stream)
   int scalar_next_side = 0;
+  long scalar_served_side = 0;
   int wbf_tpb = 0;            // wbf_gemm_k: tiles per workgroup (0 = 1)
   void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
   int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
+  void* spack = nullptr;      // packed-weight cache of the other convolution kernels (msk_conv.hip: SmallPackCache)
+  int noop_after_merge = 0;   // debug option "noop_after_merge": that many empty launches behind every merge kernel (what a 5-us launch costs the step)
+  int small_pack_cache = 1;   // option "small_pack_cache": 0 = those kernels pack into the shared scratch on every call (A/B)
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
   int ks_legacy = 0;          // option "ks_legacy" (A/B): bit 0 = one-tap-per-tile k == s weight gradient, bit 1 = fragment-shaped k == s scatter kernel
   int wgrad_fork = 1;         // fused LUConv backward: 1 = the weight gradient forks after the data-gradient GEMM is enqueued (it then overlaps the HBM-bound passes of the next layer instead of stretching that GEMM by 30 %: -0.25 ms per step), 0 = right after the dual transform
@@ -146,6 +152,10 @@ void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes);  // msk_
 int msk_wbf_prepack_impl(msk_ctx* ctx);   // rebuild every stale packed-weight row in use (end of the optimizer kernels)
 int msk_wbf_prepack_range_impl(msk_ctx* ctx, const void* p, size_t bytes);   // the stale rows inside [p, p + bytes), current stream
 void msk_wbf_pack_cache_free(msk_ctx* ctx);
+void msk_small_pack_changed(msk_ctx* ctx, const void* p, size_t bytes);   // SmallPackCache hooks (msk_conv.hip), called by the *_impl functions above
+void msk_small_pack_freed(msk_ctx* ctx, const void* p, size_t bytes);
+int msk_small_prepack(msk_ctx* ctx, const void* p, size_t bytes);        // p == nullptr: every stale row in use
+void msk_small_pack_free(msk_ctx* ctx);
 int msk_dp_wait_impl(msk_ctx* ctx);
 
 // Redirect launches of the enclosed scope to the side stream (with its own scratch) after making
@@ -166,6 +176,7 @@ struct msk_side_scope {
     std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
     std::swap(ctx->scalar_ring, ctx->scalar_ring_side);
     std::swap(ctx->scalar_next, ctx->scalar_next_side);
+    std::swap(ctx->scalar_served, ctx->scalar_served_side);
     ctx->side_dirty = true;
   }
   ~msk_side_scope() {
@@ -177,6 +188,7 @@ struct msk_side_scope {
     std::swap(ctx->ws3_bytes, ctx->ws3_side_bytes);
     std::swap(ctx->scalar_ring, ctx->scalar_ring_side);
     std::swap(ctx->scalar_next, ctx->scalar_next_side);
+    std::swap(ctx->scalar_served, ctx->scalar_served_side);
   }
 };
 

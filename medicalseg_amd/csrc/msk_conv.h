@@ -69,6 +69,12 @@ struct WGrad {
 int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps,
                      int kd, int kh, int kw, int mfma, int K, int N, int KC, int npad, float* out);
 
+// Cached packed images (round 5, msk_conv.hip SmallPackCache): same layouts, a persistent image per (weights, layout) that the
+// optimizer kernels rebuild in one launch; nullptr on failure (msk_pack_scatter_get: also with option "small_pack_cache" 0)
+const float* msk_pack_weights_get(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps, int kd, int kh,
+                                  int kw, int mfma, int K, int N, int KC, int npad);
+const float* msk_pack_scatter_get(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int CK, int CN, int KC, int jpad);
+
 // MFMA kernels (msk_conv_mfma.hip).  Return 1 if the problem was handled, 0 if not eligible,
 // <0 on error.
 int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);

@@ -13,41 +13,200 @@ constexpr int kThreads = 256;
 // ---------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------
+// one element of a packed weight image (layouts: msk_conv.h)
+__device__ __forceinline__ float pack_weights_elem(const float* __restrict__ w, int B, int taps, int swap, int flip, int kd, int kh,
+                                                   int kw, int mfma, int K, int N, int KC, int npad, long idx) {
+  int tap, k, n;
+  if (mfma) {
+    // idx = ((((tap*KC + kc)*2 + h)*npad + n)*4 + q)
+    int q = (int)(idx & 3);
+    long r = idx >> 2;
+    n = (int)(r % npad);
+    r /= npad;
+    int h = (int)(r & 1);
+    r >>= 1;
+    int kc = (int)(r % KC);
+    tap = (int)(r / KC);
+    k = kc * 8 + h * 4 + q;
+  } else {
+    const int NP = npad > 0 ? npad : N;  // direct layout with a padded row pitch (columns >= N are zero)
+    n = (int)(idx % NP);
+    long r = idx / NP;
+    k = (int)(r % K);
+    tap = (int)(r / K);
+  }
+  float v = 0.f;
+  if (k < K && n < N) {
+    int st = tap;
+    if (flip) {
+      int a = tap / (kh * kw), b = (tap / kw) % kh, c = tap % kw;
+      st = ((kd - 1 - a) * kh + (kh - 1 - b)) * kw + (kw - 1 - c);
+    }
+    int ia = swap ? n : k, ib = swap ? k : n;  // w[a][b][tap]
+    v = w[((long)ia * B + ib) * taps + st];
+  }
+  return v;
+}
+
 __global__ void __launch_bounds__(kThreads)
 pack_weights_k(const float* __restrict__ w, int A, int B, int taps, int swap, int flip, int kd, int kh,
                int kw, int mfma, int K, int N, int KC, int npad, float* __restrict__ out, long total) {
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int tap, k, n;
-    if (mfma) {
-      // idx = ((((tap*KC + kc)*2 + h)*npad + n)*4 + q)
-      int q = (int)(idx & 3);
-      long r = idx >> 2;
-      n = (int)(r % npad);
-      r /= npad;
-      int h = (int)(r & 1);
-      r >>= 1;
-      int kc = (int)(r % KC);
-      tap = (int)(r / KC);
-      k = kc * 8 + h * 4 + q;
+  (void)A;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    out[idx] = pack_weights_elem(w, B, taps, swap, flip, kd, kh, kw, mfma, K, N, KC, npad, idx);
+}
+
+// ---------------------------------------------------------------------------
+// Round 5: the packed images of the non-Winograd kernels are CACHED (the Winograd pipelines have had WbfPackCache since round 3).
+// Every call of a kernel == stride convolution, a gather kernel or a 1x1x1 head used to launch its own 5-us pack kernel in
+// front of the convolution: 20 launches per VNet step on the compute stream.  A row = (canonical weight pointer, layout
+// parameters) -> persistent device image; rows go stale through the same hooks as the Winograd rows (msk_weights_changed_impl /
+// msk_weights_freed_impl) and are rebuilt TOGETHER, one launch over a device-side descriptor table (blockIdx.y = row), where
+// the Winograd rows are: at the end of the optimizer kernels (msk_wbf_prepack_impl; per slice on the optimizer's stream in the
+// eager form, msk_wbf_prepack_range_impl).  A row that is still stale when a convolution asks for it is rebuilt alone, on the
+// asking stream.  kind 0: pack_weights_k layouts; kind 1: the scatter layout Bf[kc][h][jpad][4] (msk_conv_scatter.hip).
+// ---------------------------------------------------------------------------
+struct SmallPackDesc {
+  const float* w;
+  float* out;
+  long total;      // elements (kind 0: floats, kind 1: float4)
+  int kind, A, B, taps, swap, flip, kd, kh, kw, mfma, K, N, KC, npad;
+};
+struct SmallPackList {
+  int n;
+  unsigned char rows[60];
+};
+struct SmallPackEntry {
+  SmallPackDesc d{};
+  size_t bytes = 0;
+  bool live = false, valid = false;
+  long last_use = 0;
+};
+struct SmallPackCache {
+  static constexpr int kRows = 128;
+  SmallPackEntry e[kRows];
+  SmallPackDesc* table = nullptr;   // device copy of the descriptors
+  long tick = 0;
+};
+
+__global__ void small_pack_desc_store_k(SmallPackDesc* slot, SmallPackDesc d) { *slot = d; }
+
+__global__ void __launch_bounds__(kThreads)
+small_pack_batch_k(const SmallPackDesc* __restrict__ table, SmallPackList l) {
+  const SmallPackDesc d = table[l.rows[blockIdx.y]];
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < d.total; idx += (long)gridDim.x * blockDim.x) {
+    if (d.kind == 0) {
+      d.out[idx] = pack_weights_elem(d.w, d.B, d.taps, d.swap, d.flip, d.kd, d.kh, d.kw, d.mfma, d.K, d.N, d.KC, d.npad, idx);
     } else {
-      const int NP = npad > 0 ? npad : N;  // direct layout with a padded row pitch (columns >= N are zero)
-      n = (int)(idx % NP);
-      long r = idx / NP;
-      k = (int)(r % K);
-      tap = (int)(r / K);
-    }
-    float v = 0.f;
-    if (k < K && n < N) {
-      int st = tap;
-      if (flip) {
-        int a = tap / (kh * kw), b = (tap / kw) % kh, c = tap % kw;
-        st = ((kd - 1 - a) * kh + (kh - 1 - b)) * kw + (kw - 1 - c);
+      // Bf[kc][h][jpad][4]: k = kc*8 + h*4 + q, j = tap*CN + cn (zero padded to jpad = d.npad, K = CK to 8*KC)
+      const int jpad = d.npad;
+      const int j = (int)(idx % jpad);
+      const int h = (int)((idx / jpad) & 1);
+      const int kc = (int)(idx / (2L * jpad));
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (j < d.taps * d.N) {
+        const int tap = j / d.N, n = j % d.N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = kc * 8 + h * 4 + q;
+          if (k < d.K) {
+            const int ia = d.swap ? n : k, ib = d.swap ? k : n;  // canonical w[a][b][tap]
+            v[q] = d.w[((long)ia * d.B + ib) * d.taps + tap];
+          }
+        }
       }
-      int ia = swap ? n : k, ib = swap ? k : n;  // w[a][b][tap]
-      v = w[((long)ia * B + ib) * taps + st];
+      reinterpret_cast<float4*>(d.out)[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    out[idx] = v;
   }
+}
+
+bool small_pack_same(const SmallPackDesc& a, const SmallPackDesc& b) {
+  return a.w == b.w && a.kind == b.kind && a.A == b.A && a.B == b.B && a.taps == b.taps && a.swap == b.swap && a.flip == b.flip &&
+         a.kd == b.kd && a.kh == b.kh && a.kw == b.kw && a.mfma == b.mfma && a.K == b.K && a.N == b.N && a.KC == b.KC &&
+         a.npad == b.npad;
+}
+
+int small_pack_build(msk_ctx* ctx, SmallPackCache* c, const std::vector<int>& rows) {
+  for (size_t i0 = 0; i0 < rows.size(); i0 += sizeof(SmallPackList::rows)) {
+    SmallPackList l{};
+    long most = 0;
+    for (size_t i = i0; i < rows.size() && l.n < (int)sizeof(l.rows); ++i) {
+      l.rows[l.n++] = (unsigned char)rows[i];
+      if (c->e[rows[i]].d.total > most) most = c->e[rows[i]].d.total;
+    }
+    long gx = (most + kThreads - 1) / kThreads;
+    if (gx > 2L * ctx->num_cu) gx = 2L * ctx->num_cu;
+    if (gx < 1) gx = 1;
+    msk_launch_scope ls(ctx, "pack_weights_batch");
+    hipLaunchKernelGGL(small_pack_batch_k, dim3((unsigned)gx, (unsigned)l.n), dim3(kThreads), 0, ctx->stream, c->table, l);
+    MSK_LAUNCH_CHECK(ctx);
+    for (int i = 0; i < l.n; ++i) c->e[l.rows[i]].valid = true;
+  }
+  return 0;
+}
+
+// the cached image of a row (created on first use); nullptr on failure (error set)
+const float* small_pack_get(msk_ctx* ctx, SmallPackDesc key, size_t bytes) {
+  if (!ctx->spack) {
+    SmallPackCache* nc = new SmallPackCache();
+    if (hipMalloc((void**)&nc->table, sizeof(SmallPackDesc) * SmallPackCache::kRows) != hipSuccess) {
+      delete nc;
+      msk_fail(ctx, __FILE__, __LINE__, "small_pack_get", "hipMalloc failed");
+      return nullptr;
+    }
+    ctx->spack = nc;
+  }
+  SmallPackCache* c = (SmallPackCache*)ctx->spack;
+  c->tick += 1;
+  int row = -1, free_row = -1, lru = -1;
+  for (int r = 0; r < SmallPackCache::kRows; ++r) {
+    SmallPackEntry& e = c->e[r];
+    if (!e.live) {
+      if (free_row < 0) free_row = r;
+      continue;
+    }
+    if (small_pack_same(e.d, key)) {
+      row = r;
+      break;
+    }
+    if (lru < 0 || e.last_use < c->e[lru].last_use) lru = r;
+  }
+  if (row < 0) {
+    row = free_row >= 0 ? free_row : lru;
+    SmallPackEntry& e = c->e[row];
+    // a row keeps its image's allocation across tenants (stream order protects a reused image: it is rewritten on the stream
+    // whose kernels read it, or behind that stream's tail); a larger one is allocated behind everything in flight
+    float* out = e.d.out;
+    if (out && e.bytes < bytes) {
+      hipStreamSynchronize(ctx->stream);
+      if (ctx->side) hipStreamSynchronize(ctx->side);
+      hipFree(out);
+      out = nullptr;
+      e.d.out = nullptr;
+      e.bytes = 0;
+    }
+    if (!out) {
+      if (hipMalloc((void**)&out, bytes) != hipSuccess) {
+        e.live = false;
+        msk_fail(ctx, __FILE__, __LINE__, "small_pack_get", "hipMalloc failed");
+        return nullptr;
+      }
+      e.bytes = bytes;
+    }
+    e.d = key;
+    e.d.out = out;
+    e.live = true;
+    e.valid = false;
+    hipLaunchKernelGGL(small_pack_desc_store_k, dim3(1), dim3(1), 0, ctx->stream, c->table + row, e.d);
+    if (hipGetLastError() != hipSuccess) {
+      msk_fail(ctx, __FILE__, __LINE__, "small_pack_get", "kernel launch");
+      return nullptr;
+    }
+  }
+  SmallPackEntry& e = c->e[row];
+  e.last_use = c->tick;
+  if (!e.valid && small_pack_build(ctx, c, std::vector<int>{row}) != 0) return nullptr;
+  return e.d.out;
 }
 
 // ---------------------------------------------------------------------------
@@ -704,9 +863,8 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
   const int taps = g.kd * g.kh * g.kw;
   if (ctx->conv_impl != 1 && ctx->conv_impl != 4 && taps == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 &&
       g.ph == 0 && g.pw == 0 && g.CK <= 8 && g.CN <= 8) {
-    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    const float* wp1 = msk_pack_weights_get(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0);
     if (!wp1) return -1;
-    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_small");
     hipLaunchKernelGGL(pointwise_small_k, dim3(grid_for(M, ctx->num_cu)), dim3(kThreads), 0, ctx->stream, g, (const float*)wp1);
@@ -717,9 +875,8 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
       g.pw == 0 && ((g.CN <= 4 && g.CK > 8 && g.CK <= 32 && g.CK % 4 == 0 && g.sld % 4 == 0 && (((uintptr_t)g.src) & 15) == 0) ||
                     (g.CK <= 4 && g.CN > 8 && g.CN <= 32 && g.CN % 4 == 0 && g.dld % 4 == 0 && (((uintptr_t)g.dst) & 15) == 0))) {
     // thick <-> thin 1x1x1 (the 32 -> ncls head of UNet3D and its data gradient): streaming VALU kernel; 6 = A/B: the general gather kernel
-    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    const float* wp1 = msk_pack_weights_get(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0);
     if (!wp1) return -1;
-    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_thin");
     const int thick = g.CN <= 4 ? g.CK : g.CN;
@@ -739,9 +896,8 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
       g.pw == 0 && g.CK <= 32 && g.CN <= 32 && g.CK % 4 == 0 && g.CN % 4 == 0 && g.sld % 4 == 0 && g.dld % 4 == 0 &&
       (((uintptr_t)g.src) & 15) == 0 && (((uintptr_t)g.dst) & 15) == 0 && (!g.bias || (((uintptr_t)g.bias) & 15) == 0)) {
     // 1x1x1 with 12 .. 32 channels (the 20-class heads): streaming VALU kernel; 6 = A/B: the general gather kernel
-    float* wp1 = (float*)msk_workspace2(ctx, (size_t)g.CK * g.CN * sizeof(float));
+    const float* wp1 = msk_pack_weights_get(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0);
     if (!wp1) return -1;
-    if (msk_pack_weights(ctx, w, A, B, 1, swap, 0, 1, 1, 1, 0, g.CK, g.CN, 0, 0, wp1) != 0) return -1;
     const long M = (long)g.N * g.DD * g.DH * g.DW;
     msk_launch_scope ls(ctx, "pointwise_mid");
     const int cmax = g.CK > g.CN ? g.CK : g.CN;
@@ -818,9 +974,8 @@ int run_gconv_dispatch(msk_ctx* ctx, GConv g, const float* w, int A, int B, int 
   // reference path
   g.flip = 0;
   const long wn = (long)taps * g.CK * g.CN;
-  float* wp = (float*)msk_workspace2(ctx, wn * sizeof(float));
+  const float* wp = msk_pack_weights_get(ctx, w, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 0, g.CK, g.CN, 0, 0);
   if (!wp) return -1;
-  if (msk_pack_weights(ctx, w, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 0, g.CK, g.CN, 0, 0, wp) != 0) return -1;
   const long total = (long)g.N * g.DD * g.DH * g.DW * g.CN;
   if (ctx->prof && ctx->prof_shapes) {
     char buf[160];
@@ -951,6 +1106,88 @@ int msk_pack_weights(msk_ctx* ctx, const float* w, int A, int B, int taps, int s
                      swap, flip_taps, kd, kh, kw, mfma, K, N, KC, npad, out, total);
   MSK_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+// Cached form of msk_pack_weights (see SmallPackCache above): the packed image of (w, layout); option "small_pack_cache" 0 =
+// pack into the shared scratch on every call (A/B, the round-4 behaviour).  nullptr on failure.
+const float* msk_pack_weights_get(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int flip_taps, int kd, int kh,
+                                  int kw, int mfma, int K, int N, int KC, int npad) {
+  const long total = mfma ? (long)taps * KC * 2 * npad * 4 : (long)taps * K * (npad > 0 ? npad : N);
+  if (!ctx->small_pack_cache) {
+    float* out = (float*)msk_workspace2(ctx, (size_t)total * sizeof(float));
+    if (!out) return nullptr;
+    return msk_pack_weights(ctx, w, A, B, taps, swap, flip_taps, kd, kh, kw, mfma, K, N, KC, npad, out) == 0 ? out : nullptr;
+  }
+  SmallPackDesc d{};
+  d.w = w; d.total = total; d.kind = 0; d.A = A; d.B = B; d.taps = taps; d.swap = swap; d.flip = flip_taps;
+  d.kd = kd; d.kh = kh; d.kw = kw; d.mfma = mfma; d.K = K; d.N = N; d.KC = KC; d.npad = npad;
+  return small_pack_get(ctx, d, (size_t)total * sizeof(float));
+}
+// the scatter layout of msk_conv_scatter.hip, cached the same way (the caller packs itself when this returns nullptr with the cache off)
+const float* msk_pack_scatter_get(msk_ctx* ctx, const float* w, int A, int B, int taps, int swap, int CK, int CN, int KC, int jpad) {
+  if (!ctx->small_pack_cache) return nullptr;
+  SmallPackDesc d{};
+  d.w = w; d.total = (long)KC * 2 * jpad; d.kind = 1; d.A = A; d.B = B; d.taps = taps; d.swap = swap;
+  d.K = CK; d.N = CN; d.KC = KC; d.npad = jpad;
+  return small_pack_get(ctx, d, (size_t)d.total * 4 * sizeof(float));
+}
+void msk_small_pack_changed(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->spack || !p) return;
+  SmallPackCache* c = (SmallPackCache*)ctx->spack;
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  for (int r = 0; r < SmallPackCache::kRows; ++r) {
+    SmallPackEntry& e = c->e[r];
+    if (!e.live) continue;
+    const char* b0 = (const char*)e.d.w;
+    const char* b1 = b0 + (size_t)e.d.A * e.d.B * e.d.taps * sizeof(float);
+    if (a0 < b1 && b0 < a1) e.valid = false;
+  }
+}
+void msk_small_pack_freed(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->spack || !p) return;
+  SmallPackCache* c = (SmallPackCache*)ctx->spack;
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  for (int r = 0; r < SmallPackCache::kRows; ++r) {
+    SmallPackEntry& e = c->e[r];
+    if (!e.live) continue;
+    const char* b0 = (const char*)e.d.w;
+    const char* b1 = b0 + (size_t)e.d.A * e.d.B * e.d.taps * sizeof(float);
+    if (bytes ? (a0 < b1 && b0 < a1) : b0 == a0) {   // the image stays allocated for the row's next tenant
+      e.live = false;
+      e.valid = false;
+      e.d.w = nullptr;
+    }
+  }
+}
+// rebuild the stale rows in use (all of them, or those whose weights lie wholly inside [p, p + bytes)) in one launch on the current stream
+int msk_small_prepack(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->spack) return 0;
+  SmallPackCache* c = (SmallPackCache*)ctx->spack;
+  const char* a0 = (const char*)p;
+  const char* a1 = a0 + bytes;
+  std::vector<int> rows;
+  for (int r = 0; r < SmallPackCache::kRows; ++r) {
+    const SmallPackEntry& e = c->e[r];
+    if (!e.live || e.valid || e.last_use + 4096 < c->tick) continue;   // rows nothing has asked for in a long while wait for their next use
+    if (p) {
+      const char* b0 = (const char*)e.d.w;
+      const char* b1 = b0 + (size_t)e.d.A * e.d.B * e.d.taps * sizeof(float);
+      if (!(b0 >= a0 && b1 <= a1)) continue;
+    }
+    rows.push_back(r);
+  }
+  return rows.empty() ? 0 : small_pack_build(ctx, c, rows);
+}
+void msk_small_pack_free(msk_ctx* ctx) {
+  if (!ctx->spack) return;
+  SmallPackCache* c = (SmallPackCache*)ctx->spack;
+  for (int r = 0; r < SmallPackCache::kRows; ++r)
+    if (c->e[r].d.out) hipFree(c->e[r].d.out);
+  if (c->table) hipFree(c->table);
+  delete c;
+  ctx->spack = nullptr;
 }
 
 // float4 variant (CB % 4 == 0): a lane owns 4 consecutive cb of one (tap, ca) row -> 1 KiB per wavefront load,

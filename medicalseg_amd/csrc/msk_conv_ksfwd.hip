@@ -250,9 +250,8 @@ int msk_gconv_kst(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int
   const int taps = g.kd * g.kh * g.kw;
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
-  float* wm = (float*)msk_workspace2(ctx, (size_t)taps * KC * 2 * npad * 4 * sizeof(float));
+  const float* wm = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad);
   if (!wm) return -1;
-  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
   const int ntn = npad / 32;
   const long wpc = (per_class + 31) / 32;                 // wavefronts per parity class
   const bool pair = g.CN <= 16 && g.kh == 2 && g.sh == 2 && ctx->kst_pair;
@@ -299,9 +298,8 @@ int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, 
   if (sbytes >= 0xFFFFFFF0ull || M >= (1L << 31)) return 0;
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
-  float* wm = (float*)msk_workspace2(ctx, (size_t)taps * KC * 2 * npad * 4 * sizeof(float));
+  const float* wm = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad);
   if (!wm) return -1;
-  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
   const int ntn = npad / 32;
   const long mtiles = (M + 127) / 128;
   // N tiles per workgroup: as many as divide ntn (x is then read once), fewer when the grid would not fill the GPU

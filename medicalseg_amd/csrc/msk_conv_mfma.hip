@@ -1061,9 +1061,8 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   const bool valu_out = ks == 5 && g.CK == 32 && g.CN >= 1 && g.CN <= 4;   // out_tr.conv1 forward
   const bool valu_outT = ks == 5 && g.CN == 32 && g.CK >= 1 && g.CK <= 4;  // out_tr.conv1 data gradient
   if (valu_in || valu_out || valu_outT) {
-    float* wp = (float*)msk_workspace2(ctx, (size_t)taps * g.CK * g.CN * sizeof(float));
+    const float* wp = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, flip, ks, ks, ks, 0, g.CK, g.CN, 0, 0);
     if (!wp) return -1;
-    if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, flip, ks, ks, ks, 0, g.CK, g.CN, 0, 0, wp) != 0) return -1;
     HaloArgs a{};
     a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
     a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW;
@@ -1093,9 +1092,8 @@ int msk_gconv_halo_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int 
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
   const size_t wbytes = (size_t)taps * KC * 2 * npad * 4 * sizeof(float);
-  float* wm = (float*)msk_workspace2(ctx, wbytes);
+  const float* wm = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, flip, ks, ks, ks, 1, g.CK, g.CN, KC, npad);
   if (!wm) return -1;
-  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, flip, ks, ks, ks, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
 
   HaloArgs a{};
   a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
@@ -1150,9 +1148,8 @@ int msk_gconv_gather_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, in
   const int taps = g.kd * g.kh * g.kw;
   const int KC = (g.CK + 7) / 8;
   const int npad = ((g.CN + 31) / 32) * 32;
-  float* wm = (float*)msk_workspace2(ctx, (size_t)taps * KC * 2 * npad * 4 * sizeof(float));
+  const float* wm = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad);
   if (!wm) return -1;
-  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, 0, g.kd, g.kh, g.kw, 1, g.CK, g.CN, KC, npad, wm) != 0) return -1;
   const int ntn = npad / 32;
   const int NR = (ntn == 1 || ntn == 2 || ntn == 4 || ntn == 8) ? ntn : 1;
   const int cs_d = g.transposed ? g.sd : 1, cs_h = g.transposed ? g.sh : 1, cs_w = g.transposed ? g.sw : 1;

@@ -263,14 +263,17 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   if (M < 16384 && ctx->conv_impl != 7) return 0;
   const int KC = (g.CK + 7) / 8;
   const int jpad = ((taps * g.CN + 31) / 32) * 32;
-  float4* bf = (float4*)msk_workspace2(ctx, (size_t)KC * 2 * jpad * sizeof(float4));
-  if (!bf) return -1;
-  {
+  const float4* bf = (const float4*)msk_pack_scatter_get(ctx, w_canon, A, B, taps, swap, g.CK, g.CN, KC, jpad);   // cached image (round 5)
+  if (!bf && ctx->small_pack_cache) return -1;
+  if (!bf) {
+    float4* bfw = (float4*)msk_workspace2(ctx, (size_t)KC * 2 * jpad * sizeof(float4));
+    if (!bfw) return -1;
+    bf = bfw;
     msk_launch_scope ls(ctx, "pack_weights_scatter");
     long blocks = ((long)KC * 2 * jpad + 255) / 256;
     if (blocks > 4L * ctx->num_cu) blocks = 4L * ctx->num_cu;
     hipLaunchKernelGGL(pack_scatter_weights_k, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, w_canon, A, B, taps, swap,
-                       g.CK, g.CN, KC, jpad, bf);
+                       g.CK, g.CN, KC, jpad, bfw);
     MSK_LAUNCH_CHECK(ctx);
   }
   const char* tag = "convT_scatter_mfma";

@@ -160,9 +160,8 @@ int msk_gconv_halo_valu2(msk_ctx* ctx, const GConv& g, const float* w_canon, int
   // CN = 3 runs as 4 columns with a zero one: measured 1.69 ms vs 1.85 ms for the odd-width instantiation
   // (pairs of output channels map straight onto v_pk_fma_f32)
   const int cw = g.CN == 3 ? 4 : g.CN;
-  float* wp = (float*)msk_workspace2(ctx, (size_t)taps * g.CK * cw * sizeof(float));
+  const float* wp = msk_pack_weights_get(ctx, w_canon, A, B, taps, swap, g.transposed ? 1 : 0, ks, ks, ks, 0, g.CK, g.CN, 0, cw);
   if (!wp) return -1;
-  if (msk_pack_weights(ctx, w_canon, A, B, taps, swap, g.transposed ? 1 : 0, ks, ks, ks, 0, g.CK, g.CN, 0, cw, wp) != 0) return -1;
   V2Args a{};
   a.src = g.src; a.sld = g.sld; a.dst = g.dst; a.dld = g.dld;
   a.N = g.N; a.D = g.DD; a.H = g.DH; a.W = g.DW; a.CNout = g.CN;

@@ -1825,6 +1825,7 @@ bool msk_gconv_wino_bf3_accepts(msk_ctx* ctx, const GConv& g) { return wino_bf3_
 
 // ---- packed-weight cache: invalidation and the batched rebuild (see WbfPackCache above)
 void msk_weights_changed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
+  msk_small_pack_changed(ctx, p, bytes);
   if (!ctx->wpack || !p) return;
   WbfPackCache* c = (WbfPackCache*)ctx->wpack;
   const char* a0 = (const char*)p;
@@ -1841,6 +1842,7 @@ void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
   // msk_free: every row whose weights lie (even partly) inside the freed allocation [p, p + bytes) is DROPPED -- a row that
   // was only invalidated would be rebuilt by the next optimizer call (msk_wbf_prepack_impl) from freed memory, and its
   // packed buffer would stay allocated until the LRU evicts it.  bytes == 0 (range unknown): the rows that begin at p.
+  msk_small_pack_freed(ctx, p, bytes);
   if (!ctx->wpack || !p) return;
   WbfPackCache* c = (WbfPackCache*)ctx->wpack;
   const char* a0 = (const char*)p;
@@ -1854,6 +1856,7 @@ void msk_weights_freed_impl(msk_ctx* ctx, const void* p, size_t bytes) {
   }
 }
 int msk_wbf_prepack_impl(msk_ctx* ctx) {
+  if (ctx->wbf_prepack && msk_small_prepack(ctx, nullptr, 0) != 0) return -1;
   if (!ctx->wpack || !ctx->wbf_prepack) return 0;
   WbfPackCache* c = (WbfPackCache*)ctx->wpack;
   std::vector<int> rows;
@@ -1867,6 +1870,7 @@ int msk_wbf_prepack_impl(msk_ctx* ctx) {
 // the rows whose weights lie inside [p, p + bytes) only, on the CURRENT stream; the use epoch does not advance
 // (msk_sgd_momentum_eager: one call per block of the model, msk_wbf_prepack_impl closes the step)
 int msk_wbf_prepack_range_impl(msk_ctx* ctx, const void* p, size_t bytes) {
+  if (ctx->wbf_prepack && p && msk_small_prepack(ctx, p, bytes) != 0) return -1;
   if (!ctx->wpack || !ctx->wbf_prepack || !p) return 0;
   WbfPackCache* c = (WbfPackCache*)ctx->wpack;
   const char* a0 = (const char*)p;

@@ -174,7 +174,9 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   drain_prof(ctx);
   for (auto e : ctx->event_pool) hipEventDestroy(e);
   for (auto e : ctx->marks) if (e) hipEventDestroy(e);
+  if (ctx->ev_xctx) hipEventDestroy(ctx->ev_xctx);
   msk_wbf_pack_cache_free(ctx);
+  msk_small_pack_free(ctx);
   if (ctx->ws) hipFree(ctx->ws);
   if (ctx->ws2) hipFree(ctx->ws2);
   if (ctx->ws3) hipFree(ctx->ws3);
@@ -334,6 +336,15 @@ int msk_mark(msk_ctx* ctx, int idx) {
   MSK_CHECK_HIP(ctx, hipEventRecord(ctx->marks[idx], ctx->stream));
   return 0;
 }
+int msk_ctx_wait(msk_ctx* ctx, msk_ctx* other) {
+  MSK_REQUIRE(ctx, other != nullptr && other->device == ctx->device, "msk_ctx_wait: two contexts on the same device");
+  if (other == ctx) return 0;
+  MSK_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->ev_xctx) MSK_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_xctx, hipEventDisableTiming));
+  MSK_CHECK_HIP(ctx, hipEventRecord(ctx->ev_xctx, other->stream));
+  MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_xctx, 0));
+  return 0;
+}
 int msk_mark_elapsed(msk_ctx* ctx, int a, int b, float* ms) {
   MSK_REQUIRE(ctx, a >= 0 && b >= 0 && a < (int)ctx->marks.size() && b < (int)ctx->marks.size() && ctx->marks[a] && ctx->marks[b],
               "mark not recorded");
@@ -376,6 +387,11 @@ int msk_get_option(msk_ctx* ctx, const char* key, int* value) {
   else if (strcmp(key, "wgrad_async") == 0) *value = ctx->wgrad_async ? 1 : 0;
   else if (strcmp(key, "world") == 0) *value = ctx->world;
   else if (strcmp(key, "rank") == 0) *value = ctx->rank;
+  // amax arrays handed out so far by the compute stream's ring / the weight-gradient stream's ring (modulo 2^30): an array is
+  // zeroed again 512 requests after it was handed out -- a holder that spans a whole step (Tensor.amax: forward -> weight
+  // gradient) is safe while a step stays under that (device.Arena.reset checks)
+  else if (strcmp(key, "scalar_ring_served") == 0) *value = (int)(ctx->scalar_served & 0x3FFFFFFF);
+  else if (strcmp(key, "scalar_ring_served_side") == 0) *value = (int)(ctx->scalar_served_side & 0x3FFFFFFF);
   else return msk_fail(ctx, __FILE__, __LINE__, "msk_get_option", "unknown key");
   return 0;
 }
@@ -426,6 +442,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wbf_pack_cache") == 0) {  // 0 = pack the weights of the Winograd pipelines on every call (A/B)
     ctx->wbf_pack_cache = value;
+    return 0;
+  }
+  if (strcmp(key, "noop_after_merge") == 0) {  // debug: empty launches behind every bn_stats_merge / sums_merge (measures the price of a tiny launch in the step)
+    ctx->noop_after_merge = value;
+    return 0;
+  }
+  if (strcmp(key, "small_pack_cache") == 0) {  // 0 = the non-Winograd kernels pack their weights on every call (A/B; msk_conv.hip SmallPackCache)
+    ctx->small_pack_cache = value;
     return 0;
   }
   if (strcmp(key, "wbf_prepack") == 0) {  // 0 = stale packed weights are rebuilt lazily at their next use only

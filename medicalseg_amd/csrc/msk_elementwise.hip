@@ -393,6 +393,10 @@ affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restric
     if (!res) return make_float4(0.f, 0.f, 0.f, 0.f);
     if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
     const float* r = res + v * ldr;
+    if (cres == 1) {  // in_tr: the tiled one-channel input (vnet.py:76-78) -- one load, not four modulo-indexed ones
+      const float r0 = r[0];
+      return make_float4(r0, r0, r0, r0);
+    }
     return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
   };
   auto body = [&](long v, const float4 xq, const float4 rq) {
@@ -571,6 +575,10 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
       if (!res) return make_float4(0.f, 0.f, 0.f, 0.f);
       if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
       const float* r = res + v * ldr;
+      if (cres == 1) {  // in_tr: the tiled one-channel input (vnet.py:76-78) -- one load, not four modulo-indexed ones
+        const float r0 = r[0];
+        return make_float4(r0, r0, r0, r0);
+      }
       return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
     };
     long v = v0 + vl;
@@ -746,6 +754,10 @@ affine_act_bwd_apply_cs_k(const float* __restrict__ x, int ldx, const float* __r
     if (!need_res) return make_float4(0.f, 0.f, 0.f, 0.f);
     if (cres == C) return *reinterpret_cast<const float4*>(res + v * ldr + c);
     const float* r = res + v * ldr;
+    if (cres == 1) {  // in_tr: the tiled one-channel input (vnet.py:76-78) -- one load, not four modulo-indexed ones
+      const float r0 = r[0];
+      return make_float4(r0, r0, r0, r0);
+    }
     return make_float4(r[c % cres], r[(c + 1) % cres], r[(c + 2) % cres], r[(c + 3) % cres]);
   };
   auto body = [&](long v, const float4 xq, const float4 dq, const float4 rq) {
@@ -992,10 +1004,18 @@ int msk_ndhwc_to_ncdhw(msk_ctx* ctx, msk_tensor src, float* dst) {
 
 }  // extern "C"
 
+namespace {
+__global__ void noop_k() {}
+inline void noop_launches(msk_ctx* ctx) {
+  for (int i = 0; i < ctx->noop_after_merge; ++i) hipLaunchKernelGGL(noop_k, dim3(1), dim3(64), 0, ctx->stream);
+}
+}  // namespace
+
 int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats, const msk_bn_fin* fin) {
   msk_launch_scope ls(ctx, "bn_stats_merge");
   hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(kMergeThreads), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
   MSK_LAUNCH_CHECK(ctx);
+  noop_launches(ctx);
   return 0;
 }
 
@@ -1021,6 +1041,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
     hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
     return 0;
   }
   ChanGeom g = chan_geom(x.c);
@@ -1039,6 +1060,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
     hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
   }
   return 0;
 }
@@ -1159,6 +1181,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
     hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c, 4 * QCB, 3, sums, 0, dbeta, dgamma,
                        dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
     return 0;
   }
   ChanGeom g = chan_geom(x.c);
@@ -1178,6 +1201,7 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
     hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c,
                        g.CB, 3, sums, 0, dbeta, dgamma, dalpha, (float*)nullptr);
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
   }
   return 0;
 }
@@ -1257,6 +1281,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
     hipLaunchKernelGGL(sums_merge_k, dim3(4 * a.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial4, nb, a.c, 4 * QCB, 4, unit_sums, 0, u_dbeta,
                        u_dgamma, u_dalpha, dalpha);
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
     return 0;
   }
   float* partial = (float*)msk_workspace(ctx, (size_t)nb * 4 * QCB * sizeof(float));
@@ -1272,6 +1297,7 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
   msk_launch_scope ls(ctx, "sums_merge");
   hipLaunchKernelGGL(sums_merge_k, dim3(a.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, a.c, 4 * QCB, 1, dalpha, 1);
   MSK_LAUNCH_CHECK(ctx);
+  noop_launches(ctx);
   return 0;
 }
 
@@ -1371,6 +1397,7 @@ int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
     hipLaunchKernelGGL(sums_merge_k, dim3(x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
                        out, accumulate);
     MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
   }
   return 0;
 }
@@ -1491,6 +1518,7 @@ float* msk_scalar_slots(msk_ctx* ctx, int n) {
     }
   }
   ctx->scalar_next = start + n;
+  ctx->scalar_served += n / kWbfAmaxWays;
   return ctx->scalar_ring + start;
 }
 

@@ -163,12 +163,18 @@ minmax_partial_k(const float* __restrict__ src, size_t n, float* __restrict__ pa
   }
 }
 __global__ void minmax_final_k(float* partial, int nb) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float lo = partial[0], hi = partial[1];
-    for (int b = 1; b < nb; ++b) {
-      lo = fminf(lo, partial[2 * b]);
-      hi = fmaxf(hi, partial[2 * b + 1]);
-    }
+  // one wavefront: the lanes stride over the block partials, then a shuffle tree (min / max are exact in any order).  Round 4 had
+  // ONE thread walk up to 1024 partials -- a chain of dependent loads: 55 of msk_max_norm's 75 us at 512 x 512 x 12
+  float lo = INFINITY, hi = -INFINITY;
+  for (int b = threadIdx.x; b < nb; b += 64) {
+    lo = fminf(lo, partial[2 * b]);
+    hi = fmaxf(hi, partial[2 * b + 1]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, o, 64));
+    hi = fmaxf(hi, __shfl_down(hi, o, 64));
+  }
+  if (threadIdx.x == 0) {
     partial[0] = lo;
     partial[1] = hi;
   }

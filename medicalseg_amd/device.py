@@ -47,6 +47,11 @@ class Device:
         self.call("msk_malloc", C.c_size_t(max(int(nbytes), 16)), C.byref(p))
         return p.value
 
+    def wait_for(self, other: "Device"):
+        """this device object's compute stream waits, on the GPU, for everything enqueued so far on `other`'s (a second
+        Device() on the same GPU is a second stream: in-loop preprocessing beside the training step)"""
+        self.call("msk_ctx_wait", other.ctx)
+
     def amax_new(self, n=1) -> int:
         """n consecutive zeroed device amax arrays (64 floats each, from the context's ring: valid for the current step)"""
         p = self.lib.msk_amax_new(self.ctx, n)
@@ -141,10 +146,27 @@ class ActivationArena:
         self.gen = 0
         self.peak = 0
 
+    RING_HALF = 512      # msk_scalar_slots: a handed-out amax array is zeroed again this many requests later
+
     def reset(self):
         self.cur = 0
         self.off = 0
         self.gen += 1
+        # amax arrays taken in forward are read at the end of backward (Tensor.amax -> msk_conv3d_wgrad_ex3): the ring must not
+        # wrap inside one arena generation (advisor, round 4) -- a zeroed array would give a wrong fp16 scale, silently
+        try:
+            served = (self.dev.get_option("scalar_ring_served"), self.dev.get_option("scalar_ring_served_side"))
+        except Exception:      # a stand-in library without the keys (tests/fake_msegk.c)
+            served = None
+        last = getattr(self, "_ring_served", None)
+        self._ring_served = served
+        if served is not None and last is not None:
+            used = max((a - b) & 0x3FFFFFFF for a, b in zip(served, last))
+            self.ring_used = used
+            if used > self.RING_HALF - 64:
+                raise MskError("one step took %d amax arrays from a ring that recycles them after %d requests: arrays held from "
+                               "forward to backward would be zeroed under their readers (enlarge kRing in msk_scalar_slots)"
+                               % (used, self.RING_HALF))
 
     def alloc(self, nbytes: int) -> int:
         nbytes = (int(nbytes) + 255) & ~255
@@ -185,7 +207,7 @@ class Tensor:
     ``shape`` reports the reference's logical NCDHW order so code written against the
     reference (``_, c, d, h, w = images.shape``; core/train.py:266) keeps working."""
 
-    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "_amax", "_amax_gen")
+    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "_amax", "_amax_gen", "_pool_bytes")
 
     def __init__(self, dev, ptr, n, d, h, w, c, ld=None, gen=None):
         self.dev, self.ptr = dev, ptr
@@ -286,7 +308,7 @@ class Tensor:
 class IntTensor:
     """int32 device array (labels N x D x H x W, argmax predictions)."""
 
-    __slots__ = ("dev", "ptr", "shape_", "gen")
+    __slots__ = ("dev", "ptr", "shape_", "gen", "_pool_bytes")
 
     def __init__(self, dev, ptr, shape, gen=None):
         self.dev, self.ptr, self.shape_, self.gen = dev, ptr, tuple(int(s) for s in shape), gen

@@ -116,15 +116,18 @@ def upload(image, dev=None) -> DeviceVolume:
     return DeviceVolume(dev, ptr, a.shape, a.dtype)
 
 
-def resample_device(vol: DeviceVolume, new_shape, order=1) -> DeviceVolume:
+def resample_device(vol: DeviceVolume, new_shape, order=1, pooled=False) -> DeviceVolume:
     dev = vol.dev
     new_shape = tuple(int(s) for s in new_shape)
     if order not in (0, 1):
         raise ValueError("only order 0 and 1 are built (the orders the reference pipelines use)")
-    out = dev.malloc(int(np.prod(new_shape)) * 4)
-    dev.call("msk_resample3d", C.c_void_p(vol.ptr), *vol.shape, C.c_void_p(out), *new_shape, int(order),
+    if pooled:
+        res = _pooled_volume(dev, new_shape, vol.dtype)
+    else:
+        res = DeviceVolume(dev, dev.malloc(int(np.prod(new_shape)) * 4), new_shape, vol.dtype)
+    dev.call("msk_resample3d", C.c_void_p(vol.ptr), *vol.shape, C.c_void_p(res.ptr), *new_shape, int(order),
              0 if vol.dtype == np.float32 else 1)
-    return DeviceVolume(dev, out, new_shape, vol.dtype)
+    return res
 
 
 def resample(image, spacing=None, new_spacing=[1.0, 1.0, 1.0], new_shape=None, order=1):
@@ -211,9 +214,22 @@ class DevicePipeline:
         y = pipe.label(raw_label).resample([128, 128, 128], 0).int_tensor()
     """
 
-    def __init__(self, dev=None):
+    def __init__(self, dev=None, pooled=False):
+        """pooled: device buffers come from (and intermediate ones return to) the stream-ordered pool instead of
+        hipMalloc / hipFree per op -- hipFree synchronises the whole device, which an in-loop pipeline running BESIDE a
+        training step (a second Device() = a second stream, tools/bench_workloads.py --inloop-preprocess) cannot afford;
+        the caller hands a finished sample's buffers back with release()."""
         self.dev = dev or get_device()
         self._pinned = [None, 0]
+        self.pooled = bool(pooled)
+
+    def release(self, *tensors):
+        """return the buffers of finished samples (tensor() / int_tensor() results) to the pool: the NEXT op enqueued on this
+        pipeline's stream may overwrite them, so order that stream behind their last reader first (Device.wait_for)"""
+        for t in tensors:
+            if t is not None and getattr(t, "_pool_bytes", 0):
+                _pool_release(self.dev, t.ptr, t._pool_bytes)
+                t._pool_bytes = 0
 
     def _stage(self, a: np.ndarray) -> DeviceVolume:
         dev = self.dev
@@ -228,9 +244,26 @@ class DevicePipeline:
         else:
             dev.sync()  # the previous copy out of the staging buffer must have drained
         C.memmove(self._pinned[0], a.ctypes.data, a.nbytes)
-        ptr = dev.malloc(a.nbytes)
-        dev.call("msk_h2d_async", C.c_void_p(ptr), C.c_void_p(self._pinned[0]), C.c_size_t(a.nbytes))
-        return DeviceVolume(dev, ptr, a.shape, a.dtype)
+        if self.pooled:
+            vol = _pooled_volume(dev, a.shape, a.dtype)
+        else:
+            vol = DeviceVolume(dev, dev.malloc(a.nbytes), a.shape, a.dtype)
+        dev.call("msk_h2d_async", C.c_void_p(vol.ptr), C.c_void_p(self._pinned[0]), C.c_size_t(a.nbytes))
+        return vol
+
+    def from_pinned(self, pinned_ptr: int, shape, dtype=np.float32) -> "_Chain":
+        """a raw volume that already sits in PINNED host memory (msk_pinned_alloc: a loader that reads into pinned buffers):
+        one asynchronous copy, no staging memmove and no host synchronisation -- the caller keeps the buffer unchanged until the
+        copy has run"""
+        dev = self.dev
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * 4
+        if self.pooled:
+            vol = _pooled_volume(dev, shape, dtype)
+        else:
+            vol = DeviceVolume(dev, dev.malloc(nbytes), shape, dtype)
+        dev.call("msk_h2d_async", C.c_void_p(vol.ptr), C.c_void_p(pinned_ptr), C.c_size_t(nbytes))
+        return _Chain(self, vol)
 
     def image(self, raw) -> "_Chain":
         return _Chain(self, self._stage(np.asarray(raw, dtype=np.float32)))
@@ -257,7 +290,7 @@ class _Chain:
         return self
 
     def resample(self, new_shape, order=1):
-        out = resample_device(self.vol, new_shape, order)
+        out = resample_device(self.vol, new_shape, order, pooled=self.pipe.pooled)
         old, self.vol = self.vol, out
         # the source is still being read by the enqueued kernel: free() synchronises first
         old.free()
@@ -272,11 +305,15 @@ class _Chain:
         """[1, 1, D, H, W] model input (one channel: NDHWC and NCDHW coincide); keeps the buffer."""
         from .device import Tensor
         d, h, w = self.vol.shape
-        return Tensor(self.vol.dev, self.vol.ptr, 1, d, h, w, 1, 1, None)
+        t = Tensor(self.vol.dev, self.vol.ptr, 1, d, h, w, 1, 1, None)
+        t._pool_bytes = self.vol.size * 4 if self.vol.pooled else 0      # DevicePipeline.release
+        return t
 
     def int_tensor(self):
         from .device import IntTensor
-        return IntTensor(self.vol.dev, self.vol.ptr, (1,) + tuple(self.vol.shape))
+        t = IntTensor(self.vol.dev, self.vol.ptr, (1,) + tuple(self.vol.shape))
+        t._pool_bytes = self.vol.size * 4 if self.vol.pooled else 0
+        return t
 
     def numpy(self):
         return self.vol.numpy()

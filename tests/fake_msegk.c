@@ -32,6 +32,7 @@ int msk_pinned_free(void* c, void* p) { return msk_free(c, p); }
 int msk_mem_info(void* c, size_t* f, size_t* t) { (void)c; *f = *t = (size_t)1 << 38; return 0; }
 int msk_timer_start(void* c) { (void)c; return 0; }
 int msk_mark(void* c, int i) { (void)c; (void)i; return 0; }
+int msk_ctx_wait(void* c, void* o) { (void)c; (void)o; return 0; }
 int msk_mark_elapsed(void* c, int a, int b, float* ms) { (void)c; (void)a; (void)b; *ms = 1.0f; return 0; }
 int msk_timer_stop(void* c, float* ms) { (void)c; *ms = 1.0f; return 0; }
 int msk_prof_enable(void* c, int on) { (void)c; (void)on; return 0; }
