@@ -261,6 +261,16 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
                          const void* xform /*nullable*/, void* ybuf /*nullable*/,
                          const float* maxes /*nullable: msk_affine_act_bwd_reduce_ex's, needed by the fused forms under "conv_split" 2*/);
+/* Backward of an up-convolution unit  convT -> BatchNorm(batch statistics) -> PReLU  (UpTransition.up_conv / bn1 / relu1,
+ * vnet.py:133-150; autograd of core/train.py:139) behind its reduce pass, in one call:
+ *     dx (+)= convT^T(dy, w),  dw (+)= sum x * dy,   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1)
+ * where the data gradient evaluates dy from (y, dout) in its own loads (<= 16 output channels of the convT, kernel == stride)
+ * and the pass that writes dy_scratch runs on the weight-gradient stream in front of the weight gradient, its only reader.
+ * Returns 0 = done, 1 = not eligible (NOTHING was launched: use msk_affine_act_bwd_apply + msk_convT3d_wgrad / _dgrad). */
+int msk_convT3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                          const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd,
+                          msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                          int dx_accumulate, float* dw, int dw_accumulate);
 /* The in_tr.conv1 unit (vnet.py:57-79: out = PReLU(BN(conv5^3(x: ONE channel)) + tile(x)), no data gradient): weight gradient
  * with dy evaluated inside the kernel from (y, dout); `res` is either a null tensor or x itself (the tiled residual, read from the
  * kernel's own halo of x).  Returns 0 = done, 1 = not this class / declined (nothing was launched: use msk_affine_act_bwd_apply +

@@ -72,6 +72,7 @@ struct msk_ctx {
   void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
   int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
   void* spack = nullptr;      // packed-weight cache of the other convolution kernels (msk_conv.hip: SmallPackCache)
+  int wbf_ks_blocks = 2;      // option "wbf_ks_blocks": workgroups per CU the split-K of wbf_gemm_k aims for (deep levels; every slab is a round trip of M through HBM)
   int noop_after_merge = 0;   // debug option "noop_after_merge": that many empty launches behind every merge kernel (what a 5-us launch costs the step)
   int small_pack_cache = 1;   // option "small_pack_cache": 0 = those kernels pack into the shared scratch on every call (A/B)
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
@@ -115,6 +116,7 @@ struct msk_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr, ev_comm_back = nullptr;
   int c1_h2 = 1;          // one-input-channel convolutions on the 16-bit pipe (conv_c1_h2_k): 1 = the 3^3 class (UNet3D), 2 = also 5^3 (in_tr), 0 = off
+  int ks_lds = 1;         // option "ks_lds": 2x2x2 / stride 2 convolutions with <= 16 source channels through the LDS tile (gconv_ks_lds_k); 0 = the per-lane gather form (A/B)
   int ks_nr_max = 4;      // gconv_ks_fwd / gconv_kst: most N tiles per workgroup (4: x read once but 160 registers -- such a wavefront finds no room
                           // on a SIMD that holds three weight-gradient wavefronts of the side stream; 2: 94 registers)
   int wgrad_lds_pad = 0;  // bytes of dynamic LDS added to every wbf_wgrad_k launch: caps its workgroups per CU (33.5 KB static: 3 per CU
@@ -143,6 +145,7 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag);
 void msk_prof_end(msk_ctx* ctx);
 const char* msk_intern_tag(msk_ctx* ctx, const std::string& s);
 int msk_join_side_impl(msk_ctx* ctx);
+void msk_set_dense12(int v);           // option "dense12" (msk_elementwise.hip)
 void msk_set_reduce_vpl(int v);
 void msk_set_reduce_vpl_site(int v);   // option "reduce_vpl_site"          // option "reduce_vpl"
 void msk_set_ew_caps(int ew, int red);   // msk_elementwise.hip tuning knobs

@@ -105,6 +105,10 @@ bool msk_wgrad_wbf_fusable(msk_ctx* ctx, const WGrad& g, size_t* y_bytes);  // s
 int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 // kernel == stride forward gather (down-convs, up-conv data gradients): flattened K, two operand batches in flight (msk_conv_ksfwd.hip)
 int msk_gconv_ks_fwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
+// msk_gconv_ks_fwd with the source evaluated from (y, dout) behind a BatchNorm + PReLU (msk_convT3d_bwd_bnact); dry: eligibility only
+int msk_gconv_ks_fwd_bnbwd(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap, const float* y, int yld,
+                           const float* dout, int dld, const float* scale, const float* shift, const float* alpha, const float* mean,
+                           const float* invstd, const float* sums, double M_total, bool dry);
 // transposed gather with kernel == stride along D, H and stride 1 along W: the anisotropic MRI levels (msk_conv_ksfwd.hip)
 int msk_gconv_kst(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int B, int swap);
 int msk_wgrad_mfma(msk_ctx* ctx, const WGrad& g);

@@ -1845,6 +1845,50 @@ int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float
   return run_gconv(ctx, g, w, dx.c, dy.c, 1, "convT3d_dgrad_direct");
 }
 
+// Backward of an up-convolution unit convT -> BatchNorm -> PReLU (vnet.py:133-150; autograd of core/train.py:139) behind its
+// reduce pass (msk_affine_act_bwd_reduce*): the data gradient evaluates dy from (y, dout) in its own loads on the compute stream
+// (gconv_ks_fwd_k<.., FUSE>), the pass that writes dy and the weight gradient that reads it run on the weight-gradient stream.
+// Returns 0 = done, 1 = not eligible (nothing launched: the caller runs apply / wgrad / dgrad), < 0 error.
+int msk_convT3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                          const float* shift, const float* alpha, const float* mean, const float* invstd, msk_tensor dout,
+                          const float* sums_total, double M_total, msk_tensor dy, msk_tensor dx, int dx_accumulate, float* dw,
+                          int dw_accumulate) {
+  if (check_conv_shapes(ctx, cd, x, y, true) != 0) return -1;
+  MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && w && dw, "msk_convT3d_bwd_bnact: null argument");
+  MSK_REQUIRE(ctx, dout.c == y.c && msk_voxels(dout) == msk_voxels(y) && dy.c == y.c && msk_voxels(dy) == msk_voxels(y) &&
+                       dx.c == x.c && msk_voxels(dx) == msk_voxels(x), "msk_convT3d_bwd_bnact: shape mismatch");
+  GConv g{};
+  g.src = (const float*)y.p; g.sld = y.ld; g.dst = (float*)dx.p; g.dld = dx.ld;
+  g.N = dx.n; g.SD = y.d; g.SH = y.h; g.SW = y.w; g.DD = dx.d; g.DH = dx.h; g.DW = dx.w;
+  g.CK = y.c; g.CN = dx.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.transposed = 0; g.bias = nullptr; g.accumulate = dx_accumulate; g.flip = 0;
+  if (ctx->conv_impl != 0 || ctx->no_winograd) return 1;
+  const size_t per = (size_t)y.d * y.h * y.w * (y.ld > dout.ld ? y.ld : dout.ld) * sizeof(float);
+  if (per > 0 && (size_t)g.N > kChunkBytes / per) return 1;     // chunked problems: the plain path
+  // w[Cin][Cout][tap]: k = Cout = b, n = Cin = a -> swap (msk_convT3d_dgrad)
+  const int ok = msk_gconv_ks_fwd_bnbwd(ctx, g, w, dx.c, y.c, 1, (const float*)y.p, y.ld, (const float*)dout.p, dout.ld, scale, shift,
+                                        alpha, mean, invstd, sums_total, M_total, true);
+  if (ok != 1) return ok < 0 ? ok : 1;
+  {
+    // weight-gradient stream (forks HERE, in front of the data gradient): dy for the weight gradient, then the weight gradient
+    msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(x) <= ctx->wgrad_async_max_m);
+    msk_tensor none{};
+    if (msk_affine_act_bwd_apply_amax(ctx, y, scale, shift, none, alpha, mean, invstd, nullptr, dout, sums_total, M_total, 1, dy,
+                                      none, 0, nullptr) != 0) return -1;
+    WGrad wg{};
+    wg.A = (const float*)dy.p; wg.ald = dy.ld; wg.B = (const float*)x.p; wg.bld = x.ld;
+    wg.N = x.n; wg.AD = dy.d; wg.AH = dy.h; wg.AW = dy.w; wg.BD = x.d; wg.BH = x.h; wg.BW = x.w;
+    wg.CA = dy.c; wg.CB = x.c;
+    wg.kd = cd.kd; wg.kh = cd.kh; wg.kw = cd.kw; wg.sd = cd.sd; wg.sh = cd.sh; wg.sw = cd.sw;
+    wg.dw = dw; wg.accumulate = dw_accumulate;
+    if (int rc = run_wgrad(ctx, wg, dy, nullptr, dw_accumulate)) return rc;
+  }
+  const int rc = msk_gconv_ks_fwd_bnbwd(ctx, g, w, dx.c, y.c, 1, (const float*)y.p, y.ld, (const float*)dout.p, dout.ld, scale, shift,
+                                        alpha, mean, invstd, sums_total, M_total, false);
+  return rc == 1 ? 0 : (rc < 0 ? rc : msk_fail(ctx, __FILE__, __LINE__, "msk_convT3d_bwd_bnact", "the data gradient declined after its dry run"));
+}
+
 int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy, float* dw, float* db, int accumulate) {
   if (check_conv_shapes(ctx, cd, x, dy, true) != 0) return -1;
   msk_side_scope side(ctx, ctx->wgrad_async_max_m <= 0 || msk_voxels(x) <= ctx->wgrad_async_max_m);

@@ -1501,7 +1501,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
   const long base_blocks = (long)NXI * ngrp * tiles_h * tiles_d * T * g.N;
   int ksplit = 1, kc_per = KC;
   if (base_blocks < 3L * ctx->num_cu && ctx->wbf_fuse != 2) {  // ("wbf_fuse" 2: tests force the one-kernel form, which has no split-K)
-    long want = (8L * ctx->num_cu + base_blocks - 1) / base_blocks;
+    long want = ((long)ctx->wbf_ks_blocks * ctx->num_cu + base_blocks - 1) / base_blocks;
     if (want > KC) want = KC;
     kc_per = (int)((KC + want - 1) / want);
     ksplit = (KC + kc_per - 1) / kc_per;

@@ -444,6 +444,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_pack_cache = value;
     return 0;
   }
+  if (strcmp(key, "wbf_ks_blocks") == 0) {  // tuning: workgroups per CU targeted by the split-K of wbf_gemm_k (default 2; round 5 sweep on one box, two repetitions: 16 / 8 / 4 / 2 = 18.58 / 18.46 / 18.39 / 18.28 ms -- every slab is a round trip of M through HBM and a term of wbf_tout_k)
+    ctx->wbf_ks_blocks = value > 0 ? value : 2;
+    return 0;
+  }
   if (strcmp(key, "noop_after_merge") == 0) {  // debug: empty launches behind every bn_stats_merge / sums_merge (measures the price of a tiny launch in the step)
     ctx->noop_after_merge = value;
     return 0;
@@ -464,6 +468,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "ew_cap") == 0) {      // tuning: blocks per CU of the elementwise kernels (default 32)
     msk_set_ew_caps(value, 0);
+    return 0;
+  }
+  if (strcmp(key, "ks_lds") == 0) {  // 0 = gconv_ks_fwd_k for the 16-channel k == s problems as well (A/B of gconv_ks_lds_k)
+    ctx->ks_lds = value;
+    return 0;
+  }
+  if (strcmp(key, "dense12") == 0) {  // 0 = the scalar elementwise kernels for dense 1/2/3/6-channel tensors (A/B of the float4-triple kernels)
+    msk_set_dense12(value);
     return 0;
   }
   if (strcmp(key, "reduce_vpl") == 0) {  // tuning: voxels per lane of the per-channel reduction kernels before more workgroups are added

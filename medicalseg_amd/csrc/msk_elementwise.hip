@@ -967,6 +967,250 @@ ndhwc_to_ncdhw_k(const float* __restrict__ src, int ld, float* __restrict__ dst,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 5: DENSE tensors with 1, 2, 3 or 6 channels (the ncls = 3 tensors of out_tr, vnet.py:159-175: its BatchNorm / PReLU and
+// their adjoints, the bias gradient of the 1x1x1 head).  The scalar kernels above moved 4 bytes per lane per load and ran at
+// 1.5-2.3 TB/s on these 50 MB tensors (213 us per step in five passes).  12 consecutive floats of a dense tensor are 12 / C whole
+// voxels, so a thread that owns float4 triples sees a FIXED channel per slot (slot % C): 16-byte accesses, coefficients in
+// registers, no index arithmetic.  Eligible: ld == C, 12 % C == 0, voxels * C % 12 == 0, 16-byte aligned.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ld12(const float* __restrict__ p, float (&v)[12]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  const float4 a = q[0], b = q[1], c = q[2];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ __forceinline__ void st12(float* __restrict__ p, const float (&v)[12]) {
+  float4* q = reinterpret_cast<float4*>(p);
+  q[0] = make_float4(v[0], v[1], v[2], v[3]);
+  q[1] = make_float4(v[4], v[5], v[6], v[7]);
+  q[2] = make_float4(v[8], v[9], v[10], v[11]);
+}
+
+template <int C>
+__global__ void __launch_bounds__(kThreads)
+affine_act_fwd_d12_k(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ res, const float* __restrict__ alpha, float* __restrict__ out, long groups,
+                     unsigned* __restrict__ out_amax) {
+  float sc[C], sf[C], al[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    sc[c] = scale ? scale[c] : 1.f;
+    sf[c] = scale ? shift[c] : 0.f;
+    al[c] = alpha ? alpha[c] : 1.f;
+  }
+  float mx = 0.f;
+  for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < groups; g += (long)gridDim.x * kThreads) {
+    float v[12], r[12], o[12];
+    ld12(x + 12 * g, v);
+    if (res) ld12(res + 12 * g, r);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      float u = scale ? fmaf(v[s], sc[s % C], sf[s % C]) : v[s];
+      if (res) u += r[s];
+      o[s] = (alpha && !(u > 0.f)) ? al[s % C] * u : u;
+      mx = fmaxf(mx, fabsf(o[s]));
+    }
+    st12(out + 12 * g, o);
+  }
+  if (out_amax) block_atomic_max(out_amax, mx);
+}
+
+// BatchNorm statistics: per-slot shifted sums, slots of a channel and then the block's threads merged (Chan) -> one record
+// per block in bn_stats_partial's layout [nb][CB][3]
+template <int C>
+__global__ void __launch_bounds__(kThreads)
+bn_stats_partial_d12_k(const float* __restrict__ x, long groups, int CB, float* __restrict__ partial) {
+  __shared__ WF sh[C][kThreads];
+  const int t = threadIdx.x, nb = gridDim.x;
+  const long per = (groups + nb - 1) / nb;
+  const long g0 = (long)blockIdx.x * per;
+  long g1 = g0 + per;
+  if (g1 > groups) g1 = groups;
+  float K[12], s1[12], s2[12];
+  float n = 0.f;
+#pragma unroll
+  for (int s = 0; s < 12; ++s) { K[s] = 0.f; s1[s] = 0.f; s2[s] = 0.f; }
+  if (g0 + t < g1) ld12(x + 12 * (g0 + t), K);
+  for (long g = g0 + t; g < g1; g += kThreads) {
+    float v[12];
+    ld12(x + 12 * g, v);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const float d = v[s] - K[s];
+      s1[s] += d;
+      s2[s] = fmaf(d, d, s2[s]);
+    }
+    n += 1.f;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    WF w = {0.f, 0.f, 0.f};
+    if (n > 0.f) {
+#pragma unroll
+      for (int s = c; s < 12; s += C) {   // the slots of channel c, in slot order
+        WF e;
+        e.n = n;
+        e.mean = K[s] + s1[s] / n;
+        e.m2 = fmaxf(s2[s] - s1[s] * s1[s] / n, 0.f);
+        w = wf_merge(w, e);
+      }
+    }
+    sh[c][t] = w;
+  }
+  __syncthreads();
+  for (int k = kThreads >> 1; k > 0; k >>= 1) {
+    if (t < k) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) sh[c][t] = wf_merge(sh[c][t], sh[c][t + k]);
+    }
+    __syncthreads();
+  }
+  if (t < C) {
+    float* p = partial + ((long)blockIdx.x * CB + t) * 3;
+    p[0] = sh[t][0].n;
+    p[1] = sh[t][0].mean;
+    p[2] = sh[t][0].m2;
+  }
+}
+
+// backward pass 1 (affine_act_bwd_reduce_k's sums, same partial layout [nb][3][CB]); NQ == 1: plain channel sums of x
+// (channel_sum_partial_k's layout [nb][1][CB])
+template <int C, int NQ>
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_reduce_d12_k(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                            const float* __restrict__ res, const float* __restrict__ alpha, const float* __restrict__ mean,
+                            const float* __restrict__ invstd, const float* __restrict__ dout, long groups, int CB,
+                            float* __restrict__ partial) {
+  __shared__ float sh[NQ * C][kThreads];
+  const int t = threadIdx.x, nb = gridDim.x;
+  const long per = (groups + nb - 1) / nb;
+  const long g0 = (long)blockIdx.x * per;
+  long g1 = g0 + per;
+  if (g1 > groups) g1 = groups;
+  float sc[C], sf[C], al[C], mu[C], is[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    sc[c] = (NQ == 3 && scale) ? scale[c] : 1.f;
+    sf[c] = (NQ == 3 && scale) ? shift[c] : 0.f;
+    al[c] = (NQ == 3 && alpha) ? alpha[c] : 1.f;
+    mu[c] = (NQ == 3 && mean) ? mean[c] : 0.f;
+    is[c] = (NQ == 3 && mean) ? invstd[c] : 0.f;
+  }
+  float a_du[12], a_dux[12], a_da[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) { a_du[s] = 0.f; a_dux[s] = 0.f; a_da[s] = 0.f; }
+  for (long g = g0 + t; g < g1; g += kThreads) {
+    float v[12];
+    ld12(x + 12 * g, v);
+    if (NQ == 1) {
+#pragma unroll
+      for (int s = 0; s < 12; ++s) a_du[s] += v[s];
+    } else {
+      float d[12], r[12];
+      ld12(dout + 12 * g, d);
+      if (res) ld12(res + 12 * g, r);
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        float u = fmaf(v[s], sc[s % C], sf[s % C]);
+        if (res) u += r[s];
+        float du = d[s];
+        if (alpha && !(u > 0.f)) {
+          du = al[s % C] * d[s];
+          a_da[s] = fmaf(d[s], u, a_da[s]);
+        }
+        a_du[s] += du;
+        a_dux[s] = fmaf(du, (v[s] - mu[s % C]) * is[s % C], a_dux[s]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int s = c; s < 12; s += C) { q0 += a_du[s]; q1 += a_dux[s]; q2 += a_da[s]; }
+    sh[c][t] = q0;
+    if (NQ == 3) { sh[C + c][t] = q1; sh[2 * C + c][t] = q2; }
+  }
+  __syncthreads();
+  for (int k = kThreads >> 1; k > 0; k >>= 1) {
+    if (t < k) {
+#pragma unroll
+      for (int j = 0; j < NQ * C; ++j) sh[j][t] += sh[j][t + k];
+    }
+    __syncthreads();
+  }
+  if (t < NQ * C) {
+    const int q = t / C, c = t % C;
+    partial[((long)blockIdx.x * NQ + q) * CB + c] = sh[t][0];
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(kThreads)
+affine_act_bwd_apply_d12_k(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                           const float* __restrict__ res, const float* __restrict__ alpha, const float* __restrict__ mean,
+                           const float* __restrict__ invstd, const float* __restrict__ dout, const float* __restrict__ sums,
+                           float invM, int bn_mode, float* __restrict__ dx, float* __restrict__ dres, int dres_acc, long groups,
+                           int Ctot, unsigned* __restrict__ dx_amax) {
+  float sc[C], sf[C], al[C], mu[C], is[C], s1[C], s2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    sc[c] = scale ? scale[c] : 1.f;
+    sf[c] = scale ? shift[c] : 0.f;
+    al[c] = alpha ? alpha[c] : 1.f;
+    mu[c] = bn_mode == 1 ? mean[c] : 0.f;
+    is[c] = bn_mode == 1 ? invstd[c] : 0.f;
+    s1[c] = bn_mode == 1 ? sums[c] * invM : 0.f;
+    s2[c] = bn_mode == 1 ? sums[Ctot + c] * invM : 0.f;
+  }
+  float mx = 0.f;
+  for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < groups; g += (long)gridDim.x * kThreads) {
+    float v[12], d[12], r[12], o[12], du[12];
+    ld12(x + 12 * g, v);
+    ld12(dout + 12 * g, d);
+    const bool need_res = res && alpha;
+    if (need_res) ld12(res + 12 * g, r);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      float t = d[s];
+      if (alpha) {
+        float u = scale ? fmaf(v[s], sc[s % C], sf[s % C]) : v[s];
+        if (need_res) u += r[s];
+        if (!(u > 0.f)) t *= al[s % C];
+      }
+      du[s] = t;
+      if (bn_mode == 1) {
+        const float xh = (v[s] - mu[s % C]) * is[s % C];
+        o[s] = sc[s % C] * (t - s1[s % C] - xh * s2[s % C]);
+      } else if (bn_mode == 2) {
+        o[s] = sc[s % C] * t;
+      } else {
+        o[s] = t;
+      }
+      mx = fmaxf(mx, fabsf(o[s]));
+    }
+    if (dx) st12(dx + 12 * g, o);
+    if (dres) {
+      if (dres_acc) {
+        float a[12];
+        ld12(dres + 12 * g, a);
+#pragma unroll
+        for (int s = 0; s < 12; ++s) du[s] += a[s];
+      }
+      st12(dres + 12 * g, du);
+    }
+  }
+  if (dx_amax) block_atomic_max(dx_amax, mx);
+}
+
+// is every (non-null) tensor of a pass dense, 16-byte aligned, with a channel count that divides 12?
+inline bool d12_ok(const msk_tensor& t) { return t.p == nullptr || (t.ld == t.c && (((uintptr_t)t.p) % 16 == 0)); }
+inline bool d12_shape(const msk_tensor& x, long voxels) {
+  return (x.c == 1 || x.c == 2 || x.c == 3 || x.c == 6) && (voxels * x.c) % 12 == 0;
+}
+int g_dense12 = 1;   // option "dense12": 0 = the scalar kernels (A/B)
+
 inline bool vec4_ok(const msk_tensor& t) {
   return t.p == nullptr || ((t.c % 4 == 0) && (t.ld % 4 == 0) && (((uintptr_t)t.p) % 16 == 0));
 }
@@ -1049,6 +1293,22 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
   size_t bytes = (size_t)g.cblocks * nb * g.CB * 3 * sizeof(float);
   float* partial = (float*)msk_workspace(ctx, bytes);
   if (!partial) return -1;
+  if (g_dense12 && d12_shape(x, voxels) && d12_ok(x)) {
+    const long groups = voxels * x.c / 12;
+    {
+      msk_launch_scope ls(ctx, "bn_stats_partial");
+#define D12_ST(C_) hipLaunchKernelGGL(bn_stats_partial_d12_k<C_>, dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)x.p, groups, g.CB, partial)
+      if (x.c == 1) D12_ST(1); else if (x.c == 2) D12_ST(2); else if (x.c == 3) D12_ST(3); else D12_ST(6);
+#undef D12_ST
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "bn_stats_merge");
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
+                       fin ? *fin : msk_bn_fin{});
+    MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
+    return 0;
+  }
   {
     msk_launch_scope ls(ctx, "bn_stats_partial");
     hipLaunchKernelGGL(bn_stats_partial, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
@@ -1096,6 +1356,16 @@ static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, c
   const bool v4 = vec4_ok(x) && vec4_ok(out) && (res.p == nullptr || res.c != x.c || vec4_ok(res));
   msk_launch_scope ls(ctx, "affine_act_fwd");
   const int cq = x.c / 4;
+  if (g_dense12 && !v4 && !alpha_in && d12_shape(x, voxels) && d12_ok(x) && d12_ok(out) && (res.p == nullptr || (res.c == x.c && d12_ok(res)))) {
+    const long groups = voxels * x.c / 12;
+    const dim3 grid(ew_blocks(groups, ctx->num_cu));
+#define D12_FWD(C_) hipLaunchKernelGGL(affine_act_fwd_d12_k<C_>, grid, dim3(kThreads), 0, ctx->stream, (const float*)x.p, scale, shift, \
+                                       (const float*)res.p, alpha, (float*)out.p, groups, (unsigned*)out_amax)
+    if (x.c == 1) D12_FWD(1); else if (x.c == 2) D12_FWD(2); else if (x.c == 3) D12_FWD(3); else D12_FWD(6);
+#undef D12_FWD
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   if (v4 && cq >= 1 && (cq & (cq - 1)) == 0 && cq <= kThreads) {
     int cshift = 0;
     while ((1 << cshift) < cq) ++cshift;
@@ -1189,6 +1459,23 @@ int msk_affine_act_bwd_reduce_pg(msk_ctx* ctx, msk_tensor x, const float* scale,
   size_t bytes = (size_t)g.cblocks * nb * 3 * g.CB * sizeof(float);
   float* partial = (float*)msk_workspace(ctx, bytes);
   if (!partial) return -1;
+  if (g_dense12 && d12_shape(x, voxels) && d12_ok(x) && d12_ok(dout) && (res.p == nullptr || (res.c == x.c && d12_ok(res)))) {
+    const long groups = voxels * x.c / 12;
+    {
+      msk_launch_scope ls(ctx, "affine_act_bwd_reduce");
+#define D12_RD(C_) hipLaunchKernelGGL((affine_act_bwd_reduce_d12_k<C_, 3>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)x.p, scale, shift, \
+                                      (const float*)res.p, alpha, mean, invstd, (const float*)dout.p, groups, g.CB, partial)
+      if (x.c == 1) D12_RD(1); else if (x.c == 2) D12_RD(2); else if (x.c == 3) D12_RD(3); else D12_RD(6);
+#undef D12_RD
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "sums_merge");
+    hipLaunchKernelGGL(sums_merge_k, dim3(3 * x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c,
+                       g.CB, 3, sums, 0, dbeta, dgamma, dalpha, (float*)nullptr);
+    MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
+    return 0;
+  }
   {
     msk_launch_scope ls(ctx, "affine_act_bwd_reduce");
     hipLaunchKernelGGL(affine_act_bwd_reduce_k, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
@@ -1230,6 +1517,18 @@ int msk_affine_act_bwd_apply_amax(msk_ctx* ctx, msk_tensor x, const float* scale
   const float invM = (float)(1.0 / M_total);
   msk_launch_scope ls(ctx, "affine_act_bwd_apply");
   const int cq = x.c / 4;
+  if (g_dense12 && !v4 && d12_shape(x, voxels) && d12_ok(x) && d12_ok(dout) && d12_ok(dx) && d12_ok(dres) &&
+      (res.p == nullptr || (res.c == x.c && d12_ok(res)))) {
+    const long groups = voxels * x.c / 12;
+    const dim3 grid(ew_blocks(groups, ctx->num_cu));
+#define D12_AP(C_) hipLaunchKernelGGL(affine_act_bwd_apply_d12_k<C_>, grid, dim3(kThreads), 0, ctx->stream, (const float*)x.p, scale, shift, \
+                                      (const float*)res.p, alpha, mean, invstd, (const float*)dout.p, sums_total, invM, bn_mode, (float*)dx.p, \
+                                      (float*)dres.p, dres_acc, groups, x.c, (unsigned*)dx_amax)
+    if (x.c == 1) D12_AP(1); else if (x.c == 2) D12_AP(2); else if (x.c == 3) D12_AP(3); else D12_AP(6);
+#undef D12_AP
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   if (v4 && cq >= 1 && (cq & (cq - 1)) == 0 && cq <= kThreads) {
     int cshift = 0;
     while ((1 << cshift) < cq) ++cshift;
@@ -1386,6 +1685,24 @@ int msk_channel_sum(msk_ctx* ctx, msk_tensor x, float* out, int accumulate) {
   int nb = reduce_blocks(voxels, g.VPB, ctx->num_cu, 3);
   float* partial = (float*)msk_workspace(ctx, (size_t)g.cblocks * nb * g.CB * sizeof(float));
   if (!partial) return -1;
+  if (g_dense12 && d12_shape(x, voxels) && d12_ok(x)) {
+    const long groups = voxels * x.c / 12;
+    {
+      msk_launch_scope ls(ctx, "channel_sum_partial");
+#define D12_CS(C_) hipLaunchKernelGGL((affine_act_bwd_reduce_d12_k<C_, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, (const float*)x.p, (const float*)nullptr, \
+                                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, \
+                                      (const float*)nullptr, groups, g.CB, partial)
+      if (x.c == 1) D12_CS(1); else if (x.c == 2) D12_CS(2); else if (x.c == 3) D12_CS(3); else D12_CS(6);
+#undef D12_CS
+      MSK_LAUNCH_CHECK(ctx);
+    }
+    msk_launch_scope ls(ctx, "sums_merge");
+    hipLaunchKernelGGL(sums_merge_k, dim3(x.c), dim3(nb > 256 ? 256 : 64), 0, ctx->stream, partial, nb, x.c, g.CB, 1,
+                       out, accumulate);
+    MSK_LAUNCH_CHECK(ctx);
+    noop_launches(ctx);
+    return 0;
+  }
   {
     msk_launch_scope ls(ctx, "channel_sum_partial");
     hipLaunchKernelGGL(channel_sum_partial_k, dim3(nb, g.cblocks), dim3(kThreads), 0, ctx->stream,
@@ -1626,6 +1943,7 @@ int msk_elu_bwd(msk_ctx* ctx, msk_tensor out, msk_tensor dout, float alpha, msk_
 }
 }  // extern "C"
 
+void msk_set_dense12(int v) { g_dense12 = v; }
 void msk_set_reduce_vpl(int v) { if (v > 0) g_reduce_vpl = v; }
 void msk_set_reduce_vpl_site(int v) { if (v >= 0 && v < 4000) g_reduce_vpl_site[v / 1000] = v % 1000; }
 void msk_set_ew_caps(int ew, int red) {

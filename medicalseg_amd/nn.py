@@ -514,6 +514,11 @@ FUSE_SMALL = os.environ.get("MSEGK_FUSE_SMALL", "1") != "0"
 FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
 # A/B switch (env MSEGK_BWD_FUSE_C1=0): in_tr.conv1's BatchNorm backward as a pass of its own in front of its weight gradient
 FUSE_BN_BACKWARD_C1 = os.environ.get("MSEGK_BWD_FUSE_C1", "1") != "0"
+# Switch (env MSEGK_BWD_FUSE_T=1, default OFF): up-convolution units evaluate dy inside the data gradient's loads and move the pass
+# that writes dy to the weight-gradient stream (msk_convT3d_bwd_bnact).  Measured in the step (round 5, one box, two
+# repetitions): 18.71 ms with it against 18.51 without -- the compute stream loses 0.14 ms of kernel time, but (y, dout) are
+# read twice and the step is bound by the sum of its HBM and matrix work, not by the compute stream's chain alone
+FUSE_BN_BACKWARD_T = os.environ.get("MSEGK_BWD_FUSE_T", "0") == "1"
 
 
 class ConvBNAct:
@@ -704,6 +709,23 @@ class ConvBNAct:
             conv._xform = None
             self.dy = dy if ybuf is None else None
             return
+        if (FUSE_BN_BACKWARD and FUSE_BN_BACKWARD_T and type(self.conv) is Conv3DTranspose and self.bn_mode == 1 and need_dx
+                and res is None and not isinstance(self.act, ELU) and self.conv.cout <= 16):
+            # up-convolution unit (vnet.py:133-150): the data gradient evaluates dy from (y, dout) in its own loads; the pass that
+            # writes dy runs on the weight-gradient stream in front of the weight gradient.  1 = declined (nothing launched)
+            conv, x = self.conv, self.x
+            dx = x.ensure_grad()
+            rc = dev.lib.msk_convT3d_bwd_bnact(dev.ctx, conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                                               _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(),
+                                               _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(),
+                                               1 if x.grad_written else 0, _fp(conv.weight.grad_ptr), 1)
+            if rc < 0:
+                raise MskError(f"msk_convT3d_bwd_bnact failed: {_lib.last_error(dev.ctx)}")
+            if rc == 0:
+                _count_flops(conv, x.n, x.d * x.h * x.w, 2)
+                x.grad_written = True
+                self.dy = dy
+                return
         dres = NULL_TENSOR
         dres_acc = 0
         if res is not None and res_needs_grad and res.c == y.c:

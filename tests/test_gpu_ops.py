@@ -57,6 +57,9 @@ CONV_CASES = [
     (8, 16, (2, 2, 4), (2, 2, 4), (0, 0, 0), (1, 5, 6, 13)),      # k == s with 16 taps: two tap groups in wgrad_ks, floor dims
     (4, 8, (3, 3, 3), (3, 3, 3), (0, 0, 0), (2, 7, 9, 10)),       # k == s with 27 taps (4 tap groups, last one partial)
     (48, 40, (2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 9, 6, 34)),     # k == s, two channel tiles each side, odd D
+    (16, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 4, 6, 64)),     # round 5: gconv_ks_lds_k (<= 16 source channels, runs of 32 destination voxels along W)
+    (16, 64, (2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 4, 4, 128)),    # ... two N tiles per workgroup, two runs per row
+    (8, 32, (2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 2, 6, 64)),      # ... one 8-channel chunk
 ]
 
 
@@ -296,7 +299,10 @@ def test_conv_strided_channel_slice():
     assert rel_err(yt.numpy(), y_ref) < 5e-5
 
 
-@pytest.mark.parametrize("C_,shape", [(16, (2, 9, 10, 11)), (3, (1, 7, 8, 9)), (256, (2, 4, 4, 4)), (20, (1, 5, 6, 7))])
+@pytest.mark.parametrize("C_,shape", [(16, (2, 9, 10, 11)), (3, (1, 7, 8, 9)), (256, (2, 4, 4, 4)), (20, (1, 5, 6, 7)),
+                                      # dense 1/2/3/6-channel tensors: the float4-triple kernels of round 5 (voxels * C % 12 == 0) ...
+                                      (3, (2, 8, 12, 20)), (2, (1, 6, 8, 9)), (6, (1, 4, 5, 6)), (1, (2, 6, 6, 8)),
+                                      (3, (1, 7, 7, 9))])                      # ... and a size they decline (the scalar kernels)
 def test_bn_stats_and_affine_act(C_, shape):
     d = dev()
     N, D, H, W = shape
@@ -345,6 +351,21 @@ def test_bn_stats_and_affine_act(C_, shape):
            vp(sums), C.c_double(M), 1, dxt.msk(), drt.msk(), 1)
     assert rel_err(t_to_ncdhw(dxt), dx_ref) < 2e-4
     assert rel_err(t_to_ncdhw(drt), du + 1.0) < 1e-5
+    csum = vec(np.ones(C_))
+    d.call("msk_channel_sum", dt.msk(), vp(csum), 1)
+    assert rel_err(vec_back(csum, C_), dout.astype(np.float64).sum(axis=(0, 2, 3, 4)) + 1.0) < 1e-5
+    if C_ in (1, 2, 3, 6):
+        # A/B: the scalar kernels (option dense12 0) give the same data gradients bit for bit (same arithmetic per element)
+        d.set_option("dense12", 0)
+        try:
+            dx0, dr0, o0 = t_empty(N, C_, D, H, W), t_empty(N, C_, D, H, W, fill=1.0), t_empty(N, C_, D, H, W)
+            d.call("msk_affine_act_bwd_apply", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), vp(sm), vp(si), vp(g), dt.msk(),
+                   vp(sums), C.c_double(M), 1, dx0.msk(), dr0.msk(), 1)
+            d.call("msk_affine_act_fwd", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), o0.msk())
+        finally:
+            d.set_option("dense12", 1)
+        assert np.array_equal(t_to_ncdhw(dr0), t_to_ncdhw(drt)) and np.array_equal(t_to_ncdhw(o0), t_to_ncdhw(ot))
+        assert rel_err(t_to_ncdhw(dx0), t_to_ncdhw(dxt)) < 1e-6
     # eval-mode coefficients
     d.call("msk_bn_eval_coeffs", C_, vp(g), vp(b_), vp(rmp), vp(rvp), C.c_float(1e-5), vp(sm), vp(si), vp(sc), vp(sh))
     d.call("msk_affine_act_fwd", xt.msk(), vp(sc), vp(sh), rt.msk(), vp(al), ot.msk())
@@ -1282,3 +1303,58 @@ def test_small_pack_cache_follows_every_weight_write():
             check(wp2, w5, "cache off")
         finally:
             d.set_option("small_pack_cache", 1)
+
+
+@pytest.mark.parametrize("cin,cout,src", [(64, 16, (2, 8, 8, 8)), (32, 8, (1, 5, 6, 7)), (64, 16, (1, 16, 16, 16)),
+                                          (64, 16, (1, 2, 4, 32)), (32, 8, (2, 2, 3, 64)), (96, 16, (1, 2, 2, 32))])   # the last three: the LDS-staged form (W % 32 == 0)
+def test_convT_bwd_bnact_equals_the_three_call_form(cin, cout, src):
+    """msk_convT3d_bwd_bnact (round 5): backward of an up-convolution unit convT -> BatchNorm -> PReLU (vnet.py:133-150) with dy
+    evaluated inside the data gradient's loads, against msk_affine_act_bwd_apply + msk_convT3d_dgrad + msk_convT3d_wgrad.  dout is
+    a channel slice of a wider buffer (the concat gradient), dx is accumulated into."""
+    from medicalseg_amd._lib import NULL_TENSOR
+    d = dev()
+    N, D, H, W = src
+    rng = np.random.default_rng(cin + cout)
+    k = s_ = (2, 2, 2)
+    cd = _desc(k, s_, (0, 0, 0))
+    x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+    y = (rng.standard_normal((N, cout, 2 * D, 2 * H, 2 * W)) * 2 + 0.5).astype(np.float32)
+    dwide = rng.standard_normal((N, 2 * cout, 2 * D, 2 * H, 2 * W)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout) + k) / np.sqrt(cin)).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    alpha = rng.uniform(0.05, 0.4, cout).astype(np.float32)
+    mean, invstd = rng.standard_normal(cout).astype(np.float32), rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    M = N * 8 * D * H * W
+    sums = (rng.standard_normal(2 * cout) * np.sqrt(M)).astype(np.float32)
+    xt, yt, wide = t_from_ncdhw(x), t_from_ncdhw(y), t_from_ncdhw(dwide)
+    dt = wide.channel_slice(0, cout)
+    wp = vec(w.ravel())
+    psc, psf, pal, pmu, pis, psm = vec(scale), vec(shift), vec(alpha), vec(mean), vec(invstd), vec(sums)
+    dx0 = rng.standard_normal(x.shape).astype(np.float32)
+    # three calls
+    dy1 = t_empty(N, cout, 2 * D, 2 * H, 2 * W)
+    dx1, dw1 = t_from_ncdhw(dx0), vec(np.full(w.size, 0.25, np.float32))
+    d.call("msk_affine_act_bwd_apply", yt.msk(), vp(psc), vp(psf), NULL_TENSOR, vp(pal), vp(pmu), vp(pis), None, dt.msk(),
+           vp(psm), C.c_double(M), 1, dy1.msk(), NULL_TENSOR, 0)
+    d.call("msk_convT3d_wgrad", cd, xt.msk(), dy1.msk(), vp(dw1), None, 1)
+    d.call("msk_convT3d_dgrad", cd, dy1.msk(), vp(wp), dx1.msk(), 1)
+    # one call
+    dy2 = t_empty(N, cout, 2 * D, 2 * H, 2 * W, fill=7.0)
+    dx2, dw2 = t_from_ncdhw(dx0), vec(np.full(w.size, 0.25, np.float32))
+    rc = d.lib.msk_convT3d_bwd_bnact(d.ctx, cd, xt.msk(), vp(wp), yt.msk(), vp(psc), vp(psf), vp(pal), vp(pmu), vp(pis), dt.msk(),
+                                     vp(psm), C.c_double(M), dy2.msk(), dx2.msk(), 1, vp(dw2), 1)
+    assert rc == 0, rc
+    d.sync()
+    assert np.array_equal(t_to_ncdhw(dy2), t_to_ncdhw(dy1))                       # the same pass, on the other stream
+    assert np.array_equal(vec_back(dw2, w.size), vec_back(dw1, w.size))           # the same weight-gradient kernels on the same dy
+    ref = t_to_ncdhw(dx1)
+    assert rel_err(t_to_ncdhw(dx2), ref) < 2e-6, rel_err(t_to_ncdhw(dx2), ref)   # dy re-evaluated in registers: fp32 contraction only
+    # float64 oracle of the whole chain
+    f8 = lambda a: a.astype(np.float64)
+    sh = (1, cout, 1, 1, 1)
+    u = f8(y) * f8(scale).reshape(sh) + f8(shift).reshape(sh)
+    du = f8(dwide[:, :cout]) * np.where(u > 0, 1.0, f8(alpha).reshape(sh))
+    xh = (f8(y) - f8(mean).reshape(sh)) * f8(invstd).reshape(sh)
+    dy = f8(scale).reshape(sh) * (du - f8(sums[:cout]).reshape(sh) / M - xh * f8(sums[cout:]).reshape(sh) / M)
+    dx_ref = O.conv3d(dy, np.transpose(f8(w), (0, 1, 2, 3, 4)), None, s_, 0) + f8(dx0)   # convT^T = a k == s convolution with w[ci][co]
+    assert rel_err(t_to_ncdhw(dx2), dx_ref) < 2e-5
