@@ -470,6 +470,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(value, 0);
     return 0;
   }
+  if (strcmp(key, "wgrad_reduce_rows") == 0) {  // 0 = wbf_wgrad_reduce_k for the deep layers as well (A/B of wbf_wgrad_reduce_rows_k)
+    ctx->wgrad_reduce_rows = value;
+    return 0;
+  }
   if (strcmp(key, "ks_lds") == 0) {  // 0 = gconv_ks_fwd_k for the 16-channel k == s problems as well (A/B of gconv_ks_lds_k)
     ctx->ks_lds = value;
     return 0;

@@ -343,6 +343,64 @@ wbf_wgrad_reduce_k(const float* __restrict__ P, int ksplit, int NS, int KCA, int
   }
 }
 
+// Round 5 -- the same reduction for the deep layers (>= 128 input channels, <= 4 slabs), one workgroup per (ca, 32-cb group):
+// the form above hands a wavefront's 32 lanes 32 DIFFERENT cb rows of dw[cb][ca][125] -- 20-byte pieces at a stride of
+// CA * 500 bytes (1.1 TB/s on the 33 MB tensors of the 256-channel layers: 77-80 us per launch, four launches per step).  Here
+// the 8 half-wavefronts share the 25 (kd, kh) rows, the 5 kw values of every row go to an LDS tile [32 cb][125 taps] and the
+// workgroup writes 32 runs of 500 contiguous bytes.  Slabs are added in order, in double (as above).
+template <int K>
+__global__ void __launch_bounds__(256)
+wbf_wgrad_reduce_rows_k(const float* __restrict__ P, int ksplit, int KCA, int ncob, int CA, int CB, int tsd, int tsh, int tsw,
+                        float* __restrict__ dw, int accumulate, const float* __restrict__ y_amax, const float* __restrict__ v_amax,
+                        int scaled) {
+  constexpr int NXI = wg_nxi(K), T2 = K * K, T3 = K * K * K, PITCH = T3 + 4;   // 129 floats: odd in dwords -> conflict-free column writes
+  const double G5[8][5] = {{-1, 0, 0, 0, 0},
+                           {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                           {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                           {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                           {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                           {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                           {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                           {0, 0, 0, 0, 1}};
+  const double G3[6][3] = {{0.25, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+  __shared__ float tile[32 * PITCH];
+  const double oscale = scaled ? 1.0 / ((double)wbf_scale_of(y_amax) * (double)wbf_scale_of(v_amax)) : 1.0;
+  const int lane = threadIdx.x & 31, w8 = threadIdx.x >> 5;
+  const int cob = blockIdx.x % ncob, ca = blockIdx.x / ncob;
+  const long slab = (long)KCA * ncob * T2 * 512;    // floats per (xi, ks)
+  const long xstep = (long)ksplit * slab;
+  for (int row = w8; row < T2; row += 8) {
+    const float* p = P + ((((long)(ca >> 4) * ncob + cob) * T2 + row) * 16 + (ca & 15)) * 32 + lane;
+    double acc[NXI];
+#pragma unroll
+    for (int xi = 0; xi < NXI; ++xi) acc[xi] = 0.0;
+    for (int z = 0; z < ksplit; ++z) {
+      float v[NXI];
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) v[xi] = p[(long)xi * xstep + (long)z * slab];
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) acc[xi] += (double)v[xi];
+    }
+    float* o = tile + lane * PITCH + (row / K) * tsd + (row % K) * tsh;
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      double v = 0.0;
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) v += (K == 5 ? G5[xi][kw] : G3[xi][kw]) * acc[xi];
+      o[kw * tsw] = (float)(v * oscale);
+    }
+  }
+  __syncthreads();
+  float* base = dw + ((long)cob * 32 * CA + ca) * T3;
+  for (int i = threadIdx.x; i < 32 * T3; i += 256) {
+    const int cb = i / T3, tap = i - cb * T3;
+    float* q = base + (long)cb * CA * T3 + tap;
+    const float v = tile[cb * PITCH + tap];
+    *q = accumulate ? *q + v : v;
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -454,6 +512,13 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
   }
   {
     msk_launch_scope ls(ctx, "wbf_wgrad_reduce");
+    if (ctx->wgrad_reduce_rows && ksplit <= 4 && (long)g.CA * ncob >= 2L * ctx->num_cu && g.CB % 32 == 0) {
+      // deep layers: one workgroup per (ca, cb group), 500-byte runs of dw (wbf_wgrad_reduce_rows_k)
+      hipLaunchKernelGGL((wbf_wgrad_reduce_rows_k<K>), dim3((unsigned)(g.CA * ncob)), dim3(256), 0, ctx->stream, (const float*)P, (int)ksplit,
+                         KCA, ncob, g.CA, g.CB, tstr[pm[0]], tstr[pm[1]], tstr[pm[2]], g.dw, g.accumulate, y_amax, v_amax, NP != 3 ? 1 : 0);
+      MSK_LAUNCH_CHECK(ctx);
+      return 1;
+    }
     const int NS = ksplit >= 8 ? 8 : (ksplit >= 4 ? 4 : (ksplit >= 2 ? 2 : 1));
     long blocks = ((long)T2 * g.CA * ncob + (8 / NS) - 1) / (8 / NS);
     if (blocks > 32L * ctx->num_cu) blocks = 32L * ctx->num_cu;

@@ -147,6 +147,7 @@ WGRAD_CASES = [
     (32, 32, (1, 32, 32, 9)),       # ragged transform axis: A dy of a tile's missing outputs is zero
     (64, 64, (2, 16, 16, 6)),
     (256, 256, (1, 16, 16, 2)),
+    (128, 128, (1, 8, 16, 7)),      # round 5: the row-coalesced reduce (>= 128 channels) with a permuted transform axis
 ]
 
 
