@@ -74,7 +74,7 @@ def lu_conv_work(n, d, h, w, products=6):
 # HIP-event tag (msk_launch_scope) -> bucket of tools/summarize_rocprof.py
 TAG_BUCKETS = (("lu_gemm", ("wbf_gemm_",)), ("lu_wgrad", ("wbf_wgrad_",)),
                ("lu_transforms", ("wbf_tin_", "wbf_ty_", "wbf_tout_k", "wbf_pack_", "absmax")),
-               ("ks_convs", ("gconv_ks_fwd", "convT_scatter_mfma", "gconv_gather_mfma", "wgrad_ks_mfma", "wgrad_ks2_mfma", "wgrad_mfma")),
+               ("ks_convs", ("gconv_ks_fwd", "gconv_ks_lds", "convT_scatter_mfma", "gconv_gather_mfma", "wgrad_ks_mfma", "wgrad_ks2_mfma", "wgrad_mfma")),
                ("tiny_channel", ("conv_foldn", "conv_tk_", "conv_halo_tightk", "wgrad_cbs", "conv_c1_", "wgrad_c1_", "wgrad_pw_small",
                                  "pointwise_small", "pack_weights_foldn", "pack_weights_tightk")),
                ("loss_optim", ("loss_", "sgd_momentum", "adam", "class_weights")),
@@ -402,7 +402,7 @@ def main():
     kms = line["avg_launch_ms"] * line["launches"]
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic, traffic_src, hbm = None, None, None
-    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
                                   os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) if os.path.exists(pth)), None)
     if tpath and S == 128 and B == 2:   # PMC passes of this exact workload (tools/profile_gpu.sh, tools/summarize_rocprof.py)
         try:

@@ -1,6 +1,6 @@
 """Two-stream picture of ONE training step from a rocprofv3 --kernel-trace csv of bench.py (default launch mode):
    python tools/stream_timeline.py <kernel_trace.csv> [step_index_from_end=1]
-Steps are cut at the weight re-pack that ends the optimizer call (wbf_pack_weights_k).  Per hardware queue: busy time, the kernels' own time; then how long
+Steps are cut at in_tr's forward convolution (conv_c1_*, one launch per step).  Per hardware queue: busy time, the kernels' own time; then how long
 both queues are busy at once, how long the side queue runs ALONE (exposed weight-gradient tail) and which compute-queue
 kernels the side queue's kernels ran next to (by overlap time)."""
 import csv
@@ -17,10 +17,11 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-# one weight re-pack per step, in the optimizer's epilogue (the optimizer itself is two or three launches since the late-gradient split)
-cuts = [i for i, r in enumerate(rows) if "wbf_pack_weights_k" in r[2]]
+# a step starts with in_tr's forward convolution (one launch per step; round 5: the eager optimizer re-packs the weights per block,
+# so the re-pack no longer marks the end of a step)
+cuts = [i for i, r in enumerate(rows) if "conv_c1_" in r[2] and "wgrad" not in r[2]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-lo, hi = cuts[-back - 1] + 1, cuts[-back] + 1
+lo, hi = cuts[-back - 1], cuts[-back]
 step = rows[lo:hi]
 t0, t1 = step[0][0], step[-1][1]
 print("step: %d kernels, %.3f ms" % (len(step), (t1 - t0) / 1e6))

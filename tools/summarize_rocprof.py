@@ -27,15 +27,15 @@ def agg(path, counter):
 
 
 BUCKETS = (("lu_gemm", ("wbf_gemm_k", "wbf_gemm_fused_k")),
-           ("lu_wgrad", ("wbf_wgrad_k", "wbf_wgrad_reduce_k")),
+           ("lu_wgrad", ("wbf_wgrad_k", "wbf_wgrad_reduce")),
            ("lu_transforms", ("wbf_tin_k", "wbf_tin_dual_k", "wbf_tout_k", "wbf_pack_", "absmax_k")),
-           ("ks_convs", ("gconv_ks_fwd_k", "gconv_kst_k", "convT_scatter_mfma_k", "convT_scatter_lds_k", "gconv_gather_mfma_k", "wgrad_ks_mfma_k", "wgrad_ks2_k", "wgrad_mfma_k")),
+           ("ks_convs", ("gconv_ks_fwd_k", "gconv_ks_lds_k", "gconv_kst_k", "convT_scatter_mfma_k", "convT_scatter_lds_k", "gconv_gather_mfma_k", "wgrad_ks_mfma_k", "wgrad_ks2_k", "wgrad_mfma_k")),
            ("tiny_channel", ("conv_foldn", "conv_tk_", "conv_halo_tightk", "wgrad_cbs", "conv_c1_", "wgrad_c1_", "wgrad_pw_small",
                              "pointwise_small", "conv_halo_valu", "pack_foldn", "pack_tk")),
            ("loss_optim", ("loss_", "sgd_momentum_k", "adam_k", "class_weights")),
            ("bn_prelu_join", ("affine_act", "bn_", "sums_merge_k", "param_grads_k", "copy_scale_k", "dropout_mask_k",
                               "channel_sum", "bias_grad")),
-           ("weight_packs_reduces", ("pack_weights_k", "wgrad_reduce", "wgrad_prereduce")))
+           ("weight_packs_reduces", ("pack_weights_k", "small_pack_", "pack_scatter", "wgrad_reduce", "wgrad_prereduce")))
 
 
 def bucket_of(name):
