@@ -298,6 +298,11 @@ int msk_conv3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy
  * out = (in-1)*s + k                                                           */
 int msk_convT3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w,
                     const float* bias /*nullable*/, msk_tensor y);
+/* the same + the BatchNorm statistics of y for the unit UpTransition.up_conv -> bn1 (vnet.py:133-150): stats_local [2 C] = (mean, M2)
+ * of this rank's values, fin (nullable) = msk_bn_finalize(world 1) in the merge launch -- taken in the convolution's store pass where
+ * the kernel can (no separate read of y), by msk_bn_stats_fin otherwise.  Same results to fp32 rounding. */
+int msk_convT3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                       float* stats_local, const msk_bn_fin* fin /*nullable*/);
 int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w,
                       msk_tensor dx, int accumulate);
 int msk_convT3d_wgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, msk_tensor dy,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "msk_conv3d_wgrad_ex3": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i, _vp, _vp, _vp]),
     "msk_conv3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_convT3d_fwd": (_i, [_vp, _CD, _T, _vp, _vp, _T]),
+    "msk_convT3d_fwd_ex": (_i, [_vp, _CD, _T, _vp, _vp, _T, _vp, _vp]),
     "msk_convT3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),
     "msk_convT3d_wgrad": (_i, [_vp, _CD, _T, _T, _vp, _vp, _i]),
     "msk_bn_stats": (_i, [_vp, _T, _vp]),

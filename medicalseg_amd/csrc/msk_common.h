@@ -117,6 +117,7 @@ struct msk_ctx {
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr, ev_comm_back = nullptr;
   int c1_h2 = 1;          // one-input-channel convolutions on the 16-bit pipe (conv_c1_h2_k): 1 = the 3^3 class (UNet3D), 2 = also 5^3 (in_tr), 0 = off
   int wgrad_reduce_rows = 1;   // option "wgrad_reduce_rows": split-K reduce of the deep Winograd weight gradients with 500-byte output runs (wbf_wgrad_reduce_rows_k); 0 = the lane-per-cb form (A/B)
+  int ks_stats = 1;       // option "ks_stats": BatchNorm statistics in the store pass of the k == s kernels (convT_scatter_lds_k, gconv_ks_lds_k); 0 = the separate pass (A/B)
   int ks_lds = 1;         // option "ks_lds": 2x2x2 / stride 2 convolutions with <= 16 source channels through the LDS tile (gconv_ks_lds_k); 0 = the per-lane gather form (A/B)
   int ks_nr_max = 4;      // gconv_ks_fwd / gconv_kst: most N tiles per workgroup (4: x read once but 160 registers -- such a wavefront finds no room
                           // on a SIMD that holds three weight-gradient wavefronts of the side stream; 2: 94 registers)

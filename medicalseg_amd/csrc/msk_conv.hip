@@ -1832,6 +1832,34 @@ int msk_convT3d_fwd(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w
   return run_gconv(ctx, g, w, x.c, y.c, 0, "convT3d_fwd_direct");
 }
 
+// msk_convT3d_fwd + the BatchNorm statistics of y (stats_local [2 C]: mean, M2; fin nullable: msk_bn_finalize(world 1) in the
+// merge launch), taken in the store pass of the kernel where it can (convT_scatter_lds_k), by msk_bn_stats_fin otherwise
+int msk_convT3d_fwd_ex(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, const float* bias, msk_tensor y,
+                       float* stats_local, const msk_bn_fin* fin) {
+  if (check_conv_shapes(ctx, cd, x, y, true) != 0) return -1;
+  if (fin && !fin->scale) fin = nullptr;
+  MSK_REQUIRE(ctx, stats_local != nullptr, "msk_convT3d_fwd_ex: stats_local required");
+  GConv g{};
+  g.src = (const float*)x.p; g.sld = x.ld; g.dst = (float*)y.p; g.dld = y.ld;
+  g.N = x.n; g.SD = x.d; g.SH = x.h; g.SW = x.w; g.DD = y.d; g.DH = y.h; g.DW = y.w;
+  g.CK = x.c; g.CN = y.c;
+  g.kd = cd.kd; g.kh = cd.kh; g.kw = cd.kw; g.sd = cd.sd; g.sh = cd.sh; g.sw = cd.sw;
+  g.pd = 0; g.ph = 0; g.pw = 0;
+  g.transposed = 1; g.bias = bias; g.accumulate = 0; g.flip = 0;
+  g.w_persistent = true;
+  const size_t sper = (size_t)g.SD * g.SH * g.SW * g.sld * sizeof(float), dper = (size_t)g.DD * g.DH * g.DW * g.dld * sizeof(float);
+  const size_t per = sper > dper ? sper : dper;
+  const bool chunked = per > 0 && (size_t)g.N > kChunkBytes / per;
+  ctx->stats_fused = false;
+  if (!chunked) {
+    g.stats = stats_local;
+    g.fin = fin;
+  }
+  if (int rc = run_gconv(ctx, g, w, x.c, y.c, 0, "convT3d_fwd_direct")) return rc;
+  if (!ctx->stats_fused) return msk_bn_stats_fin(ctx, y, stats_local, fin);
+  return 0;
+}
+
 int msk_convT3d_dgrad(msk_ctx* ctx, msk_conv_desc cd, msk_tensor dy, const float* w, msk_tensor dx, int accumulate) {
   if (check_conv_shapes(ctx, cd, dx, dy, true) != 0) return -1;
   GConv g{};

@@ -8,6 +8,7 @@
 // source voxels ONCE (A fragments stay in registers), loops over the N tiles, and a wavefront's stores
 // cover contiguous destination rows (tap pairs along W are adjacent voxels).
 #include "msk_conv.h"
+#include "msk_wbf.h"   // msk_bn_stats_merge
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -137,9 +138,25 @@ convT_scatter_mfma_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
 // ds_read_b128 (voxel pitch = an odd number of 16-byte slots: conflict-free), and every wavefront owns whole 32-row tiles
 // (for 16 output channels: the two W-adjacent fine voxels of one (kd, kh)) whose results go through a private LDS patch and
 // leave as 1 KB contiguous stores -- the accumulate reads and the bias ride on the same coalesced pass.
-template <int TPW>  // 32-row tiles of (tap, cn) per wavefront
+// STATS (round 5, msk_convT3d_fwd_ex): the BatchNorm statistics of the stored values ride along -- every lane keeps (n, mean, M2)
+// of the 4 channels of its store quad over the 8 voxels it stores per tile (shifted by its first value), the 8 lane groups of a
+// wavefront are merged with shuffles (Chan), the (tile, quad) records of the workgroup meet in LDS and thread c merges the taps of
+// channel c in tap order: one record per workgroup and channel for msk_bn_stats_merge.  The separate pass over the up-convolution's
+// output (268 MB at 16ch@128^3, 47 us) is gone.
+struct ScWF { float n, mean, m2; };
+__device__ __forceinline__ ScWF sc_merge(ScWF a, ScWF b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  ScWF r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean, f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+template <int TPW, bool STATS = false>  // 32-row tiles of (tap, cn) per wavefront
 __global__ void __launch_bounds__(256, TPW == 1 ? 4 : 3)
-convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
+convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad, float* __restrict__ stat_partial /*[gridDim.x][CN][3]*/) {
   extern __shared__ float4 smem4[];
   float* smem = reinterpret_cast<float*>(smem4);
   const int tid = threadIdx.x;
@@ -149,6 +166,7 @@ convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
   float* Xs = smem;                                // [64][XP]
   float* Os = smem + 64 * XP + wave * (32 * OP);   // [32][OP] per wavefront
   unsigned* vbase = reinterpret_cast<unsigned*>(smem + 64 * XP + 4 * 32 * OP);  // [64] destination element offset of a source voxel
+  ScWF* rec = reinterpret_cast<ScWF*>(smem + 64 * XP + 4 * 32 * OP + 64);       // STATS: [4 * TPW tiles][8 quads][4] records
   const long M = (long)g.N * g.SD * g.SH * g.SW;
   const long m0 = (long)blockIdx.x * 64;
 
@@ -217,6 +235,7 @@ convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
     const int ta = tap / khw, tb = (tap - ta * khw) / g.kw, tc = tap - ta * khw - tb * g.kw;
     const unsigned toff = ((unsigned)(ta * g.DH + tb) * g.DW + tc) * g.dld + cn;
     const float4 bv = (g.bias && rok) ? *reinterpret_cast<const float4*>(g.bias + cn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float sK[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, sn = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // D[row][col = voxel li]: lane holds rows 8q + 4lh + {0..3}
@@ -237,8 +256,63 @@ convT_scatter_lds_k(GConv g, const float4* __restrict__ bf, int KC, int jpad) {
             o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
           }
           *reinterpret_cast<float4*>(dp) = o;
+          if constexpr (STATS) {
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            if (sn == 0.f) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sK[j] = ov[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float d = ov[j] - sK[j];
+              s1[j] += d;
+              s2[j] = fmaf(d, d, s2[j]);
+            }
+            sn += 1.f;
+          }
         }
       }
+    }
+    if constexpr (STATS) {
+      // the lane's quad over its <= 8 voxels -> the wavefront's 32 voxels (lane groups lane >> 3, fixed order of the merges)
+      ScWF w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[j].n = sn;
+        w[j].mean = sn > 0.f ? sK[j] + s1[j] / sn : 0.f;
+        w[j].m2 = sn > 0.f ? fmaxf(s2[j] - s1[j] * s1[j] / sn, 0.f) : 0.f;
+      }
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ScWF o2;
+          o2.n = __shfl_xor(w[j].n, off, 64);
+          o2.mean = __shfl_xor(w[j].mean, off, 64);
+          o2.m2 = __shfl_xor(w[j].m2, off, 64);
+          // both partners must add in the same order: the lane with the lower group index first
+          w[j] = (lane & off) ? sc_merge(o2, w[j]) : sc_merge(w[j], o2);
+        }
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rec[(tile * 8 + lane) * 4 + j] = w[j];
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    if (tid < g.CN) {
+      const int taps = g.kd * khw;
+      ScWF a = {0.f, 0.f, 0.f};
+      for (int tap = 0; tap < taps; ++tap) {
+        const int row = tap * g.CN + tid;
+        a = sc_merge(a, rec[((row >> 5) * 8 + ((row & 31) >> 2)) * 4 + (row & 3)]);
+      }
+      float* p = stat_partial + ((long)blockIdx.x * g.CN + tid) * 3;
+      p[0] = a.n;
+      p[1] = a.mean;
+      p[2] = a.m2;
     }
   }
 }
@@ -286,14 +360,29 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
   msk_launch_scope ls(ctx, tag);
   const int ntiles = jpad / 32;
   // LDS-staged form: up to 16 row tiles (4 per wavefront), the staged voxels + patches within 64 KB; option ks_legacy bit 1 = fragment-shaped kernel (A/B)
-  const size_t lds = ((size_t)64 * (KC * 8 + 4) + 4 * 32 * 36 + 64) * sizeof(float);
+  const int tpw0 = (ntiles + 3) / 4, tpw_t = tpw0 <= 1 ? 1 : (tpw0 == 2 ? 2 : 4);
+  const size_t lds = ((size_t)64 * (KC * 8 + 4) + 4 * 32 * 36 + 64 + 4 * tpw_t * 32 * 3) * sizeof(float);
   if (ntiles <= 16 && lds <= 65536 && (!g.bias || ((uintptr_t)g.bias) % 16 == 0) && !(ctx->ks_legacy & 2)) {
     const dim3 grid((unsigned)((M + 63) / 64));
-    const int tpw = (ntiles + 3) / 4;
-    if (tpw <= 1) hipLaunchKernelGGL((convT_scatter_lds_k<1>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
-    else if (tpw == 2) hipLaunchKernelGGL((convT_scatter_lds_k<2>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
-    else hipLaunchKernelGGL((convT_scatter_lds_k<4>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad);
+    // BatchNorm statistics of the output in the store pass (msk_convT3d_fwd_ex; option "ks_stats" 0 = the separate pass)
+    const bool stats = g.stats != nullptr && !g.accumulate && !g.stats_ps && g.CN <= 256 && ctx->ks_stats;
+    float* sp = nullptr;
+    if (stats) {
+      sp = (float*)msk_workspace(ctx, (size_t)grid.x * g.CN * 3 * sizeof(float));
+      if (!sp) return -1;
+    }
+#define SC_LDS(T_) \
+    do { \
+      if (stats) hipLaunchKernelGGL((convT_scatter_lds_k<T_, true>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad, sp); \
+      else hipLaunchKernelGGL((convT_scatter_lds_k<T_, false>), grid, dim3(256), lds, ctx->stream, g, (const float4*)bf, KC, jpad, sp); \
+    } while (0)
+    if (tpw_t == 1) SC_LDS(1); else if (tpw_t == 2) SC_LDS(2); else SC_LDS(4);
+#undef SC_LDS
     MSK_LAUNCH_CHECK(ctx);
+    if (stats) {
+      if (msk_bn_stats_merge(ctx, sp, (int)grid.x, g.CN, g.stats, g.fin) != 0) return -1;
+      ctx->stats_fused = true;
+    }
     return 1;
   }
   const int ntg = ntiles % 4 == 0 ? 4 : (ntiles % 2 == 0 ? 2 : 1);

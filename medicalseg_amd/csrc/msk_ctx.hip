@@ -474,6 +474,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wgrad_reduce_rows = value;
     return 0;
   }
+  if (strcmp(key, "ks_stats") == 0) {  // 0 = BatchNorm statistics of the k == s convolutions' outputs as a pass of their own (A/B)
+    ctx->ks_stats = value;
+    return 0;
+  }
   if (strcmp(key, "ks_lds") == 0) {  // 0 = gconv_ks_fwd_k for the 16-channel k == s problems as well (A/B of gconv_ks_lds_k)
     ctx->ks_lds = value;
     return 0;

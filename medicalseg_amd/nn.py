@@ -510,6 +510,8 @@ def _amax_for(out: Tensor):
 FUSE_SMALL = os.environ.get("MSEGK_FUSE_SMALL", "1") != "0"
 
 
+# A/B switch (env MSEGK_KS_STATS=0): up-convolution units take their BatchNorm statistics in a pass of their own
+KS_STATS = os.environ.get("MSEGK_KS_STATS", "1") != "0"
 # A/B switch (env MSEGK_BWD_FUSE=0): conv -> BN -> PReLU units run their backward as three calls (apply, dgrad, wgrad)
 FUSE_BN_BACKWARD = os.environ.get("MSEGK_BWD_FUSE", "1") != "0"
 # A/B switch (env MSEGK_BWD_FUSE_C1=0): in_tr.conv1's BatchNorm backward as a pass of its own in front of its weight gradient
@@ -578,6 +580,16 @@ class ConvBNAct:
         if bn.training and type(self.conv) is Conv3D:
             # statistics from the convolution's output stage, transformed input kept for the weight gradient
             y = self.conv.run_forward(x, stats_ptr=sc["stats"], keep_xform=True, fin=fin)
+        elif bn.training and type(self.conv) is Conv3DTranspose and KS_STATS:
+            # up-convolution (vnet.py:133-150): the statistics ride in the convolution's store pass where its kernel can
+            conv = self.conv
+            if x.c != conv.cin:
+                raise ValueError(f"Conv3DTranspose expects {conv.cin} input channels, got {x.c}")
+            od, oh, ow = conv.out_dims(x)
+            y = Tensor.empty(dev, x.n, od, oh, ow, conv.cout)
+            _count_flops(conv, x.n, x.d * x.h * x.w, 1)
+            dev.call("msk_convT3d_fwd_ex", conv.desc(), x.msk(), _fp(conv.weight.ptr), _fp(conv.bias.ptr), y.msk(), _fp(sc["stats"]),
+                     C.byref(fin) if fin is not None else None)
         else:
             y = self.conv.run_forward(x)
             if bn.training:

@@ -51,7 +51,7 @@ static float fake_amax[128];
 float* msk_amax_new(void* c, int n) { (void)c; (void)n; return fake_amax; }
 NOOP(msk_conv3d_fwd_ex3) NOOP(msk_conv3d_fwd_in) NOOP(msk_bn_stats_fin) NOOP(msk_affine_act_bwd_reduce_pg) NOOP(msk_add_act_join_bwd_pg)
 NOOP(msk_conv3d_fwd) NOOP(msk_conv_fold_bn) NOOP(msk_conv3d_fwd_act) NOOP(msk_conv3d_fwd_ex) NOOP(msk_conv3d_wgrad_ex) NOOP(msk_conv3d_bwd_bnact) NOOP(msk_conv3d_dgrad) NOOP(msk_conv3d_wgrad)
-NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
+NOOP(msk_convT3d_fwd) NOOP(msk_convT3d_fwd_ex) NOOP(msk_convT3d_dgrad) NOOP(msk_convT3d_wgrad)
 NOOP(msk_bn_stats) NOOP(msk_bn_finalize) NOOP(msk_bn_eval_coeffs)
 NOOP(msk_affine_act_fwd) NOOP(msk_affine_act_bwd_reduce) NOOP(msk_affine_act_bwd_reduce_ex) NOOP(msk_affine_act_join_fwd) NOOP(msk_add_act_join_bwd) NOOP(msk_add_act_join_bwd_ex) NOOP(msk_affine_act_bwd_apply) NOOP(msk_affine_act_param_grads)
 NOOP(msk_add_act_bwd) NOOP(msk_bn_bias_grad) NOOP(msk_copy_scale) NOOP(msk_dropout_mask) NOOP(msk_channel_sum) NOOP(msk_argmax_c) NOOP(msk_softmax_c)

@@ -1358,3 +1358,41 @@ def test_convT_bwd_bnact_equals_the_three_call_form(cin, cout, src):
     dy = f8(scale).reshape(sh) * (du - f8(sums[:cout]).reshape(sh) / M - xh * f8(sums[cout:]).reshape(sh) / M)
     dx_ref = O.conv3d(dy, np.transpose(f8(w), (0, 1, 2, 3, 4)), None, s_, 0) + f8(dx0)   # convT^T = a k == s convolution with w[ci][co]
     assert rel_err(t_to_ncdhw(dx2), dx_ref) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,src", [(64, 16, (1, 16, 32, 32)), (128, 32, (1, 16, 32, 32)), (32, 16, (1, 17, 31, 33)),
+                                          (256, 64, (1, 26, 26, 26)), (64, 16, (2, 4, 4, 4))])
+def test_convT_fwd_ex_statistics_in_the_store_pass(cin, cout, src):
+    """msk_convT3d_fwd_ex (round 5): the up-convolution's output and its BatchNorm statistics (+ finalisation) from ONE call -- in
+    convT_scatter_lds_k's store pass for >= 16384 source voxels (1, 2 and 4 row tiles per wavefront, a ragged last workgroup), by
+    the separate pass otherwise -- against msk_convT3d_fwd + msk_bn_stats and the float64 moments of the output."""
+    from medicalseg_amd._lib import MskBnFin
+    d = dev()
+    N, D, H, W = src
+    rng = np.random.default_rng(cin)
+    k = s_ = (2, 2, 2)
+    cd = _desc(k, s_, (0, 0, 0))
+    x = (rng.standard_normal((N, cin, D, H, W)) + 0.3).astype(np.float32)
+    w = (rng.standard_normal((cin, cout) + k) / np.sqrt(cin)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 3).astype(np.float32)      # a large mean per channel: the shifted sums must not cancel
+    xt, wp, bp = t_from_ncdhw(x), vec(w.ravel()), vec(b)
+    y1, y2 = t_empty(N, cout, 2 * D, 2 * H, 2 * W), t_empty(N, cout, 2 * D, 2 * H, 2 * W)
+    st1, st2 = vec(np.zeros(2 * cout)), vec(np.zeros(2 * cout))
+    d.call("msk_convT3d_fwd", cd, xt.msk(), vp(wp), vp(bp), y1.msk())
+    d.call("msk_bn_stats", y1.msk(), vp(st1))
+    gamma, beta = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    rm, rv = vec(np.zeros(cout)), vec(np.ones(cout))
+    sm, si, sc, sh = vec(np.zeros(cout)), vec(np.zeros(cout)), vec(np.zeros(cout)), vec(np.zeros(cout))
+    M = N * 8 * D * H * W
+    fin = MskBnFin(vec(gamma), vec(beta), 1e-5, 0.9, float(M), rm, rv, sm, si, sc, sh)
+    d.call("msk_convT3d_fwd_ex", cd, xt.msk(), vp(wp), vp(bp), y2.msk(), vp(st2), C.byref(fin))
+    ya, yb = t_to_ncdhw(y1), t_to_ncdhw(y2)
+    assert np.array_equal(ya, yb)
+    y64 = ya.astype(np.float64)
+    mean, var = y64.mean(axis=(0, 2, 3, 4)), y64.var(axis=(0, 2, 3, 4))
+    a, b2 = vec_back(st1, 2 * cout), vec_back(st2, 2 * cout)
+    assert np.abs(b2[:cout] - mean).max() < 2e-6 * max(1.0, np.abs(mean).max()), np.abs(b2[:cout] - mean).max()
+    assert rel_err(b2[cout:] / M, var) < 1e-5 and rel_err(a[cout:] / M, var) < 1e-5
+    assert rel_err(vec_back(si, cout), 1.0 / np.sqrt(var + 1e-5)) < 1e-5
+    assert rel_err(vec_back(sc, cout), gamma / np.sqrt(var + 1e-5)) < 1e-5
+    assert rel_err(vec_back(rm, cout), 0.1 * mean) < 1e-5
