@@ -270,7 +270,10 @@ inline bool wbf_pick_geom(int D, int H, int W, int minTD, int minTH, WbfGeom* ou
 // a (TD x TH) position tiling fits the planes and wastes no more of the matrix work on padding than the geometry's limit
 inline bool wbf_tile_ok(const WbfGeom& g, int TD, int TH) {
   const int td = (g.LD + TD - 1) / TD * TD, th = (g.LH + TH - 1) / TH * TH;
-  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th <= g.max_pad * (double)g.LD * g.LH;
+  // the same inequality wbf_pick_geom accepted the geometry under: the ragged last W tile counts as padded work too (advisor,
+  // round 4: without the LW factor a ragged axis let a tiling through at max_pad * LW4 / LW of padded work)
+  const int lw4 = (g.LW + 3) / 4 * 4;
+  return td + 4 <= g.DP && th + 4 <= g.HP && (double)td * th * lw4 <= g.max_pad * (double)g.LD * g.LH * g.LW;
 }
 size_t msk_wbf_xform_bytes(int n, int d, int h, int w, int c, int cout, int K, int NP);
 size_t msk_wbf_fwd_xform_bytes(const msk_ctx* ctx, int n, int d, int h, int w, int c, int cout, int K);
