@@ -770,3 +770,50 @@ def test_vnet_elu_matches_oracle(train):
     # 16^3: the deep BatchNorm layers see 1-8 voxels per channel in train mode (same bounds as the PReLU net's test above)
     assert max(errs) < (2e-2 if train else 1e-4)
     model.clear_gradients()
+
+
+@pytest.mark.parametrize("which", ["VNetDeepSup", "UNet3D"])
+def test_eager_optimizer_other_models_bitwise(which):
+    """The eager optimizer on the other two models that report their blocks (VNetDeepSup: the deep-supervision heads are read
+    AFTER some decoder blocks reported -- they are not blocks, their parameters wait for step(); UNet3D: InstanceNorm units):
+    three training steps bitwise equal to the plain order, as tools/bench_workloads.py and core.train() now run them."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd import models
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    ncls, N, shape = 3, 2, (32, 32, 16)
+    results = []
+    for eager in (False, True):
+        rng = np.random.default_rng(9)
+        nn.seed(21)
+        nn.Dropout3D._site_counter = 0
+        if which == "UNet3D":
+            model = models.UNet3D(in_channels=1, num_classes=ncls, base_channels=16, depth=3)
+        else:
+            model = models.VNetDeepSup(elu=False, in_channels=1, num_classes=ncls)
+        n_out = getattr(model, "num_outputs", 1)
+        opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        if eager:
+            assert opt.enable_eager(model) is True
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1]) for _ in range(n_out)], "coef": [1.0 / n_out] * n_out}
+        model.train()
+        nn.Dropout3D.step, nn.Dropout3D.seed = 0, 3
+        vals = []
+        for step in range(3):
+            x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+            y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+            loss_list, _ = loss_computation(model(x), to_labels(y), losses)
+            loss = sum(loss_list)
+            loss.backward()
+            if eager:
+                assert len(opt._eager_done) >= 3
+            opt.step()
+            model.clear_gradients()
+            vals.append(float(loss))
+        results.append((vals, model.state_dict(), dev().d2h(opt.velocity_ptr, (model.arena.count,), np.float32)))
+    (va, sda, vela), (vb, sdb, velb) = results
+    assert va == vb, (va, vb)
+    for k in sda:
+        assert np.array_equal(sda[k], sdb[k]), k
+    assert np.array_equal(vela, velb) and np.abs(vela).max() > 0

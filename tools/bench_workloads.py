@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--iso", action="store_true", help="isotropic 2x2x2 kernels/strides (lung) instead of the MRI ones")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="msk_set_option knob for experiments")
+    ap.add_argument("--eager-opt", type=int, default=1, choices=(0, 1), help="optimizer update per block during backward (Momentum.enable_eager; models with block hooks)")
     ap.add_argument("--inloop-preprocess", action="store_true",
                     help="BASELINE configs[4] as worded: every step takes a RAW sample from host memory (2x the model's in-plane "
                          "size, e.g. 1008x1008x12 MRI: pinned H2D -> normalize(0, 2650) -> resample(order 1) -> max-normalise; label "
@@ -52,6 +53,7 @@ def main():
     losses = {"types": [models.MixedLoss([models.CrossEntropyLoss(), models.DiceLoss()], [1, 1]) for _ in range(n_out)],
               "coef": [1.0 / n_out] * n_out}
     opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+    eager = bool(a.eager_opt) and opt.enable_eager(model)     # as core.train() / bench.py at one rank: update + re-pack per block on the weight-gradient stream
     rng = np.random.default_rng(0)
     x = to_tensor(rng.random((a.batch, 1) + shape, dtype=np.float32))
     y = to_tensor(rng.integers(0, a.num_classes, (a.batch,) + shape).astype(np.int32))
@@ -96,7 +98,7 @@ def main():
         # else at the fp32 MFMA peak
         prod3 = 1.0 if (a.model == "UNet3D" and a.precision == "fp16") else 3.0
         floor_s = (F["same_k5"] * 0.4 * 3.0 + F["same_k3"] * 0.5 * prod3) / 2500e12 + F["other"] / 157.3e12
-        res = {"workload": f"{a.model} {shape} ncls={a.num_classes} batch={a.batch} precision={a.precision}",
+        res = {"workload": f"{a.model} {shape} ncls={a.num_classes} batch={a.batch} precision={a.precision}", "eager_optimizer": eager,
                "ms_per_step": round(ms, 3), "voxels_per_s": round(vox / ms * 1e3, 1),
                "algorithmic_flop_per_step": alg, "algorithmic_tflops": round(alg / ms / 1e9, 1),
                "algorithmic_speedup_vs_fp32_mfma_peak": round(alg / ms / 1e9 / 157.3, 3),
