@@ -292,3 +292,57 @@ def test_mri_inloop_preprocess_at_full_size_matches_oracle():
     assert got.shape == (512, 512, 12)
     assert np.abs(got - ref).max() < 2e-6                       # order 1: within 1 fp32 ulp of values in [0, 1]
     assert np.array_equal(lab.numpy(), P.resample(raw_lab, [512, 512, 12], 0)[0])   # labels: bit-exact
+
+
+def test_inloop_preprocess_on_a_second_context_feeds_the_training_context():
+    """Round 5 (configs[4] as worded): the pipeline of the previous test on a SECOND context (= a second stream), raw samples in
+    pinned memory, pooled buffers, handed to the training context with msk_ctx_wait (no host synchronisation between the two) --
+    what tools/bench_workloads.py --inloop-preprocess times.  The tensor the training context reads must be the oracle's, for
+    several samples in a row through recycled buffers, and a kernel of the training context that consumes it right behind the
+    wait must see the finished data."""
+    import ctypes as C
+    from oracle import preprocess_numpy as P
+    from medicalseg_amd.device import Device, Tensor, get_device
+    from medicalseg_amd.preprocess import DevicePipeline
+    dev = get_device()
+    pre = Device(dev.index)
+    pipe_x, pipe_y = DevicePipeline(pre, pooled=True), DevicePipeline(pre, pooled=True)
+    raw_shape, shape = (240, 240, 12), (128, 128, 12)
+    nraw = int(np.prod(raw_shape))
+    rng = np.random.default_rng(3)
+    raws = []
+    for _ in range(2):
+        pi, pl = C.c_void_p(), C.c_void_p()
+        pre.call("msk_pinned_alloc", C.c_size_t(nraw * 4), C.byref(pi))
+        pre.call("msk_pinned_alloc", C.c_size_t(nraw * 4), C.byref(pl))
+        img = (rng.random(raw_shape) * 2650).astype(np.float32)
+        lab = rng.integers(0, 20, raw_shape).astype(np.int32)
+        np.ctypeslib.as_array((C.c_float * nraw).from_address(pi.value))[:] = img.ravel()
+        np.ctypeslib.as_array((C.c_int32 * nraw).from_address(pl.value))[:] = lab.ravel()
+        ref, _ = P.resample(P.normalize(img.copy(), 0, 2650), list(shape), 1)
+        raws.append((pi.value, pl.value, P.max_normalize(ref).astype(np.float32)[0], P.resample(lab, list(shape), 0)[0]))
+    old = None
+    for i in range(5):
+        pi, pl, ref_x, ref_y = raws[i % 2]
+        pre.wait_for(dev)                       # the buffers going back to the pool were last read by the training context
+        if old is not None:
+            pipe_x.release(old[0])
+            pipe_y.release(old[1])
+        x = pipe_x.from_pinned(pi, raw_shape).normalize(0, 2650).resample(list(shape), 1).max_normalize().tensor()
+        y = pipe_y.from_pinned(pl, raw_shape, np.int32).resample(list(shape), 0).int_tensor()
+        dev.wait_for(pre)                       # device-side hand-over: NO host synchronisation of `pre`
+        x.dev = dev
+        # a kernel of the training context right behind the wait: out = 2 * x (msk_copy_scale with a per-(n, c) factor of 2)
+        out = Tensor.empty(dev, 1, *shape, 1, arena=False)
+        two = dev.malloc(16)
+        dev.h2d(two, np.array([2.0], np.float32))
+        dev.call("msk_copy_scale", x.msk(), C.c_void_p(two), out.msk(), 0)
+        got2 = out.numpy()[0, 0]
+        assert np.abs(got2 - 2.0 * ref_x).max() < 4e-6, i
+        assert np.array_equal(dev.d2h(y.ptr, shape, np.int32), ref_y), i
+        dev.free(two)
+        dev.free(out.ptr)
+        old = (x, y)
+    for pi, pl, _, _ in raws:
+        pre.call("msk_pinned_free", C.c_void_p(pi))
+        pre.call("msk_pinned_free", C.c_void_p(pl))
