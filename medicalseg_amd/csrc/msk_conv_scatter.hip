@@ -7,6 +7,8 @@
 // 0.69 ms for 32ch@64^3 -> 16ch@128^3 against ~0.1 ms of HBM time.  Here a workgroup reads its 128
 // source voxels ONCE (A fragments stay in registers), loops over the N tiles, and a wavefront's stores
 // cover contiguous destination rows (tap pairs along W are adjacent voxels).
+#include <optional>
+
 #include "msk_conv.h"
 #include "msk_wbf.h"   // msk_bn_stats_merge
 
@@ -357,7 +359,8 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
              g.DD, g.DH, g.DW);
     tag = msk_intern_tag(ctx, buf);
   }
-  msk_launch_scope ls(ctx, tag);
+  std::optional<msk_launch_scope> ls;   // (ended by hand in front of the statistics merge: profile brackets do not nest)
+  ls.emplace(ctx, tag);
   const int ntiles = jpad / 32;
   // LDS-staged form: up to 16 row tiles (4 per wavefront), the staged voxels + patches within 64 KB; option ks_legacy bit 1 = fragment-shaped kernel (A/B)
   const int tpw0 = (ntiles + 3) / 4, tpw_t = tpw0 <= 1 ? 1 : (tpw0 == 2 ? 2 : 4);
@@ -379,6 +382,7 @@ int msk_gconv_scatter_mfma(msk_ctx* ctx, const GConv& g, const float* w_canon, i
     if (tpw_t == 1) SC_LDS(1); else if (tpw_t == 2) SC_LDS(2); else SC_LDS(4);
 #undef SC_LDS
     MSK_LAUNCH_CHECK(ctx);
+    ls.reset();
     if (stats) {
       if (msk_bn_stats_merge(ctx, sp, (int)grid.x, g.CN, g.stats, g.fin) != 0) return -1;
       ctx->stats_fused = true;

@@ -660,7 +660,11 @@ __device__ __forceinline__ void frag_pos(int r, int& a, int& b) {
 // and ONE 32-channel column fragment: its B fragments come straight from L2/L1 (NP slots per tap and 16-channel chunk,
 // used by MR*6 (or MR) MFMAs), A fragments from the LDS halo tile (TD+K-1) x (TH+K-1) that the whole workgroup shares
 // and every one of the K*K taps re-reads.  The tile is filled by LDS-DMA (buffer_load ... lds, 16 B per lane), no registers.
-template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
+// BPF (round 5): how many taps ahead the B (weight) fragments are requested.  One tap ahead leaves ~200 cycles of matrix
+// instructions between a request and its use -- an L2 round trip is several times that -- which the big launches hide behind
+// three or four resident workgroups per CU; the deep levels (<= 2048 workgroups of one or two chunks each) run one or two
+// per CU and waited on every tap.  BPF = 4: a ring of five fragment sets (+24 registers).
+template <int MR, int WM, int WN, int TD, int TH, int K, int NP, int BPF = 1>
 __global__ void __launch_bounds__(WM * WN * 64)
 wbf_gemm_k(GemmArgs a) {
   static_assert((WM * WN == 4 || WM * WN == 2) && WM * MR * 32 == TD * TH, "tile shape");
@@ -738,9 +742,12 @@ wbf_gemm_k(GemmArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * NT + wave * 64), 16,
                                                (int)voff[r], (int)vsoff, 0, 0);
     const unsigned ukc = (unsigned)kc * uchunk;
-    uint4 bq[2][NP];
+    constexpr int BR = BPF + 1;   // ring of B fragment sets: tap t lives in bq[t % BR]
+    uint4 bq[BR][NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) bq[0][p] = buf_load16(ures, ulane, ukc + p * ustep);
+    for (int t0 = 0; t0 < BPF && t0 < T2; ++t0)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bq[t0][p] = buf_load16(ures, ulane, (unsigned)t0 * utap + ukc + p * ustep);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -757,12 +764,15 @@ wbf_gemm_k(GemmArgs a) {
 #pragma unroll
     for (int tap = 0; tap < T2; ++tap) {
       const int cur = tap & 1, nx = cur ^ 1;
-      if (tap + 1 < T2) {
-        const unsigned ub = (unsigned)(tap + 1) * utap + ukc;
+      const int bcur = tap % BR;
+      if (tap + BPF < T2) {
+        const unsigned ub = (unsigned)(tap + BPF) * utap + ukc;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          bq[nx][p] = buf_load16(ures, ulane, ub + p * ustep);
+          bq[(tap + BPF) % BR][p] = buf_load16(ures, ulane, ub + p * ustep);
         }
+      }
+      if (tap + 1 < T2) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
           const uint4* ap = lds + arow[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
@@ -776,30 +786,30 @@ wbf_gemm_k(GemmArgs a) {
       if (NP == 3) {
         // small terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[bcur][0]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][NP - 1]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][NP / 2]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[bcur][NP / 2]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[bcur][0]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP / 2]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][NP / 2]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][0]);
       } else if (NP == 2) {
         // small terms first: lo*hi, hi*lo, hi*hi.  The activation's low piece is stored times 2^11 (msk_wbf.h): its partner
         // is the weight's high piece times 2^-11, made here
-        const uint4 bdown = wbf_hi_down(bq[cur][0]);
+        const uint4 bdown = wbf_hi_down(bq[bcur][0]);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][NP - 1]);
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][0]);
       } else {
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][0]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1290,6 +1300,15 @@ void launch_gemm(msk_ctx* ctx, const GemmArgs& a, long nblk) {
   long grid = (nblk + tpb - 1) / tpb;
   grid = (grid + 7) & ~7L;
   b.tpb = (int)((nblk + grid - 1) / grid);
+  // weight fragments four taps ahead for the launches that cannot hide an L2 round trip behind other workgroups (option "wbf_bpf":
+  // 0 = by grid size, 1 / 4 = force)
+  const bool deep = MR == 2 && (ctx->wbf_bpf == 4 || (ctx->wbf_bpf == 0 && nblk <= 8L * ctx->num_cu));
+  if constexpr (MR == 2) {
+    if (deep) {
+      hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP, 4>), dim3((unsigned)grid), dim3(WM * WN * 64), 0, ctx->stream, b);
+      return;
+    }
+  }
   hipLaunchKernelGGL((wbf_gemm_k<MR, WM, WN, TD, TH, K, NP>), dim3((unsigned)grid), dim3(WM * WN * 64), 0, ctx->stream, b);
 }
 

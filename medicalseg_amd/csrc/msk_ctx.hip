@@ -444,6 +444,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_pack_cache = value;
     return 0;
   }
+  if (strcmp(key, "wbf_bpf") == 0) {  // weight-fragment prefetch depth of wbf_gemm_k: 0 auto (by grid size), 1, 4
+    ctx->wbf_bpf = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_ks_blocks") == 0) {  // tuning: workgroups per CU targeted by the split-K of wbf_gemm_k (default 2; round 5 sweep on one box, two repetitions: 16 / 8 / 4 / 2 = 18.58 / 18.46 / 18.39 / 18.28 ms -- every slab is a round trip of M through HBM and a term of wbf_tout_k)
     ctx->wbf_ks_blocks = value > 0 ? value : 2;
     return 0;

@@ -346,3 +346,40 @@ def test_inloop_preprocess_on_a_second_context_feeds_the_training_context():
     for pi, pl, _, _ in raws:
         pre.call("msk_pinned_free", C.c_void_p(pi))
         pre.call("msk_pinned_free", C.c_void_p(pl))
+
+
+def test_training_step_under_the_per_kernel_profile():
+    """bench.py --profile-out / train.py --profiler_options bracket EVERY launch with a pair of events (msk_launch_scope); the
+    brackets do not nest -- a kernel entry point that calls another bracketed entry point inside its own bracket leaves an event
+    unrecorded and the report fails with 'invalid resource handle' (round 5: the statistics merge inside the up-convolution's
+    bracket).  One VNet step at a size that reaches every product kernel class (64^3: the LDS-staged scatter / gather kernels of
+    the k = s convolutions need >= 16384 source voxels), profile on, report read back."""
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.device import get_device, to_tensor
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation
+    dev = get_device()
+    rng = np.random.default_rng(2)
+    model = VNet(num_classes=3)
+    model.train()
+    opt = optim.Momentum(1e-3, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+    assert opt.enable_eager(model)
+    losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+    x = to_tensor(rng.standard_normal((2, 1, 64, 64, 64)).astype(np.float32))
+    y = to_tensor(rng.integers(0, 3, (2, 64, 64, 64)).astype(np.int32))
+    for on in (False, True, True):
+        dev.set_option("prof_only_halo", 0)
+        dev.prof_reset()
+        dev.prof_enable(on)
+        ll, _ = loss_computation(model(x), y, losses)
+        loss = sum(ll)
+        loss.backward()
+        opt.step()
+        model.clear_gradients()
+        dev.sync()
+        dev.prof_enable(False)
+        rep = dev.prof_report()
+        assert np.isfinite(float(loss))
+        if on:
+            assert any(t.startswith("convT_scatter") for t in rep) and any(t.startswith("wbf_gemm") for t in rep), sorted(rep)
+            assert all(ms >= 0.0 for _, ms in rep.values())
