@@ -108,40 +108,39 @@ def _run_case(name, grads_only=False):
                 wb=wb, e_bn=e_bn)
 
 
-def _fp32_spread(name, r):
-    """The step once more with ANOTHER summation order of the forward BatchNorm statistics (debug option "reduce_vpl_site":
-    64 instead of 8 voxels per lane in bn_stats_partial -- activations move by 3e-7 ... 3e-6, i.e. by fp32 rounding): how far
-    two equally valid fp32 evaluations of each gradient tensor lie apart, relative to the oracle's norm.  Measured (round 4,
-    tools/diag_fullsize_ab.py): 1e-3 ... 9e-3 per tensor -- the backward pass amplifies fp32 rounding of the forward pass by
-    ~1000x (gradients of 1e-6 behind 24 BatchNorm backward projections), so any single evaluation sits anywhere inside that
-    band (sweep of eight orders: worst tensor 1.9e-3 ... 9.7e-3 against the float64 oracle, tools/diag_fullsize_parity.py)."""
-    d = dev()
-    d.set_option("reduce_vpl_site", 64)
-    try:
-        other = _run_case(name, grads_only=True)
-    finally:
-        d.set_option("reduce_vpl_site", 0)
-    spread = {}
-    for pname, (g, refnorm) in r["grads"].items():
-        g2, idx = other[pname]
-        g2 = g2 if idx is None else g2[idx]
-        spread[pname] = float(np.linalg.norm(g - g2) / (refnorm + 1e-300))
-    return spread
+def _fixture_bounds(name):
+    """Per-tensor gradient bound from two fixtures that do not involve the HIP path (round-4 verdict, Next 3):
+      noise  = ||g32 - g64|| / ||g64|| of the torch-CPU restatement evaluated in FLOAT32 (three runs: two thread counts = two
+               summation orders, and an im2col convolution), tests/golden/make_fullsize_fp32_noise.py;
+      kink   = how far the float64 gradient moves when the PReLU branch decisions no fp32 evaluation can make -- pre-activations
+               within 4e-6 of their layer's maximum, the accuracy class the product's convolutions are held to -- are made the
+               other way (all of them / a fixed half), tests/golden/make_fullsize_kink_sensitivity.py;
+               profiles/r05_fullsize_bimodal_root_cause.txt shows ONE such element accounts for round 4's 9.6e-3.
+    bound(tensor) = max(8e-3, 3 x noise + kink).  No second HIP evaluation, no cap."""
+    gdir = os.path.join(HERE, "golden")
+    noise = np.load(os.path.join(gdir, "fullsize_%s_fp32_noise.npz" % name))
+    kink = np.load(os.path.join(gdir, "fullsize_%s_kink.npz" % name))
+    case = FC.build(name)
+    assert str(noise["digest"]) == FC.digest(case) and str(kink["digest"]) == FC.digest(case)
+    lim = {}
+    for k in noise.files:
+        if k.startswith("noise_max/"):
+            p = k[len("noise_max/"):]
+            kk = max(float(kink["kink_all/" + p]), float(kink["kink_half/" + p])) if ("kink_all/" + p) in kink.files else 0.0
+            lim[p] = (max(8e-3, 3.0 * float(noise[k]) + kk), float(noise[k]), kk)
+    return lim
 
 
 def _assert_bounds(r, name):
     assert r["e_lg"] < 2e-5, r["e_lg"]
     assert r["e_w"] < 1e-5 and r["e_ce"] < 2e-5 and r["e_dl"] < 2e-5 and r["e_per"] < 1e-5
-    # per tensor: the 32^3-calibrated 8e-3, or -- where fp32 itself is less certain than that -- twice the distance between
-    # two fp32 evaluations of this very step (rounding noise has no preferred evaluation; a defect would stand out of it);
-    # never beyond 3e-2, and the systematic part (scale bias, below) stays at 1e-3
-    spread = _fp32_spread(name, r) if r["l2s"][r["worst"]] >= 4e-3 else {}
+    lim = _fixture_bounds(name)
     for pname, e in r["l2s"].items():
-        lim = min(3e-2, max(8e-3, 2e-3 + 2.0 * spread.get(pname, 0.0)))
-        assert e < lim, (pname, e, spread.get(pname))
-    if spread:
-        ws = max(spread, key=spread.get)
-        print("fp32 spread between two summation orders: worst %.2e (%s), at the worst tensor %.2e" % (spread[ws], ws, spread[r["worst"]]))
+        bound, n32, kk = lim.get(pname, (8e-3, 0.0, 0.0))
+        assert e < bound, (pname, e, "bound %.2e = max(8e-3, 3 x fp32 noise %.2e + kink sensitivity %.2e)" % (bound, n32, kk))
+    w = r["worst"]
+    print("worst tensor %s: %.2e against a fixture bound of %.2e (fp32 noise of the CPU restatement %.2e, kink sensitivity %.2e)"
+          % ((w, r["l2s"][w]) + lim.get(w, (8e-3, 0.0, 0.0))))
     assert r["med"] < 4e-3
     assert abs(r["bias"][r["wb"]]) < 1e-3, (r["wb"], r["bias"][r["wb"]])
     assert r["e_bn"] < 2e-5
