@@ -10,8 +10,9 @@ weights, both losses, per-class dice, every parameter gradient -- whole when <= 
 
 Bounds (the 32^3-calibrated ones of tests/test_gpu_model.py::test_vnet_32cube_batch2_gradients_calibrated, tightened where
 the full-size problem is better conditioned): logits 2e-5 of max|logit|, CE 2e-5 relative, Dice loss 2e-5, per-class dice
-1e-5, class weights 1e-5 relative; per parameter tensor rel-L2 <= 8e-3 (or, where two fp32 evaluations of the step differ by
-more than that bound allows, 2e-3 + twice their distance: _fp32_spread) with the median <= 4e-3, and the SYSTEMATIC part
+1e-5, class weights 1e-5 relative; per parameter tensor rel-L2 <= max(8e-3, 3 x the float32 noise of the CPU restatement + the
+tensor's sensitivity to the PReLU branches fp32 cannot decide) -- both from committed CPU-only fixtures, _fixture_bounds; no
+second evaluation on the HIP path (round-4 verdict, Next 3) -- with the median <= 4e-3, and the SYSTEMATIC part
 separately: least-squares scale of every tensor's gradient against the oracle's within 1e-3 of one; BatchNorm running
 statistics 2e-5.  The kernels the smaller parity tests cannot reach are asserted to have run (HIP-event tags with shapes):
 the fused matrix + output-transform kernel at 128^3, the 512-way split in_tr weight gradient, out_tr's three kernels."""
@@ -33,7 +34,7 @@ def _l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
 
 
-def _run_case(name, grads_only=False):
+def _run_case(name):
     from medicalseg_amd.device import to_tensor
     from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
     from medicalseg_amd.utils import loss_computation
@@ -73,9 +74,6 @@ def _run_case(name, grads_only=False):
     e_ce = abs(float(loss_list[0]) / float(gold["ce"]) - 1)
     e_dl = abs(float(loss_list[1]) - float(gold["dice_loss"]))
     e_per = float(np.abs(np.asarray(per, np.float64) - gold["per_channel_dice"]).max())
-    if grads_only:   # second evaluation of the same step (another summation order): the parameter gradients only
-        return {pname: (p.grad_numpy().astype(np.float64).ravel(), FC.sample_indices(pname, int(np.prod(p.shape))))
-                for pname, p in model.named_parameters()}
     l2s, bias, zero, grads = {}, {}, 0, {}
     for pname, p in model.named_parameters():
         ref = gold["g/" + pname]
