@@ -1,6 +1,7 @@
 """Optimizers and LR schedules with paddle.optimizer's surface as used by the reference
 (cvlibs/config.py:156-232, core/train.py:140-151, utils/utils.py:125)."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -111,6 +112,7 @@ class Momentum:
         dev.memset(self.velocity_ptr, 0, max(self.arena.count, 4) * 4)
 
         self._eager = False
+        self.eager_min_floats = int(os.environ.get("MSEGK_EAGER_MIN_FLOATS", 1 << 20))   # blocks below this stay with step() (launch count; A/B: 0 = every block)
         self._eager_done = []     # [(lo, hi)] slices of the arena already updated during this backward pass
 
     def get_lr(self):
@@ -164,6 +166,8 @@ class Momentum:
         sl = self._block_slice(block)
         if sl is None or any(lo < sl[1] and sl[0] < hi for lo, hi in self._eager_done):
             return
+        if sl[1] - sl[0] < self.eager_min_floats:
+            return      # small blocks (in_tr, down_tr32/64, up_tr64/32, out_tr: 7 MB of 182) wait for step(): one update per run of them
         a = self.arena
         lo, hi = sl
         a.dev.call("msk_sgd_momentum_eager", C.c_void_p(a.value_ptr + 4 * lo), C.c_void_p(a.grad_ptr + 4 * lo),
