@@ -72,6 +72,7 @@ struct msk_ctx {
   void* wpack = nullptr;      // packed-weight cache of the Winograd pipelines (msk_conv_wbf.hip: WbfPackCache)
   int wbf_pack_cache = 1;     // 0 = pack the weights on every call (A/B)
   void* spack = nullptr;      // packed-weight cache of the other convolution kernels (msk_conv.hip: SmallPackCache)
+  int wbf_pack_lds = 1;       // option "wbf_pack_lds": packed Winograd weights through an LDS tile with whole-run loads and 16-byte stores (wbf_pack_weights_lds_k); 0 = one thread per element (A/B)
   int wbf_bpf = 1;            // option "wbf_bpf": weight-fragment prefetch depth of wbf_gemm_k: 1 (default), 4 = four taps ahead, 0 = 4 for launches of <= 8 workgroups per CU (round 5 A/B: 18.45 ms with 1, 18.58 with 0 / 4 -- the deeper ring costs more than the waits it removes)
   int wbf_ks_blocks = 2;      // option "wbf_ks_blocks": workgroups per CU the split-K of wbf_gemm_k aims for (deep levels; every slab is a round trip of M through HBM)
   int noop_after_merge = 0;   // debug option "noop_after_merge": that many empty launches behind every merge kernel (what a 5-us launch costs the step)

@@ -128,11 +128,13 @@ wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfP
     for (int xi = 0; xi < NXI; ++xi) {
       double s_ = 0.0;
 #pragma unroll
-      for (int kw = 0; kw < K; ++kw) s_ += g_coef(K, xi, kw) * t[kw];
+      for (int kw = 0; kw < K; ++kw) s_ = fma(g_coef(K, xi, kw), t[kw], s_);   // (explicit: both pack kernels must round alike)
       unsigned short* o = out + (long)xi * xi_stride + base;
       if (NP == 3) {
         unsigned short hi, mid, lo;
-        split3_one((float)s_, hi, mid, lo);
+        float xf = (float)s_;
+        asm volatile("" : "+v"(xf));   // (one rounding to fp32 first, in both pack kernels: the compiler may otherwise fold double -> float -> bf16)
+        split3_one(xf, hi, mid, lo);
         o[0] = hi;
         o[pstep] = mid;
         o[2 * pstep] = lo;
@@ -153,6 +155,94 @@ wbf_pack_weights_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfP
         float vf = (float)(s_ * wsc);
         asm volatile("" : "+v"(vf));
         o[0] = __builtin_bit_cast(unsigned short, (_Float16)vf);
+      }
+    }
+  }
+}
+
+// Round 5 -- the same packing through an LDS tile.  Above, a thread owns ONE element (row, k, n): its five kw taps are 20 bytes
+// at a stride of 500 (or 500 B) bytes from its neighbour's, every 128-byte line of the weight tensor is requested by ~25
+// different wavefronts (the 25 (kd, kh) rows), and the results leave as 2-byte stores.  Here a workgroup owns 16 input
+// channels x 8 output channels: their 128 canonical rows of 125 taps are 8 (or 16) contiguous stretches of 8000 (4000) bytes --
+// float4 loads of consecutive lanes -- and a thread then produces the 8 channels of one 16-byte operand slot for all NXI
+// points and NP pieces: 16-byte stores, 1 KiB per store instruction.  Same arithmetic per element, bitwise the same image.
+template <int K, int NP>
+__global__ void __launch_bounds__(256)
+wbf_pack_weights_lds_k(const WbfPackDesc* __restrict__ table, WbfPackList list, WbfPackDesc single) {
+  constexpr int NXI = nxi_of(K), T2 = K * K, T3 = K * K * K, NN = 8;   // NN output channels per workgroup
+  extern __shared__ __attribute__((aligned(16))) float wt[];           // [128 pairs][T3]
+  const WbfPackDesc d = list.n < 0 ? single : table[list.row[blockIdx.y]];
+  const int B = d.B, swap = d.swap, flip = d.flip, CN = d.CN, KC = d.KC, tsd = d.tsd, tsh = d.tsh, tsw = d.tsw;
+  const int ntile = CN / NN;
+  const double wsc = NP != 3 ? (double)wbf_scale_of(d.amax) : 1.0;
+  for (int blk = blockIdx.x; blk < KC * ntile; blk += gridDim.x) {
+    const int kc = blk / ntile, n0 = (blk - kc * ntile) * NN, k0 = kc * 16;
+    __syncthreads();   // the previous tile's readers are done
+    // canonical w[ia][ib][T3], (ia, ib) = swap ? (n, k) : (k, n): per outer index one contiguous run over the inner indices
+    const int NO = swap ? NN : 16, NI = swap ? 16 : NN;      // outer / inner counts
+    const int o0 = swap ? n0 : k0, i0 = swap ? k0 : n0;
+    const int run4 = NI * T3 / 4;                            // float4 per run (NI * 125 * 4 bytes: a multiple of 16)
+    for (int f = threadIdx.x; f < NO * run4; f += 256) {
+      const int o = f / run4, r4 = f - o * run4;
+      // (CK % 16 == 0 and CN % 8 == 0 are launch conditions: every row of the tile exists)
+      const float4 v = *reinterpret_cast<const float4*>(d.w + ((long)(o0 + o) * B + i0) * T3 + (long)r4 * 4);
+      *reinterpret_cast<float4*>(wt + (long)o * NI * T3 + r4 * 4) = v;   // pair (o, i) at (o * NI + i) * T3
+    }
+    __syncthreads();
+    // items: (row, khalf, n_l) -> the slot of channels k0 + khalf * 8 + 0..7 at output channel n0 + n_l
+    for (int it = threadIdx.x; it < T2 * 2 * NN; it += 256) {
+      const int n_l = it % NN, khalf = (it / NN) & 1, row = it / (2 * NN);
+      const int tap0 = (row / K) * tsd + (row % K) * tsh;
+      double t[8][K];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k_l = khalf * 8 + j;
+        const float* pr = wt + (long)(swap ? n_l * 16 + k_l : k_l * NN + n_l) * T3;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int tap = tap0 + kw * tsw;
+          t[j][kw] = (double)pr[flip ? T3 - 1 - tap : tap];
+        }
+      }
+      const long base = ((((long)row * KC + kc) * NP * 2 + khalf) * CN + (n0 + n_l)) * 8;
+      const long pstep = 2L * CN * 8;
+#pragma unroll
+      for (int xi = 0; xi < NXI; ++xi) {
+        unsigned short q[NP][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) s_ = fma(g_coef(K, xi, kw), t[j][kw], s_);
+          if (NP == 3) {
+            float xf = (float)s_;
+            asm volatile("" : "+v"(xf));
+            split3_one(xf, q[0][j], q[NP / 2][j], q[NP - 1][j]);
+          } else if (NP == 2) {
+            const double v = s_ * wsc;
+            float vf = (float)v;
+            asm volatile("" : "+v"(vf));
+            const _Float16 h = (_Float16)vf;
+            float rf = (float)(v - (double)(float)h);
+            asm volatile("" : "+v"(rf));
+            q[0][j] = __builtin_bit_cast(unsigned short, h);
+            q[NP - 1][j] = __builtin_bit_cast(unsigned short, (_Float16)rf);
+          } else {
+            float vf = (float)(s_ * wsc);
+            asm volatile("" : "+v"(vf));
+            q[0][j] = __builtin_bit_cast(unsigned short, (_Float16)vf);
+          }
+        }
+        unsigned short* o = d.out + (long)xi * d.xi_stride + base;
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+          uint4 u;
+          u.x = (unsigned)q[pc][0] | ((unsigned)q[pc][1] << 16);
+          u.y = (unsigned)q[pc][2] | ((unsigned)q[pc][3] << 16);
+          u.z = (unsigned)q[pc][4] | ((unsigned)q[pc][5] << 16);
+          u.w = (unsigned)q[pc][6] | ((unsigned)q[pc][7] << 16);
+          *reinterpret_cast<uint4*>(o + pc * pstep) = u;
+        }
       }
     }
   }
@@ -1438,6 +1528,30 @@ int pack_rows_build(msk_ctx* ctx, WbfPackCache* c, const std::vector<int>& rows)
       if (blocks > most) most = blocks;
     }
     if (l.n == 0) continue;
+    // LDS-staged form (round 5, option "wbf_pack_lds"): every row of the class must tile into 16 x 8 (k, n) blocks of aligned runs
+    bool lds_ok = ctx->wbf_pack_lds != 0;
+    long most_lds = 0;
+    for (int i = 0; i < l.n && lds_ok; ++i) {
+      const WbfPackDesc& dd = c->e[l.row[i]].d;
+      lds_ok = dd.CK == dd.KC * 16 && dd.CN % 8 == 0 && dd.B % 4 == 0 && (((uintptr_t)dd.w) & 15) == 0 &&
+               (dd.swap ? dd.B >= dd.CK : dd.B >= dd.CN);
+      const long blocks = (long)dd.KC * (dd.CN / 8);
+      if (blocks > most_lds) most_lds = blocks;
+    }
+    if (lds_ok) {
+      if (most_lds > 4L * ctx->num_cu) most_lds = 4L * ctx->num_cu;
+      const dim3 grid((unsigned)most_lds, (unsigned)l.n);
+      if (one) l.n = -1;
+      const size_t lds = (size_t)128 * kc[0] * kc[0] * kc[0] * sizeof(float);
+      msk_launch_scope ls(ctx, "wbf_pack_weights");
+      if (kc[0] == 5 && kc[1] == 2) hipLaunchKernelGGL((wbf_pack_weights_lds_k<5, 2>), grid, dim3(256), lds, ctx->stream, c->table, l, single);
+      else if (kc[0] == 5) hipLaunchKernelGGL((wbf_pack_weights_lds_k<5, 3>), grid, dim3(256), lds, ctx->stream, c->table, l, single);
+      else if (kc[1] == 2) hipLaunchKernelGGL((wbf_pack_weights_lds_k<3, 2>), grid, dim3(256), lds, ctx->stream, c->table, l, single);
+      else if (kc[1] == 3) hipLaunchKernelGGL((wbf_pack_weights_lds_k<3, 3>), grid, dim3(256), lds, ctx->stream, c->table, l, single);
+      else hipLaunchKernelGGL((wbf_pack_weights_lds_k<3, 1>), grid, dim3(256), lds, ctx->stream, c->table, l, single);
+      MSK_LAUNCH_CHECK(ctx);
+      continue;
+    }
     if (most > 8L * ctx->num_cu) most = 8L * ctx->num_cu;
     const dim3 grid((unsigned)most, (unsigned)l.n);
     if (one) l.n = -1;

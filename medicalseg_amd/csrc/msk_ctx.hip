@@ -444,6 +444,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_pack_cache = value;
     return 0;
   }
+  if (strcmp(key, "wbf_pack_lds") == 0) {  // 0 = wbf_pack_weights_k (one thread per element) instead of the LDS-staged form (A/B)
+    ctx->wbf_pack_lds = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_bpf") == 0) {  // weight-fragment prefetch depth of wbf_gemm_k: 0 auto (by grid size), 1, 4
     ctx->wbf_bpf = value;
     return 0;

@@ -1126,3 +1126,36 @@ def test_bwd_bnact_one_input_channel_evaluates_dy_in_the_weight_gradient(mode):
     dy64 = t_to_ncdhw(dy).astype(np.float64)
     dw_or, _ = O.conv3d_wgrad(dy64, x.astype(np.float64), (5,) * 3, (1,) * 3, (2,) * 3)
     assert rel_err(a.reshape(dw_or.shape) - 0.5, dw_or) < _conv_tol(M) * 2
+
+
+@pytest.mark.parametrize("split", [2, 3])
+@pytest.mark.parametrize("case", [(32, 32, (1, 16, 16, 16)), (64, 128, (1, 8, 16, 8)), (128, 64, (1, 8, 8, 7)), (256, 256, (1, 8, 8, 4))])
+def test_wbf_pack_weights_lds_form_is_bitwise_the_elementwise_form(case, split):
+    """Round 5: the packed weight image built through the LDS tile (whole-run loads, 16-byte stores: wbf_pack_weights_lds_k) is
+    the image of the one-thread-per-element kernel bit for bit -- forward AND data gradient (swap / flip of the canonical
+    tensor, a permuted transform axis in the third case) give identical outputs under option wbf_pack_lds 1 / 0."""
+    cin, cout, (N, D, H, W) = case
+    d = dev()
+    d.set_option("conv_split", split)
+    try:
+        rng = np.random.default_rng(cin + cout)
+        k, s_, p = (5, 5, 5), (1, 1, 1), (2, 2, 2)
+        x = rng.standard_normal((N, cin, D, H, W)).astype(np.float32)
+        dy = rng.standard_normal((N, cout, D, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin) + k) / np.sqrt(cin * 125)).astype(np.float32)
+        xt, dyt = t_from_ncdhw(x), t_from_ncdhw(dy)
+        wp, bp = vec(w.ravel()), vec(np.zeros(cout, np.float32))
+        outs = []
+        for lds in (1, 0):
+            d.set_option("wbf_pack_lds", lds)
+            d.h2d(wp, w.ravel())                     # invalidates the cached image: the next call packs with the selected kernel
+            yt, dxt = t_empty(N, cout, D, H, W), t_empty(N, cin, D, H, W)
+            d.call("msk_conv3d_fwd", _desc(k, s_, p), xt.msk(), vp(wp), vp(bp), yt.msk())
+            d.call("msk_conv3d_dgrad", _desc(k, s_, p), dyt.msk(), vp(wp), dxt.msk(), 0)
+            outs.append((t_to_ncdhw(yt), t_to_ncdhw(dxt)))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        f8 = lambda a: a.astype(np.float64)
+        assert rel_err(outs[0][0], O.conv3d(f8(x), f8(w), None, s_, p)) < _conv_tol(cin * 125)
+    finally:
+        d.set_option("wbf_pack_lds", 1)
+        d.set_option("conv_split", 2)
