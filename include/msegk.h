@@ -261,6 +261,17 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
                          const void* xform /*nullable*/, void* ybuf /*nullable*/,
                          const float* maxes /*nullable: msk_affine_act_bwd_reduce_ex's, needed by the fused forms under "conv_split" 2*/);
+/* msk_conv3d_bwd_bnact for the layer behind a zero-copy concat (UpTransition.ops[0]: x = the concat buffer, vnet.py:152-154).
+ * dx accumulates into the interleaved gradient buffer as usual UNLESS the one-kernel matrix stage runs the data gradient: then
+ * the sums (old dx + new) are STORED to the two dense half tensors dx_lo / dx_hi (channels [0, c/2) / [c/2, c), voxel stride
+ * c/2) and *split_done = 1 -- the consumers of the halves (the up-convolution's and the skip's backward) read dense voxels
+ * instead of one half of every 128-byte line.  *split_done = 0: dx holds the result, dx_lo / dx_hi are untouched. */
+int msk_conv3d_bwd_bnact_split(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                               const float* shift, const float* alpha /*nullable*/, const float* mean, const float* invstd,
+                               const float* gamma, msk_tensor dout, const float* sums_total, double M_total,
+                               msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
+                               const void* xform /*nullable*/, void* ybuf /*nullable*/, const float* maxes /*nullable*/,
+                               msk_tensor dx_lo, msk_tensor dx_hi, int* split_done);
 /* Backward of an up-convolution unit  convT -> BatchNorm(batch statistics) -> PReLU  (UpTransition.up_conv / bn1 / relu1,
  * vnet.py:133-150; autograd of core/train.py:139) behind its reduce pass, in one call:
  *     dx (+)= convT^T(dy, w),  dw (+)= sum x * dy,   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1)
@@ -332,6 +343,12 @@ int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* bet
  *   (vnet.py:41,77-79,107-111,150-154,173).                                    */
 int msk_affine_act_fwd(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift,
                        msk_tensor res, const float* alpha, msk_tensor out);
+/* the same with the maximum of |out| folded into an amax array (msk_affine_act_fwd_amax) AND a second copy of the result in out2
+ * (nullable; its own voxel stride): InputTransition writes its output into the skip half of the up-transition's concat buffer
+ * (vnet.py:152) and, for the readers of that half alone, as a dense tensor -- a 16-channel half of a 32-channel voxel is 64 of
+ * every 128-byte line.  Channel-stationary float4 kernel only (C / 4 a power of two). */
+int msk_affine_act_fwd_amax2(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                             const float* alpha, msk_tensor out, float* out_amax /*nullable*/, msk_tensor out2);
 /* backward pass 1: per-channel sums over this rank:
  *   sums[0..C)   = sum du            (du = dout * (u>0 ? 1 : alpha))
  *   sums[C..2C)  = sum du * xhat     (xhat = (x-mean)*invstd; 0 if no BN)

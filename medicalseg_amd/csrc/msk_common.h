@@ -51,6 +51,7 @@ struct msk_ctx {
   int conv_impl = 0;  // 0 auto, 1 direct, 3 wgrad direct only, 4 gather-conv direct only
   bool no_winograd = false;  // env MSEGK_DIRECT_CONV=1 / option "direct_conv": direct kernels only (bit-exact fp32 fmaf chains)
   bool wbf = true;  // env MSEGK_WBF=0 / option "wino_bf3" 0: keep the fp32-MFMA Winograd kernels (exact-fp32 products)
+  bool dst_split_done = false;  // set by the one-kernel matrix stage when it honoured GConv::dst_lo / dst_hi
   bool stats_fused = false;  // set by a conv kernel that wrote GConv::stats itself
   bool wgrad_db_done = false;  // set by a weight-gradient kernel that produced WGrad::db itself
   bool xform_written = false;  // set when GConv::xform was filled
@@ -118,6 +119,7 @@ struct msk_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_main = nullptr, ev_comm_side = nullptr, ev_comm_done = nullptr, ev_comm_back = nullptr;
   int c1_h2 = 1;          // one-input-channel convolutions on the 16-bit pipe (conv_c1_h2_k): 1 = the 3^3 class (UNet3D), 2 = also 5^3 (in_tr), 0 = off
+  int dst_split = 1;      // option "dst_split": msk_conv3d_bwd_bnact_split may store the concat gradient as two dense halves; 0 = never (A/B)
   int wgrad_reduce_rows = 1;   // option "wgrad_reduce_rows": split-K reduce of the deep Winograd weight gradients with 500-byte output runs (wbf_wgrad_reduce_rows_k); 0 = the lane-per-cb form (A/B)
   int ks_stats = 1;       // option "ks_stats": BatchNorm statistics in the store pass of the k == s kernels (convT_scatter_lds_k, gconv_ks_lds_k); 0 = the separate pass (A/B)
   int ks_lds = 1;         // option "ks_lds": 2x2x2 / stride 2 convolutions with <= 16 source channels through the LDS tile (gconv_ks_lds_k); 0 = the per-lane gather form (A/B)

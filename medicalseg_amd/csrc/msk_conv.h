@@ -31,6 +31,9 @@ struct GConv {
   int stats_ps;       // msk_conv3d_fwd_in: statistics PER SAMPLE -- stats is [N][2 CN], fin's save_mean / save_invstd / scale / shift
   int fin_stride;     // advance by fin_stride floats per sample (InstanceNorm); only kernels whose records are per tile serve it
   bool w_persistent;  // the weights are the caller's tensor (covered by msk_weights_changed): derived forms may be cached
+  float* dst_lo;      // msk_conv3d_bwd_bnact_split: when the one-kernel matrix stage runs this (accumulating) problem it stores channels
+  float* dst_hi;      // [0, dst_csplit) / [dst_csplit, CN) to these dense tensors instead of dst (sets ctx->dst_split_done); else ignored
+  int dst_csplit;
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
 };

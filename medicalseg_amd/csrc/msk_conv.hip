@@ -1672,7 +1672,8 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
                                  const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
                                  msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
                                  int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
-                                 int coef_stride, int sums_stride, bool fused_only);
+                                 int coef_stride, int sums_stride, bool fused_only, float* dx_lo = nullptr, float* dx_hi = nullptr,
+                                 int dx_csplit = 0);
 
 int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
@@ -1680,6 +1681,29 @@ int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const flo
                          int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes) {
   return conv3d_bwd_bnact_impl(ctx, cd, x, w, y, scale, shift, alpha, mean, invstd, gamma, dout, sums_total, M_total, dy_scratch, dx,
                                dx_accumulate, dw, dw_accumulate, xform, ybuf, maxes, 0, 0, false);
+}
+
+// msk_conv3d_bwd_bnact for the layer behind a zero-copy concat (UpTransition: x = the concat buffer, vnet.py:152-154): dx
+// accumulates into the interleaved gradient buffer dx as usual UNLESS the one-kernel matrix stage runs the data gradient -- then
+// the sums are stored to the two dense half tensors dx_lo / dx_hi (channels [0, c/2) / [c/2, c), voxel stride c/2) and
+// *split_done = 1: the consumers of the halves read dense voxels instead of half of every 128-byte line.  *split_done = 0: dx
+// holds the result as with msk_conv3d_bwd_bnact (dx_lo / dx_hi untouched).
+int msk_conv3d_bwd_bnact_split(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                               const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                               msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                               int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
+                               msk_tensor dx_lo, msk_tensor dx_hi, int* split_done) {
+  MSK_REQUIRE(ctx, split_done != nullptr, "msk_conv3d_bwd_bnact_split: split_done required");
+  *split_done = 0;
+  const bool ok = dx.p && dx_lo.p && dx_hi.p && dx.c % 2 == 0 && dx_lo.c == dx.c / 2 && dx_hi.c == dx.c / 2 && dx_lo.ld == dx.c / 2 &&
+                  dx_hi.ld == dx.c / 2 && dx.ld == dx.c && msk_voxels(dx_lo) == msk_voxels(dx) && msk_voxels(dx_hi) == msk_voxels(dx) &&
+                  dx_accumulate && ctx->dst_split != 0;
+  const int rc = conv3d_bwd_bnact_impl(ctx, cd, x, w, y, scale, shift, alpha, mean, invstd, gamma, dout, sums_total, M_total, dy_scratch, dx,
+                                       dx_accumulate, dw, dw_accumulate, xform, ybuf, maxes, 0, 0, false, ok ? (float*)dx_lo.p : nullptr,
+                                       ok ? (float*)dx_hi.p : nullptr, ok ? dx.c / 2 : 0);
+  if (rc == 0 && ctx->dst_split_done) *split_done = 1;
+  ctx->dst_split_done = false;
+  return rc;
 }
 
 int msk_conv3d_bwd_inact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
@@ -1695,8 +1719,9 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
                                  const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
                                  msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
                                  int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
-                                 int coef_stride, int sums_stride, bool fused_only) {
+                                 int coef_stride, int sums_stride, bool fused_only, float* dx_lo, float* dx_hi, int dx_csplit) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
+  ctx->dst_split_done = false;
   MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
   MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
   MSK_REQUIRE(ctx, fused_only || (dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
@@ -1732,6 +1757,7 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
     g.pd = cd.pd; g.ph = cd.ph; g.pw = cd.pw;
     g.transposed = 1; g.bias = nullptr; g.accumulate = dx_accumulate; g.flip = 1;
     g.w_persistent = true;
+    g.dst_lo = dx_lo; g.dst_hi = dx_hi; g.dst_csplit = dx_csplit;
     WbfBnBwd bn{};
     bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
     bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;

@@ -947,6 +947,13 @@ struct FusedArgs {
   float* stat_partial;  // STATS: [tiles][CN][3] = (n, mean, M2) of the stored values
   int per_xcd;          // tiles per XCD
   int LW;               // extent of the transform axis: the last W tile may reach beyond it (ragged: stores and statistics stop there)
+  // round 5 (msk_conv3d_bwd_bnact_split): the accumulating data gradient of the layer behind a zero-copy concat READS the old
+  // values from the interleaved buffer `dst` (whole lines) but STORES channels [0, csplit) to the dense tensor st_lo and
+  // [csplit, 2 csplit) to st_hi (voxel stride csplit each; dld == 2 csplit): the consumers of the two halves -- the up-convolution's
+  // and the skip's backward -- then read dense 64-byte voxels instead of one half of every 128-byte line.  Null: store to dst.
+  float* st_lo;
+  float* st_hi;
+  int csplit;
 };
 
 struct WfRec {
@@ -1135,6 +1142,10 @@ wbf_gemm_fused_k(FusedArgs f) {
   const float sl = f.prelu ? f.prelu[co] : 1.f;
   float* obase = f.dst + ((long)n * f.dvn + (long)(4 * t) * f.dvw) * f.dld + co;
   const long wst = (long)f.dvw * f.dld;
+  // split store: the same voxel offsets at half the stride (dld == 2 csplit), per-lane base by channel half
+  const bool split_st = f.st_lo != nullptr;
+  float* sbase = split_st ? (co < f.csplit ? f.st_lo + co : f.st_hi + (co - f.csplit)) + (((long)n * f.dvn + (long)(4 * t) * f.dvw) * f.dld >> 1) : obase;
+  const long swst = split_st ? (wst >> 1) : wst;
   const int wlim = f.LW - 4 * t;   // W outputs of this tile inside the volume (wave-uniform; >= 4 except in a ragged last tile)
   float sk = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
@@ -1169,7 +1180,8 @@ wbf_gemm_fused_k(FusedArgs f) {
           float r = fmaf(yo[i][mr][jq * 4 + jj], osc, bv);
           if (f.accumulate) r += old[jj][i];
           if (f.prelu) r = r > 0.f ? r : sl * r;
-          op[jj][i * wst] = r;
+          if (split_st) sbase[((op[jj] - obase) >> 1) + i * swst] = r;
+          else op[jj][i * wst] = r;
           if (STATS) {
             if (cnt == 0.f) sk = r;
             const float dlt = r - sk;
@@ -1758,6 +1770,10 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
     fa.LW = LW;
+    if (g.dst_lo && g.dst_hi && g.dst_csplit > 0 && g.accumulate && g.dld == 2 * g.dst_csplit && g.CN == 2 * g.dst_csplit && !fuse_stats) {
+      fa.st_lo = g.dst_lo; fa.st_hi = g.dst_hi; fa.csplit = g.dst_csplit;
+      ctx->dst_split_done = true;
+    }
     {
       msk_launch_scope ls(ctx, tag);
       launch_fused_variant<K, NP>(ctx, variant, fa, fuse_stats);

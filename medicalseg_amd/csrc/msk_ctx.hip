@@ -478,6 +478,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     msk_set_ew_caps(value, 0);
     return 0;
   }
+  if (strcmp(key, "dst_split") == 0) {  // 0 = msk_conv3d_bwd_bnact_split never splits (A/B)
+    ctx->dst_split = value;
+    return 0;
+  }
   if (strcmp(key, "wgrad_reduce_rows") == 0) {  // 0 = wbf_wgrad_reduce_k for the deep layers as well (A/B of wbf_wgrad_reduce_rows_k)
     ctx->wgrad_reduce_rows = value;
     return 0;

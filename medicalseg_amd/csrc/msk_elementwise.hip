@@ -376,7 +376,9 @@ __global__ void EW_BOUNDS
 affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, int ldr, int cres,
                     const float* __restrict__ alpha, float* __restrict__ out, int ldo, long voxels, int C, int cshift,
-                    const float* __restrict__ alpha_in, unsigned* __restrict__ out_amax) {
+                    const float* __restrict__ alpha_in, unsigned* __restrict__ out_amax, float* __restrict__ out2, int ldo2) {
+  // out2 (nullable, round 5: msk_affine_act_fwd_amax2): a second copy of the result with its own voxel stride -- in_tr writes its
+  // output into the skip half of up_tr32's concat buffer AND as a dense tensor for the readers of that half alone
   float mx = 0.f;
   const long g = (long)blockIdx.x * kThreads + threadIdx.x;
   const int c = (int)(g & ((C >> 2) - 1)) * 4;
@@ -411,6 +413,7 @@ affine_act_fwd_cs_k(const float* __restrict__ x, int ldx, const float* __restric
     }
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     *reinterpret_cast<float4*>(out + v * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (out2) *reinterpret_cast<float4*>(out2 + v * ldo2 + c) = make_float4(o[0], o[1], o[2], o[3]);
   };
   long v = g >> cshift;
   for (; v + vstride < voxels; v += 2 * vstride) {
@@ -1348,7 +1351,8 @@ int msk_bn_eval_coeffs(msk_ctx* ctx, int C, const float* gamma, const float* bet
 }
 
 static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
-                               const float* alpha, msk_tensor out, const float* alpha_in, float* out_amax = nullptr) {
+                               const float* alpha, msk_tensor out, const float* alpha_in, float* out_amax = nullptr,
+                               msk_tensor out2 = msk_tensor{}) {
   MSK_REQUIRE(ctx, same_shape(x, out), "x/out shape mismatch");
   MSK_REQUIRE(ctx, (scale == nullptr) == (shift == nullptr), "scale and shift go together");
   if (res.p) MSK_REQUIRE(ctx, res.c > 0 && (res.c == x.c || x.c % res.c == 0), "residual channels must tile");
@@ -1356,7 +1360,7 @@ static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, c
   const bool v4 = vec4_ok(x) && vec4_ok(out) && (res.p == nullptr || res.c != x.c || vec4_ok(res));
   msk_launch_scope ls(ctx, "affine_act_fwd");
   const int cq = x.c / 4;
-  if (g_dense12 && !v4 && !alpha_in && d12_shape(x, voxels) && d12_ok(x) && d12_ok(out) && (res.p == nullptr || (res.c == x.c && d12_ok(res)))) {
+  if (g_dense12 && !v4 && !alpha_in && !out2.p && d12_shape(x, voxels) && d12_ok(x) && d12_ok(out) && (res.p == nullptr || (res.c == x.c && d12_ok(res)))) {
     const long groups = voxels * x.c / 12;
     const dim3 grid(ew_blocks(groups, ctx->num_cu));
 #define D12_FWD(C_) hipLaunchKernelGGL(affine_act_fwd_d12_k<C_>, grid, dim3(kThreads), 0, ctx->stream, (const float*)x.p, scale, shift, \
@@ -1371,7 +1375,11 @@ static int affine_act_fwd_impl(msk_ctx* ctx, msk_tensor x, const float* scale, c
     while ((1 << cshift) < cq) ++cshift;
     hipLaunchKernelGGL(affine_act_fwd_cs_k, dim3(ew_blocks(voxels * cq / 2, ctx->num_cu)), dim3(kThreads), 0, ctx->stream,
                        (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c, alpha, (float*)out.p,
-                       out.ld, voxels, x.c, cshift, alpha_in, (unsigned*)out_amax);
+                       out.ld, voxels, x.c, cshift, alpha_in, (unsigned*)out_amax, (float*)out2.p, out2.ld);
+    MSK_LAUNCH_CHECK(ctx);
+    return 0;
+  } else if (out2.p) {
+    return msk_fail(ctx, __FILE__, __LINE__, "msk_affine_act_fwd_amax2", "the second output needs the channel-stationary float4 kernel (C / 4 a power of two, aligned tensors)");
   } else if (v4) {
     hipLaunchKernelGGL(affine_act_fwd_k<4>, dim3(ew_blocks(voxels * x.c / 4, ctx->num_cu)), dim3(kThreads), 0,
                        ctx->stream, (const float*)x.p, x.ld, scale, shift, (const float*)res.p, res.ld, res.c,
@@ -1390,6 +1398,12 @@ float* msk_amax_new(msk_ctx* ctx, int n) { return msk_scalar_slots(ctx, n > 0 ? 
 int msk_affine_act_fwd_amax(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
                             const float* alpha, msk_tensor out, float* out_amax) {
   return affine_act_fwd_impl(ctx, x, scale, shift, res, alpha, out, nullptr, out_amax);
+}
+
+int msk_affine_act_fwd_amax2(msk_ctx* ctx, msk_tensor x, const float* scale, const float* shift, msk_tensor res,
+                             const float* alpha, msk_tensor out, float* out_amax, msk_tensor out2) {
+  if (out2.p) MSK_REQUIRE(ctx, same_shape(x, out2) && vec4_ok(out2), "out2 must have x's shape and float4 alignment");
+  return affine_act_fwd_impl(ctx, x, scale, shift, res, alpha, out, nullptr, out_amax, out2);
 }
 
 int msk_affine_act_join_fwd_amax(msk_ctx* ctx, msk_tensor y, const float* scale, const float* shift, const float* alpha_inner,

@@ -15,6 +15,12 @@ from ..cvlibs import manager
 from ..device import Tensor, get_device, to_tensor
 from ..nn import AddAct, ConvBNAct, copy_scale
 
+# A/B switches (round 5): env MSEGK_DENSE_TWIN=0 -- in_tr writes only the skip half of up_tr32's concat buffer (down_tr32 reads
+# 64 of every 128-byte line); env MSEGK_SPLIT_CONCAT_GRAD=0 -- the concat gradient of a 16 + 16-channel up-transition stays one
+# interleaved buffer
+DENSE_TWIN = os.environ.get("MSEGK_DENSE_TWIN", "1") != "0"
+SPLIT_CONCAT_GRAD = os.environ.get("MSEGK_SPLIT_CONCAT_GRAD", "1") != "0"
+
 
 class LUConv(nn.Layer):
     """conv5^3(p=2) -> BN -> PReLU (reference vnet.py:32-43)."""
@@ -73,11 +79,11 @@ class InputTransition(nn.Layer):
         self.relu1 = nn.ELU() if elu else nn.PReLU(self.num_features)
         self._unit = ConvBNAct(self.conv1, self.bn1, self.relu1)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, out2=None):
         """out: where the block's output goes (a channel slice of the concat buffer of the up-transition that takes it as
-        its skip connection: UpTransition.reserve_concat)"""
+        its skip connection: UpTransition.reserve_concat); out2: a second, dense copy for the readers of that slice alone"""
         # the tiled input is the residual: channel c of the sum reads x[..., c % in_channels]
-        return self._unit.forward(x, res=x, out=out)
+        return self._unit.forward(x, res=x, out=out, out2=out2)
 
     def backward(self, dout):
         self._unit.backward(dout, need_dx=False, res_needs_grad=False)
@@ -203,12 +209,27 @@ class UpTransition(nn.Layer):
     def backward(self, dout):
         xcat, half = self._xcat, self.outChans // 2
         self._join.backward(dout)  # -> ops_out.grad, xcat.grad
-        for op in reversed(list(self.ops)):
+        ops = list(self.ops)
+        # halves narrower than a 128-byte line (16 channels): ask the layer that completes xcat.grad -- ops[0], accumulating its
+        # data gradient behind the join's -- to store the sums as two DENSE tensors (msk_conv3d_bwd_bnact_split); the readers of
+        # one half then do not fetch the other with it (round 5).  Honoured only by the one-kernel matrix stage: else as before
+        g_lo = g_hi = None
+        skip = self._skip
+        if (SPLIT_CONCAT_GRAD and self._skip_in_place and skip.grad is None and half * 4 < 128 and self._m1 is None):
+            dev = xcat.dev
+            g_lo = Tensor.empty(dev, xcat.n, xcat.d, xcat.h, xcat.w, half)
+            g_hi = Tensor.empty(dev, xcat.n, xcat.d, xcat.h, xcat.w, half)
+            ops[0]._unit.dx_split = (g_lo, g_hi)
+        ops[0]._unit.dx_split_done = False
+        for op in reversed(ops):
             op.backward(op._unit.out.grad)
         gcat = xcat.grad
+        split_done = g_lo is not None and getattr(ops[0]._unit, "dx_split_done", False)
+        ops[0]._unit.dx_split = None
         # skip branch
-        skip = self._skip
-        if self._skip_in_place and skip.grad is None:
+        if split_done:
+            skip.grad = g_hi                      # the skip half's gradient as a dense tensor; later writers accumulate into it
+        elif self._skip_in_place and skip.grad is None:
             # the skip tensor IS the second half of the concat: so is its gradient (later writers accumulate into the slice)
             skip.grad = gcat.channel_slice(half, self.outChans)
         else:
@@ -216,7 +237,7 @@ class UpTransition(nn.Layer):
             copy_scale(gcat.channel_slice(half, self.outChans), self._m2, sg, accumulate=skip.grad_written)
         skip.grad_written = True
         # up-conv branch
-        self._up.backward(gcat.channel_slice(0, half))
+        self._up.backward(g_lo if split_done else gcat.channel_slice(0, half))
         if self._m1 is not None:
             x = self._x
             xg = x.ensure_grad()
@@ -328,8 +349,16 @@ class VNet(nn.Layer):
         if self.training:
             nn.Dropout3D.step += 1
         # the two dropout-free skip connections are produced straight into the concat buffers of their up-transitions
-        out16 = self.in_tr(x, out=self.up_tr32.reserve_concat(self.dev, x.n, (x.d, x.h, x.w)))
-        out32 = self.down_tr32(out16, out=self.up_tr64.reserve_concat(self.dev, x.n, self.down_tr32.down_conv.out_dims(out16)))
+        slot = self.up_tr32.reserve_concat(self.dev, x.n, (x.d, x.h, x.w))
+        # a 16-channel half of the 32-channel concat voxel is 64 of every 128-byte line: the readers of the skip half alone (the
+        # down-convolution and its weight gradient) get a dense twin written by the same pass (DENSE_TWIN, round 5)
+        twin = None
+        if slot is not None and DENSE_TWIN and slot.c * 4 < 128 and not isinstance(self.in_tr.relu1, nn.ELU):
+            twin = Tensor.empty(self.dev, x.n, x.d, x.h, x.w, slot.c)
+        out16 = self.in_tr(x, out=slot, out2=twin)
+        self._out16_twin = twin
+        out32 = self.down_tr32(twin if twin is not None else out16,
+                               out=self.up_tr64.reserve_concat(self.dev, x.n, self.down_tr32.down_conv.out_dims(out16)))
         out64 = self.down_tr64(out32)
         out128 = self.down_tr128(out64)
         out256 = self.down_tr256(out128)
@@ -345,6 +374,12 @@ class VNet(nn.Layer):
     def backward(self, dlogits: Tensor):
         """Adjoint of forward; accumulates parameter gradients into the flat arena."""
         out16, out32, out64, out128, out256 = self._acts
+        twin = getattr(self, "_out16_twin", None)
+
+        def share_twin_grad():
+            # the dense twin of out16 (forward) is what down_tr32 read: its data gradient accumulates into out16's gradient
+            if twin is not None and out16.grad is not None:
+                twin.grad, twin.grad_written = out16.grad, True
         for block, dout in ((self.out_tr, lambda: dlogits),
                             (self.up_tr32, lambda: self._feat.grad),
                             (self.up_tr64, lambda: self.up_tr32._x.grad),
@@ -356,6 +391,8 @@ class VNet(nn.Layer):
                             (self.down_tr32, lambda: out32.grad),
                             (self.in_tr, lambda: out16.grad)):
             block.backward(dout())
+            if block is self.up_tr32:
+                share_twin_grad()
             self._grads_ready(block)
         for hook in self._post_backward_hooks:
             hook(self)

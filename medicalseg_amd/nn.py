@@ -558,7 +558,7 @@ class ConvBNAct:
         self.x, self.res, self.y, self.out, self.bn_mode = x, None, None, out, 3   # 3: no backward through this
         return out
 
-    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None, defer_act=False) -> Tensor:
+    def forward(self, x: Tensor, res: Tensor | None = None, out: Tensor | None = None, defer_act=False, out2: Tensor | None = None) -> Tensor:
         """defer_act: stop after the BatchNorm coefficients; the caller (AddAct.forward with unit=self) applies BN + PReLU
         inside the residual join that follows (msk_affine_act_join_fwd) -- the returned tensor is allocated (it carries the
         gradient in backward) but never written."""
@@ -624,6 +624,11 @@ class ConvBNAct:
                          res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk())
                 dev.call("msk_elu_fwd", out.msk(), C.c_float(self.act.alpha), out.msk())
                 out.amax = None
+            elif out2 is not None:
+                # a second, dense copy of the output (InputTransition: `out` is the skip half of a concat buffer, msk_affine_act_fwd_amax2)
+                dev.call("msk_affine_act_fwd_amax2", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
+                         res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk(), _amax_for(out), out2.msk())
+                out2.amax = out.amax
             else:
                 dev.call("msk_affine_act_fwd_amax", y.msk(), _fp(sc["scale"]), _fp(sc["shift"]),
                          res.msk() if res is not None else NULL_TENSOR, _fp(alpha), out.msk(), _amax_for(out))
@@ -713,10 +718,21 @@ class ConvBNAct:
                     ybuf = dev.arena.alloc(nbytes)
             dx = x.ensure_grad()
             _count_flops(conv, x.n, y.d * y.h * y.w, 2)
-            dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
-                     _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
-                     _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,
-                     _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(maxes) if want_maxes else None)
+            split = getattr(self, "dx_split", None)     # (lo, hi): dense halves for the gradient of a zero-copy concat (UpTransition.backward)
+            self.dx_split, self.dx_split_done = None, False
+            if split is not None and x.grad_written:
+                done = C.c_int(0)
+                dev.call("msk_conv3d_bwd_bnact_split", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                         _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
+                         _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1,
+                         _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(maxes) if want_maxes else None,
+                         split[0].msk(), split[1].msk(), C.byref(done))
+                self.dx_split_done = bool(done.value)
+            else:
+                dev.call("msk_conv3d_bwd_bnact", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                         _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
+                         _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1 if x.grad_written else 0,
+                         _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(maxes) if want_maxes else None)
             x.grad_written = True
             conv._xform = None
             self.dy = dy if ybuf is None else None

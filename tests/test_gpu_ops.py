@@ -1396,3 +1396,27 @@ def test_convT_fwd_ex_statistics_in_the_store_pass(cin, cout, src):
     assert rel_err(vec_back(si, cout), 1.0 / np.sqrt(var + 1e-5)) < 1e-5
     assert rel_err(vec_back(sc, cout), gamma / np.sqrt(var + 1e-5)) < 1e-5
     assert rel_err(vec_back(rm, cout), 0.1 * mean) < 1e-5
+
+
+def test_affine_act_fwd_amax2_second_output():
+    """msk_affine_act_fwd_amax2 (round 5): BatchNorm apply + tiled residual + PReLU written into a channel slice of a wider buffer
+    (the skip half of a concat) AND as a dense copy, both bitwise the one-output kernel's result; the maximum folded once."""
+    d = dev()
+    rng = np.random.default_rng(4)
+    N, C_, D, H, W = 2, 16, 5, 6, 9
+    x = rng.standard_normal((N, C_, D, H, W)).astype(np.float32)
+    r = rng.standard_normal((N, 1, D, H, W)).astype(np.float32)
+    scale, shift = rng.uniform(0.5, 1.5, C_).astype(np.float32), rng.standard_normal(C_).astype(np.float32)
+    alpha = rng.uniform(0.1, 0.4, C_).astype(np.float32)
+    xt, rt = t_from_ncdhw(x), t_from_ncdhw(r)
+    ref = t_empty(N, C_, D, H, W)
+    d.call("msk_affine_act_fwd", xt.msk(), vp(vec(scale)), vp(vec(shift)), rt.msk(), vp(vec(alpha)), ref.msk())
+    wide, dense = t_empty(N, 2 * C_, D, H, W, fill=0.0), t_empty(N, C_, D, H, W, fill=5.0)
+    amax = d.amax_new()
+    d.call("msk_affine_act_fwd_amax2", xt.msk(), vp(vec(scale)), vp(vec(shift)), rt.msk(), vp(vec(alpha)),
+           wide.channel_slice(C_, 2 * C_).msk(), C.c_void_p(amax), dense.msk())
+    want = t_to_ncdhw(ref)
+    assert np.array_equal(t_to_ncdhw(dense), want)
+    got = wide.numpy()
+    assert np.array_equal(got[:, C_:], want) and np.all(got[:, :C_] == 0)
+    assert abs(d.d2h(amax, (64,), np.float32).max() - np.abs(want).max()) < 1e-6

@@ -416,6 +416,45 @@ def test_conv3d_bwd_bnact_fused_equals_three_call_form(case, split):
     d.sync()
     assert rel_err(t_to_ncdhw(dxt), 2 * dx_ref) < tol
     assert rel_err(d.d2h(dw, (w.size,), np.float32).reshape(w.shape), 2 * dw_ref) < 2 * _conv_tol(M)
+    # round 5, msk_conv3d_bwd_bnact_split: the accumulated data gradient stored as two DENSE channel halves when the one-kernel
+    # matrix stage runs it (forced here: wbf_fuse 2; c <= 64) -- bitwise the interleaved result of the same call without the split,
+    # the interleaved buffer itself left at its old values; otherwise split_done = 0 and dx holds the result
+    if eligible and c <= 64:
+        d.set_option("wbf_fuse", 2)
+        try:
+            old = (0.25 * dx_ref).astype(np.float32)
+            base = t_from_ncdhw(old)
+            dw2 = vec(np.zeros(w.size, np.float32))
+            d.call("msk_conv3d_bwd_bnact", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
+                   vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
+                   dyt.msk(), base.msk(), 1, vp(dw2), 0, vp(xf), vp(ybuf), vp(maxes))
+            want = t_to_ncdhw(base)
+            inter = t_from_ncdhw(old)
+            lo, hi = t_empty(N, c // 2, D, H, W, fill=7.0), t_empty(N, c // 2, D, H, W, fill=7.0)
+            done = C.c_int(-1)
+            d.call("msk_conv3d_bwd_bnact_split", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
+                   vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
+                   dyt.msk(), inter.msk(), 1, vp(dw2), 0, vp(xf), vp(ybuf), vp(maxes), lo.msk(), hi.msk(), C.byref(done))
+            d.sync()
+            if c == 32 and K == 5:
+                assert done.value == 1, done.value        # the one-kernel stage takes these (packed weights of all points within an XCD's L2)
+            if done.value == 1:
+                got = np.concatenate([t_to_ncdhw(lo), t_to_ncdhw(hi)], axis=1)
+                assert np.array_equal(got, want)
+                assert np.array_equal(t_to_ncdhw(inter), old)
+            else:                                         # three-stage form (e.g. 64 channels x three bf16 pieces: 4.9 MB of packed weights)
+                assert done.value == 0 and np.array_equal(t_to_ncdhw(inter), want)
+                assert np.all(t_to_ncdhw(lo) == 7.0) and np.all(t_to_ncdhw(hi) == 7.0)
+            # option dst_split 0: the plain behaviour through the same entry point
+            d.set_option("dst_split", 0)
+            inter2 = t_from_ncdhw(old)
+            d.call("msk_conv3d_bwd_bnact_split", desc, xt.msk(), vp(wp), yt.msk(), vp(cv["scale"]), vp(cv["shift"]), vp(cv["alpha"]),
+                   vp(cv["mean"]), vp(cv["invstd"]), vp(cv["gamma"]), dot.msk(), vp(cv["sums"]), C.c_double(float(M)),
+                   dyt.msk(), inter2.msk(), 1, vp(dw2), 0, vp(xf), vp(ybuf), vp(maxes), lo.msk(), hi.msk(), C.byref(done))
+            assert done.value == 0 and np.array_equal(t_to_ncdhw(inter2), want)
+        finally:
+            d.set_option("dst_split", 1)
+            d.set_option("wbf_fuse", 1)
 
 
 @pytest.mark.parametrize("case", [(32, 5, (2, 16, 32, 16), 1.0), (64, 5, (1, 8, 16, 16), 1e-6), (128, 5, (1, 8, 16, 8), 1e3),
