@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--eager-opt", type=int, default=None, choices=(0, 1),
                     help="optimizer update + weight re-pack of a block on the weight-gradient stream right behind that block's weight "
                          "gradients (Momentum.enable_eager): default 1 at one rank, 0 otherwise")
+    ap.add_argument("--roofline-every", type=int, default=4, metavar="N",
+                    help="HIP events ride on the dominant kernel's launches in every Nth timed step (1 = every step: the events' "
+                         "packets cost ~0.2 ms of a step, DESIGN.md section 6)")
     ap.add_argument("--skip-strict-fp32", action="store_true",
                     help="skip the untimed extra pass behind roofline.strict_fp32 (the step with exact bf16 x 3 operand pieces)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
@@ -263,10 +266,17 @@ def main():
     t0 = time.perf_counter()
     if use_marks:
         dev.call("msk_mark", 0)
+    # the roofline kernel's events: on every launch of every Nth step (a host-side flag, no drain and no synchronisation in between)
+    every = 1 if full_profile else max(1, args.roofline_every)
+    sampled_steps = len(range(0, args.steps, every))
     for i in range(args.steps):
+        if every > 1:
+            dev.set_option("prof_paused", 0 if i % every == 0 else 1)
         last = step()
         if use_marks:
             dev.call("msk_mark", i + 1)     # an event on the stream: no host synchronisation inside the timed region
+    if every > 1:
+        dev.set_option("prof_paused", 0)
     t_enq = time.perf_counter() - t0   # host time to ENQUEUE the steps (no synchronisation inside a step)
     dev.sync()
     parallel.barrier()
@@ -396,10 +406,10 @@ def main():
     work = lu_conv_work(B, S, S, S, SPLIT_PRODUCTS[split])
     DOM = GEMM_TAGS[split]
     flops_step, bytes_step, launches_step, exec_step = work["wbf_gemm_k"]
-    line = _kernel_line(prof, DOM, flops_step, exec_step, args.steps) or {"achieved": 0.0, "frac": 0.0,
+    line = _kernel_line(prof, DOM, flops_step, exec_step, sampled_steps) or {"achieved": 0.0, "frac": 0.0,
                                                                           "algorithmic_tflops": 0.0, "launches": 0,
                                                                           "avg_launch_ms": 0.0}
-    kms = line["avg_launch_ms"] * line["launches"]
+    kms = line["avg_launch_ms"] * line["launches"] * args.steps / max(sampled_steps, 1)   # scaled from the sampled steps to all of them
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic, traffic_src, hbm = None, None, None
     tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
@@ -440,6 +450,8 @@ def main():
     roofline = {"bound": "mfma", "kernel": DOM, "achieved": line["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": line["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "launches": line["launches"], "avg_launch_ms": line["avg_launch_ms"],
+                "events": "HIP events riding on every launch of this kernel (hipExtLaunchKernelGGL start / stop events, on the launch "
+                          "stream) in %d of the %d timed steps (every %s)" % (sampled_steps, args.steps, every),
                 "executed_16bit_flop_per_launch": round(exec_step / max(launches_step, 1), 1),
                 "algorithmic_flop_per_launch": round(flops_step / max(launches_step, 1), 1),
                 "algorithmic_tflops": line["algorithmic_tflops"],
@@ -476,6 +488,9 @@ def main():
            "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
            "value_median": round(voxels_per_step / (float(np.median(step_ms)) * 1e-3), 1) if step_ms else None,
            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)] if step_ms else None,
+           # the steps that carry the roofline kernel's events against the ones that do not (the events' packets idle the packet processor)
+           "ms_per_step_with_events": round(float(np.mean(step_ms[0::every])), 3) if step_ms and every > 1 else None,
+           "ms_per_step_without_events": round(float(np.mean([m for i, m in enumerate(step_ms) if i % every])), 3) if step_ms and every > 1 else None,
            "final_loss": round(loss_val, 6),
            # host time to enqueue one step (python + ctypes + HIP launches, no sync inside a step): the step is GPU-bound
            # while this stays below ms_per_step

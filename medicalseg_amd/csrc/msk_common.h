@@ -1,6 +1,7 @@
 // Internal definitions shared by the libmsegk translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -77,6 +78,8 @@ struct msk_ctx {
   int wbf_bpf = 1;            // option "wbf_bpf": weight-fragment prefetch depth of wbf_gemm_k: 1 (default), 4 = four taps ahead, 0 = 4 for launches of <= 8 workgroups per CU (round 5 A/B: 18.45 ms with 1, 18.58 with 0 / 4 -- the deeper ring costs more than the waits it removes)
   int wbf_ks_blocks = 2;      // option "wbf_ks_blocks": workgroups per CU the split-K of wbf_gemm_k aims for (deep levels; every slab is a round trip of M through HBM)
   int noop_after_merge = 0;   // debug option "noop_after_merge": that many empty launches behind every merge kernel (what a 5-us launch costs the step)
+  int prof_paused = 0;        // option "prof_paused": 1 = the profile takes no events until it is set back (no drain, no host synchronisation: bench.py samples every Nth step)
+  int prof_attach = 1;        // option "prof_attach": the profile's events ride on the dominant kernel's dispatch (MSK_LAUNCH_TIMED); 0 = marker brackets (A/B)
   int small_pack_cache = 1;   // option "small_pack_cache": 0 = those kernels pack into the shared scratch on every call (A/B)
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
   int ks_legacy = 0;          // option "ks_legacy" (A/B): bit 0 = one-tap-per-tile k == s weight gradient, bit 1 = fragment-shaped k == s scatter kernel
@@ -219,12 +222,33 @@ struct msk_launch_scope {
   // prof_prefix (option "prof_only_halo"): bracket only the launches whose tag starts with it -- two events
   // around EVERY launch cost ~4 % of the training step (packet-processor barriers between back-to-back kernels)
   msk_launch_scope(msk_ctx* c, const char* tag)
-      : ctx(c), on(c->prof && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0 ||
-                               strncmp(tag, "rccl_", 5) == 0)) {   // the (few) collectives are always bracketed
+      : ctx(c), on(c->prof && ((!c->prof_paused && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0)) ||
+                               strncmp(tag, "rccl_", 5) == 0)) {   // the (few) collectives are always bracketed (paused or not)
     if (on) msk_prof_begin(c, tag);
   }
   ~msk_launch_scope() { if (on) msk_prof_end(ctx); }
 };
+
+// HIP events ATTACHED to one launch (the start / stop events of hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps).
+// The bracket form above puts two marker packets around the launch, each ~6 us of idle packet processor (round 5: bench.py's
+// brackets around the 28 launches of the dominant kernel were 0.33 ms of the step it measured: tools/gap_by_kernel.py); the
+// attached form adds no packet.  Option "prof_attach" 0 = brackets (A/B).
+struct msk_launch_events {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+bool msk_prof_attach(msk_ctx* ctx, const char* tag, msk_launch_events* ev);   // true: launch with ev->a / ev->b, then msk_prof_attached
+void msk_prof_attached(msk_ctx* ctx, const msk_launch_events& ev, const char* tag);
+#define MSK_LAUNCH_TIMED(ctx, tag, kernel, grid, block, shmem, ...)                                                     \
+  do {                                                                                                                   \
+    msk_launch_events _ev;                                                                                               \
+    if (msk_prof_attach(ctx, tag, &_ev)) {                                                                               \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, _ev.a, _ev.b, 0, __VA_ARGS__);                    \
+      msk_prof_attached(ctx, _ev, tag);                                                                                  \
+    } else {                                                                                                             \
+      msk_launch_scope _ls(ctx, tag);                                                                                    \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                                        \
+    }                                                                                                                    \
+  } while (0)
 
 #define MSK_LAUNCH_CHECK(ctx)                                                            \
   do {                                                                                   \

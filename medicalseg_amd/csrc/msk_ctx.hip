@@ -72,6 +72,21 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag) {
   hipEventRecord(pe.a, ctx->stream);
   ctx->prof_pending.push_back(pe);
 }
+bool msk_prof_attach(msk_ctx* ctx, const char* tag, msk_launch_events* ev) {
+  if (!ctx->prof || ctx->prof_paused || !ctx->prof_attach) return false;
+  if (ctx->prof_prefix[0] != 0 && strncmp(tag, ctx->prof_prefix, strlen(ctx->prof_prefix)) != 0) return false;
+  ev->a = get_event(ctx);
+  ev->b = get_event(ctx);
+  return true;
+}
+void msk_prof_attached(msk_ctx* ctx, const msk_launch_events& ev, const char* tag) {
+  msk_pending_event pe;
+  pe.a = ev.a;
+  pe.b = ev.b;
+  pe.tag = tag;
+  ctx->prof_pending.push_back(pe);
+  if (ctx->prof_pending.size() > 4096) drain_prof(ctx);
+}
 void msk_prof_end(msk_ctx* ctx) {
   hipEventRecord(ctx->prof_pending.back().b, ctx->stream);
   if (ctx->prof_pending.size() > 4096) drain_prof(ctx);
@@ -454,6 +469,14 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wbf_ks_blocks") == 0) {  // tuning: workgroups per CU targeted by the split-K of wbf_gemm_k (default 2; round 5 sweep on one box, two repetitions: 16 / 8 / 4 / 2 = 18.58 / 18.46 / 18.39 / 18.28 ms -- every slab is a round trip of M through HBM and a term of wbf_tout_k)
     ctx->wbf_ks_blocks = value > 0 ? value : 2;
+    return 0;
+  }
+  if (strcmp(key, "prof_paused") == 0) {
+    ctx->prof_paused = value;
+    return 0;
+  }
+  if (strcmp(key, "prof_attach") == 0) {
+    ctx->prof_attach = value;
     return 0;
   }
   if (strcmp(key, "noop_after_merge") == 0) {  // debug: empty launches behind every bn_stats_merge / sums_merge (measures the price of a tiny launch in the step)

@@ -181,27 +181,45 @@ bn_stats_partial_v4(const float* __restrict__ x, long voxels, int C, int ld, int
 // fin.scale != NULL: the per-channel finalisation of msk_bn_finalize(world = 1) runs here as well (one launch less per
 // BatchNorm layer): the same arithmetic on the same float-rounded (mean, M2) record, so the results are bitwise those of
 // the two-kernel form.
-constexpr int kMergeThreads = 256;
-__global__ void __launch_bounds__(kMergeThreads)
+constexpr int kMergeThreads = 256, kMergeThreadsMax = 1024;
+// block size by record count: 256 threads up to 4096 records; 1024 beyond (the 8192 records of up_tr32's up-convolution were a
+// chain of 32 dependent (load, divide, update) steps per thread: 25 us for 16 channels)
+static inline int merge_threads(int nb) { return nb > 4096 ? kMergeThreadsMax : kMergeThreads; }
+__global__ void __launch_bounds__(kMergeThreadsMax)
 bn_stats_merge(const float* __restrict__ partial, int nb, int C, int CB, float* __restrict__ stats /*[2C]*/, msk_bn_fin fin) {
-  // 256 threads per channel: a thread's chain of dependent (load, divide, update) steps is nb / 256 long -- with 64 threads the
-  // 2 K - 8 K records of a 128^3 layer made this 12 us launch (24 per step) a latency chain of 128 steps
-  __shared__ double sn[kMergeThreads], sm[kMergeThreads], s2[kMergeThreads];
-  const int c = blockIdx.x, t = threadIdx.x;
+  // a thread's chain of dependent (divide, update) steps is nb / blockDim long; the records of eight steps are requested
+  // together (round 5: one load latency per eight steps instead of one per step -- 17.8 -> 12.6 us for the 4096 tile records of a
+  // 128^3 layer, 25.5 -> 18.2 us for the 8192 of up_tr32's up-convolution with 1024 threads; what remains is the fp64 divide chain)
+  __shared__ double sn[kMergeThreadsMax], sm[kMergeThreadsMax], s2[kMergeThreadsMax];
+  const int c = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   const int cb = c / CB, cl = c % CB;
   double n = 0, mean = 0, m2 = 0;
-  for (int b = t; b < nb; b += kMergeThreads) {
-    const float* p = partial + (((long)cb * nb + b) * CB + cl) * 3;
-    const double bn = p[0];
-    if (bn == 0) continue;
-    const double d = (double)p[1] - mean, tot = n + bn, f = bn / tot;
-    m2 = m2 + (double)p[2] + d * d * n * f;
-    mean = mean + d * f;
-    n = tot;
+  constexpr int PF = 8;
+  for (int b0 = t; b0 < nb; b0 += PF * nt) {
+    float r[PF][3];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int b = b0 + k * nt;
+      if (b < nb) {
+        const float* p = partial + (((long)cb * nb + b) * CB + cl) * 3;
+        r[k][0] = p[0]; r[k][1] = p[1]; r[k][2] = p[2];
+      } else {
+        r[k][0] = 0.f; r[k][1] = 0.f; r[k][2] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const double bn = r[k][0];
+      if (bn == 0) continue;
+      const double d = (double)r[k][1] - mean, tot = n + bn, f = bn / tot;
+      m2 = m2 + (double)r[k][2] + d * d * n * f;
+      mean = mean + d * f;
+      n = tot;
+    }
   }
   sn[t] = n; sm[t] = mean; s2[t] = m2;
   __syncthreads();
-  for (int s = kMergeThreads / 2; s > 0; s >>= 1) {
+  for (int s = nt / 2; s > 0; s >>= 1) {
     if (t < s && sn[t + s] > 0) {
       const double bn = sn[t + s], d = sm[t + s] - sm[t], tot = sn[t] + bn, f = bn / tot;
       s2[t] = s2[t] + s2[t + s] + d * d * sn[t] * f;
@@ -1260,7 +1278,7 @@ inline void noop_launches(msk_ctx* ctx) {
 
 int msk_bn_stats_merge(msk_ctx* ctx, const float* partial, int nb, int C, float* stats, const msk_bn_fin* fin) {
   msk_launch_scope ls(ctx, "bn_stats_merge");
-  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(kMergeThreads), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
+  hipLaunchKernelGGL(bn_stats_merge, dim3(C), dim3(merge_threads(nb)), 0, ctx->stream, partial, nb, C, C, stats, fin ? *fin : msk_bn_fin{});
   MSK_LAUNCH_CHECK(ctx);
   noop_launches(ctx);
   return 0;
@@ -1285,7 +1303,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(merge_threads(nb)), 0, ctx->stream, partial, nb, x.c, 4 * QCB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
     noop_launches(ctx);
@@ -1306,7 +1324,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
       MSK_LAUNCH_CHECK(ctx);
     }
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(merge_threads(nb)), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
     noop_launches(ctx);
@@ -1320,7 +1338,7 @@ int msk_bn_stats_fin(msk_ctx* ctx, msk_tensor x, float* stats_local, const msk_b
   }
   {
     msk_launch_scope ls(ctx, "bn_stats_merge");
-    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(kMergeThreads), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
+    hipLaunchKernelGGL(bn_stats_merge, dim3(x.c), dim3(merge_threads(nb)), 0, ctx->stream, partial, nb, x.c, g.CB, stats_local,
                        fin ? *fin : msk_bn_fin{});
     MSK_LAUNCH_CHECK(ctx);
     noop_launches(ctx);

@@ -383,3 +383,43 @@ def test_training_step_under_the_per_kernel_profile():
         if on:
             assert any(t.startswith("convT_scatter") for t in rep) and any(t.startswith("wbf_gemm") for t in rep), sorted(rep)
             assert all(ms >= 0.0 for _, ms in rep.values())
+
+
+@pytest.mark.gpu
+def test_dominant_kernel_events_attached_to_the_dispatch_agree_with_the_brackets():
+    """bench.py's live roofline measurement: the events of the matrix stage ride on its dispatch (MSK_LAUNCH_TIMED =
+    hipExtLaunchKernelGGL's start / stop events; no marker packets: the brackets idled the packet processor for ~0.2 ms of a
+    headline step), and option "prof_paused" switches them off for the steps bench.py does not sample without draining.
+    Same launches counted by both forms, the same time within the brackets' own overhead, nothing recorded while paused."""
+    from medicalseg_amd.device import get_device, to_tensor
+    from medicalseg_amd.models import VNet
+    dev = get_device()
+    rng = np.random.default_rng(4)
+    model = VNet(num_classes=3)
+    model.train()
+    x = to_tensor(rng.standard_normal((2, 1, 64, 64, 64)).astype(np.float32))
+    model(x)                       # packs, workspaces
+    dev.sync()
+    rep = {}
+    for mode in ("attached", "brackets", "paused"):
+        dev.set_option("prof_only_halo", 1)
+        dev.set_option("prof_attach", 0 if mode == "brackets" else 1)
+        dev.set_option("prof_paused", 1 if mode == "paused" else 0)
+        dev.prof_reset()
+        dev.prof_enable(True)
+        for _ in range(3):
+            model(x)
+        dev.sync()
+        dev.prof_enable(False)
+        rep[mode] = dev.prof_report()
+    dev.set_option("prof_attach", 1)
+    dev.set_option("prof_paused", 0)
+    dev.set_option("prof_only_halo", 0)
+    assert rep["paused"] == {}, rep["paused"]
+    assert rep["attached"] and all(t.startswith("wbf_gemm") for t in rep["attached"]), sorted(rep["attached"])
+    assert sorted(rep["attached"]) == sorted(rep["brackets"])
+    for t, (calls, ms) in rep["attached"].items():
+        bc, bms = rep["brackets"][t]
+        assert calls == bc and calls % 3 == 0 and ms > 0.0
+        # the bracket form includes the markers' own latency (a few us per launch); the kernel time is the same
+        assert ms <= bms * 1.10 + 0.02 * calls and bms <= ms * 1.35 + 0.02 * calls, (t, calls, ms, bms)
