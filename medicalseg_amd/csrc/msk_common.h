@@ -78,6 +78,8 @@ struct msk_ctx {
   int wbf_bpf = 1;            // option "wbf_bpf": weight-fragment prefetch depth of wbf_gemm_k: 1 (default), 4 = four taps ahead, 0 = 4 for launches of <= 8 workgroups per CU (round 5 A/B: 18.45 ms with 1, 18.58 with 0 / 4 -- the deeper ring costs more than the waits it removes)
   int wbf_ks_blocks = 2;      // option "wbf_ks_blocks": workgroups per CU the split-K of wbf_gemm_k aims for (deep levels; every slab is a round trip of M through HBM)
   int noop_after_merge = 0;   // debug option "noop_after_merge": that many empty launches behind every merge kernel (what a 5-us launch costs the step)
+  int wgrad_c1_wpc = 2;       // option "wgrad_c1_wpc": persistent workgroups per CU of wgrad_c1_mfma_k (LDS allows 3)
+  int eager_tail_main = 1;    // option "eager_tail_main": msk_sgd_momentum_eager behind a late weight gradient runs on the compute stream (idle by then) instead of queueing behind that kernel on the side stream; 0 = side stream (A/B)
   int prof_paused = 0;        // option "prof_paused": 1 = the profile takes no events until it is set back (no drain, no host synchronisation: bench.py samples every Nth step)
   int prof_attach = 1;        // option "prof_attach": the profile's events ride on the dominant kernel's dispatch (MSK_LAUNCH_TIMED); 0 = marker brackets (A/B)
   int small_pack_cache = 1;   // option "small_pack_cache": 0 = those kernels pack into the shared scratch on every call (A/B)
@@ -105,9 +107,15 @@ struct msk_ctx {
   bool late_valid = false;
   const float* late_ptr = nullptr;   // gradient tensor still being written behind ev_late
   size_t late_count = 0;
+  // the late tensor's slice of an eager update that ran on the compute stream (msk_sgd_momentum_eager): updated by
+  // msk_sgd_momentum_finish after the join
+  struct { float* param = nullptr; const float* grad = nullptr; float* velocity = nullptr; size_t count = 0;
+           float lr = 0, momentum = 0, weight_decay = 0, grad_scale = 0; } late_piece;
   int late_split = 1;                // option "late_split": 0 = the late gradient on the calling stream, one optimizer launch (A/B)
   bool wgrad_async = false;
   bool side_dirty = false;
+  hipEvent_t fork_event = nullptr;  // the event of that point when it is not ev_fork (the profile's stop event of the same dispatch)
+  int fork_attach = 1;         // option "fork_attach": the fork point of a LUConv backward rides on its last data-gradient dispatch (MSK_LAUNCH_TIMED_F) instead of a marker packet behind it (~7 us of idle packet processor on the compute stream, 14 per step); 0 = marker (A/B)
   bool fork_recorded = false;  // ev_fork already recorded at the point the next side scope has to wait for (msk_conv3d_bwd_bnact)
   // msk_h2d staging: two pinned buffers so that a batch upload neither synchronises the stream nor waits for the
   // previous step (the host may run one upload ahead)
@@ -177,10 +185,12 @@ struct msk_side_scope {
   bool active;
   explicit msk_side_scope(msk_ctx* c, bool want = true) : ctx(c), active(want && c->wgrad_async && c->side != nullptr) {
     const bool forked = ctx->fork_recorded;  // an earlier fork point was recorded for this scope
+    hipEvent_t fev = forked && ctx->fork_event ? ctx->fork_event : ctx->ev_fork;
     ctx->fork_recorded = false;
+    ctx->fork_event = nullptr;
     if (!active) return;
     if (!forked) hipEventRecord(ctx->ev_fork, ctx->stream);
-    hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+    hipStreamWaitEvent(ctx->side, fev, 0);
     std::swap(ctx->stream, ctx->side);
     std::swap(ctx->ws, ctx->ws_side);
     std::swap(ctx->ws_bytes, ctx->ws_side_bytes);
@@ -216,14 +226,18 @@ struct msk_side_scope {
   } while (0)
 
 // Launch bracket: set device stream, optional per-kernel profiling, error check.
+// does the per-kernel profile take events for this tag right now?
+static inline bool msk_prof_selected(const msk_ctx* c, const char* tag) {
+  return c->prof && ((!c->prof_paused && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0)) ||
+                     strncmp(tag, "rccl_", 5) == 0);   // the (few) collectives are always bracketed (paused or not)
+}
 struct msk_launch_scope {
   msk_ctx* ctx;
   bool on;
   // prof_prefix (option "prof_only_halo"): bracket only the launches whose tag starts with it -- two events
   // around EVERY launch cost ~4 % of the training step (packet-processor barriers between back-to-back kernels)
   msk_launch_scope(msk_ctx* c, const char* tag)
-      : ctx(c), on(c->prof && ((!c->prof_paused && (c->prof_prefix[0] == 0 || strncmp(tag, c->prof_prefix, strlen(c->prof_prefix)) == 0)) ||
-                               strncmp(tag, "rccl_", 5) == 0)) {   // the (few) collectives are always bracketed (paused or not)
+      : ctx(c), on(msk_prof_selected(c, tag)) {
     if (on) msk_prof_begin(c, tag);
   }
   ~msk_launch_scope() { if (on) msk_prof_end(ctx); }
@@ -238,12 +252,20 @@ struct msk_launch_events {
 };
 bool msk_prof_attach(msk_ctx* ctx, const char* tag, msk_launch_events* ev);   // true: launch with ev->a / ev->b, then msk_prof_attached
 void msk_prof_attached(msk_ctx* ctx, const msk_launch_events& ev, const char* tag);
-#define MSK_LAUNCH_TIMED(ctx, tag, kernel, grid, block, shmem, ...)                                                     \
+#define MSK_LAUNCH_TIMED(ctx, tag, kernel, grid, block, shmem, ...) MSK_LAUNCH_TIMED_F(ctx, tag, false, kernel, grid, block, shmem, __VA_ARGS__)
+// ... and, with `fork`, the point the next msk_side_scope waits for: the dispatch's own completion (its stop event) instead of a
+// marker packet recorded behind it
+#define MSK_LAUNCH_TIMED_F(ctx, tag, fork, kernel, grid, block, shmem, ...)                                             \
   do {                                                                                                                   \
     msk_launch_events _ev;                                                                                               \
     if (msk_prof_attach(ctx, tag, &_ev)) {                                                                               \
       hipExtLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, _ev.a, _ev.b, 0, __VA_ARGS__);                    \
       msk_prof_attached(ctx, _ev, tag);                                                                                  \
+      if (fork) { (ctx)->fork_event = _ev.b; (ctx)->fork_recorded = true; }                                              \
+    } else if ((fork) && !msk_prof_selected(ctx, tag)) {                                                                 \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, (hipEvent_t) nullptr, (ctx)->ev_fork, 0, __VA_ARGS__); \
+      (ctx)->fork_event = nullptr;                                                                                       \
+      (ctx)->fork_recorded = true;                                                                                       \
     } else {                                                                                                             \
       msk_launch_scope _ls(ctx, tag);                                                                                    \
       hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);                                        \

@@ -1614,17 +1614,17 @@ int pack_row_lookup(msk_ctx* ctx, WbfPackCache* c, const WbfPackDesc& key, int K
 }
 
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
-void launch_fused(msk_ctx* ctx, const char* tag, const FusedArgs& fa, bool stats) {
+void launch_fused(msk_ctx* ctx, const char* tag, const FusedArgs& fa, bool stats, bool fork) {
   const dim3 grid((unsigned)(8 * fa.per_xcd));
-  if (stats) MSK_LAUNCH_TIMED(ctx, tag, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true>), grid, dim3(WM * WN * 64), 0, fa);
-  else MSK_LAUNCH_TIMED(ctx, tag, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false>), grid, dim3(WM * WN * 64), 0, fa);
+  if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true>), grid, dim3(WM * WN * 64), 0, fa);
+  else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false>), grid, dim3(WM * WN * 64), 0, fa);
 }
 template <int K, int NP>
-void launch_fused_variant(msk_ctx* ctx, const char* tag, int variant, const FusedArgs& fa, bool stats) {
+void launch_fused_variant(msk_ctx* ctx, const char* tag, int variant, const FusedArgs& fa, bool stats, bool fork) {
   switch (variant) {
-    case 3: launch_fused<2, 1, 4, 8, 8, K, NP>(ctx, tag, fa, stats); break;
-    case 4: launch_fused<2, 4, 1, 16, 16, K, NP>(ctx, tag, fa, stats); break;
-    default: launch_fused<2, 2, 2, 8, 16, K, NP>(ctx, tag, fa, stats); break;
+    case 3: launch_fused<2, 1, 4, 8, 8, K, NP>(ctx, tag, fa, stats, fork); break;
+    case 4: launch_fused<2, 4, 1, 16, 16, K, NP>(ctx, tag, fa, stats, fork); break;
+    default: launch_fused<2, 2, 2, 8, 16, K, NP>(ctx, tag, fa, stats, fork); break;
   }
 }
 
@@ -1747,6 +1747,9 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       return -1;
     }
   }
+  // late fork (option "wgrad_fork" 1): the weight gradient of this layer starts behind the LAST data-gradient launch -- that launch's
+  // own completion is the fork point (no marker packet behind it)
+  const bool fork_after = g.fuse && g.fuse->Y && ctx->wgrad_async && ctx->side != nullptr && ctx->wgrad_fork == 1 && ctx->fork_attach != 0;
   GemmArgs ga{};
   ga.V = V; ga.U = U; ga.M = M;
   ga.N = g.N; ga.T = T; ga.KC = KC; ga.CN = g.CN; ga.LD = LD; ga.LH = LH; ga.DP = DP; ga.HP = HP;
@@ -1774,7 +1777,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
       fa.st_lo = g.dst_lo; fa.st_hi = g.dst_hi; fa.csplit = g.dst_csplit;
       ctx->dst_split_done = true;
     }
-    launch_fused_variant<K, NP>(ctx, tag, variant, fa, fuse_stats);   // (the profile's events ride on the dispatch: MSK_LAUNCH_TIMED)
+    launch_fused_variant<K, NP>(ctx, tag, variant, fa, fuse_stats, fork_after);   // (the profile's events ride on the dispatch: MSK_LAUNCH_TIMED)
     MSK_LAUNCH_CHECK(ctx);
     if (fuse_stats) {
       if (g.stats_ps) {
@@ -1809,12 +1812,9 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     oa.in_amax = in_amax;
     oa.w_amax = w_amax;
     oa.scaled = NP != 3 ? 1 : 0;
-    {
-      msk_launch_scope ls(ctx, "wbf_tout_k");
-      if (fuse_stats) hipLaunchKernelGGL((wbf_tout_k<true, K>), dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);
-      else hipLaunchKernelGGL((wbf_tout_k<false, K>), dim3((unsigned)tout_blocks), dim3(256), 0, ctx->stream, oa);
-      MSK_LAUNCH_CHECK(ctx);
-    }
+    if (fuse_stats) MSK_LAUNCH_TIMED_F(ctx, "wbf_tout_k", false, (wbf_tout_k<true, K>), dim3((unsigned)tout_blocks), dim3(256), 0, oa);
+    else MSK_LAUNCH_TIMED_F(ctx, "wbf_tout_k", fork_after, (wbf_tout_k<false, K>), dim3((unsigned)tout_blocks), dim3(256), 0, oa);
+    MSK_LAUNCH_CHECK(ctx);
     if (fuse_stats) {
       if (msk_bn_stats_merge(ctx, SP, (int)tout_blocks, g.CN, g.stats, g.fin) != 0) return -1;
       ctx->stats_fused = true;

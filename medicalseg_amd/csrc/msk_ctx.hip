@@ -73,8 +73,7 @@ void msk_prof_begin(msk_ctx* ctx, const char* tag) {
   ctx->prof_pending.push_back(pe);
 }
 bool msk_prof_attach(msk_ctx* ctx, const char* tag, msk_launch_events* ev) {
-  if (!ctx->prof || ctx->prof_paused || !ctx->prof_attach) return false;
-  if (ctx->prof_prefix[0] != 0 && strncmp(tag, ctx->prof_prefix, strlen(ctx->prof_prefix)) != 0) return false;
+  if (!ctx->prof_attach || !msk_prof_selected(ctx, tag)) return false;
   ev->a = get_event(ctx);
   ev->b = get_event(ctx);
   return true;
@@ -469,6 +468,18 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
   }
   if (strcmp(key, "wbf_ks_blocks") == 0) {  // tuning: workgroups per CU targeted by the split-K of wbf_gemm_k (default 2; round 5 sweep on one box, two repetitions: 16 / 8 / 4 / 2 = 18.58 / 18.46 / 18.39 / 18.28 ms -- every slab is a round trip of M through HBM and a term of wbf_tout_k)
     ctx->wbf_ks_blocks = value > 0 ? value : 2;
+    return 0;
+  }
+  if (strcmp(key, "wgrad_c1_wpc") == 0) {
+    ctx->wgrad_c1_wpc = value < 1 ? 1 : value;
+    return 0;
+  }
+  if (strcmp(key, "eager_tail_main") == 0) {
+    ctx->eager_tail_main = value;
+    return 0;
+  }
+  if (strcmp(key, "fork_attach") == 0) {
+    ctx->fork_attach = value;
     return 0;
   }
   if (strcmp(key, "prof_paused") == 0) {

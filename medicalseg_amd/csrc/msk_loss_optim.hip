@@ -706,6 +706,35 @@ int msk_sgd_momentum_eager(msk_ctx* ctx, float* param, const float* grad, float*
   if (count == 0) return 0;
   MSK_REQUIRE(ctx, ((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)velocity % 16 == 0),
               "arena slices must be 16-byte aligned");
+  // Behind a LATE weight gradient (in_tr.conv1's, the last kernel of the side stream: msk_conv.hip bwd_bnact_c1) the side stream
+  // is the step's critical path and the compute stream is idle: everything else this slice needs is complete behind ev_late,
+  // so the update and the re-pack run on the compute stream beside that kernel (0.09 ms off the tail of a VNet step); the
+  // late tensor's own slice waits for msk_sgd_momentum_finish.  Same kernels, same arithmetic per element.
+  if (ctx->late_valid && ctx->eager_tail_main && ctx->wgrad_async && ctx->side != nullptr) {
+    const float* lp = ctx->late_ptr;
+    const bool inside = lp >= grad && lp + ctx->late_count <= grad + count && ((lp - grad) & 3) == 0 && ctx->late_piece.count == 0;
+    const bool disjoint = lp + ctx->late_count <= grad || lp >= grad + count;
+    if (inside || disjoint) {
+      size_t lo = count, hi = count;
+      if (inside) {
+        lo = (size_t)(lp - grad);
+        hi = (lo + ctx->late_count + 3) & ~(size_t)3;
+        if (hi > count) hi = count;
+      }
+      MSK_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_late, 0));
+      if (sgd_launch(ctx, param, grad, velocity, lo, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+      if (sgd_launch(ctx, param + hi, grad + hi, velocity + hi, count - hi, lr, momentum, weight_decay, grad_scale) != 0) return -1;
+      msk_weights_changed_impl(ctx, param, count * sizeof(float));
+      if (msk_wbf_prepack_range_impl(ctx, param, count * sizeof(float)) != 0) return -1;
+      if (inside) {
+        ctx->late_piece.param = param + lo; ctx->late_piece.grad = grad + lo; ctx->late_piece.velocity = velocity + lo;
+        ctx->late_piece.count = hi - lo;
+        ctx->late_piece.lr = lr; ctx->late_piece.momentum = momentum; ctx->late_piece.weight_decay = weight_decay;
+        ctx->late_piece.grad_scale = grad_scale;
+      }
+      return 0;
+    }
+  }
   {
     msk_side_scope side(ctx);   // (no side stream: the same launches on the calling stream, in order)
     if (sgd_launch(ctx, param, grad, velocity, count, lr, momentum, weight_decay, grad_scale) != 0) return -1;
@@ -719,6 +748,12 @@ int msk_sgd_momentum_eager(msk_ctx* ctx, float* param, const float* grad, float*
 // packed rows that are still stale are rebuilt and the pack cache's use epoch advances as in msk_sgd_momentum.
 int msk_sgd_momentum_finish(msk_ctx* ctx) {
   if (msk_join_side_impl(ctx) != 0) return -1;
+  if (ctx->late_piece.count != 0) {   // the late tensor's slice of an update that ran beside its weight gradient (above)
+    auto lp = ctx->late_piece;
+    ctx->late_piece.count = 0;
+    if (sgd_launch(ctx, lp.param, lp.grad, lp.velocity, lp.count, lp.lr, lp.momentum, lp.weight_decay, lp.grad_scale) != 0) return -1;
+    msk_weights_changed_impl(ctx, lp.param, lp.count * sizeof(float));
+  }
   return msk_wbf_prepack_impl(ctx);
 }
 

@@ -165,7 +165,7 @@ int msk_wgrad_c1(msk_ctx* ctx, const WGrad& g) {
   const int tiles_d = (g.BD + 3) / 4, tiles_h = (g.BH + 7) / 8, tiles_w = (g.BW + 31) / 32;
   const long ntiles = (long)g.N * tiles_d * tiles_h * tiles_w;
   if (ntiles > 0x7fffffff) return 0;
-  long splits = 2L * ctx->num_cu;  // persistent workgroups (LDS: 13.8 KB halo + 32 KB reduction buffer -> 3 per CU)
+  long splits = (long)ctx->wgrad_c1_wpc * ctx->num_cu;  // persistent workgroups (LDS: 13.8 KB halo + 32 KB reduction buffer -> 3 per CU; option "wgrad_c1_wpc", default 2)
   if (splits > ntiles) splits = ntiles;
   const int taps = k5 ? 125 : 27;
   for (int cb0 = 0; cb0 < g.CB; cb0 += 16) {
