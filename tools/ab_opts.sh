@@ -1,8 +1,11 @@
-# usage: tools/ab_opts.sh "opts1" "opts2" ...   each a space-separated list of KEY=INT for bench.py --opt ("-" = none)
-for o in "$@"; do
-  args=""; [ "$o" != "-" ] && for kv in $o; do args="$args --opt $kv"; done
-  python bench.py --no-cpu-baseline --skip-strict-fp32 $args 2>/dev/null | python -c "
-import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=b['roofline']
-print('[$o]', 'step', b['ms_per_step'], 'median', b['ms_per_step_median'], 'wgrad', r['wgrad_kernel']['avg_launch_ms'], 'gemm', r['avg_launch_ms'], 'serial', r['hbm']['serialized_kernel_ms_per_step'], 'loss', b['final_loss'])"
+#!/bin/bash
+# interleaved A/B of option sets on the default bench: tools/ab_opts.sh RUNS "k=v k=v" "k=v" ...   ("-" = defaults)   (GPU box, repo root)
+B="python bench.py --no-cpu-baseline --skip-serialized --skip-strict-fp32"
+f() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('ms_per_step_without_events'), d['final_loss'])"; }
+runs=$1; shift
+for i in $(seq 1 $runs); do
+  for set in "$@"; do
+    o=""; if [ "$set" != "-" ]; then for kv in $set; do o="$o --opt $kv"; done; fi
+    echo -n "[$set] "; $B $o | f
+  done
 done
