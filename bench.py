@@ -450,6 +450,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": DOM, "achieved": line["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": line["frac"], "traffic": traffic, "traffic_source": traffic_src,
                 "launches": line["launches"], "avg_launch_ms": line["avg_launch_ms"],
+                "event_steps": sampled_steps,
                 "events": "HIP events riding on every launch of this kernel (hipExtLaunchKernelGGL start / stop events, on the launch "
                           "stream) in %d of the %d timed steps (every %s)" % (sampled_steps, args.steps, every),
                 "executed_16bit_flop_per_launch": round(exec_step / max(launches_step, 1), 1),

@@ -419,10 +419,12 @@ int run_wgrad_pipeline(msk_ctx* ctx, const WGrad& g, const WbfGeom& geo, bool sh
 
   // split K (position tiles): about 3 workgroups per CU in total
   const long base_blocks = (long)NXI * KCA * ncob;
-  // split-K target in workgroups per CU (tuning: option "wgrad_wino_rounds").  3 fill the kernel's own occupancy; 2 (round 5) leave a
+  // split-K target in workgroups per CU (tuning: option "wgrad_wino_rounds").  3 fill the kernel's own occupancy.  2 (round 5) leave a
   // third of the registers to the compute stream's kernels beside it and a third fewer slabs to the reduce: step -0.08 ms in five of
-  // five interleaved pairs (profiles/r05_ab_runs.txt), 1: +1.0 ms
-  const long per_cu = ctx->wgrad_wino_rounds > 0 ? ctx->wgrad_wino_rounds : 2;
+  // five interleaved pairs (profiles/r05_ab_runs.txt) -- but the kernel then runs longer NEXT TO the data-gradient GEMMs, whose
+  // in-step time grows by 5 % (0.252 -> 0.266 ms per launch): the dominant kernel's measured rate would pay for 0.4 % of the step.
+  // Default stays 3; 1: +1.0 ms
+  const long per_cu = ctx->wgrad_wino_rounds > 0 ? ctx->wgrad_wino_rounds : 3;
   long ksplit = (per_cu * ctx->num_cu + base_blocks / 2) / base_blocks;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > ntiles) ksplit = ntiles;

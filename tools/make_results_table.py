@@ -11,6 +11,16 @@ import os
 import re
 import sys
 
+
+def _event_steps(r, b):
+    """timed steps whose launches of the roofline kernel carried events (bench.py --roofline-every)"""
+    if "event_steps" in r:
+        return max(1, int(r["event_steps"]))
+    import re
+    m = re.search(r"in (\d+) of the (\d+) timed steps", r.get("events", ""))
+    return int(m.group(1)) if m else b["steps"]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (TAG, name))
@@ -35,7 +45,7 @@ if b:
     if sf:
         rows.append(("the same step with exact fp32 operands (`conv_split` 3, `roofline.strict_fp32`)",
                      "%.2f ms/step = %.1f M voxels/s" % (sf["ms_per_step"], sf["value"] / 1e6)))
-    rows.append(("dominant kernel `%s` (matrix stage of every LUConv forward / data gradient, %d launches per step)" % (r["kernel"], r["launches"] // b["steps"]),
+    rows.append(("dominant kernel `%s` (matrix stage of every LUConv forward / data gradient, %d launches per step)" % (r["kernel"], r["launches"] // _event_steps(r, b)),
                  "%.4f ms per launch (HIP events in the step) = %.0f TFLOP/s executed on the 16-bit pipe = **%.3f of the %.0f TFLOP/s dense peak** "
                  "(%.0f TFLOP/s algorithmic); one stream: %.4f ms = %.3f" % (r["avg_launch_ms"], r["achieved"], r["frac"], r["peak"], r["algorithmic_tflops"],
                                                                             r["serialized"]["avg_launch_ms"], r["serialized"]["frac"]) if r.get("serialized") else ""))
