@@ -94,7 +94,10 @@ int msk_mark_elapsed(msk_ctx* ctx, int a, int b, float* ms);   /* waits for mark
  * (tools/bench_workloads.py --inloop-preprocess).  Both contexts must be on the same device. */
 int msk_ctx_wait(msk_ctx* ctx, msk_ctx* other);
 /* per-kernel profile: when enabled every launch is bracketed by events and its
- * duration accumulated under the kernel's tag. */
+ * duration accumulated under the kernel's tag.  The launches of the Winograd matrix stage (wbf_gemm_*) carry their events ON
+ * the dispatch (hipExtLaunchKernelGGL start / stop events) instead of between two marker packets, which idle the queue for
+ * ~6 us each; options: "prof_only_halo" 1 = only those launches (bench.py's roofline kernel), "prof_paused" 1 = take no events
+ * until it is set back (no drain, no host synchronisation: sampling every Nth step), "prof_attach" 0 = marker brackets. */
 int msk_prof_enable(msk_ctx* ctx, int on);
 int msk_prof_reset(msk_ctx* ctx);
 /* writes "tag\tcalls\ttotal_ms\n" lines into buf (NUL terminated); returns needed size via *len */
