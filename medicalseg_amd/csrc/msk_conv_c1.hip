@@ -12,6 +12,10 @@
 #include "msk_conv.h"
 #include "msk_wbf.h"   // msk_bn_stats_merge
 
+#ifndef C1_PIPE
+#define C1_PIPE 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -119,6 +123,26 @@ conv_c1_mfma_k(C1Args a) {
         f32x4 acc0 = {bq[0], bq[1], bq[2], bq[3]}, acc1 = acc0;
         f32x4 odd0 = {0.f, 0.f, 0.f, 0.f}, odd1 = odd0;
         const int b0 = (wave * HH + h) * HW + li, b1 = b0 + 16;
+#if C1_PIPE
+        // the operands of the NEXT pair of K steps are requested before this pair's MFMAs (the compiler's own order was
+        // ds_read -> wait -> two MFMAs, one LDS round trip exposed per K step with two wavefronts per SIMD)
+        float xa0 = xs[b0 + toff[0]], xb0 = xs[b1 + toff[0]], xa1 = xs[b0 + toff[1]], xb1 = xs[b1 + toff[1]];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s += 2) {
+          float na0 = 0.f, nb0 = 0.f, na1 = 0.f, nb1 = 0.f;
+          if (s + 2 < KSTEPS) {
+            na0 = xs[b0 + toff[s + 2]]; nb0 = xs[b1 + toff[s + 2]];
+            na1 = xs[b0 + toff[s + 3]]; nb1 = xs[b1 + toff[s + 3]];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xa0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xb0, acc1, 0, 0, 0);
+          odd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xa1, odd0, 0, 0, 0);
+          odd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xb1, odd1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          xa0 = na0; xb0 = nb0; xa1 = na1; xb1 = nb1;
+        }
+#else
 #pragma unroll
         for (int s = 0; s < KSTEPS; s += 2) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xs[b0 + toff[s]], acc0, 0, 0, 0);
@@ -126,6 +150,7 @@ conv_c1_mfma_k(C1Args a) {
           odd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xs[b0 + toff[s + 1]], odd0, 0, 0, 0);
           odd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s + 1], xs[b1 + toff[s + 1]], odd1, 0, 0, 0);
         }
+#endif
         acc0 += odd0;
         acc1 += odd1;
         // D[row = co = 4*lk + j][col = voxel li]
