@@ -59,6 +59,7 @@ struct msk_ctx {
   std::set<const void*> xform_ok;  // xform buffers msk_conv3d_fwd_ex* really filled: a buffer the pipeline declined (alignment, size limits) is ignored by the weight gradient instead of failing the forward pass (advisor, round 2)
   bool conv_fp16 = false;  // option "conv_fp16": 3x3x3 convolutions with fp16 matrix operands (UNet3D precision='fp16')
   int wbf_tin_map = 1;  // lane mapping of wbf_tin_k (1: one channel group per wavefront, 1 KiB store runs; measured 3-10 % faster)
+  int wbf_mr4 = 1;       // the MR = 4 tile variants of wbf_gemm_k first for the levels the one-kernel form does not take (pick_variant)
   int wbf_variant = -1;  // tuning: force a tile variant of wbf_gemm_k (-1 = least padding)
   int halo_tile = -1;  // tuning knob: force the MFMA halo tile (index into the tile table), -1 = pick by utilisation
   int wgrad_chunk = -1;  // same for the LDS wgrad chunk table

@@ -1430,6 +1430,23 @@ const Var* pick_variant(const msk_ctx* ctx, const WbfGeom& geo, int CN, int K) {
   else if (CN >= 128 && CN % 128 == 0) v0 = 4;
   else return nullptr;
   if (K == 5 && CN == 32 && ctx->wbf_variant == 6 && wbf_tile_ok(geo, 16, 16)) return &kVars[6];
+  // Round 5 (tools/sweep_deep_gemm.sh): the levels whose packed weights do not stay in an XCD's L2 next to the tiles are bound by
+  // the weight fragments they pull from L2, and a wavefront with FOUR row fragments uses every fragment twice as often --
+  // 128ch@32^3 0.276 -> 0.258 ms, 256ch@16^3 0.148 -> 0.133, 64ch@32^3 0.074 -> 0.071, 128ch@16^3 0.042 -> 0.040 (round 2 had
+  // measured the MR = 2 tiles ahead everywhere, with six products per operand pair and no split-K cap).  The MR = 4 variant goes
+  // first where the one-kernel form (MR = 2 tiles only) would not take the layer anyway: >= 128 output channels (packed weights
+  // > 3.5 MB), 64 channels below two tiles per CU.  Option "wbf_mr4" 0 = MR 2 first (A/B).
+  if (K == 5 && ctx->wbf_variant < 0 && ctx->wbf_mr4 && CN >= 64) {
+    const Var& m4 = kVars[v0 + 1];
+    bool first = wbf_tile_ok(geo, m4.TD, m4.TH);
+    if (first && CN == 64) {
+      const Var& m2 = kVars[v0];
+      const long tiles2 = (long)geo.T * ((geo.LD + m2.TD - 1) / m2.TD) * ((geo.LH + m2.TH - 1) / m2.TH);   // per sample
+      // (two samples: the one-kernel form wants 2 tiles per CU in all; "wbf_fuse" 2 = tests force that form at any size)
+      first = ctx->wbf_fuse == 0 || (ctx->wbf_fuse != 2 && tiles2 < (long)ctx->num_cu);
+    }
+    if (first) return &m4;
+  }
   for (int c = v0; c < v0 + (K == 5 ? 2 : 1); ++c) {
     const Var& v = kVars[c];
     if (K == 5 && ctx->wbf_variant >= 0 && ctx->wbf_variant != v.id) continue;  // tuning knob "wbf_variant"

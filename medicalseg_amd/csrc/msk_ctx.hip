@@ -438,6 +438,10 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_tin_map = value;
     return 0;
   }
+  if (strcmp(key, "wbf_mr4") == 0) {
+    ctx->wbf_mr4 = value;
+    return 0;
+  }
   if (strcmp(key, "wbf_variant") == 0) {
     ctx->wbf_variant = value;
     return 0;
