@@ -52,6 +52,12 @@ if b:
     rows.append(("whole step: executed matrix work at the hardware peaks / step time (`roofline.step_executed_frac`)", "%.3f" % r["step_executed_frac"]))
     h = r.get("hbm")
     if h:
+        # the counters of the committed passes (the bench line quotes the file that was in profiles/ when it ran)
+        tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "%s_hbm_traffic.json" % TAG)
+        if os.path.exists(tj):
+            ws = json.load(open(tj)).get("_whole_step")
+            if ws:
+                h = dict(h, counter_GB_per_step=ws["hbm_bytes_per_step"] / 1e9, ratio=ws["hbm_bytes_per_step"] / 1e9 / h["algorithmic_GB_per_step"])
         rows.append(("HBM traffic of one step (PMC counters FETCH_SIZE / WRITE_SIZE over all kernels) vs algorithmic bytes",
                      "%.1f GB vs %.2f GB = **%.2fx** (%s)" % (h["counter_GB_per_step"], h["algorithmic_GB_per_step"], h["ratio"], h["source"].split(":")[0])))
     c = b.get("cpu_baseline")
