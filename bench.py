@@ -104,6 +104,50 @@ def _kernel_line(prof, name, flops_step, exec_step, steps, note=None):
     return out
 
 
+GEMM_TEMPLATES = ("wbf_gemm_k", "wbf_gemm_fused_k")   # <MR, WM, WN, TD, TH, K, NP, ...>: NP (index 6) = 16-bit pieces per operand
+GEMM_NP_INDEX = 6
+
+
+def template_args(kernel_name):
+    """('wbf_gemm_k', ['4', '1', '4', '8', '16', '5', '2', '1']) from 'wbf_gemm_k<4, 1, 4, 8, 16, 5, 2, 1>' (rocprofv3 kernel names)"""
+    base, _, rest = kernel_name.partition("<")
+    return base.strip(), [a.strip() for a in rest.rsplit(">", 1)[0].split(",")] if rest else []
+
+
+def dominant_kernel_traffic(tj, split):
+    """Mean HBM bytes per launch of the dominant kernel (ALL tile variants of both matrix-stage templates whose operand split --
+    template argument GEMM_NP_INDEX, selected by POSITION, not by suffix: trailing parameters come and go -- is `split`) from a
+    tools/summarize_rocprof.py traffic file; (bytes_per_launch, launches) or (None, 0)."""
+    ent = []
+    for k, v in tj.items():
+        if not isinstance(v, dict) or "hbm_bytes_per_launch" not in v:
+            continue
+        base, targs = template_args(k)
+        if base in GEMM_TEMPLATES and len(targs) > GEMM_NP_INDEX and targs[GEMM_NP_INDEX] == str(split):
+            ent.append(v)
+    nl = sum(v["launches"] for v in ent)
+    return (int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent) / nl) if nl else None), nl
+
+
+def physical_cores():
+    """physical cores of the host (unique (package, core) pairs of /proc/cpuinfo); None when it cannot be read"""
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("physical id"):
+                    phys = l.split(":")[1].strip()
+                elif l.startswith("core id"):
+                    core = l.split(":")[1].strip()
+                elif not l.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        return len(cores) or None
+    except OSError:
+        return None
+
+
 def step_flops_per_sample():
     return 4431.2e9  # SURVEY.md section 8 d3: fwd 1479.9 + bwd 2951.3 GFLOP per 128^3 sample, ncls 3
 
@@ -146,11 +190,92 @@ def cpu_baseline(size=128, ncls=3):
     except OSError:
         pass
     # nproc, CPU model and the threads really used, so that box-to-box variance of this line can be read off it
-    return {"value": float(size ** 3 / dt), "unit": "voxels/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+    # cores = physical cores the threads can occupy (threads <= physical cores: one thread per core)
+    pc = physical_cores()
+    return {"value": float(size ** 3 / dt), "unit": "voxels/s", "cores": min(torch.get_num_threads(), pc or torch.get_num_threads()),
+            "threads": torch.get_num_threads(), "physical_cores": pc,
             "nproc": os.cpu_count(), "cpu_model": cpu_model, "gflops": round(step_flops_per_sample() * (size / 128.0) ** 3 / dt / 1e9, 1),
             "kind": "port",
             "sample": "torch-CPU/oneDNN restatement (oracle/vnet_torch.py), %d train step(s), batch 1, %d^3 fp32: "
                       "%.1f s per step" % (nstep, size, dt)}
+
+
+METRIC = "3D-voxels/sec fwd+bwd, VNet 128^3 fp32"
+
+
+def fallback_plans(args):
+    """What `bench.py --gpus N` tries, in order, when an attempt fails or hangs (launch.run_supervised): the arrangement as
+    requested; then every collective on the compute stream's ONE communicator (dp_mode 0: a total order by construction,
+    nothing to deadlock); then additionally rank-local BatchNorm statistics (no collective besides the gradient all-reduce --
+    a documented deviation from the reference's SyncBatchNorm, reported in config.sync_bn)."""
+    plans = [{"label": "as requested (--dp-mode %s%s)" % (args.dp_mode, ", --no-sync-bn" if args.no_sync_bn else ""), "extra": []}]
+    if args.dp_mode != "0":
+        plans.append({"label": "--dp-mode 0", "extra": ["--dp-mode", "0"]})
+    if not args.no_sync_bn:
+        plans.append({"label": "--dp-mode 0 --no-sync-bn", "extra": ["--dp-mode", "0", "--no-sync-bn"]})
+    return plans
+
+
+def failure_line(args, error, attempts=None):
+    """The ONE JSON line of a job that produced no number: same keys as the success line, value null, the reason in `error`."""
+    return {"metric": METRIC, "value": None, "unit": "voxels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "error": str(error)[-2000:],
+            "config": {"workload": "VNet %dx%dx%d fp32 batch=%d per GPU, synthetic CT volumes" % (args.size, args.size, args.size, args.batch),
+                       "global_batch": args.gpus * args.batch, "parallelism": "dp%d" % args.gpus},
+            "dp": {"attempts": attempts or []}}
+
+
+def supervised_main(args):
+    """N > 1: this process does not touch a GPU.  It runs the ranks it owns (all N when no launcher set WORLD_SIZE; its own
+    RANK under `python -m torch.distributed.run`) as worker processes under a hang watchdog, walks `fallback_plans` when an
+    attempt fails or hangs, and the owner of rank 0 prints ONE JSON line on EVERY outcome: the worker's line + dp.attempts, or
+    `failure_line` with value null and the error text."""
+    from medicalseg_amd import launch
+    world, ranks, env = launch.launch_context(args.gpus)
+    is_printer = 0 in ranks
+    if world != args.gpus:
+        msg = ("bench.py --gpus %d under a launcher that set WORLD_SIZE=%d: the two must agree (or unset WORLD_SIZE and let "
+               "bench.py spawn its ranks itself)" % (args.gpus, world))
+        if is_printer:
+            print(json.dumps(failure_line(args, msg)), flush=True)
+        sys.stderr.write(msg + "\n")
+        return 2
+    os.environ.update({k: env[k] for k in ("MASTER_ADDR", "MASTER_PORT") if k in env})   # the supervisors' own rendezvous
+    total = float(os.environ.get("MSEGK_BENCH_TOTAL_S", "1500"))
+    launcher = "self (bench.py spawned %d ranks)" % world if len(ranks) == world else \
+        "external (WORLD_SIZE=%d from the environment; one supervisor + one worker per rank)" % world
+    try:
+        ok, text, attempts = launch.run_supervised([sys.executable] + sys.argv, fallback_plans(args), world, ranks, env=env,
+                                                   total_timeout=total)
+    except BaseException as e:   # incl. the supervisors' own rendezvous timing out: still one line
+        if is_printer:
+            print(json.dumps(failure_line(args, "launcher: %r" % (e,))), flush=True)
+        raise
+    if not is_printer:
+        return 0 if ok else 1
+    rec = None
+    if ok and text:
+        for l in text.splitlines():
+            if l.startswith("{"):
+                try:
+                    rec = json.loads(l)
+                except ValueError:
+                    pass
+    if rec is None:
+        err = "no attempt produced a result" if not ok else "rank 0 finished without printing its JSON line"
+        last = attempts[-1] if attempts else {}
+        if last.get("error"):
+            err += "; last attempt (%s): %s at rank %s, phase %r: %s" % (last.get("plan"), last.get("outcome"), last.get("rank"),
+                                                                        last.get("phase"), last.get("error"))
+        rec = failure_line(args, err, attempts)
+        rec["dp"]["launcher"] = launcher
+        print(json.dumps(rec), flush=True)
+        return 1
+    rec.setdefault("dp", {})["attempts"] = attempts
+    rec["dp"]["launcher"] = launcher
+    print(json.dumps(rec), flush=True)
+    return 0
 
 
 def main():
@@ -189,7 +314,13 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msk_set_option knob for experiments, e.g. --opt wgrad_async=0 (not for the headline run)")
     args = ap.parse_args()
+    if args.gpus > 1 and os.environ.get("MSEGK_SUPERVISED") != "1":
+        raise SystemExit(supervised_main(args))
+    worker_main(args)
 
+
+def worker_main(args):
+    from medicalseg_amd import launch
     from medicalseg_amd import optimizer as optim
     from medicalseg_amd import parallel
     from medicalseg_amd.datasets import SyntheticCT
@@ -200,14 +331,13 @@ def main():
     env = parallel.ParallelEnv()
     world, rank = env.nranks, env.rank
     if world != args.gpus:
-        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            # plain `python bench.py --gpus N`: no external launcher -- become the launcher (one rank per GPU, same command line)
-            raise SystemExit(parallel.spawn_ranks(args.gpus))
         raise SystemExit("bench.py --gpus %d under a launcher that set WORLD_SIZE=%d: the two must agree (or unset WORLD_SIZE and "
                          "let bench.py spawn its ranks itself)" % (args.gpus, world))
     dev = get_device()
+    launch.heartbeat("import")
     if world > 1:
         parallel.init_parallel_env(dp_mode=args.dp_mode)
+        launch.heartbeat("dp_init")
 
     S, B, ncls = args.size, args.batch, args.num_classes
     ds = SyntheticCT(num_samples=B, shape=(S, S, S), num_classes=ncls, seed=1234 + 1000 * rank)
@@ -250,10 +380,15 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         dev.set_option(k, int(v))
-    for _ in range(args.warmup):
+    launch.heartbeat("model")
+    for i in range(args.warmup):
         last = step()
+        if i == 0 and world > 1:
+            dev.sync()     # untimed: the FIRST step with collectives has completed on this rank -- the watchdog's main checkpoint
+        launch.heartbeat("warmup %d" % (i + 1))
     parallel.barrier()
     dev.sync()
+    launch.heartbeat("warm")
     dev.prof_reset()
     if args.shapes:
         dev.set_option("prof_shapes", 1)
@@ -281,6 +416,7 @@ def main():
     dev.sync()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
+    launch.heartbeat("timed")
     dev.prof_enable(False)
     step_ms = []
     if use_marks:
@@ -306,6 +442,7 @@ def main():
         dev.prof_enable(False)
         prof_serial = dev.prof_report()
         dev.set_option("wgrad_async", 1)
+        launch.heartbeat("serialized")
 
     # untimed extra pass with EXACT fp32 operands (conv_split 3: every fp32 operand as three bf16 pieces, six MFMAs per product,
     # no dropped significand bits) -- the reference's arithmetic is plain fp32 (vnet.py:36, no AMP), the headline uses 22-bit
@@ -332,6 +469,26 @@ def main():
                   "note": "untimed extra pass (stream marks): the same step with exact fp32 operands (option conv_split 3: bf16 x 3 "
                           "pieces, 6 MFMAs per fp32 product)"}
 
+    # untimed extra pass in the PLAIN optimizer order (loss.backward(); optimizer.step() as one pass over the arena -- what every rank
+    # of an N > 1 job runs, because there the gradients are final only after the all-reduce): the like-for-like base of a scaling curve
+    plain = None
+    if world == 1 and eager and not args.skip_strict_fp32:
+        import ctypes as _C
+        opt.enable_eager(model, on=False)
+        for _ in range(2):
+            step()
+        dev.sync()
+        nst = 10
+        dev.call("msk_mark", 0)
+        for _ in range(nst):
+            step()
+        dev.call("msk_mark", 1)
+        ms = _C.c_float()
+        dev.call("msk_mark_elapsed", 0, 1, _C.byref(ms))
+        opt.enable_eager(model)
+        plain = {"ms_per_step": round(float(ms.value) / nst, 3), "value": round(B * S ** 3 / (float(ms.value) / nst * 1e-3), 1), "steps": nst}
+        launch.heartbeat("plain_order")
+
     # max over ranks; per-rank time inside the RCCL collectives (HIP events on the stream each one is enqueued on: it
     # includes waiting for the slowest peer), so that the first multi-GPU run is diagnosable
     dp_info = None
@@ -353,9 +510,10 @@ def main():
         dev.call("msk_mark_elapsed", 0, 1, C.byref(msd))
         parallel.set_dry_run(False)
         compute_only_ms = float(msd.value) / ndry
+        launch.heartbeat("compute_only")
         parallel.barrier()
         tags = ("rccl_allreduce", "rccl_allreduce_stats", "rccl_allgather", "rccl_allreduce_bucket")
-        mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags] + [compute_only_ms]
+        mine = [elapsed] + [sum(v[1] for k, v in prof.items() if k == t) / args.steps for t in tags] + [compute_only_ms, float(dev.index)]
         sp, rp = dev.small(len(mine)), dev.small(world * len(mine))
         dev.h2d(sp, np.array(mine, np.float32))
         dev.call("msk_dp_allgather", C.c_void_p(sp), C.c_void_p(rp), C.c_size_t(len(mine)))
@@ -364,7 +522,12 @@ def main():
         arena_bytes = 4.0 * model.arena.count
         ar_ms = [float(a + b) for a, b in zip(allv[:, 1], allv[:, 4])]    # one piece on the compute stream or buckets on the communication stream
         co_ms = float(allv[:, 5].max())
+        bind = parallel.binding_info(env, dev)
         dp_info = {"dp_mode": dev.get_option("dp_mode"), "dp_mode_requested": args.dp_mode,
+                   # where it ran: rank -> HIP device of every rank, rank 0's device, the IPC mode and the RCCL version in effect
+                   "binding": {"device_index_per_rank": [int(v) for v in allv[:, 6]], "rank0_device": bind["device"],
+                               "rank0_pci": bind["pci"], "visible_devices": bind["visible_devices"]},
+                   "HSA_ENABLE_IPC_MODE_LEGACY": bind["HSA_ENABLE_IPC_MODE_LEGACY"], "rccl_version": bind["rccl_version"],
                    "overlap_buckets": bool(getattr(net, "overlap", False)),
                    # the step (max over ranks) minus the same step with every collective removed (max over ranks): what the
                    # collectives cost on the critical path in THIS arrangement; budget for >= 6.5x at 8 GPUs: 4.45 ms at 19.3 ms/step
@@ -412,17 +575,12 @@ def main():
     kms = line["avg_launch_ms"] * line["launches"] * args.steps / max(sampled_steps, 1)   # scaled from the sampled steps to all of them
     total_kernel_ms = sum(v[1] for v in prof.values())
     traffic, traffic_src, hbm = None, None, None
-    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
-                                  os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) if os.path.exists(pth)), None)
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", "r%02d_hbm_traffic.json" % r) for r in range(6, 1, -1)) if os.path.exists(pth)), None)
     if tpath and S == 128 and B == 2:   # PMC passes of this exact workload (tools/profile_gpu.sh, tools/summarize_rocprof.py)
         try:
             tj = json.load(open(tpath))
             rel = os.path.relpath(tpath, ROOT)
-            # all tile variants of the matrix-stage templates with this operand split
-            ent = [v for k, v in tj.items() if (k.startswith("wbf_gemm_k<") or k.startswith("wbf_gemm_fused_k<")) and isinstance(v, dict)
-                   and (", %d>" % split in k or ", %d, true>" % split in k or ", %d, false>" % split in k)]
-            nl = sum(v["launches"] for v in ent)
-            traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent) / nl) if nl else None
+            traffic, _ = dominant_kernel_traffic(tj, split)
             traffic_src = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, captured %s, NOT measured in " \
                           "this run" % (rel, tj.get("_captured", "earlier"))
             ws = tj.get("_whole_step")
@@ -448,7 +606,10 @@ def main():
     # time the executed work needs at the peaks: LUConv layers on the bf16 pipe, everything else at the fp32 peak
     t_floor = lu_exec / (PEAK_BF16_MFMA_TFLOPS * 1e12) + max(total_flops - lu_flops, 0.0) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
     roofline = {"bound": "mfma", "kernel": DOM, "achieved": line["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": line["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": line["frac"],
+                # the same launches priced on the ALGORITHMIC (direct-convolution) FLOPs against the same 16-bit peak: the other convention
+                "frac_algorithmic": round(line["algorithmic_tflops"] / PEAK_BF16_MFMA_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches": line["launches"], "avg_launch_ms": line["avg_launch_ms"],
                 "event_steps": sampled_steps,
                 "events": "HIP events riding on every launch of this kernel (hipExtLaunchKernelGGL start / stop events, on the launch "
@@ -492,6 +653,10 @@ def main():
            # the steps that carry the roofline kernel's events against the ones that do not (the events' packets idle the packet processor)
            "ms_per_step_with_events": round(float(np.mean(step_ms[0::every])), 3) if step_ms and every > 1 else None,
            "ms_per_step_without_events": round(float(np.mean([m for i, m in enumerate(step_ms) if i % every])), 3) if step_ms and every > 1 else None,
+           # N = 1 runs the eager optimizer (config.eager_optimizer); N > 1 cannot: this is the same step in the plain order,
+           # untimed extra pass of 10 steps between stream marks -- divide N > 1 values by THIS for a like-for-like scaling base
+           "value_plain_order": plain["value"] if plain else None,
+           "ms_per_step_plain_order": plain["ms_per_step"] if plain else None,
            "final_loss": round(loss_val, 6),
            # host time to enqueue one step (python + ctypes + HIP launches, no sync inside a step): the step is GPU-bound
            # while this stays below ms_per_step

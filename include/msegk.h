@@ -56,6 +56,8 @@ int msk_sync(msk_ctx* ctx);
  * msk_sync and msk_d2h join implicitly. */
 int msk_join_side(msk_ctx* ctx);
 int msk_device_name(msk_ctx* ctx, char* buf, int buflen);
+/* PCI bus id of the context's device ("0000:05:00.0"): the rank -> GPU binding a multi-rank job logs (parallel.py) */
+int msk_device_pci_bus_id(msk_ctx* ctx, char* buf, int buflen);
 int msk_malloc(msk_ctx* ctx, size_t bytes, void** out);
 int msk_free(msk_ctx* ctx, void* p);
 int msk_memset(msk_ctx* ctx, void* p, int value, size_t bytes);
@@ -535,6 +537,7 @@ int msk_interp_trilinear_bwd(msk_ctx* ctx, msk_tensor ddst, msk_tensor dsrc, int
 /* ---- data parallel (RCCL over xGMI; core/train.py:81-85 fleet DataParallel) ---- */
 #define MSK_UNIQUE_ID_BYTES 128
 int msk_dp_unique_id(char* id128);                       /* rank 0 */
+int msk_dp_rccl_version(int* version);                   /* ncclGetVersion: e.g. 22703 for 2.27.3; no context, no GPU needed */
 int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world);
 int msk_dp_allreduce_sum(msk_ctx* ctx, float* buf, size_t count);   /* joins the weight-gradient side stream first */
 /* SyncBatchNorm backward sums (2*C floats, produced on the main stream): same reduction WITHOUT the join,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "msk_sync": (_i, [_vp]),
     "msk_join_side": (_i, [_vp]),
     "msk_device_name": (_i, [_vp, C.c_char_p, _i]),
+    "msk_device_pci_bus_id": (_i, [_vp, C.c_char_p, _i]),
     "msk_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "msk_free": (_i, [_vp, _vp]),
     "msk_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "msk_interp_scratch_bytes": (_i, [_vp, _T, _T, C.POINTER(_sz)]),
     "msk_interp_trilinear_bwd": (_i, [_vp, _T, _T, _i, _vp, _sz]),
     "msk_dp_unique_id": (_i, [C.c_char_p]),
+    "msk_dp_rccl_version": (_i, [C.POINTER(_i)]),
     "msk_dp_init": (_i, [_vp, C.c_char_p, _i, _i]),
     "msk_dp_allreduce_sum": (_i, [_vp, _vp, _sz]),
     "msk_dp_allreduce_stats": (_i, [_vp, _vp, _sz]),

@@ -108,6 +108,9 @@ struct msk_ctx {
   bool late_valid = false;
   const float* late_ptr = nullptr;   // gradient tensor still being written behind ev_late
   size_t late_count = 0;
+  // the late kernel evaluates PReLU backward in its prologue: its slopes live in the PARAMETER arena, which the optimizer
+  // updates behind ev_late while the kernel still runs -- it reads this snapshot (taken before ev_late) instead (advisor, round 5)
+  float* late_alpha = nullptr;
   // the late tensor's slice of an eager update that ran on the compute stream (msk_sgd_momentum_eager): updated by
   // msk_sgd_momentum_finish after the join
   struct { float* param = nullptr; const float* grad = nullptr; float* velocity = nullptr; size_t count = 0;

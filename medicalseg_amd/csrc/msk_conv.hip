@@ -1624,7 +1624,16 @@ static int bwd_bnact_c1(msk_ctx* ctx, const WGrad& gw, msk_tensor y, const float
     // for that event only, updates every other parameter and re-packs the weights while this kernel (matrix-bound) still runs,
     // then joins and updates this tensor (msk_loss_optim.hip)
     msk_side_scope side(ctx, true);
-    if (side.active) hipEventRecord(ctx->ev_late, ctx->stream);
+    if (side.active) {
+      // everything the kernel reads from the parameter arena (the PReLU slopes) as a snapshot taken BEFORE ev_late: the
+      // optimizer updates the arena behind that event while the kernel is still running (read / write race otherwise)
+      if (!ctx->late_alpha) MSK_CHECK_HIP(ctx, hipMalloc((void**)&ctx->late_alpha, 1024 * sizeof(float)));
+      if (alpha && gw.CB <= 1024) {
+        MSK_CHECK_HIP(ctx, hipMemcpyAsync(ctx->late_alpha, alpha, (size_t)gw.CB * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        bn.alpha = ctx->late_alpha;
+      }
+      hipEventRecord(ctx->ev_late, ctx->stream);
+    }
     const int r = msk_wgrad_c1(ctx, gc);
     if (r == 1 && side.active) {
       ctx->late_valid = true;

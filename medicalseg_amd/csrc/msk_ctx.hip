@@ -206,6 +206,7 @@ int msk_ctx_destroy(msk_ctx* ctx) {
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->ev_late) hipEventDestroy(ctx->ev_late);
+  if (ctx->late_alpha) hipFree(ctx->late_alpha);
   hipEventDestroy(ctx->t0);
   hipEventDestroy(ctx->t1);
   hipStreamDestroy(ctx->stream);
@@ -228,6 +229,12 @@ int msk_device_name(msk_ctx* ctx, char* buf, int buflen) {
   hipDeviceProp_t prop;
   MSK_CHECK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
   snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+int msk_device_pci_bus_id(msk_ctx* ctx, char* buf, int buflen) {
+  MSK_REQUIRE(ctx, buf != nullptr && buflen >= 16, "buffer of at least 16 bytes");
+  MSK_CHECK_HIP(ctx, hipDeviceGetPCIBusId(buf, buflen, ctx->device));
   return 0;
 }
 

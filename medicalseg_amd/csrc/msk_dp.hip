@@ -238,6 +238,12 @@ int msk_dp_unique_id(char* id128) {
   return 0;
 }
 
+int msk_dp_rccl_version(int* version) {
+  if (!version) return -1;
+  *version = 0;
+  return ncclGetVersion(version) == ncclSuccess ? 0 : -1;
+}
+
 int msk_dp_init(msk_ctx* ctx, const char* id128, int rank, int world) {
   MSK_REQUIRE(ctx, ctx->comm == nullptr, "communicator already initialised");
   MSK_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "bad rank/world");

@@ -85,6 +85,11 @@ class Device:
         self.call("msk_device_name", buf, 256)
         return buf.value.decode()
 
+    def pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(64)
+        self.call("msk_device_pci_bus_id", buf, 64)
+        return buf.value.decode()
+
     def set_option(self, key: str, value: int):
         self.call("msk_set_option", key.encode(), int(value))
 
@@ -128,10 +133,34 @@ class Device:
         return ptr
 
 
+_MASK_VARS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
+
+
+def local_device_index(local_rank=None, count=None, env=None):
+    """LOCAL_RANK -> HIP device index of this process (one process per GPU), checked against the devices that are visible:
+      * LOCAL_RANK < count: device LOCAL_RANK;
+      * exactly one device visible AND a *_VISIBLE_DEVICES mask is set: the launcher gave every rank its own GPU -> device 0;
+      * otherwise MskError naming both numbers (before any communicator is created: a rank that silently shared a GPU with
+        another would fail much later inside RCCL, or worse, run at half speed).
+    Replaces paddle.set_device / ParallelEnv().device_id (reference core/train.py:69-70)."""
+    env = os.environ if env is None else env
+    lr = int(env.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    if count is None:
+        n = C.c_int(0)
+        _lib.load().msk_device_count(C.byref(n))
+        count = n.value
+    if count <= 0 or lr < count:
+        return lr            # count 0: Device() raises "no HIP device" (there is no CPU path)
+    if count == 1 and any(env.get(v) for v in _MASK_VARS):
+        return 0
+    raise MskError("LOCAL_RANK=%d but only %d HIP device(s) are visible (masks: %s): one process per GPU needs "
+                   "LOCAL_RANK < device count" % (lr, count, {v: env[v] for v in _MASK_VARS if env.get(v)} or "none"))
+
+
 def get_device() -> Device:
-    """The process-wide device (one process per GPU; LOCAL_RANK selects it)."""
+    """The process-wide device (one process per GPU; LOCAL_RANK selects it, `local_device_index` checks it)."""
     if Device._current is None:
-        Device._current = Device(int(os.environ.get("LOCAL_RANK", "0")))
+        Device._current = Device(local_device_index())
     return Device._current
 
 

@@ -142,6 +142,10 @@ class Momentum:
             return False
         if not any(getattr(h, "__self__", None) is self for h in model._grad_ready_hooks):
             model._grad_ready_hooks.append(self._block_ready)
+        if not self._eager:
+            from .utils import logger
+            logger.info("optimizer: eager mode on -- parameters of a block change DURING backward (right behind its weight "
+                        "gradients); results are bitwise those of loss.backward(); optimizer.step()")
         self._eager = True
         self._slices = {}
         return True
@@ -164,6 +168,13 @@ class Momentum:
         if not self._eager or not model.training:
             return
         sl = self._block_slice(block)
+        if sl is not None and sl in self._eager_done:
+            # the SAME block reported twice with no step() in between: a second backward() (gradient accumulation, a custom
+            # loop) -- its parameters were already updated from the first one's gradients; silently skipping it would drop
+            # the second gradient (advisor, round 5)
+            raise RuntimeError("optimizer eager mode: backward() ran twice without optimizer.step() in between; eager updates "
+                               "apply a block's gradient during backward -- call enable_eager(model, on=False) for gradient "
+                               "accumulation or custom loops")
         if sl is None or any(lo < sl[1] and sl[0] < hi for lo, hi in self._eager_done):
             return
         if sl[1] - sl[0] < self.eager_min_floats:

@@ -42,8 +42,8 @@ class ParallelEnv:
         return int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
 
 
-def _job_token(world):
-    s = "{}:{}:{}".format(os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"), world)
+def _job_token(world, channel=0):
+    s = "{}:{}:{}:{}".format(os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"), world, channel)
     return hashlib.sha256(s.encode()).digest()[:16]
 
 
@@ -57,14 +57,18 @@ def _recv_exact(conn, n):
     return buf
 
 
-def exchange_bytes(payload: bytes | None, rank: int, world: int, timeout=300.0) -> bytes:
+def exchange_bytes(payload: bytes | None, rank: int, world: int, timeout=300.0, channel=None) -> bytes:
     """Rank 0 broadcasts ``payload`` to all other ranks (used for the RCCL unique id).
-    Protocol: client sends MAGIC+token+rank; server answers MAGIC+len+payload."""
+    Protocol: client sends MAGIC+token+rank; server answers MAGIC+len+payload.
+    channel (default: $MSEGK_RDZV_CHANNEL or 0): independent rendezvous of the same job use disjoint port ranges and tokens
+    (MASTER_PORT + 1 + 16 * channel ...) -- launch.py gives every relaunched attempt and the supervisors their own."""
     if world == 1:
         return payload
+    if channel is None:
+        channel = int(os.environ.get("MSEGK_RDZV_CHANNEL", "0"))
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    base = int(os.environ.get("MASTER_PORT", "29500")) + 1
-    token = _job_token(world)
+    base = int(os.environ.get("MASTER_PORT", "29500")) + 1 + _PORT_SPAN * int(channel)
+    token = _job_token(world, channel)
     if rank == 0:
         srv = None
         for port in range(base, base + _PORT_SPAN):
@@ -120,45 +124,29 @@ def spawn_ranks(n, argv=None, env=None, timeout=None):
     """Self-launch: run `argv` (default: this process's own command line) as n ranks of ONE node, one process per GPU --
     what `python -m torch.distributed.run --nproc-per-node n` would do for this package's launch contract, without torch:
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT=<a free port> in each child's environment (the
-    RCCL id then travels over `exchange_bytes` on MASTER_PORT+1..).  The children inherit stdout / stderr, so rank 0's
-    single JSON line is this process's.  If a rank fails the others are terminated (a rank that died before the
-    rendezvous would otherwise leave its peers waiting).  Returns the largest exit code.
-    Replaces `python -m paddle.distributed.launch train.py ...` (reference README / run-vnet.sh) for bench.py and
-    train.py when no external launcher set WORLD_SIZE."""
-    import subprocess
+    RCCL id then travels over `exchange_bytes`).  The ranks run under launch.run_supervised: a rank that fails OR hangs
+    (no heartbeat within the phase limits of launch.py; workers that never call launch.heartbeat are only bounded by
+    `timeout`) takes the others down; SIGINT / SIGTERM and the death of this process kill the ranks.  Rank 0's stdout is
+    this process's stdout.  Returns 0, or 1 / 124 (failed / timed out).
+    Replaces `python -m paddle.distributed.launch train.py ...` (reference README / run-vnet.sh) for train.py when no
+    external launcher set WORLD_SIZE (bench.py drives launch.run_supervised itself, with fall-back plans)."""
     import sys
+    from . import launch
     argv = list(argv) if argv is not None else [sys.executable] + sys.argv
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     base = dict(os.environ if env is None else env)
-    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSEGK_SELF_LAUNCHED="1")
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
-    procs = []
-    for r in range(n):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(argv, env=e))
-    deadline = None if timeout is None else time.time() + timeout
-    rc = 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0:
-                rc = max(rc, code if code > 0 else 1)
-                for o in live:              # a failed rank takes the job down: its peers would wait in a collective
-                    procs[o].terminate()
-        if deadline is not None and time.time() > deadline:
-            for o in live:
-                procs[o].kill()
-            return 124
-        if live:
-            time.sleep(0.05)
-    return rc
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        base.pop(k, None)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()), MSEGK_SELF_LAUNCHED="1")
+    # a generic worker sends no heartbeats: only `timeout` (or MSEGK_WATCHDOG_S) bounds it
+    wd = None if os.environ.get("MSEGK_WATCHDOG_S") else (timeout if timeout is not None else 10 ** 9)
+    ok, text, attempts = launch.run_supervised(argv, [{"label": "as launched", "extra": []}], n, range(n), env=base,
+                                               total_timeout=timeout, watchdog_s=wd)
+    if text:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    if ok:
+        return 0
+    return 124 if attempts and attempts[-1]["outcome"] == "hang" else 1
 
 
 _initialised = False
@@ -192,6 +180,27 @@ def resolve_dp_mode(dp_mode, world):
     return dp_mode
 
 
+def rccl_version():
+    """'2.27.3' from ncclGetVersion's 22703 (RCCL's own numbering), or None"""
+    v = C.c_int(0)
+    if _lib.load().msk_dp_rccl_version(C.byref(v)) != 0 or v.value <= 0:
+        return None
+    n = v.value
+    return "%d.%d.%d" % (n // 10000, (n // 100) % 100, n % 100) if n >= 10000 else "%d.%d.%d" % (n // 1000, (n // 100) % 10, n % 100)
+
+
+def binding_info(env=None, dev=None):
+    """What a multi-rank run logs about where it runs (bench.py dp.binding): the device this rank is bound to, how many are
+    visible, the IPC mode RCCL will use, the RCCL version."""
+    env = env or ParallelEnv()
+    dev = dev or get_device()
+    n = C.c_int(0)
+    _lib.load().msk_device_count(C.byref(n))
+    return {"rank": env.rank, "local_rank": env.local_rank, "device_index": dev.index, "device": dev.name(),
+            "pci": dev.pci_bus_id(), "visible_devices": n.value,
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "rccl_version": rccl_version()}
+
+
 def init_parallel_env(dp_mode=None):
     """Create the RCCL communicator for this process's device (idempotent).  dp_mode (msk_dp.hip; train.py / bench.py
     --dp-mode): 0 = every collective on the compute stream (default), 2 = gradient buckets on a second communicator and
@@ -212,6 +221,13 @@ def init_parallel_env(dp_mode=None):
     if dp_mode is not None:
         dev.set_option("dp_mode", int(dp_mode))
     lib = _lib.load()
+    # the rank -> GPU binding, checked (device.local_device_index) and logged BEFORE the communicator exists
+    info = binding_info(env, dev)
+    import sys
+    sys.stderr.write("[msegk] rank %d/%d: LOCAL_RANK %d -> HIP device %d (%s, PCI %s), %d device(s) visible, "
+                     "HSA_ENABLE_IPC_MODE_LEGACY=%s, RCCL %s\n"
+                     % (env.rank, env.nranks, env.local_rank, dev.index, info["device"], info["pci"], info["visible_devices"],
+                        info["HSA_ENABLE_IPC_MODE_LEGACY"], info["rccl_version"]))
     uid = None
     if env.rank == 0:
         buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)

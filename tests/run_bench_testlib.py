@@ -10,5 +10,6 @@ from medicalseg_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmsegk_test.so")
 _lib._lib = None
+os.environ["MSEGK_LIB"] = _lib.LIB_PATH    # bench.py --gpus N re-executes itself as the supervised workers: they inherit the choice
 sys.argv[0] = os.path.join(ROOT, "bench.py")
 runpy.run_path(sys.argv[0], run_name="__main__")

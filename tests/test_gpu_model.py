@@ -235,6 +235,46 @@ def test_eager_optimizer_is_bitwise_the_plain_order(shape):
     assert np.abs(vela).max() > 0
 
 
+def test_late_weight_gradient_does_not_see_the_updated_prelu_slopes():
+    """Advisor, round 5: in_tr.conv1's weight gradient (the LAST kernel of the side stream) evaluates PReLU backward from the
+    slopes of in_tr.relu1 -- a tensor of the parameter arena that the optimizer updates behind ev_late while that kernel is
+    still running.  With a learning rate that moves the slopes by O(1) per step, a kernel that read them after the update
+    would produce a visibly different conv1 gradient; it reads a snapshot taken before ev_late, so two steps in the eager /
+    late-split order leave in_tr bitwise equal to the plain order (full join before one update).  64^3: the late kernel runs
+    for longer than the update that follows ev_late, so the two do overlap."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    ncls, K, S, shape = 3, ((2, 2, 2),) * 4, ((2, 2, 2),) * 4, (64, 64, 64)
+    results = []
+    for eager in (False, True, True):
+        rng = np.random.default_rng(11)
+        nn.Dropout3D._site_counter = 0
+        model, _ = _build(ncls, K, S, seed=6)
+        opt = optim.Momentum(0.5, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        if eager:
+            assert opt.enable_eager(model) is True
+        losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+        model.train()
+        model.set_dropout_masks({})
+        x = rng.standard_normal((1, 1) + shape).astype(np.float32)
+        y = rng.integers(0, ncls, (1,) + shape).astype(np.int32)
+        a0 = model.state_dict()["in_tr.relu1._weight"].copy()
+        for step in range(2):
+            logits = model(x)
+            loss_list, per = loss_computation(logits, to_labels(y), losses)
+            sum(loss_list).backward()
+            opt.step()
+            model.clear_gradients()
+        sd = model.state_dict()
+        results.append({k: v for k, v in sd.items() if k.startswith("in_tr.")})
+        assert np.abs(sd["in_tr.relu1._weight"] - a0).max() > 1e-3      # the slopes DID move by something a gradient would show
+    for other in results[1:]:
+        for k in results[0]:
+            assert np.array_equal(results[0][k], other[k]), k
+
+
 def test_eval_mdice_matches_oracle():
     """core.val.evaluate's mDice on a synthetic validation set == oracle soft dice."""
     from medicalseg_amd.core import evaluate
