@@ -33,6 +33,9 @@
 #define WBF_TIN_SYNC 1   // transform kernels: one barrier per W tile keeps a block's four wavefronts on the same 128-byte lines (0 = A/B)
 #endif
 
+#ifndef WBF_PROBE
+#define WBF_PROBE 0   // knock-out probes of wbf_gemm_fused_k (tools/probe_fused.sh): 1 no tile refill, 2 no B loads, 4 no A reads, 8 no stores, 16 no MFMAs -- WRONG RESULTS, timing only
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -946,6 +949,8 @@ struct FusedArgs {
   int scaled;
   float* stat_partial;  // STATS: [tiles][CN][3] = (n, mean, M2) of the stored values
   int per_xcd;          // tiles per XCD
+  int stagger;          // BL: the second workgroup slot of every CU (first dispatch round) starts this many s_sleep(127) late
+  int cu_per_xcd;
   int LW;               // extent of the transform axis: the last W tile may reach beyond it (ragged: stores and statistics stop there)
   // round 5 (msk_conv3d_bwd_bnact_split): the accumulating data gradient of the layer behind a zero-copy concat READS the old
   // values from the interleaved buffer `dst` (whole lines) but STORES channels [0, csplit) to the dense tensor st_lo and
@@ -985,7 +990,18 @@ __device__ __forceinline__ void at_column(int xi, float& c0, float& c1, float& c
   c3 = sg * p * p * p;
 }
 
-template <int MR, int WM, int WN, int TD, int TH, int K, int NP, bool STATS>
+#ifndef WBF_FUSED_BPF
+#define WBF_FUSED_BPF 3   // B (weight) fragments of the one-kernel form are requested this many taps ahead (fp16 x 2 pieces: +24 VGPRs over 1)
+#endif
+// BL (round 6, 32 output channels = ONE column fragment, WN == 1): the B (weight) fragments of a stage -- K*K taps x NP pieces
+// of 1 KB -- come through LDS as well, fetched ONCE per workgroup by LDS-DMA next to the halo tile, instead of by every
+// wavefront from L1 inside the tap loop (4 x the bytes: all four wavefronts of a CN = 32 tile read the same fragments).
+// Knock-out probes (profiles/r06_fused_probes.txt): without the in-loop B loads the kernel ran 15 % faster, a deeper
+// prefetch ring (BPF 1 -> 3) recovered only 4 % -- the texture path (B loads + tile fill, ~70 % busy at the full matrix rate),
+// not the latency.  The tap loop is then LDS -> MFMA only (ds_read_b128 at 256 B/clk/CU: A + B reads = half of that at the
+// full matrix rate).  LDS: 25 KB tile + 50 KB weights per workgroup (exact sizes: the last fill round is wave-granular), two
+// workgroups per CU = 150 of 160 KB.
+template <int MR, int WM, int WN, int TD, int TH, int K, int NP, bool STATS, int BPF = (NP == 2 ? WBF_FUSED_BPF : 1), bool BL = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
 wbf_gemm_fused_k(FusedArgs f) {
   static_assert(WM * WN == 4 && WM * MR * 32 == TD * TH, "tile shape");
@@ -993,7 +1009,10 @@ wbf_gemm_fused_k(FusedArgs f) {
   constexpr int NT = WM * WN * 64;
   constexpr int NXI = nxi_of(K), T2 = K * K, PADK = (K - 1) / 2;
   constexpr int HDt = TD + K - 1, HPt = TH + K - 1, NSLOT = HDt * HPt, NPL = 2 * NP, NIT = NPL * NSLOT, ROUNDS = (NIT + NT - 1) / NT;
-  __shared__ uint4 lds[ROUNDS * NT];
+  constexpr int NBF = T2 * NP;                      // BL: B fragments (64 slots of 16 B) per stage
+  constexpr int BROUNDS = (NBF + WM * WN - 1) / (WM * WN);
+  static_assert(!BL || (WN == 1 && NIT % 64 == 0), "B through LDS: one column fragment, wave-granular tile");
+  __shared__ uint4 lds[BL ? NIT + NBF * 64 : ROUNDS * NT];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -1002,6 +1021,14 @@ wbf_gemm_fused_k(FusedArgs f) {
   // block -> tile: XCD x (= blockIdx % 8) walks the contiguous tile range [x * per_xcd, (x + 1) * per_xcd)
   int b = (blockIdx.x & 7) * f.per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= f.per_xcd || b >= a.nblk) return;
+  if constexpr (BL) {
+    // Two workgroups share a CU and alternate "fill the stage's tile + weights" (no matrix work) with "25 taps of MFMAs": started
+    // together they stay in lock-step -- both fill, then both compute -- and the fill is never hidden.  The workgroups of the
+    // second slot of the first dispatch round start half a stage late; equal stage times keep the offset from then on.
+    const int lx = (int)(blockIdx.x >> 3);
+    if (f.stagger > 0 && lx >= f.cu_per_xcd && lx < 2 * f.cu_per_xcd)
+      for (int q = 0; q < f.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+  }
   const int tile_id = b;
   const int thi = b % a.tiles_h;
   b /= a.tiles_h;
@@ -1056,16 +1083,100 @@ wbf_gemm_fused_k(FusedArgs f) {
 
 #pragma unroll 1
     for (int kc = 0; kc < a.KC; ++kc) {
+      if constexpr (BL) {
+        __syncthreads();  // every wavefront is done reading the previous stage's tile and weights
+        const unsigned vsoff = (unsigned)(kc * NPL * a.v_plane);
+        const bool fill = !(WBF_PROBE & 1) || (xi == 0 && kc == 0);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+          if (fill && r * NT + wave * 64 < NIT)   // (wave-uniform: the last round stops where the tile does, the weights follow it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * NT + wave * 64), 16,
+                                                     (int)voff[r], (int)vsoff, 0, 0);
+        const unsigned ukc = (unsigned)kc * uchunk;
+#pragma unroll
+        for (int r = 0; r < BROUNDS; ++r) {
+          const int q = r * (WM * WN) + wave;   // fragment q = tap * NP + piece: 1 KB, lane-linear in U and in LDS
+          if (fill && q < NBF)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ures, (__attribute__((address_space(3))) void*)(lds + NIT + q * 64), 16,
+                                                     (int)(lane * 16), (int)((unsigned)(q / NP) * utap + ukc + (unsigned)(q % NP) * ustep), 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const uint4* bl = lds + NIT + lane;
+        uint4 aq[2][MR][NP], bq[2][NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bq[0][p] = bl[p * 64];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+          const uint4* ap = lds + arow[mr];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) aq[0][mr][p] = ap[p * 2 * NSLOT];
+        }
+#pragma unroll
+        for (int tap = 0; tap < T2; ++tap) {
+          const int cur = tap & 1, nx = cur ^ 1;
+          if (tap + 1 < T2) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { if (WBF_PROBE & 2) bq[nx][p] = bq[cur][p]; else bq[nx][p] = bl[((tap + 1) * NP + p) * 64]; }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+              const uint4* ap = lds + arow[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
+#pragma unroll
+              for (int p = 0; p < NP; ++p) { if (WBF_PROBE & 4) aq[nx][mr][p] = aq[cur][mr][p]; else aq[nx][mr][p] = ap[p * 2 * NSLOT]; }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (NP == 3) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][NP / 2]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][0]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP / 2]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          } else if (NP == 2 && (WBF_PROBE & 16)) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+              for (int p = 0; p < NP; ++p)
+                asm volatile("" ::"v"(aq[cur][mr][p].x), "v"(aq[cur][mr][p].y), "v"(aq[cur][mr][p].z), "v"(aq[cur][mr][p].w),
+                             "v"(bq[cur][p].x), "v"(bq[cur][p].y), "v"(bq[cur][p].z), "v"(bq[cur][p].w));
+          } else if (NP == 2) {
+            const uint4 bdown = wbf_hi_down(bq[cur][0]);  // partner of the scaled low piece (msk_wbf.h)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          } else {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       __syncthreads();  // every wavefront is done reading the previous stage's tile
       const unsigned vsoff = (unsigned)(kc * NPL * a.v_plane);
+      if (!(WBF_PROBE & 1) || (xi == 0 && kc == 0)) {
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (__attribute__((address_space(3))) void*)(lds + r * NT + wave * 64), 16,
                                                  (int)voff[r], (int)vsoff, 0, 0);
+      }
       const unsigned ukc = (unsigned)kc * uchunk;
-      uint4 bq[2][NP];
+      constexpr int BR = BPF + 1;   // ring of B fragment sets: tap t lives in bq[t % BR]
+      uint4 bq[BR][NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bq[0][p] = buf_load16(ures, ulane, ukc + p * ustep);
+      for (int t0 = 0; t0 < BPF && t0 < T2; ++t0)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bq[t0][p] = buf_load16(ures, ulane, (unsigned)t0 * utap + ukc + p * ustep);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 
@@ -1079,45 +1190,56 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
       for (int tap = 0; tap < T2; ++tap) {
         const int cur = tap & 1, nx = cur ^ 1;
-        if (tap + 1 < T2) {
-          const unsigned ub = (unsigned)(tap + 1) * utap + ukc;
+        const int bcur = tap % BR;
+        if (tap + BPF < T2) {
+          const unsigned ub = (unsigned)(tap + BPF) * utap + ukc;
 #pragma unroll
-          for (int p = 0; p < NP; ++p) bq[nx][p] = buf_load16(ures, ulane, ub + p * ustep);
+          for (int p = 0; p < NP; ++p) { if (WBF_PROBE & 2) bq[(tap + BPF) % BR][p] = bq[bcur][p]; else bq[(tap + BPF) % BR][p] = buf_load16(ures, ulane, ub + p * ustep); }
+        }
+        if (tap + 1 < T2) {
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) {
             const uint4* ap = lds + arow[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) aq[nx][mr][p] = ap[p * 2 * NSLOT];
+            for (int p = 0; p < NP; ++p) { if (WBF_PROBE & 4) aq[nx][mr][p] = aq[cur][mr][p]; else aq[nx][mr][p] = ap[p * 2 * NSLOT]; }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (NP == 3) {
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP - 1], bq[bcur][0]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][NP - 1]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][NP / 2]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[bcur][NP / 2]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][NP / 2], bq[bcur][0]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][NP / 2]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][NP / 2]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA(acc[mr], aq[cur][mr][0], bq[bcur][0]);
+        } else if (NP == 2 && (WBF_PROBE & 16)) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+              asm volatile("" ::"v"(aq[cur][mr][p].x), "v"(aq[cur][mr][p].y), "v"(aq[cur][mr][p].z), "v"(aq[cur][mr][p].w),
+                           "v"(bq[bcur][p].x), "v"(bq[bcur][p].y), "v"(bq[bcur][p].z), "v"(bq[bcur][p].w));
         } else if (NP == 2) {
-          const uint4 bdown = wbf_hi_down(bq[cur][0]);  // partner of the scaled low piece (msk_wbf.h)
+          const uint4 bdown = wbf_hi_down(bq[bcur][0]);  // partner of the scaled low piece (msk_wbf.h)
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][NP - 1]);
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][0]);
         } else {
 #pragma unroll
-          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+          for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[bcur][0]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      }  // !BL
     }
     // output transform, one column of A^T: wave-uniform coefficients (scalar registers)
     float c0, c1, c2, c3;
@@ -1180,6 +1302,7 @@ wbf_gemm_fused_k(FusedArgs f) {
           float r = fmaf(yo[i][mr][jq * 4 + jj], osc, bv);
           if (f.accumulate) r += old[jj][i];
           if (f.prelu) r = r > 0.f ? r : sl * r;
+          if ((WBF_PROBE & 8) && r != 12345.678f) continue;   // probe: no stores (the value still has to be computed)
           if (split_st) sbase[((op[jj] - obase) >> 1) + i * swst] = r;
           else op[jj][i * wst] = r;
           if (STATS) {
@@ -1633,6 +1756,15 @@ int pack_row_lookup(msk_ctx* ctx, WbfPackCache* c, const WbfPackDesc& key, int K
 template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
 void launch_fused(msk_ctx* ctx, const char* tag, const FusedArgs& fa, bool stats, bool fork) {
   const dim3 grid((unsigned)(8 * fa.per_xcd));
+  constexpr int NITc = 2 * NP * (TD + K - 1) * (TH + K - 1);
+  if constexpr (WN == 1 && NP == 2 && NITc % 64 == 0) {
+    // one column fragment (32 output channels): the stage's weights through LDS as well ("wbf_fused_bl", default on)
+    if (ctx->wbf_fused_bl && fa.g.CN == 32) {
+      if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true, 1, true>), grid, dim3(WM * WN * 64), 0, fa);
+      else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false, 1, true>), grid, dim3(WM * WN * 64), 0, fa);
+      return;
+    }
+  }
   if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true>), grid, dim3(WM * WN * 64), 0, fa);
   else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false>), grid, dim3(WM * WN * 64), 0, fa);
 }
@@ -1789,6 +1921,8 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP != 3 ? 1 : 0;
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
+    fa.stagger = ctx->wbf_stagger;
+    fa.cu_per_xcd = ctx->num_cu / 8;
     fa.LW = LW;
     if (g.dst_lo && g.dst_hi && g.dst_csplit > 0 && g.accumulate && g.dld == 2 * g.dst_csplit && g.CN == 2 * g.dst_csplit && !fuse_stats) {
       fa.st_lo = g.dst_lo; fa.st_hi = g.dst_hi; fa.csplit = g.dst_csplit;
