@@ -158,9 +158,10 @@ def cpu_baseline(size=128, ncls=3):
     steps of a size^3 volume (as many as fit in ~12 s, at most 8) after one untimed warm-up step."""
     import torch
     from oracle.vnet_torch import TorchVNet, torch_mixed_loss  # baseline only
-    # oneDNN's 3D convolutions stop scaling (and regress) beyond a few dozen threads: 256 threads on
-    # the GPU box's host took 90 s for the step that 8 threads do in 15 s -> cap at 32 and report it
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    # oneDNN's 3D convolutions stop scaling (and regress) beyond a few dozen threads.  Thread sweep on the GPU box's host
+    # (profiles/r06_cpu_baseline_threads.json, tools/cpu_baseline_sweep.py; EPYC 9575F x 2, 128 cores / 256 threads), seconds per
+    # step: 16 threads 3.58, 32: 4.01, 64: 6.07, 128: 10.26, 256: 91.9 -> the fastest measured setting, reported in the line
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     torch.manual_seed(0)
     m = TorchVNet(1, ncls)
     m.train()

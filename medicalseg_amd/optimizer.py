@@ -223,18 +223,25 @@ class Momentum:
         sd["@msegk_dropout_step"] = np.array([_nn.Dropout3D.step], dtype=np.int64)
         return sd
 
-    def set_state_dict(self, sd):
-        """Velocity keys are `<structured parameter name>_velocity_0` -- what this package's own `state_dict` writes.
-        A model.pdopt written by PADDLE names them after its internal parameter names (`conv3d_0.w_0_velocity_0`): those
-        match nothing here, the momentum restarts from zero, and this is reported rather than skipped silently
-        (model.pdparams interoperates both ways; model.pdopt only package -> package)."""
+    def set_state_dict(self, sd, name_map=None):
+        """Velocity keys are `<structured parameter name>_velocity_0` -- what this package's own `state_dict` writes -- or, in a
+        model.pdopt written by PADDLE, `<internal parameter name>_velocity_0` (`conv3d_0.w_0_velocity_0`).  `name_map` is the
+        `StructuredToParameterName@@` table of the sibling model.pdparams ({structured name: internal name}; reference
+        utils/utils.py:115-135 loads both files, `utils.resume` passes the table on): with it a Paddle-written optimizer
+        state resumes with its momentum.  Keys that match neither way are reported, never skipped silently."""
         dev = self.arena.dev
         flat = dev.d2h(self.velocity_ptr, (self.arena.count,), np.float32)
         used, missing = set(), []
+        name_map = name_map or {}
         for p in self.arena.params:
             k = p.name + "_velocity_0"
+            if k not in sd and p.name in name_map:
+                k = str(name_map[p.name]) + "_velocity_0"
             if k in sd:
-                flat[p.offset:p.offset + p.size] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
+                v = np.asarray(sd[k], dtype=np.float32)
+                if v.size != p.size:
+                    raise ValueError("optimizer state %r has %d elements, parameter %s has %d" % (k, v.size, p.name, p.size))
+                flat[p.offset:p.offset + p.size] = v.reshape(-1)
                 used.add(k)
             else:
                 missing.append(k)
@@ -320,28 +327,36 @@ class Adam:
         sd["@msegk_dropout_step"] = np.array([_nn.Dropout3D.step], dtype=np.int64)
         return sd
 
-    def set_state_dict(self, sd):
+    def set_state_dict(self, sd, name_map=None):
+        """name_map: `StructuredToParameterName@@` of the sibling model.pdparams -- a Paddle-written model.pdopt names its
+        accumulators after the internal parameter names (see Momentum.set_state_dict)."""
         dev = self.arena.dev
         m1 = dev.d2h(self.moment1_ptr, (self.arena.count,), np.float32)
         m2 = dev.d2h(self.moment2_ptr, (self.arena.count,), np.float32)
         used, missing = set(), []
+        name_map = name_map or {}
         for p in self.arena.params:
             for buf, suffix in ((m1, "_moment1_0"), (m2, "_moment2_0")):
                 k = p.name + suffix
+                if k not in sd and p.name in name_map:
+                    k = str(name_map[p.name]) + suffix
                 if k in sd:
                     buf[p.offset:p.offset + p.size] = np.asarray(sd[k], dtype=np.float32).reshape(-1)
                     used.add(k)
                 else:
                     missing.append(k)
             for suffix in ("_beta1_pow_acc_0", "_beta2_pow_acc_0"):
-                if p.name + suffix in sd:
-                    used.add(p.name + suffix)
+                for nm in (p.name, str(name_map.get(p.name, ""))):
+                    if nm and nm + suffix in sd:
+                        used.add(nm + suffix)
         dev.h2d(self.moment1_ptr, m1)
         dev.h2d(self.moment2_ptr, m2)
         if "@msegk_beta_pows" in sd:
             self.beta1_pow, self.beta2_pow = [float(v) for v in np.asarray(sd["@msegk_beta_pows"]).ravel()[:2]]
         else:
             first = self.arena.params[0].name
+            if first + "_beta1_pow_acc_0" not in sd and first in name_map:
+                first = str(name_map[first])
             if first + "_beta1_pow_acc_0" in sd:
                 self.beta1_pow = float(np.asarray(sd[first + "_beta1_pow_acc_0"]).ravel()[0])
                 self.beta2_pow = float(np.asarray(sd[first + "_beta2_pow_acc_0"]).ravel()[0])

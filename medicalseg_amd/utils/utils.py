@@ -74,11 +74,19 @@ def resume(model, optimizer, resume_model):
     if not os.path.exists(resume_model):
         raise ValueError('Directory of the model needed to resume is not Found: {}'.format(resume_model))
     resume_model = os.path.normpath(resume_model)
-    missing, unexpected = model.set_state_dict(load(os.path.join(resume_model, 'model.pdparams')))
+    para = load(os.path.join(resume_model, 'model.pdparams'))
+    missing, unexpected = model.set_state_dict(para)
     if missing or unexpected:
         logger.warning('resume: {} parameters missing from model.pdparams (e.g. {}), {} unexpected keys (e.g. {})'
                        .format(len(missing), missing[:2], len(unexpected), unexpected[:2]))
-    optimizer.set_state_dict(load(os.path.join(resume_model, 'model.pdopt')))
+    # a Paddle-written model.pdopt names its accumulators after Paddle's INTERNAL parameter names; the table that maps the
+    # structured names onto them travels in model.pdparams
+    name_map = para.get("StructuredToParameterName@@") if isinstance(para, dict) else None
+    opt_state = load(os.path.join(resume_model, 'model.pdopt'))
+    try:
+        optimizer.set_state_dict(opt_state, name_map=name_map)
+    except TypeError:      # an optimizer without accumulator names (no name_map argument)
+        optimizer.set_state_dict(opt_state)
     return int(resume_model.split('_')[-1])
 
 

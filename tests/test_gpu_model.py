@@ -461,6 +461,74 @@ def test_checkpoint_resume_continues_bitwise(tmp_path):
     assert ref_opt["LR_Scheduler"] == opt_sd2["LR_Scheduler"]
 
 
+def test_resume_from_a_paddle_written_optimizer_state(tmp_path):
+    """SURVEY 8 f2 / round-5 verdict item 8 (reference utils/utils.py:115-135 loads model.pdparams AND model.pdopt): a model.pdopt
+    written by Paddle names its accumulators after Paddle's INTERNAL parameter names (`conv3d_0.w_0_velocity_0`); the table
+    `StructuredToParameterName@@` inside the sibling model.pdparams maps the structured names onto them.  A fabricated pair in that
+    naming must resume with its momentum: the continued trajectory equals the uninterrupted one bit for bit."""
+    from medicalseg_amd import nn
+    from medicalseg_amd import optimizer as optim
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss, VNet
+    from medicalseg_amd.utils import loss_computation, resume, save
+    shape, ncls, N = (16, 16, 16), 3, 1
+    rng = np.random.default_rng(12)
+    xs = [rng.standard_normal((N, 1) + shape).astype(np.float32) for _ in range(3)]
+    ys = [rng.integers(0, ncls, (N,) + shape).astype(np.int32) for _ in range(3)]
+
+    def make():
+        nn.seed(4)
+        model = VNet(num_classes=ncls)
+        model.train()
+        model.set_dropout_masks({})
+        opt = optim.Momentum(1e-2, parameters=model.parameters(), momentum=0.9, weight_decay=1e-4)
+        losses = {"types": [MixedLoss([CrossEntropyLoss(weight=[1.0, 2.0, 0.5]), DiceLoss()], [1, 1])], "coef": [1]}
+        return model, opt, losses
+
+    def step(model, opt, losses, i):
+        ll, _ = loss_computation(model(xs[i]), to_labels(ys[i]), losses)
+        sum(ll).backward()
+        opt.step()
+        model.clear_gradients()
+
+    model, opt, losses = make()
+    step(model, opt, losses, 0)
+    sd, od = model.state_dict(), opt.state_dict()
+    # Paddle's naming: parameters conv3d_<i>.w_0 / .b_0, batch_norm3d_<i>.w_0 ..., accumulators <internal>_velocity_0
+    table, kinds = {}, {}
+    trainable = {p.name for p in model.arena.params}
+    for k in sd:
+        if k not in trainable:
+            continue
+        layer = k.rsplit(".", 1)[0]
+        kinds.setdefault(layer, len(kinds))
+        table[k] = "layer_%d.%s_0" % (kinds[layer], "w" if k.endswith(("weight", "_weight")) else "b")
+    assert len(set(table.values())) == len(table)
+    paddle_opt = {table[k[:-len("_velocity_0")]] + "_velocity_0": v for k, v in od.items() if k.endswith("_velocity_0")}
+    assert len(paddle_opt) == len(table) and not any(k in od for k in paddle_opt)     # none of the keys is one of ours
+    paddle_opt["LR_Scheduler"] = {"last_epoch": 1, "last_lr": 1e-2}
+    ck = tmp_path / "iter_1"
+    save(dict(sd, **{"StructuredToParameterName@@": table}), str(ck / "model.pdparams"))
+    save(paddle_opt, str(ck / "model.pdopt"))
+    for i in (1, 2):
+        step(model, opt, losses, i)
+    ref = model.state_dict()
+
+    model2, opt2, losses2 = make()
+    assert resume(model2, opt2, str(ck)) == 1
+    assert opt2.last_load["missing"] == [] and opt2.last_load["unexpected"] == []
+    vel = dev().d2h(opt2.velocity_ptr, (model2.arena.count,), np.float32)
+    assert np.abs(vel).max() > 0                                     # the momentum DID arrive
+    for i in (1, 2):
+        step(model2, opt2, losses2, i)
+    got = model2.state_dict()
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    # without the table the same file is reported as foreign (momentum restarts): nothing is skipped silently
+    model3, opt3, _ = make()
+    opt3.set_state_dict(paddle_opt)
+    assert len(opt3.last_load["missing"]) == len(table) and len(opt3.last_load["unexpected"]) == len(table)
+
+
 def test_winograd_and_direct_kernels_agree_on_a_training_step():
     """The product dispatch uses the Winograd F(4,5) / F(2,5) kernels for the 5^3 layers; `direct_conv` (env
     MSEGK_DIRECT_CONV=1) selects the direct kernels (exact fp32 fmaf chains).  One training step at 32^3 (every level
