@@ -949,8 +949,6 @@ struct FusedArgs {
   int scaled;
   float* stat_partial;  // STATS: [tiles][CN][3] = (n, mean, M2) of the stored values
   int per_xcd;          // tiles per XCD
-  int stagger;          // BL: the second workgroup slot of every CU (first dispatch round) starts this many s_sleep(127) late
-  int cu_per_xcd;
   int LW;               // extent of the transform axis: the last W tile may reach beyond it (ragged: stores and statistics stop there)
   // round 5 (msk_conv3d_bwd_bnact_split): the accumulating data gradient of the layer behind a zero-copy concat READS the old
   // values from the interleaved buffer `dst` (whole lines) but STORES channels [0, csplit) to the dense tensor st_lo and
@@ -1021,14 +1019,6 @@ wbf_gemm_fused_k(FusedArgs f) {
   // block -> tile: XCD x (= blockIdx % 8) walks the contiguous tile range [x * per_xcd, (x + 1) * per_xcd)
   int b = (blockIdx.x & 7) * f.per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= f.per_xcd || b >= a.nblk) return;
-  if constexpr (BL) {
-    // Two workgroups share a CU and alternate "fill the stage's tile + weights" (no matrix work) with "25 taps of MFMAs": started
-    // together they stay in lock-step -- both fill, then both compute -- and the fill is never hidden.  The workgroups of the
-    // second slot of the first dispatch round start half a stage late; equal stage times keep the offset from then on.
-    const int lx = (int)(blockIdx.x >> 3);
-    if (f.stagger > 0 && lx >= f.cu_per_xcd && lx < 2 * f.cu_per_xcd)
-      for (int q = 0; q < f.stagger; ++q) __builtin_amdgcn_s_sleep(127);
-  }
   const int tile_id = b;
   const int thi = b % a.tiles_h;
   b /= a.tiles_h;
@@ -1921,8 +1911,6 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP != 3 ? 1 : 0;
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
-    fa.stagger = ctx->wbf_stagger;
-    fa.cu_per_xcd = ctx->num_cu / 8;
     fa.LW = LW;
     if (g.dst_lo && g.dst_hi && g.dst_csplit > 0 && g.accumulate && g.dld == 2 * g.dst_csplit && g.CN == 2 * g.dst_csplit && !fuse_stats) {
       fa.st_lo = g.dst_lo; fa.st_hi = g.dst_hi; fa.csplit = g.dst_csplit;

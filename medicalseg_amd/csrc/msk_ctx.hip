@@ -599,10 +599,6 @@ int msk_set_option(msk_ctx* ctx, const char* key, int value) {
     ctx->wbf_fuse = value;
     return 0;
   }
-  if (strcmp(key, "wbf_stagger") == 0) {
-    ctx->wbf_stagger = value;
-    return 0;
-  }
   if (strcmp(key, "wbf_fused_bl") == 0) {
     ctx->wbf_fused_bl = value;
     return 0;
