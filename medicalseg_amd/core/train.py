@@ -40,6 +40,9 @@ def train(model, train_dataset, val_dataset=None, optimizer=None, save_dir='outp
     if nranks > 1:
         init_parallel_env(dp_mode=dp_mode)    # train.py --dp_mode: auto = 2 (overlapped buckets) when there are several ranks; 0 = one all-reduce after backward
         ddp_model = DataParallel(model)
+        logger.info("data parallel: {} ranks, dp_mode {} requested -> {} in effect (MSEGK_DP_MODE {}), gradient buckets overlapped with "
+                    "backward: {}".format(nranks, dp_mode, model.dev.get_option("dp_mode"), os.environ.get("MSEGK_DP_MODE", "unset"),
+                                          bool(getattr(ddp_model, "overlap", False))))
     elif hasattr(optimizer, "enable_eager") and os.environ.get("MSEGK_EAGER_OPT", "1") != "0":
         # one rank: a block's parameters are updated on the weight-gradient stream as soon as its backward is enqueued;
         # optimizer.step() below joins.  This loop never looks at parameters between backward() and step().

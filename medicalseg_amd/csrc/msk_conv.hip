@@ -177,6 +177,17 @@ const float* small_pack_get(msk_ctx* ctx, SmallPackDesc key, size_t bytes) {
     // a row keeps its image's allocation across tenants (stream order protects a reused image: it is rewritten on the stream
     // whose kernels read it, or behind that stream's tail); a larger one is allocated behind everything in flight
     float* out = e.d.out;
+    if (out && e.live && ctx->side != nullptr) {
+      // a live row changes tenant (all rows in use: LRU): its image and descriptor are rewritten on THIS stream -- the other
+      // stream may still hold launches that read the old tenant's image, so this one waits for the other's current tail first
+      // (rare: more than kRows live weight images; advisor, round 5)
+      static thread_local hipEvent_t ev = nullptr;
+      if (!ev) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (ev) {
+        hipEventRecord(ev, ctx->side);
+        hipStreamWaitEvent(ctx->stream, ev, 0);
+      }
+    }
     if (out && e.bytes < bytes) {
       hipStreamSynchronize(ctx->stream);
       if (ctx->side) hipStreamSynchronize(ctx->side);

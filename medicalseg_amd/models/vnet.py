@@ -215,17 +215,20 @@ class UpTransition(nn.Layer):
         # one half then do not fetch the other with it (round 5).  Honoured only by the one-kernel matrix stage: else as before
         g_lo = g_hi = None
         skip = self._skip
-        if (SPLIT_CONCAT_GRAD and self._skip_in_place and skip.grad is None and half * 4 < 128 and self._m1 is None):
+        first = ops[0]._unit if ops else None       # nConvs = 0 (vnet.py:130-131 allows it): no layer behind the concat, nothing to split
+        if (first is not None and SPLIT_CONCAT_GRAD and self._skip_in_place and skip.grad is None and half * 4 < 128 and self._m1 is None):
             dev = xcat.dev
             g_lo = Tensor.empty(dev, xcat.n, xcat.d, xcat.h, xcat.w, half)
             g_hi = Tensor.empty(dev, xcat.n, xcat.d, xcat.h, xcat.w, half)
-            ops[0]._unit.dx_split = (g_lo, g_hi)
-        ops[0]._unit.dx_split_done = False
+            first.dx_split = (g_lo, g_hi)
+        if first is not None:
+            first.dx_split_done = False
         for op in reversed(ops):
             op.backward(op._unit.out.grad)
         gcat = xcat.grad
-        split_done = g_lo is not None and getattr(ops[0]._unit, "dx_split_done", False)
-        ops[0]._unit.dx_split = None
+        split_done = g_lo is not None and getattr(first, "dx_split_done", False)
+        if first is not None:
+            first.dx_split = None
         # skip branch
         if split_done:
             skip.grad = g_hi                      # the skip half's gradient as a dense tensor; later writers accumulate into it
@@ -353,7 +356,7 @@ class VNet(nn.Layer):
         # a 16-channel half of the 32-channel concat voxel is 64 of every 128-byte line: the readers of the skip half alone (the
         # down-convolution and its weight gradient) get a dense twin written by the same pass (DENSE_TWIN, round 5)
         twin = None
-        if slot is not None and DENSE_TWIN and slot.c * 4 < 128 and not isinstance(self.in_tr.relu1, nn.ELU):
+        if slot is not None and DENSE_TWIN and self.training and slot.c * 4 < 128 and not isinstance(self.in_tr.relu1, nn.ELU):   # (eval: no backward reads it)
             twin = Tensor.empty(self.dev, x.n, x.d, x.h, x.w, slot.c)
         out16 = self.in_tr(x, out=slot, out2=twin)
         self._out16_twin = twin

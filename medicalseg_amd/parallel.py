@@ -235,7 +235,16 @@ def init_parallel_env(dp_mode=None):
             raise _lib.MskError("msk_dp_unique_id failed: " + _lib.last_error(None))
         uid = buf.raw
     uid = exchange_bytes(uid, env.rank, env.nranks)
-    dev.call("msk_dp_init", uid, env.rank, env.nranks)
+    try:
+        dev.call("msk_dp_init", uid, env.rank, env.nranks)
+    except _lib.MskError as e:
+        from .device import _MASK_VARS
+        masks = {v: os.environ[v] for v in _MASK_VARS if os.environ.get(v)}
+        raise _lib.MskError("%s -- rank %d of %d: LOCAL_RANK %d -> HIP device %d (PCI %s), %d device(s) visible, masks %s.  RCCL "
+                            "reports 'invalid usage' when two ranks are bound to the same GPU (fewer visible devices than ranks "
+                            "per node, or one *_VISIBLE_DEVICES mask shared by all ranks)"
+                            % (e, env.rank, env.nranks, env.local_rank, dev.index, info["pci"], info["visible_devices"],
+                               masks or "none")) from None
     dev.rank, dev.world = env.rank, env.nranks
     _initialised = True
     return env

@@ -18,6 +18,10 @@ CASES = {
     "vnet128": dict(shape=(128, 128, 128), N=2, ncls=3, K=ISO, S=ISO, seed=2, golden="fullsize_vnet128_golden.npz"),
     # BASELINE.json configs[4]: VNet MRISpineSeg 512x512x12, 20 classes, anisotropic kernels
     "mri": dict(shape=(512, 512, 12), N=1, ncls=20, K=MRI_K, S=MRI_S, seed=3, golden="fullsize_mri_golden.npz"),
+    # the reference's other model on the MRI slab (configs/mri_spine_seg/vnetdeepsup_mri_spine_seg_512_512_12_15k.yml:12-20;
+    # models/vnet_deepsup.py:247-281): four outputs, one MixedLoss[CE, Dice] each, coef 0.25 each (round-5 verdict, Next 7)
+    "mri_deepsup": dict(shape=(512, 512, 12), N=1, ncls=20, K=MRI_K, S=MRI_S, seed=5, golden="fullsize_mri_deepsup_golden.npz",
+                        model="VNetDeepSup", coef=0.25),
 }
 SAMPLE = 8192          # entries kept per parameter-gradient tensor larger than that
 LOGIT_SAMPLE = 32768   # voxels (all samples, all classes) kept of the logits
@@ -60,10 +64,13 @@ def build(name):
     if name == "vnet128":
         items = [synthetic_ct(i, c["shape"]) for i in range(c["N"])]
     else:
-        items = [mri_slab(c["shape"], c["ncls"], 100 + i) for i in range(c["N"])]
+        items = [mri_slab(c["shape"], c["ncls"], (100 if name == "mri" else 200) + i) for i in range(c["N"])]
     x = np.stack([i[0] for i in items])[:, None].astype(np.float32)
     y = np.stack([i[1] for i in items]).astype(np.int32)
-    params = O.init_params(c["seed"], 1, c["ncls"], c["K"], c["S"])
+    if c.get("model") == "VNetDeepSup":
+        params = O.init_params_deepsup(c["seed"], 1, c["ncls"], c["K"], c["S"])
+    else:
+        params = O.init_params(c["seed"], 1, c["ncls"], c["K"], c["S"])
     rng = np.random.default_rng(17)
     masks = {s: (rng.random((c["N"], ch)) < 0.5).astype(np.float32) * 2.0 for s, ch in SITES}
     return dict(x=x, y=y, params=params, masks=masks, cfg=c)
@@ -86,3 +93,37 @@ def sample_indices(name, size):
         return None
     seed = int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
     return np.sort(np.random.default_rng(seed).choice(size, SAMPLE, replace=False)).astype(np.int64)
+
+
+def torch_model(case, dtype):
+    """The torch-CPU restatement of the case's network (oracle/vnet_torch.py) with the case's parameters loaded -- generator side
+    only (the GPU tests never import torch)."""
+    import torch
+    from oracle import vnet_torch as VT
+    c = case["cfg"]
+    cls = VT.TorchVNetDeepSup if c.get("model") == "VNetDeepSup" else VT.TorchVNet
+    tm = cls(1, c["ncls"], c["K"], c["S"])
+    tm = tm.double() if dtype == torch.float64 else tm.float()
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    tm.load_oracle_params({k: np.asarray(v, dtype=npdt) for k, v in case["params"].items()})
+    tm.train()
+    return tm
+
+
+def torch_losses(case, outs, y):
+    """-> (total loss, [(ce, dice loss, per-class dice, class weights)] per output): one MixedLoss[CE, Dice] per output, each with
+    its own first-call class weights (losses/loss_utils.py:31-40), outer coefficient cfg['coef'] (1 for the single-output net)."""
+    import torch
+    from oracle import vnet_torch as VT
+    c = case["cfg"]
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    coef = float(c.get("coef", 1.0))
+    total, parts = 0.0, []
+    for lg in outs:
+        with torch.no_grad():
+            p = torch.softmax(lg, 1).transpose(0, 1).reshape(c["ncls"], -1)
+            w = (1.0 - p).sum(-1) / p.sum(-1)
+        ce, dl, per = VT.torch_mixed_loss(lg, y, w)
+        total = total + coef * (ce + dl)
+        parts.append((ce, dl, per, w))
+    return total, parts

@@ -37,11 +37,8 @@ def step(case, dtype, threads, slab):
     c = case["cfg"]
     torch.set_num_threads(threads)
     VT.SLAB_BYTES = slab
-    tm = VT.TorchVNet(1, c["ncls"], c["K"], c["S"])
-    tm = tm.double() if dtype == torch.float64 else tm.float()
+    tm = FC.torch_model(case, dtype)
     npdt = np.float64 if dtype == torch.float64 else np.float32
-    tm.load_oracle_params({k: np.asarray(v, dtype=npdt) for k, v in case["params"].items()})
-    tm.train()
     stats = {}
 
     def hook(mod_name):
@@ -57,12 +54,11 @@ def step(case, dtype, threads, slab):
     x = torch.tensor(case["x"], dtype=dtype)
     y = torch.tensor(case["y"])
     masks = {k: np.asarray(v, dtype=npdt) for k, v in case["masks"].items()}
-    lg = tm(x, masks)
-    with torch.no_grad():
-        p = torch.softmax(lg, 1).transpose(0, 1).reshape(c["ncls"], -1)
-        w = (1.0 - p).sum(-1) / p.sum(-1)
-    ce, dl, per = VT.torch_mixed_loss(lg, y, w)
-    (ce + dl).backward()
+    outs = tm(x, masks)
+    total, parts = FC.torch_losses(case, outs, y)
+    lg = outs[0] if isinstance(outs, (list, tuple)) else outs      # forward-pass noise is reported for the main output
+    ce, dl, per, w = parts[0]
+    total.backward()
     grads = {k: g.astype(np.float64) for k, g in tm.named_oracle_grads().items()}
     return dict(logits=lg.detach().double().numpy(), ce=float(ce), dl=float(dl), per=per.detach().double().numpy(),
                 w=w.double().numpy(), grads=grads, stats=stats)

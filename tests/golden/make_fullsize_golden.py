@@ -29,9 +29,7 @@ def run(name):
     c = case["cfg"]
     torch.set_num_threads(os.cpu_count() or 1)
     VT.SLAB_BYTES = 2 << 30
-    tm = VT.TorchVNet(1, c["ncls"], c["K"], c["S"]).double()
-    tm.load_oracle_params({k: np.asarray(v, dtype=np.float64) for k, v in case["params"].items()})
-    tm.train()
+    tm = FC.torch_model(case, torch.float64)
     stats = {}
 
     def hook(mod_name):
@@ -47,24 +45,33 @@ def run(name):
     t0 = time.time()
     x = torch.tensor(case["x"], dtype=torch.float64)
     y = torch.tensor(case["y"])
-    lg = tm(x, case["masks"])
-    with torch.no_grad():   # losses/loss_utils.py:31-40 (first-call class weights, detached)
-        p = torch.softmax(lg, 1).transpose(0, 1).reshape(c["ncls"], -1)
-        w = (1.0 - p).sum(-1) / p.sum(-1)
-    ce, dl, per = VT.torch_mixed_loss(lg, y, w)
+    outs = tm(x, case["masks"])
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    total, parts = FC.torch_losses(case, outs, y)     # losses/loss_utils.py:31-40: first-call class weights, detached, per output
+    ce, dl, per, w = parts[0]
     t1 = time.time()
-    (ce + dl).backward()
+    total.backward()
     t2 = time.time()
-    print("%s: forward %.0f s, backward %.0f s; ce %.9f dice %.9f" % (name, t1 - t0, t2 - t1, float(ce), float(dl)), flush=True)
+    print("%s: forward %.0f s, backward %.0f s; ce %.9f dice %.9f (%d output(s))" % (name, t1 - t0, t2 - t1, float(ce), float(dl), len(outs)), flush=True)
     out = {"digest": np.array(FC.digest(case)), "class_weights": w.numpy(), "ce": np.float64(ce.item()),
            "dice_loss": np.float64(dl.item()), "per_channel_dice": per.detach().numpy()}
-    lgn = lg.detach().numpy()
-    N, C = lgn.shape[:2]
-    vox = int(np.prod(lgn.shape[2:]))
+    N, C = outs[0].shape[:2]
+    vox = int(np.prod(outs[0].shape[2:]))
     li = np.sort(np.random.default_rng(5).choice(N * vox, FC.LOGIT_SAMPLE, replace=False))
-    flat = np.moveaxis(lgn.reshape(N, C, vox), 1, 2).reshape(N * vox, C)
-    out["logit_idx"], out["logit_val"] = li, flat[li]
-    out["logit_absmax"] = np.float64(np.abs(lgn).max())
+    out["logit_idx"] = li
+    for oi, (lg, (ce_i, dl_i, per_i, w_i)) in enumerate(zip(outs, parts)):
+        lgn = lg.detach().numpy()
+        flat = np.moveaxis(lgn.reshape(N, C, vox), 1, 2).reshape(N * vox, C)
+        sfx = "" if oi == 0 else "@%d" % oi      # output 0 keeps the single-output key names
+        sel = li if oi == 0 else li[::4]         # the extra outputs of a deep-supervision net: a quarter of the sample (fixture size)
+        if oi:
+            out["logit_idx" + sfx] = sel
+        out["logit_val" + sfx] = flat[sel]
+        out["logit_absmax" + sfx] = np.float64(np.abs(lgn).max())
+        if oi:
+            out["class_weights" + sfx], out["ce" + sfx] = w_i.numpy(), np.float64(ce_i.item())
+            out["dice_loss" + sfx], out["per_channel_dice" + sfx] = np.float64(dl_i.item()), per_i.detach().numpy()
+    out["n_outputs"] = np.int64(len(outs))
     for k, g in tm.named_oracle_grads().items():
         idx = FC.sample_indices(k, g.size)
         out["g/" + k] = g.ravel() if idx is None else g.ravel()[idx]

@@ -75,19 +75,14 @@ def run(name):
     assert str(gold["digest"]) == FC.digest(case)
     torch.set_num_threads(os.cpu_count() or 1)
     VT.SLAB_BYTES = 2 << 30
-    tm = VT.TorchVNet(1, c["ncls"], c["K"], c["S"]).double()
-    tm.load_oracle_params({k: np.asarray(v, dtype=np.float64) for k, v in case["params"].items()})
-    tm.train()
+    tm = FC.torch_model(case, torch.float64)
     patch(tm)
     t0 = time.time()
     x = torch.tensor(case["x"], dtype=torch.float64)
     y = torch.tensor(case["y"])
-    lg = tm(x, case["masks"])
-    with torch.no_grad():
-        p = torch.softmax(lg, 1).transpose(0, 1).reshape(c["ncls"], -1)
-        w = (1.0 - p).sum(-1) / p.sum(-1)
-    ce, dl, per = VT.torch_mixed_loss(lg, y, w)
-    loss = ce + dl
+    outs = tm(x, case["masks"])
+    loss, parts = FC.torch_losses(case, outs, y)
+    ce, dl, per, w = parts[0]
     print("%s: forward %.0f s; ce %.9f dice %.9f" % (name, time.time() - t0, float(ce.detach()), float(dl.detach())), flush=True)
     assert abs(float(ce.detach()) - float(gold["ce"])) < 1e-12
     grads = {}
