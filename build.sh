@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build libmsegk.so (gfx950 HIP kernels + C ABI) and the oracle's C restatement.
+# Build libmsegk.so (gfx950 HIP kernels + C ABI) and libmsegk_test.so (same objects + the host transport of tests/test_gpu_dp2.py).
 # hipcc cross-compiles without a GPU.  Usage: ./build.sh [-v]
 set -e
 cd "$(dirname "$0")"
@@ -29,4 +29,4 @@ if [ ! -f $T ] || [ medicalseg_amd/csrc/msk_dp.hip -nt $T ] || [ medicalseg_amd/
 fi
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libmsegk_test.so ${OBJS/build\/msk_dp.o/$T} -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT/libmsegk_test.so"
-if [ -f oracle/c/Makefile ]; then make -s -C oracle/c; fi
+

@@ -10,4 +10,5 @@ bash tools/profile_gpu.sh > gpurun_out/e_profile_gpu.log 2>&1
 python tools/bench_workloads.py --model VNet --shape 512,512,12 --num-classes 20 --batch 1 --inloop-preprocess --steps 8 --json-out gpurun_out/e_mri_vnet.json 2>&1 | grep -E "ms/step"
 python tools/bench_workloads.py --model VNetDeepSup --shape 512,512,12 --num-classes 20 --batch 1 --json-out gpurun_out/e_mri_ds.json 2>&1 | grep -E "ms/step"
 python tools/bench_workloads.py --model UNet3D --precision fp16 --shape 192,192,64 --num-classes 3 --batch 2 --json-out gpurun_out/e_unet_fp16.json 2>&1 | grep -E "ms/step"
+python tools/bench_preprocess_roofline.py --out gpurun_out/e_preprocess.json > gpurun_out/e_preprocess.txt 2>&1
 bash tools/probes/clock_sample.sh > gpurun_out/e_clocks.txt 2>&1; tail -3 gpurun_out/e_clocks.txt

@@ -41,14 +41,22 @@ if b:
     rows.append(("training step, VNet 128^3 fp32, batch 2, 1 GPU (`python bench.py`; BASELINE configs[1])",
                  "**%.2f ms/step = %.1f M voxels/s** (%d steps after %d warm-up; synthetic CT volumes resident in HBM)"
                  % (b["ms_per_step"], b["value"] / 1e6, b["steps"], b["warmup"])))
+    if b.get("ms_per_step_sustained"):
+        rows.append(("the same step sustained over 150 further steps (clocks / power settled) | plain optimizer order (what an N > 1 rank runs)",
+                     "%.2f ms/step = %.1f M voxels/s | %s" % (b["ms_per_step_sustained"], b["value_sustained"] / 1e6,
+                                                             ("%.2f ms/step" % b["ms_per_step_plain_order"]) if b.get("ms_per_step_plain_order") else "n/a")))
     sf = r.get("strict_fp32")
     if sf:
         rows.append(("the same step with exact fp32 operands (`conv_split` 3, `roofline.strict_fp32`)",
                      "%.2f ms/step = %.1f M voxels/s" % (sf["ms_per_step"], sf["value"] / 1e6)))
     rows.append(("dominant kernel `%s` (matrix stage of every LUConv forward / data gradient, %d launches per step)" % (r["kernel"], r["launches"] // _event_steps(r, b)),
                  "%.4f ms per launch (HIP events in the step) = %.0f TFLOP/s executed on the 16-bit pipe = **%.3f of the %.0f TFLOP/s dense peak** "
-                 "(%.0f TFLOP/s algorithmic); one stream: %.4f ms = %.3f" % (r["avg_launch_ms"], r["achieved"], r["frac"], r["peak"], r["algorithmic_tflops"],
+                 "(%.0f TFLOP/s algorithmic = %s of it); one stream: %.4f ms = %.3f" % (r["avg_launch_ms"], r["achieved"], r["frac"], r["peak"], r["algorithmic_tflops"],
+                                                                            ("%.3f" % r["frac_algorithmic"]) if "frac_algorithmic" in r else "?",
                                                                             r["serialized"]["avg_launch_ms"], r["serialized"]["frac"]) if r.get("serialized") else ""))
+    if r.get("traffic"):
+        rows.append(("HBM traffic of that kernel (PMC counters of the committed passes) vs its algorithmic bytes",
+                     "%.1f MB per launch vs %.1f MB = %.2fx" % (r["traffic"] / 1e6, r["algorithmic_bytes_per_launch"] / 1e6, r["traffic"] / r["algorithmic_bytes_per_launch"])))
     rows.append(("whole step: executed matrix work at the hardware peaks / step time (`roofline.step_executed_frac`)", "%.3f" % r["step_executed_frac"]))
     h = r.get("hbm")
     if h:
@@ -78,7 +86,7 @@ try:
                 a += int(calls) / steps
                 bb += float(total) / steps
     rows.append(("launches per step (HIP-event tags, weight gradients on the compute stream)",
-                 "%d launches, %.2f ms of kernel time; %d of them under 40 us = %.2f ms.  A dependent empty launch costs 2.2 us in the step (DESIGN section 4, round 5)" % (n, t, a, bb)))
+                 "%d launches, %.2f ms of kernel time; %d of them under 40 us = %.2f ms.  A dependent empty launch costs 2.2 us in the step (HISTORY.md section 4, round 5)" % (n, t, a, bb)))
 except (OSError, AttributeError):
     pass
 try:
