@@ -322,6 +322,8 @@ def main():
 
 def worker_main(args):
     from medicalseg_amd import launch
+    from medicalseg_amd.utils import logger as _logger
+    _logger.stream = sys.stderr       # stdout carries exactly ONE JSON line
     from medicalseg_amd import optimizer as optim
     from medicalseg_amd import parallel
     from medicalseg_amd.datasets import SyntheticCT

@@ -10,6 +10,7 @@ from datetime import datetime
 ERROR, WARNING, INFO, DEBUG = range(4)
 levels = {ERROR: 'ERROR', WARNING: 'WARNING', INFO: 'INFO', DEBUG: 'DEBUG'}
 log_level = INFO  # messages above this verbosity are dropped
+stream = None     # None = sys.stdout (the reference prints its log there); bench.py points it at stderr: its stdout carries ONE JSON line
 
 
 def _master_rank() -> bool:
@@ -21,8 +22,9 @@ def log(level=INFO, message=""):
     if level > log_level or not _master_rank():
         return
     stamp = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
-    sys.stdout.write("%s [%s]\t%s\n" % (stamp, levels[level], message))
-    sys.stdout.flush()
+    out = stream if stream is not None else sys.stdout
+    out.write("%s [%s]\t%s\n" % (stamp, levels[level], message))
+    out.flush()
 
 
 def _at(level):

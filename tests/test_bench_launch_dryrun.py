@@ -90,6 +90,7 @@ def test_bench_single_process_defaults(tmp_path):
                           "--size", "16", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:500]     # ONE line on stdout: log messages go to stderr
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["dtype"] == "f32" and rec["data"] == "synthetic" and rec["vs_baseline"] is None
     assert rec["config"]["eager_optimizer"] is True
