@@ -42,9 +42,9 @@ if b:
                  "**%.2f ms/step = %.1f M voxels/s** (%d steps after %d warm-up; synthetic CT volumes resident in HBM)"
                  % (b["ms_per_step"], b["value"] / 1e6, b["steps"], b["warmup"])))
     if b.get("ms_per_step_sustained"):
-        rows.append(("the same step sustained over 150 further steps (clocks / power settled) | plain optimizer order (what an N > 1 rank runs)",
-                     "%.2f ms/step = %.1f M voxels/s | %s" % (b["ms_per_step_sustained"], b["value_sustained"] / 1e6,
-                                                             ("%.2f ms/step" % b["ms_per_step_plain_order"]) if b.get("ms_per_step_plain_order") else "n/a")))
+        rows.append(("the same step sustained over 150 further steps (untimed extra pass); in the plain optimizer order (what a rank of an N > 1 job runs)",
+                     "%.2f ms/step = %.1f M voxels/s; %s" % (b["ms_per_step_sustained"], b["value_sustained"] / 1e6,
+                                                            ("%.2f ms/step" % b["ms_per_step_plain_order"]) if b.get("ms_per_step_plain_order") else "n/a")))
     sf = r.get("strict_fp32")
     if sf:
         rows.append(("the same step with exact fp32 operands (`conv_split` 3, `roofline.strict_fp32`)",
@@ -65,7 +65,8 @@ if b:
         if os.path.exists(tj):
             ws = json.load(open(tj)).get("_whole_step")
             if ws:
-                h = dict(h, counter_GB_per_step=ws["hbm_bytes_per_step"] / 1e9, ratio=ws["hbm_bytes_per_step"] / 1e9 / h["algorithmic_GB_per_step"])
+                h = dict(h, counter_GB_per_step=ws["hbm_bytes_per_step"] / 1e9, ratio=ws["hbm_bytes_per_step"] / 1e9 / h["algorithmic_GB_per_step"],
+                         source="profiles/%s_hbm_traffic.json:" % TAG)
         rows.append(("HBM traffic of one step (PMC counters FETCH_SIZE / WRITE_SIZE over all kernels) vs algorithmic bytes",
                      "%.1f GB vs %.2f GB = **%.2fx** (%s)" % (h["counter_GB_per_step"], h["algorithmic_GB_per_step"], h["ratio"], h["source"].split(":")[0])))
     c = b.get("cpu_baseline")
