@@ -87,7 +87,7 @@ struct msk_ctx {
   int wbf_prepack = 1;        // 1 = rebuild all packed weights in one launch at the end of the optimizer kernels
   int ks_legacy = 0;          // option "ks_legacy" (A/B): bit 0 = one-tap-per-tile k == s weight gradient, bit 1 = fragment-shaped k == s scatter kernel
   int wgrad_fork = 1;         // fused LUConv backward: 1 = the weight gradient forks after the data-gradient GEMM is enqueued (it then overlaps the HBM-bound passes of the next layer instead of stretching that GEMM by 30 %: -0.25 ms per step), 0 = right after the dual transform
-  int wbf_fused_bl = 1;       // 1 = 32-output-channel tiles of wbf_gemm_fused_k fetch the stage's weights through LDS too (round 6); 0 = per-wavefront L1 loads (A/B)
+  int wbf_fused_bl = 2;       // one-kernel matrix stage, weights through LDS (round 6): 2 = pipelined fills (32 and 64 output channels; default), 1 = whole stage behind one wait (32 channels), 0 = per-wavefront L1 loads (A/B)
   int wbf_fuse = 1;           // 1 = wbf_gemm_fused_k (matrix stage + output transform in one kernel) where eligible; 0 = three stages (A/B)
   int conv_split = 2;         // operand split of the Winograd pipelines: 2 = fp16 two-piece with per-tensor power-of-two scales (product), 3 = exact bf16x3
   int bwd_fuse = -1;          // msk_conv3d_bwd_bnact: -1 auto, 0 three calls, 1 one dual transform, 2 one transform per stream

@@ -28,6 +28,7 @@
 //                                            address arithmetic, no bounds checks; channel = kc*16 + khalf*8 + j
 //   U [xi][tap][kc][piece][khalf][CN]        B fragment of lane (khalf, co) is one contiguous slot
 //   M [ks][xi][n][t][d][h][CN] fp32
+#include <type_traits>
 #include "msk_wbf.h"
 #ifndef WBF_TIN_SYNC
 #define WBF_TIN_SYNC 1   // transform kernels: one barrier per W tile keeps a block's four wavefronts on the same 128-byte lines (0 = A/B)
@@ -714,6 +715,13 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned l
   return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// One LDS-DMA request (64 lanes x 16 B, global -> LDS at the wave-uniform byte address lds_addr + lane * 16) issued BEHIND THE
+// COMPILER'S BACK: see wbf_gemm_fused_k, pipelined form.  m0 = LDS address of the request (the instruction's implicit operand).
+__device__ __forceinline__ void wbf_dma16(i32x4 rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 #define WBF_MFMA(acc, av, bv) \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0)
 #define WBF_MFMA_H(acc, av, bv) \
@@ -999,7 +1007,7 @@ __device__ __forceinline__ void at_column(int xi, float& c0, float& c1, float& c
 // not the latency.  The tap loop is then LDS -> MFMA only (ds_read_b128 at 256 B/clk/CU: A + B reads = half of that at the
 // full matrix rate).  LDS: 25 KB tile + 50 KB weights per workgroup (exact sizes: the last fill round is wave-granular), two
 // workgroups per CU = 150 of 160 KB.
-template <int MR, int WM, int WN, int TD, int TH, int K, int NP, bool STATS, int BPF = (NP == 2 ? WBF_FUSED_BPF : 1), bool BL = false>
+template <int MR, int WM, int WN, int TD, int TH, int K, int NP, bool STATS, int BPF = (NP == 2 ? WBF_FUSED_BPF : 1), int BL = 0>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
 wbf_gemm_fused_k(FusedArgs f) {
   static_assert(WM * WN == 4 && WM * MR * 32 == TD * TH, "tile shape");
@@ -1009,8 +1017,16 @@ wbf_gemm_fused_k(FusedArgs f) {
   constexpr int HDt = TD + K - 1, HPt = TH + K - 1, NSLOT = HDt * HPt, NPL = 2 * NP, NIT = NPL * NSLOT, ROUNDS = (NIT + NT - 1) / NT;
   constexpr int NBF = T2 * NP;                      // BL: B fragments (64 slots of 16 B) per stage
   constexpr int BROUNDS = (NBF + WM * WN - 1) / (WM * WN);
-  static_assert(!BL || (WN == 1 && NIT % 64 == 0), "B through LDS: one column fragment, wave-granular tile");
-  __shared__ uint4 lds[BL ? NIT + NBF * 64 : ROUNDS * NT];
+  static_assert(BL == 0 || NIT % 64 == 0, "weights through LDS: wave-granular tile");
+  static_assert(BL != 1 || WN == 1, "B through LDS, whole stage: one column fragment");
+  // BL == 2 (pipelined): two tile buffers + two weight slots of one PHASE of a stage: PH phases of T2 / PH taps (K = 5: 6 6 6 7
+  // taps with one column fragment, 5 x 5 taps = the kd rows with two), slot = the fragments of the largest (last) phase
+  constexpr int PH = WN == 1 ? 4 : 5;
+  constexpr int PQ_T[6] = {0, T2 * 1 / PH, T2 * 2 / PH, T2 * 3 / PH, PH > 4 ? T2 * 4 / PH : T2, T2};
+  constexpr int PQ_FR = (T2 - PQ_T[PH - 1]) * NP * WN;
+  constexpr int PQ_SLOT = PQ_FR * 64;
+  static_assert(BL != 2 || (NP == 2 && WM * WN == 4 && WN <= 2 && PQ_T[1] * NP * WN >= 4), "pipelined form: fp16 x 2 pieces, four wavefronts");
+  __shared__ uint4 lds[BL == 2 ? 2 * NIT + 2 * PQ_SLOT : (BL ? NIT + NBF * 64 : ROUNDS * NT)];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -1059,6 +1075,134 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) yo[i][mr][j] = 0.f;
 
+  if constexpr (BL == 2) {
+    // ---- pipelined form (round 6): nothing the tap loop reads is waited for where it is requested ------------------------
+    // A stage (point xi, 16-channel chunk kc) runs in FOUR phases of 6/6/6/7 taps.  LDS holds two tile buffers (stage s reads
+    // [s & 1] while LDS-DMA fills the other with stage s + 1) and two quarter-stage weight slots (phase q reads slot q & 1 while
+    // the other receives the fragments of the next phase).  Every fill is requested one whole phase (weights) or two (tile)
+    // before its first read, so the only synchronisation is ONE counted s_waitcnt + ONE raw s_barrier per phase.  The fills are
+    // issued by inline assembly: hipcc drains every LDS-DMA it knows about before the next ds_read (s_waitcnt vmcnt(0) right
+    // behind the request -- profiles/r06_fused_probes.txt (h)); what it does not see it does not wait for, and the waits
+    // here are counted by hand (loads retire in order: "vmcnt(7)" = everything but the 7 requests of the next tile).
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)lds;
+    const int NS = NXI * a.KC;
+    const unsigned voff_last = (ROUNDS - 1) * NT + wave * 64 < NIT ? voff[ROUNDS - 1] : voff[ROUNDS - 2];   // (uniform choice: the
+    const int r_last = (ROUNDS - 1) * NT + wave * 64 < NIT ? ROUNDS - 1 : ROUNDS - 2;   // last round of three wavefronts repeats the one before: equal request counts)
+    auto rsrc_of = [](const char* p_) {
+      const unsigned long pa = (unsigned long)p_;
+      i32x4 r_ = {(int)__builtin_amdgcn_readfirstlane((unsigned)pa), (int)(__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) & 0xffffu),
+                  (int)0xFFFFFFF0u, 0x00020000};
+      return r_;
+    };
+    auto fill_tile = [&](int s_) {        // ROUNDS requests per wavefront
+      const int xi_ = s_ / a.KC, kc_ = s_ - xi_ * a.KC;
+      const i32x4 vr = rsrc_of(vtile0 + (long)xi_ * a.v_xi);
+      const unsigned so = (unsigned)(kc_ * NPL * a.v_plane);
+      const unsigned dst = lds0 + (unsigned)((s_ & 1) * NIT + wave * 64) * 16u;
+#pragma unroll
+      for (int r = 0; r < ROUNDS - 1; ++r) wbf_dma16(vr, dst + (unsigned)(r * NT) * 16u, voff[r], so);
+      wbf_dma16(vr, dst + (unsigned)(r_last * NT) * 16u, voff_last, so);
+    };
+    auto fill_weights = [&](int s_, auto qc) {   // ceil(fragments / 4) requests per wavefront
+      constexpr int q = decltype(qc)::value;
+      constexpr int f0 = PQ_T[q] * NP * WN, nf = (PQ_T[q + 1] - PQ_T[q]) * NP * WN, rounds = (nf + 3) / 4;   // fragment = ((tap, piece), column fragment)
+      const int xi_ = s_ / a.KC, kc_ = s_ - xi_ * a.KC;
+      const i32x4 ur = rsrc_of(a.U + (long)xi_ * a.u_xi);
+      const unsigned ukc = (unsigned)kc_ * uchunk;
+#pragma unroll
+      for (int r = 0; r < rounds; ++r) {
+        int fr = r * 4 + wave;
+        if (fr >= nf) fr -= 4;             // (uniform) repeat a fragment of the round before: equal request counts
+        const int fg = (f0 + fr) / WN, fw = (f0 + fr) % WN;     // (tap, piece) and column fragment: lane (lh, li) -> slot lh * CN + fw * 32 + li
+        wbf_dma16(ur, lds0 + (unsigned)(2 * NIT + ((q + (s_ & PH & 1)) & 1) * PQ_SLOT + fr * 64) * 16u, (unsigned)(lh * a.CN + fw * 32 + li) * 16u,
+                  (unsigned)(fg / NP) * utap + ukc + (unsigned)(fg % NP) * ustep);
+      }
+    };
+    f32x16 acc[MR];
+    int abase[MR];
+    auto run_phase = [&](int s_, auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int T0 = PQ_T[q], T1 = PQ_T[q + 1];
+      const bool more = s_ + 1 < NS;
+      // (1) what this phase reads has landed -- in THIS wavefront's requests; the barrier extends that to all four
+      if (q == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // (2) the slots the previous phase was reading are free: request the next phase's weights, then (phase 0) the next tile
+      if constexpr (q < PH - 1) fill_weights(s_, std::integral_constant<int, q + 1>{});
+      else if (more) fill_weights(s_ + 1, std::integral_constant<int, 0>{});
+      if (q == 0 && more) fill_tile(s_ + 1);
+      // (3) the taps of this phase: LDS -> MFMA only
+      const uint4* bl = lds + 2 * NIT + ((q + (s_ & PH & 1)) & 1) * PQ_SLOT + wn * 64 + lane;   // slot = parity of the running phase count s * PH + q
+      uint4 aq[2][MR][NP], bq[2][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bq[T0 & 1][p] = bl[p * WN * 64];
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) {
+        const uint4* ap = lds + abase[mr] + (T0 / K) * HPt + (T0 % K);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) aq[T0 & 1][mr][p] = ap[p * 2 * NSLOT];
+      }
+#pragma unroll
+      for (int tap = T0; tap < T1; ++tap) {
+        const int cur = tap & 1, nx = cur ^ 1;
+        if (tap + 1 < T1) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bq[nx][p] = bl[((tap + 1 - T0) * NP + p) * WN * 64];
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) {
+            const uint4* ap = lds + abase[mr] + ((tap + 1) / K) * HPt + ((tap + 1) % K);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) aq[nx][mr][p] = ap[p * 2 * NSLOT];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4 bdown = wbf_hi_down(bq[cur][0]);  // partner of the scaled low piece (msk_wbf.h)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][NP - 1], bdown);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][NP - 1]);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) WBF_MFMA_H(acc[mr], aq[cur][mr][0], bq[cur][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    fill_weights(0, std::integral_constant<int, 0>{});
+    fill_tile(0);
+#pragma unroll 1
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int xi = s_ / a.KC, kc = s_ - xi * a.KC;
+      if (kc == 0) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[mr][j] = 0.f;
+      }
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) abase[mr] = arow[mr] + (s_ & 1) * NIT;
+      run_phase(s_, std::integral_constant<int, 0>{});
+      run_phase(s_, std::integral_constant<int, 1>{});
+      run_phase(s_, std::integral_constant<int, 2>{});
+      run_phase(s_, std::integral_constant<int, 3>{});
+      if constexpr (PH > 4) run_phase(s_, std::integral_constant<int, 4>{});
+      if (kc == a.KC - 1) {
+        float c0, c1, c2, c3;
+        at_column<K>(xi, c0, c1, c2, c3);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float m = acc[mr][j];
+            yo[0][mr][j] = fmaf(c0, m, yo[0][mr][j]);
+            yo[1][mr][j] = fmaf(c1, m, yo[1][mr][j]);
+            yo[2][mr][j] = fmaf(c2, m, yo[2][mr][j]);
+            yo[3][mr][j] = fmaf(c3, m, yo[3][mr][j]);
+          }
+      }
+    }
+    __syncthreads();   // (nothing is in flight any more: the statistics epilogue reuses the LDS)
+  } else {
 #pragma unroll 1
   for (int xi = 0; xi < NXI; ++xi) {
     const __amdgpu_buffer_rsrc_t vres =
@@ -1073,7 +1217,7 @@ wbf_gemm_fused_k(FusedArgs f) {
 
 #pragma unroll 1
     for (int kc = 0; kc < a.KC; ++kc) {
-      if constexpr (BL) {
+      if constexpr (BL != 0) {
         __syncthreads();  // every wavefront is done reading the previous stage's tile and weights
         const unsigned vsoff = (unsigned)(kc * NPL * a.v_plane);
         const bool fill = !(WBF_PROBE & 1) || (xi == 0 && kc == 0);
@@ -1246,6 +1390,7 @@ wbf_gemm_fused_k(FusedArgs f) {
       }
   }
 
+  }  // BL != 2
   // epilogue: y = yo / (operand scales) + bias [+ dst] [PReLU]; a lane owns ONE output channel (column li of the MFMA
   // result) and MR x 16 positions x 4 W outputs of it
   const int co = wn * 32 + li;
@@ -1747,11 +1892,24 @@ template <int MR, int WM, int WN, int TD, int TH, int K, int NP>
 void launch_fused(msk_ctx* ctx, const char* tag, const FusedArgs& fa, bool stats, bool fork) {
   const dim3 grid((unsigned)(8 * fa.per_xcd));
   constexpr int NITc = 2 * NP * (TD + K - 1) * (TH + K - 1);
+  if constexpr (WN == 2 && WM == 2 && NP == 2 && NITc % 64 == 0) {
+    if (ctx->wbf_fused_bl == 2 && fa.g.CN == 64) {   // pipelined fills, two column fragments (round 6)
+      if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true, 1, 2>), grid, dim3(WM * WN * 64), 0, fa);
+      else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false, 1, 2>), grid, dim3(WM * WN * 64), 0, fa);
+      return;
+    }
+  }
   if constexpr (WN == 1 && NP == 2 && NITc % 64 == 0) {
-    // one column fragment (32 output channels): the stage's weights through LDS as well ("wbf_fused_bl", default on)
+    // one column fragment (32 output channels): the stage's weights through LDS as well ("wbf_fused_bl": 2 = pipelined (default),
+    // 1 = whole stage behind one wait, 0 = per-wavefront L1 loads)
+    if (ctx->wbf_fused_bl == 2 && fa.g.CN == 32) {   // pipelined fills (round 6)
+      if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true, 1, 2>), grid, dim3(WM * WN * 64), 0, fa);
+      else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false, 1, 2>), grid, dim3(WM * WN * 64), 0, fa);
+      return;
+    }
     if (ctx->wbf_fused_bl && fa.g.CN == 32) {
-      if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true, 1, true>), grid, dim3(WM * WN * 64), 0, fa);
-      else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false, 1, true>), grid, dim3(WM * WN * 64), 0, fa);
+      if (stats) MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, true, 1, 1>), grid, dim3(WM * WN * 64), 0, fa);
+      else MSK_LAUNCH_TIMED_F(ctx, tag, fork, (wbf_gemm_fused_k<MR, WM, WN, TD, TH, K, NP, false, 1, 1>), grid, dim3(WM * WN * 64), 0, fa);
       return;
     }
   }
