@@ -1198,3 +1198,45 @@ def test_wbf_pack_weights_lds_form_is_bitwise_the_elementwise_form(case, split):
     finally:
         d.set_option("wbf_pack_lds", 1)
         d.set_option("conv_split", 2)
+
+
+@pytest.mark.parametrize("c,size", [(32, 64), (64, 64)])
+def test_pipelined_one_kernel_matrix_stage_is_bitwise_reproducible(c, size):
+    """Round 6: wbf_gemm_fused_k's pipelined form issues its LDS-DMA fills by inline assembly and synchronises with hand-counted
+    s_waitcnt vmcnt(N) + raw s_barrier (msk_conv_wbf.hip, BL == 2) -- a miscounted wait or a slot reused too early would show as a
+    result that depends on timing.  The same forward + accumulating data gradient, six times on unchanged inputs, must be bitwise
+    identical, and the one-kernel form must be the one that ran (32 channels: four phases per stage; 64: five)."""
+    import hashlib
+    d = dev()
+    d.set_option("conv_split", 2)
+    rng = np.random.default_rng(3)
+    n = 2
+    vox = n * size ** 3
+    from medicalseg_amd.device import Tensor
+    mk = lambda: Tensor(d, d.malloc(vox * c * 4), n, size, size, size, c, c, None)
+    x, y, dx = mk(), mk(), mk()
+    d.h2d(x.ptr, rng.standard_normal(vox * c, dtype=np.float32))
+    w = d.malloc(c * c * 125 * 4)
+    d.h2d(w, (rng.standard_normal(c * c * 125) * 0.01).astype(np.float32))
+    b = d.small(c)
+    cd = _desc((5, 5, 5), (1, 1, 1), (2, 2, 2))
+    d.prof_reset()
+    d.set_option("prof_only_halo", 0)
+    d.set_option("prof_shapes", 1)
+    d.prof_enable(True)
+    hashes = set()
+    try:
+        for _ in range(6):
+            d.call("msk_conv3d_fwd", cd, x.msk(), C.c_void_p(w), C.c_void_p(b), y.msk())
+            d.memset(dx.ptr, 0, vox * c * 4)
+            d.call("msk_conv3d_dgrad", cd, y.msk(), C.c_void_p(w), dx.msk(), 1)
+            hashes.add(hashlib.sha256(d.d2h(y.ptr, (vox * c,), np.float32).tobytes() + d.d2h(dx.ptr, (vox * c,), np.float32).tobytes()).hexdigest())
+    finally:
+        d.prof_enable(False)
+        d.set_option("prof_shapes", 0)
+        for t in (x, y, dx):
+            d.free(t.ptr)
+        d.free(w)
+    tags = d.prof_report()
+    assert any(k.startswith("wbf_gemm_h2_k") and "fused" in k for k in tags), sorted(tags)
+    assert len(hashes) == 1, "results differ between runs: %d distinct" % len(hashes)
