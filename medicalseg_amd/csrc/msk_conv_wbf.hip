@@ -1438,7 +1438,7 @@ wbf_gemm_fused_k(FusedArgs f) {
           if (f.accumulate) r += old[jj][i];
           if (f.prelu) r = r > 0.f ? r : sl * r;
           if ((WBF_PROBE & 8) && r != 12345.678f) continue;   // probe: no stores (the value still has to be computed)
-          if (split_st) sbase[((op[jj] - obase) >> 1) + i * swst] = r;
+          if (split_st) sbase[((op[jj] - obase) >> 1) + i * swst] = r;     // (nontemporal stores: measured, no difference)
           else op[jj][i * wst] = r;
           if (STATS) {
             if (cnt == 0.f) sk = r;
