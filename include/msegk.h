@@ -277,6 +277,16 @@ int msk_conv3d_bwd_bnact_split(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, con
                                msk_tensor dy_scratch, msk_tensor dx, int dx_accumulate, float* dw, int dw_accumulate,
                                const void* xform /*nullable*/, void* ybuf /*nullable*/, const float* maxes /*nullable*/,
                                msk_tensor dx_lo, msk_tensor dx_hi, int* split_done);
+/* msk_conv3d_bwd_bnact(_split) whose accumulating data gradient takes its OLD values from another tensor, dx_old (geometry and voxel
+ * stride of dx), and writes the sums to dx (or to the dense halves dx_lo / dx_hi when the one-kernel matrix stage runs it:
+ * *split_done = 1).  The residual joins of vnet.py:110-111,154 hand one gradient to both operands: msk_add_act_bwd /
+ * msk_add_act_join_bwd_* accept a null second destination, and the layer behind the join reads the first one here -- one full
+ * write of the tensor less per join.  dx_old.p == NULL: msk_conv3d_bwd_bnact(_split).  dx_lo / dx_hi / split_done may be null. */
+int msk_conv3d_bwd_bnact_acc(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                             const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                             msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                             int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
+                             msk_tensor dx_old, msk_tensor dx_lo, msk_tensor dx_hi, int* split_done);
 /* Backward of an up-convolution unit  convT -> BatchNorm(batch statistics) -> PReLU  (UpTransition.up_conv / bn1 / relu1,
  * vnet.py:133-150; autograd of core/train.py:139) behind its reduce pass, in one call:
  *     dx (+)= convT^T(dy, w),  dw (+)= sum x * dy,   dy = msk_affine_act_bwd_apply(y, ..., dout, sums_total, M_total, bn_mode 1)

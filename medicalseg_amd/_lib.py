@@ -96,6 +96,7 @@ SIGNATURES = {
     "msk_conv3d_bwd_bnact": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i, _vp, _vp, _vp]),
     "msk_convT3d_bwd_bnact": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i]),
     "msk_conv3d_bwd_bnact_split": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i, _vp, _vp, _vp, _T, _T, C.POINTER(_i)]),
+    "msk_conv3d_bwd_bnact_acc": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _vp, _T, _vp, _d, _T, _T, _i, _vp, _i, _vp, _vp, _vp, _T, _T, _T, C.POINTER(_i)]),
     "msk_conv3d_bwd_inact": (_i, [_vp, _CD, _T, _vp, _T, _vp, _vp, _vp, _vp, _vp, _i, _T, _vp, _i, _d, _T, _i, _vp, _i, _vp, _vp, _vp]),
     "msk_conv3d_bwd_bnact_c1": (_i, [_vp, _CD, _T, _T, _vp, _vp, _vp, _vp, _vp, _T, _T, _vp, _d, _vp, _i]),
     "msk_conv3d_dgrad": (_i, [_vp, _CD, _T, _vp, _T, _i]),

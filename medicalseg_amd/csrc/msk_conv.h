@@ -34,6 +34,8 @@ struct GConv {
   float* dst_lo;      // msk_conv3d_bwd_bnact_split: when the one-kernel matrix stage runs this (accumulating) problem it stores channels
   float* dst_hi;      // [0, dst_csplit) / [dst_csplit, CN) to these dense tensors instead of dst (sets ctx->dst_split_done); else ignored
   int dst_csplit;
+  const float* acc_src;  // msk_conv3d_bwd_bnact_acc: an ACCUMULATING problem reads its old values from this tensor (geometry and voxel
+                         // stride of dst) instead of dst -- the pass that would have written them to dst first is skipped (round 6)
   const float* prelu; // inference (msk_conv3d_fwd_act): per-channel PReLU slope applied after the bias, or null.  The
                       // Winograd kernels apply it in their epilogue; for every other kernel run_gconv_one adds a pass.
 };

@@ -1693,7 +1693,7 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
                                  msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
                                  int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
                                  int coef_stride, int sums_stride, bool fused_only, float* dx_lo = nullptr, float* dx_hi = nullptr,
-                                 int dx_csplit = 0);
+                                 int dx_csplit = 0, const float* dx_old = nullptr);
 
 int msk_conv3d_bwd_bnact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
@@ -1726,6 +1726,33 @@ int msk_conv3d_bwd_bnact_split(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, con
   return rc;
 }
 
+// msk_conv3d_bwd_bnact / _split for a data gradient that accumulates onto values which live in ANOTHER tensor: dx_old (geometry and
+// voxel stride of dx; e.g. the gradient a residual join hands to both of its operands, written once).  The output stage reads the
+// old values from dx_old and writes the sums to dx (or, with dx_lo / dx_hi and the one-kernel matrix stage, to the dense halves:
+// *split_done = 1) -- dx itself need not have been written.  dx_old.p == null: exactly msk_conv3d_bwd_bnact(_split) with
+// dx_accumulate as given.  Replaces the in-place `x.grad += ...` of paddle's autograd behind vnet.py:110-111,154.
+int msk_conv3d_bwd_bnact_acc(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
+                             const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
+                             msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
+                             int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
+                             msk_tensor dx_old, msk_tensor dx_lo, msk_tensor dx_hi, int* split_done) {
+  if (split_done) *split_done = 0;
+  if (dx_old.p) {
+    MSK_REQUIRE(ctx, dx.p && dx_old.n == dx.n && dx_old.d == dx.d && dx_old.h == dx.h && dx_old.w == dx.w && dx_old.c == dx.c &&
+                         dx_old.ld == dx.ld && dx_old.p != dx.p, "dx_old must have the geometry and voxel stride of dx");
+    dx_accumulate = 1;
+  }
+  const bool ok = split_done && dx.p && dx_lo.p && dx_hi.p && dx.c % 2 == 0 && dx_lo.c == dx.c / 2 && dx_hi.c == dx.c / 2 &&
+                  dx_lo.ld == dx.c / 2 && dx_hi.ld == dx.c / 2 && dx.ld == dx.c && msk_voxels(dx_lo) == msk_voxels(dx) &&
+                  msk_voxels(dx_hi) == msk_voxels(dx) && dx_accumulate && ctx->dst_split != 0;
+  const int rc = conv3d_bwd_bnact_impl(ctx, cd, x, w, y, scale, shift, alpha, mean, invstd, gamma, dout, sums_total, M_total, dy_scratch, dx,
+                                       dx_accumulate, dw, dw_accumulate, xform, ybuf, maxes, 0, 0, false, ok ? (float*)dx_lo.p : nullptr,
+                                       ok ? (float*)dx_hi.p : nullptr, ok ? dx.c / 2 : 0, (const float*)dx_old.p);
+  if (rc == 0 && ok && ctx->dst_split_done) *split_done = 1;
+  ctx->dst_split_done = false;
+  return rc;
+}
+
 int msk_conv3d_bwd_inact(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, const float* w, msk_tensor y, const float* scale,
                          const float* shift, const float* alpha, const float* mean, const float* invstd, int coef_stride,
                          msk_tensor dout, const float* sums, int sums_stride, double M_sample, msk_tensor dx, int dx_accumulate,
@@ -1739,9 +1766,11 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
                                  const float* shift, const float* alpha, const float* mean, const float* invstd, const float* gamma,
                                  msk_tensor dout, const float* sums_total, double M_total, msk_tensor dy_scratch, msk_tensor dx,
                                  int dx_accumulate, float* dw, int dw_accumulate, const void* xform, void* ybuf, const float* maxes,
-                                 int coef_stride, int sums_stride, bool fused_only, float* dx_lo, float* dx_hi, int dx_csplit) {
+                                 int coef_stride, int sums_stride, bool fused_only, float* dx_lo, float* dx_hi, int dx_csplit,
+                                 const float* dx_old) {
   if (check_conv_shapes(ctx, cd, x, y, false) != 0) return -1;
   ctx->dst_split_done = false;
+  if (!dx_accumulate || !dx.p) dx_old = nullptr;
   MSK_REQUIRE(ctx, scale && shift && mean && invstd && sums_total && M_total > 0, "training-mode BatchNorm coefficients required");
   MSK_REQUIRE(ctx, dout.n == y.n && dout.d == y.d && dout.h == y.h && dout.w == y.w && dout.c == y.c, "dout must match y");
   MSK_REQUIRE(ctx, fused_only || (dy_scratch.p && dy_scratch.n == y.n && dy_scratch.d == y.d && dy_scratch.h == y.h && dy_scratch.w == y.w &&
@@ -1778,6 +1807,7 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
     g.transposed = 1; g.bias = nullptr; g.accumulate = dx_accumulate; g.flip = 1;
     g.w_persistent = true;
     g.dst_lo = dx_lo; g.dst_hi = dx_hi; g.dst_csplit = dx_csplit;
+    g.acc_src = dx_old;      // both output stages of the pipeline (one-kernel epilogue, wbf_tout_k) read the old values from there
     WbfBnBwd bn{};
     bn.y = (const float*)y.p; bn.yld = y.ld; bn.dout = (const float*)dout.p; bn.dld = dout.ld;
     bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean = mean; bn.invstd = invstd; bn.sums = sums_total;
@@ -1850,6 +1880,11 @@ static int conv3d_bwd_bnact_impl(msk_ctx* ctx, msk_conv_desc cd, msk_tensor x, c
   if (fused_only) return 1;   // declined, nothing launched: the caller runs its own passes
   // ---- three-kernel form: dy through HBM
   (void)gamma;
+  if (dx_old) {   // the general data-gradient kernels accumulate in place: put the old values where they expect them
+    msk_tensor so = dx;
+    so.p = (void*)dx_old;
+    if (int rc = msk_copy_scale(ctx, so, nullptr, dx, 0)) return rc;
+  }
   if (int rc = msk_affine_act_bwd_apply(ctx, y, scale, shift, msk_tensor{}, alpha, mean, invstd, gamma, dout, sums_total, M_total, 1,
                                         dy_scratch, msk_tensor{}, 0))
     return rc;

@@ -965,6 +965,7 @@ struct FusedArgs {
   float* st_lo;
   float* st_hi;
   int csplit;
+  const float* acc_src;   // accumulate: the old values come from here (same geometry / voxel stride as dst) instead of dst; null = dst
 };
 
 struct WfRec {
@@ -1403,6 +1404,7 @@ wbf_gemm_fused_k(FusedArgs f) {
   const bool split_st = f.st_lo != nullptr;
   float* sbase = split_st ? (co < f.csplit ? f.st_lo + co : f.st_hi + (co - f.csplit)) + (((long)n * f.dvn + (long)(4 * t) * f.dvw) * f.dld >> 1) : obase;
   const long swst = split_st ? (wst >> 1) : wst;
+  const long aoff = f.acc_src ? (f.acc_src - f.dst) : 0;   // (element distance between the tensor the old values are read from and dst)
   const int wlim = f.LW - 4 * t;   // W outputs of this tile inside the volume (wave-uniform; >= 4 except in a ragged last tile)
   float sk = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
@@ -1426,7 +1428,7 @@ wbf_gemm_fused_k(FusedArgs f) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) old[jj][i] = (ok[jj] && i < wlim) ? __builtin_nontemporal_load(op[jj] + i * wst) : 0.f;
+          for (int i = 0; i < 4; ++i) old[jj][i] = (ok[jj] && i < wlim) ? __builtin_nontemporal_load(op[jj] + aoff + i * wst) : 0.f;
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1500,6 +1502,7 @@ struct ToutArgs {
   const float* bias;
   const float* prelu;
   int accumulate;
+  const float* acc_src; // accumulate: read the old values from this tensor (geometry of dst) instead of dst; null = dst
   const float* in_amax; // NP = 2: the device scalars the input transform and the weight pack scaled by (wbf_scale_of)
   const float* w_amax;
   int scaled;           // NP = 2
@@ -1584,7 +1587,7 @@ wbf_tout_k(ToutArgs a) {
     float4 old4[4];   // accumulate: the four old values are loaded before the first store (load -> add -> store per row serialised)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      old4[i] = (a.accumulate && 4 * t + i < a.LW) ? *reinterpret_cast<const float4*>(o + (long)i * a.dvw * a.dld) : make_float4(0.f, 0.f, 0.f, 0.f);
+      old4[i] = (a.accumulate && 4 * t + i < a.LW) ? *reinterpret_cast<const float4*>((a.acc_src ? a.acc_src + (o - a.dst) : o) + (long)i * a.dvw * a.dld) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (4 * t + i < a.LW) {
@@ -2066,6 +2069,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     fa.dst = g.dst; fa.dld = g.dld;
     fa.dvn = (long)g.DD * g.DH * g.DW; fa.dvd = vstr[pm[0]]; fa.dvh = vstr[pm[1]]; fa.dvw = vstr[pm[2]];
     fa.bias = g.bias; fa.prelu = g.prelu; fa.accumulate = g.accumulate;
+    fa.acc_src = g.accumulate ? g.acc_src : nullptr;
     fa.in_amax = in_amax; fa.w_amax = w_amax; fa.scaled = NP != 3 ? 1 : 0;
     fa.stat_partial = SP;
     fa.per_xcd = (fa.g.nblk + 7) / 8;
@@ -2105,6 +2109,7 @@ int run_pipeline(msk_ctx* ctx, const GConv& g, const float* w_canon, int A, int 
     oa.dst = g.dst; oa.dld = g.dld;
     oa.dvn = (long)g.DD * g.DH * g.DW; oa.dvd = vstr[pm[0]]; oa.dvh = vstr[pm[1]]; oa.dvw = vstr[pm[2]];
     oa.bias = g.bias; oa.prelu = g.prelu; oa.accumulate = g.accumulate;
+    oa.acc_src = g.accumulate ? g.acc_src : nullptr;
     oa.stat_partial = SP;
     oa.in_amax = in_amax;
     oa.w_amax = w_amax;

@@ -583,12 +583,14 @@ affine_act_bwd_reduce_v4_k(const float* __restrict__ x, int ldx, const float* __
       if (JOIN) {
         const float4 o = make_float4(du[0], du[1], du[2], du[3]);
         *reinterpret_cast<float4*>(da + v * ldda + c) = o;
-        float4* bp = reinterpret_cast<float4*>(db + v * lddb + c);
-        if (db_acc) {
-          const float4 old = *bp;
-          *bp = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
-        } else {
-          *bp = o;
+        if (db) {   // (uniform; null: the consumer of db reads da instead)
+          float4* bp = reinterpret_cast<float4*>(db + v * lddb + c);
+          if (db_acc) {
+            const float4 old = *bp;
+            *bp = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+          } else {
+            *bp = o;
+          }
         }
       }
     };
@@ -1588,10 +1590,13 @@ static int add_act_bwd_impl(msk_ctx* ctx, msk_tensor a, const float* scale, cons
                            float* dalpha, const float* mean = nullptr, const float* invstd = nullptr, float* unit_sums = nullptr,
                            float* maxes = nullptr, int clear_maxes = 1, float* u_dgamma = nullptr, float* u_dbeta = nullptr,
                            float* u_dalpha = nullptr) {
-  MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && same_shape(a, db), "shape mismatch");
+  // db.p == null (round 6): the second operand's gradient is NOT written -- it equals da, and its consumer reads da instead
+  // (msk_conv3d_bwd_bnact_acc's dx_old): one write of the tensor less per join
+  MSK_REQUIRE(ctx, same_shape(a, b) && same_shape(a, dout) && same_shape(a, da) && (!db.p || same_shape(a, db)), "shape mismatch");
+  MSK_REQUIRE(ctx, db.p || !db_accumulate, "a skipped second gradient cannot accumulate");
   MSK_REQUIRE(ctx, alpha != nullptr && dalpha != nullptr, "join needs alpha and its gradient");
   MSK_REQUIRE(ctx, a.c % 4 == 0 && a.c / 4 <= kThreads && vec4_ok(a) && vec4_ok(b) && vec4_ok(dout) && vec4_ok(da) &&
-                       vec4_ok(db), "join backward needs float4-aligned tensors with C % 4 == 0");
+                       (!db.p || vec4_ok(db)), "join backward needs float4-aligned tensors with C % 4 == 0");
   const long voxels = msk_voxels(a);
   const int QCB = pow2ceil(a.c / 4), VL = kThreads / QCB;
   const int nb = reduce_blocks(voxels, VL, ctx->num_cu, 2);

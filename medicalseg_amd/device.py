@@ -236,7 +236,7 @@ class Tensor:
     ``shape`` reports the reference's logical NCDHW order so code written against the
     reference (``_, c, d, h, w = images.shape``; core/train.py:266) keeps working."""
 
-    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "producer", "out_index", "_amax", "_amax_gen", "_pool_bytes")
+    __slots__ = ("dev", "ptr", "n", "d", "h", "w", "c", "ld", "gen", "grad", "grad_written", "grad_from", "producer", "out_index", "_amax", "_amax_gen", "_pool_bytes")
 
     def __init__(self, dev, ptr, n, d, h, w, c, ld=None, gen=None):
         self.dev, self.ptr = dev, ptr
@@ -245,6 +245,10 @@ class Tensor:
         self.gen = gen
         self.grad = None
         self.grad_written = False
+        # a Tensor whose VALUES are this tensor's gradient so far although `grad` itself has not been written (a residual join hands
+        # the same gradient to both operands and writes it once, nn.AddAct.backward(share_b=True)): the next accumulating writer reads
+        # its old values from there (msk_conv3d_bwd_bnact_acc), anyone else calls nn.materialize_grad first
+        self.grad_from = None
         self.producer = None
         self.out_index = 0
         # device "amax array" (msk_amax_new) that the passes WRITING this tensor fold max |value| into, or None.  A channel

@@ -122,10 +122,14 @@ class DownTransition(nn.Layer):
 
     def backward(self, dout):
         down = self._t_down
-        self._join.backward(dout)  # -> ops_out.grad (write), down.grad (write)
-        for op in reversed(list(self.ops)):
+        ops = list(self.ops)
+        # without a dropout between them the first LUConv reads `down` itself: the join's gradient is written once (ops_out.grad) and
+        # that layer's accumulating data gradient takes its old values from there (nn.AddAct.backward, share_b)
+        self._join.backward(dout, share_b=bool(ops) and self._mask is None and ops[0]._unit.x is down)
+        for op in reversed(ops):
             g = op._unit.out.grad
             op.backward(g)
+        nn.materialize_grad(down)      # (no-op when ops[0] consumed the shared gradient)
         if self._mask is not None:
             copy_scale(self._dropped.grad, self._mask, down.grad, accumulate=True)
         self._down.backward(down.grad)
@@ -208,8 +212,8 @@ class UpTransition(nn.Layer):
 
     def backward(self, dout):
         xcat, half = self._xcat, self.outChans // 2
-        self._join.backward(dout)  # -> ops_out.grad, xcat.grad
         ops = list(self.ops)
+        self._join.backward(dout, share_b=bool(ops) and ops[0]._unit.x is xcat)  # -> ops_out.grad (+ xcat.grad unless shared, DownTransition.backward)
         # halves narrower than a 128-byte line (16 channels): ask the layer that completes xcat.grad -- ops[0], accumulating its
         # data gradient behind the join's -- to store the sums as two DENSE tensors (msk_conv3d_bwd_bnact_split); the readers of
         # one half then do not fetch the other with it (round 5).  Honoured only by the one-kernel matrix stage: else as before
@@ -225,6 +229,7 @@ class UpTransition(nn.Layer):
             first.dx_split_done = False
         for op in reversed(ops):
             op.backward(op._unit.out.grad)
+        nn.materialize_grad(xcat)
         gcat = xcat.grad
         split_done = g_lo is not None and getattr(first, "dx_split_done", False)
         if first is not None:

@@ -523,6 +523,23 @@ FUSE_BN_BACKWARD_C1 = os.environ.get("MSEGK_BWD_FUSE_C1", "1") != "0"
 FUSE_BN_BACKWARD_T = os.environ.get("MSEGK_BWD_FUSE_T", "0") == "1"
 
 
+# A/B switch (env MSEGK_SHARE_JOIN_GRAD=0): a residual join writes the gradient of BOTH operands (round 5) instead of one tensor that
+# the layer behind the join reads as its old values (msk_conv3d_bwd_bnact_acc)
+SHARE_JOIN_GRAD = os.environ.get("MSEGK_SHARE_JOIN_GRAD", "1") != "0"
+
+
+def materialize_grad(t: Tensor):
+    """t.grad_from (see device.Tensor) -> t.grad: the copy the shared-gradient shortcut avoids, for consumers that accumulate in place"""
+    src = getattr(t, "grad_from", None)
+    if src is None:
+        return
+    t.grad_from = None
+    g = t.ensure_grad()
+    src.dev.call("msk_copy_scale", src.msk(), None, g.msk(), 1 if t.grad_written else 0)
+    g.amax = None
+    t.grad_written = True
+
+
 class ConvBNAct:
     """conv (or convT) -> BatchNorm -> (+ residual) -> PReLU, forward and adjoint.
 
@@ -652,6 +669,8 @@ class ConvBNAct:
         resm = res.msk() if res is not None else NULL_TENSOR
         fuse = (FUSE_BN_BACKWARD and type(self.conv) is Conv3D and res is None and self.bn_mode == 1 and need_dx
                 and self.conv.cin == self.conv.cout)
+        if not fuse:
+            materialize_grad(self.x)      # (only the fused data gradient below reads old values from another tensor)
         # the maxima of |du| and |xhat| ride along when the fused backward may need to scale dy into fp16 range
         want_maxes = fuse and Cn % 4 == 0 and y.ld % 4 == 0 and dout.ld % 4 == 0 and y.ptr % 16 == 0 and dout.ptr % 16 == 0
         pg_done = False
@@ -720,7 +739,21 @@ class ConvBNAct:
             _count_flops(conv, x.n, y.d * y.h * y.w, 2)
             split = getattr(self, "dx_split", None)     # (lo, hi): dense halves for the gradient of a zero-copy concat (UpTransition.backward)
             self.dx_split, self.dx_split_done = None, False
-            if split is not None and x.grad_written:
+            old = getattr(x, "grad_from", None)         # the join behind this layer wrote ITS gradient once: the old values of dx live there
+            if old is not None and (old.ld != dx.ld or old.c != dx.c or x.grad_written):
+                materialize_grad(x)
+                old = None
+            if old is not None:
+                x.grad_from = None
+                done = C.c_int(0)
+                dev.call("msk_conv3d_bwd_bnact_acc", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
+                         _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
+                         _fp(sums_total), C.c_double(m_total), dy.msk(), dx.msk(), 1,
+                         _fp(conv.weight.grad_ptr), 1, _fp(xfp), _fp(ybuf), _fp(maxes) if want_maxes else None,
+                         old.msk(), split[0].msk() if split is not None else NULL_TENSOR,
+                         split[1].msk() if split is not None else NULL_TENSOR, C.byref(done))
+                self.dx_split_done = bool(done.value)
+            elif split is not None and x.grad_written:
                 done = C.c_int(0)
                 dev.call("msk_conv3d_bwd_bnact_split", conv.desc(), x.msk(), _fp(conv.weight.ptr), y.msk(), _fp(sc["scale"]),
                          _fp(sc["shift"]), _fp(alpha), _fp(sc["mean"]), _fp(sc["invstd"]), _fp(bn.weight.ptr), dout.msk(),
@@ -805,7 +838,11 @@ class AddAct:
                        _amax_for(out))
         return out
 
-    def backward(self, dout: Tensor):
+    def backward(self, dout: Tensor, share_b=False):
+        """share_b: d(a + b) goes to both operands unchanged -- write it ONCE (a.grad) and mark b's gradient as living there
+        (b.grad_from) when nothing has been written to b.grad yet; the layer that accumulates onto it next reads a.grad as its old
+        values (ConvBNAct.backward -> msk_conv3d_bwd_bnact_acc).  The caller guarantees that this layer is b's next consumer and
+        calls nn.materialize_grad(b) afterwards in case it was not."""
         dev = dout.dev
         a, b = self.a, self.b
         Cn = a.c
@@ -814,6 +851,9 @@ class AddAct:
         ga, gb = a.ensure_grad(), b.ensure_grad()
         if a.grad_written:
             raise MskError("AddAct.backward expects to be the first writer of its first operand's gradient")
+        share_b = bool(share_b and SHARE_JOIN_GRAD and not b.grad_written and not isinstance(self.act, ELU) and ga.ld == gb.ld
+                       and Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga)))
+        gbm = NULL_TENSOR if share_b else gb.msk()
         if isinstance(self.act, ELU):
             g = Tensor.empty(dev, dout.n, dout.d, dout.h, dout.w, dout.c)
             dev.call("msk_elu_bwd", self.out.msk(), dout.msk(), C.c_float(self.act.alpha), g.msk(), 0)
@@ -831,19 +871,19 @@ class AddAct:
             if FUSE_SMALL:
                 mx = dev.amax_new(2)
                 dev.call("msk_add_act_join_bwd_pg", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
-                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(),
+                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gbm,
                          1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(mx), 0,
                          _fp(u.bn.weight.grad_ptr), _fp(u.bn.bias.grad_ptr), _fp(u.act._weight.grad_ptr))
                 u.presummed_pg, u.presummed_maxes = True, mx
             else:
                 dev.call("msk_add_act_join_bwd_ex", u.y.msk(), _fp(sc["scale"]), _fp(sc["shift"]), _fp(u.act._weight.ptr),
-                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gb.msk(),
+                         b.msk(), alpha, _fp(sc["mean"]), _fp(sc["invstd"]), dout.msk(), ga.msk(), gbm,
                          1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr), _fp(sc["sums"]), _fp(sc["maxes"]))
                 u.presummed_pg, u.presummed_maxes = False, None
             u.presummed = True
         elif Cn % 4 == 0 and all(t.ld % 4 == 0 and t.ptr % 16 == 0 for t in (a, b, dout, ga, gb)):
             # one pass: both data gradients and the alpha-gradient sum (a join has no BatchNorm)
-            dev.call("msk_add_act_bwd", a.msk(), b.msk(), alpha, dout.msk(), ga.msk(), gb.msk(),
+            dev.call("msk_add_act_bwd", a.msk(), b.msk(), alpha, dout.msk(), ga.msk(), gbm,
                      1 if b.grad_written else 0, _fp(self.act._weight.grad_ptr))
         else:
             dev.call("msk_affine_act_bwd_reduce", a.msk(), None, None, b.msk(), alpha, None, None, dout.msk(),
@@ -852,7 +892,10 @@ class AddAct:
             dev.call("msk_affine_act_bwd_apply", a.msk(), None, None, b.msk(), alpha, None, None, None, dout.msk(),
                      None, C.c_double(1.0), 0, ga.msk(), gb.msk(), 1 if b.grad_written else 0)
         a.grad_written = True
-        b.grad_written = True
+        if share_b:
+            b.grad_from = ga          # b.grad itself is still unwritten
+        else:
+            b.grad_written = True
 
 
 def copy_scale(src: Tensor, mask_ptr, dst: Tensor, accumulate=False):

@@ -71,7 +71,7 @@ size_t msk_conv3d_xform_bytes() { return 0; }
 size_t msk_conv3d_bwd_bnact_bytes() { return 0; }
 #define NOOP(name) int name() { ++g_calls; return 0; }
 NOOP(msk_ncdhw_to_ndhwc) NOOP(msk_ndhwc_to_ncdhw)
-NOOP(msk_conv3d_fwd_ex2) NOOP(msk_affine_act_fwd_amax) NOOP(msk_affine_act_fwd_amax2) NOOP(msk_conv3d_bwd_bnact_split) NOOP(msk_affine_act_join_fwd_amax) NOOP(msk_copy_scale_amax) NOOP(msk_conv3d_dgrad_ex) NOOP(msk_conv3d_bwd_bnact_c1) NOOP(msk_convT3d_bwd_bnact) NOOP(msk_conv3d_bwd_inact) NOOP(msk_conv3d_wgrad_ex2) NOOP(msk_conv3d_wgrad_ex3) NOOP(msk_affine_act_bwd_apply_amax)
+NOOP(msk_conv3d_fwd_ex2) NOOP(msk_affine_act_fwd_amax) NOOP(msk_affine_act_fwd_amax2) NOOP(msk_conv3d_bwd_bnact_split) NOOP(msk_conv3d_bwd_bnact_acc) NOOP(msk_affine_act_join_fwd_amax) NOOP(msk_copy_scale_amax) NOOP(msk_conv3d_dgrad_ex) NOOP(msk_conv3d_bwd_bnact_c1) NOOP(msk_convT3d_bwd_bnact) NOOP(msk_conv3d_bwd_inact) NOOP(msk_conv3d_wgrad_ex2) NOOP(msk_conv3d_wgrad_ex3) NOOP(msk_affine_act_bwd_apply_amax)
 static float fake_amax[128];
 float* msk_amax_new(void* c, int n) { (void)c; (void)n; return fake_amax; }
 NOOP(msk_conv3d_fwd_ex3) NOOP(msk_conv3d_fwd_in) NOOP(msk_bn_stats_fin) NOOP(msk_affine_act_bwd_reduce_pg) NOOP(msk_add_act_join_bwd_pg)
