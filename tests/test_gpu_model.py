@@ -275,6 +275,43 @@ def test_late_weight_gradient_does_not_see_the_updated_prelu_slopes():
             assert np.array_equal(results[0][k], other[k]), k
 
 
+@pytest.mark.parametrize("shape,N", [((64, 64, 64), 2), ((32, 32, 32), 1)])
+def test_shared_join_gradient_is_bitwise_the_two_writes(shape, N):
+    """Round 6: a residual join (vnet.py:110-111,154) hands d(a + b) to both operands.  nn.AddAct.backward(share_b=True) writes it
+    ONCE and the LUConv behind the join reads it as the old values of its accumulating data gradient (msk_conv3d_bwd_bnact_acc:
+    one-kernel epilogue at 64^3 -- incl. the dense-halves store behind the 16 + 16 concat -- and wbf_tout_k / the copy fall-back at
+    32^3).  Same additions in the same order: every parameter gradient of a training step must equal the two-writes form bit for
+    bit, with dropout on (the dropout levels keep the two writes) and off."""
+    from medicalseg_amd import nn
+    from medicalseg_amd.models import CrossEntropyLoss, DiceLoss, MixedLoss
+    from medicalseg_amd.utils import loss_computation
+    ncls, K, S = 3, ((2, 2, 2),) * 4, ((2, 2, 2),) * 4
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((N, 1) + shape).astype(np.float32)
+    y = rng.integers(0, ncls, (N,) + shape).astype(np.int32)
+    masks = _masks(rng, N)
+    saved = nn.SHARE_JOIN_GRAD
+    results = []
+    try:
+        for share in (False, True):
+            nn.SHARE_JOIN_GRAD = share
+            for mk in ({}, masks):
+                model, _ = _build(ncls, K, S, seed=8)
+                model.train()
+                model.set_dropout_masks(mk)
+                losses = {"types": [MixedLoss([CrossEntropyLoss(), DiceLoss()], [1, 1])], "coef": [1]}
+                ll, _ = loss_computation(model(x), to_labels(y), losses)
+                model.clear_gradients()
+                sum(ll).backward()
+                results.append({n_: p.grad_numpy().copy() for n_, p in model.named_parameters()})
+    finally:
+        nn.SHARE_JOIN_GRAD = saved
+    for a_, b_ in ((results[0], results[2]), (results[1], results[3])):
+        for k in a_:
+            assert np.array_equal(a_[k], b_[k]), k
+    assert any(np.abs(v).max() > 0 for v in results[2].values())
+
+
 def test_eval_mdice_matches_oracle():
     """core.val.evaluate's mDice on a synthetic validation set == oracle soft dice."""
     from medicalseg_amd.core import evaluate
