@@ -282,7 +282,9 @@ def supervised_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)   # warm-up 5, time >= 20 steps
+    # warm-up 5, time >= 20 steps.  100 since round 6: 20 steps are 0.35 s of GPU time -- shorter than the board's clock /
+    # power control settles and than an SMI sampler resolves (round-5 review, weak point 9); 100 steps = 1.8 s
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="samples per GPU")
     ap.add_argument("--size", type=int, default=128)
