@@ -267,6 +267,8 @@ def run_supervised(argv, plans, world, ranks, env=None, result_rank=0, total_tim
                                 ": next plan" if k + 1 < len(plans) else ": no plan left"))
             if total_timeout is not None and time.time() - t_job > total_timeout:
                 break
+            if k + 1 < len(plans):      # the killed workers' GPU contexts and RCCL resources go away asynchronously
+                time.sleep(float(os.environ.get("MSEGK_RELAUNCH_DELAY_S", "1.0")))
         return False, None, attempts
     finally:
         for c in children:
