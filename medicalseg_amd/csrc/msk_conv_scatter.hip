@@ -10,6 +10,11 @@
 #include <optional>
 
 #include "msk_conv.h"
+#ifdef KS_PROBE_NOMFMA   // knock-out probe (timing only, wrong results): the fp32 matrix instructions of this file become register moves
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, x_, y_, z_) ks_probe_keep((a_), (b_), (c_))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, x_, y_, z_) ks_probe_keep((a_), (b_), (c_))
+template <typename T> __device__ __forceinline__ T ks_probe_keep(float a, float b, T c) { asm volatile("" ::"v"(a), "v"(b)); c[0] += a * 1e-30f + b * 1e-30f; return c; }
+#endif
 #include "msk_wbf.h"   // msk_bn_stats_merge
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

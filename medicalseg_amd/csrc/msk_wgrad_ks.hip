@@ -7,6 +7,11 @@
 // 1.3 ms per VNet step for ~0.25 ms of HBM time.  Here: no range checks (k == s, no padding: every tap of every output
 // voxel is inside the volume), one base offset per step, tap offsets wave-uniform.
 #include "msk_conv.h"
+#ifdef KS_PROBE_NOMFMA   // knock-out probe (timing only, wrong results): the fp32 matrix instructions of this file become register moves
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, x_, y_, z_) ks_probe_keep((a_), (b_), (c_))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, x_, y_, z_) ks_probe_keep((a_), (b_), (c_))
+template <typename T> __device__ __forceinline__ T ks_probe_keep(float a, float b, T c) { asm volatile("" ::"v"(a), "v"(b)); c[0] += a * 1e-30f + b * 1e-30f; return c; }
+#endif
 
 namespace {
 
